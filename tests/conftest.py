@@ -1,0 +1,34 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
+
+
+def rel_err(a, b):
+    """max-norm error relative to max|b| (the parity metric of SURVEY.md 8d)."""
+    a = np.asarray(a)
+    b = np.asarray(b)
+    scale = np.max(np.abs(b))
+    if scale == 0:
+        return float(np.max(np.abs(a)))
+    return float(np.max(np.abs(a - b)) / scale)
