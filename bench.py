@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: wavefronts/s through the 20-surface SYN20 chain.
+
+    python bench.py --gpus 1 --steps 5 --warmup 1            # 4096^2 complex128 (default)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" propagates one batch of ``--batch`` wavefronts (wavelength sweep
+lambda_k = 1 um (1 + k/512)) per GPU through all 20 surfaces on the HIP path; fields
+are created and stay in HBM.  With N GPUs every rank gets its own contiguous block of
+the sweep (weak scaling) after ONE broadcast of the work description from rank 0.
+Rank 0 prints one JSON line (contract in the task statement) with two extra objects:
+``roofline`` (dominant kernel: the FFT row pass, HIP-event timed inside the timed
+region) and ``cpu_baseline`` (the NumPy oracle on a bounded sample, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def chain_fft_counts(wavelength, gridsize):
+    """(n_ptp, n_stw, n_wts) the planner executes for SYN20 at this wavelength."""
+    from paos_amd.chains import syn20_chain
+    from paos_amd.run import _Item, _plan_surface
+
+    st = _Item(1.0, wavelength, gridsize, 4, {"us": 0.0, "ut": 0.0})
+    counts = {"ptp": 0, "stw": 0, "wts": 0}
+    for item in syn20_chain().values():
+        for step in _plan_surface(st, item)["steps"]:
+            counts[step[0]] += 1
+    return counts["ptp"], counts["stw"], counts["wts"]
+
+
+def cpu_baseline(gridsize):
+    """NumPy oracle ("port") on the host, 1 core: full SYN20 at a reduced grid, scaled by
+    the pixel ratio to the benchmark grid (flatters the CPU: its cost per pixel grows with
+    the grid).  ~10-30 s."""
+    from oracle.run_np import run as oracle_run
+    from paos_amd.chains import syn20_chain
+
+    n_s = min(gridsize, 1024)
+    t0 = time.perf_counter()
+    oracle_run(1.0, 1.0e-6, n_s, 4, {"us": 0.0, "ut": 0.0}, syn20_chain())
+    dt = time.perf_counter() - t0
+    scale = (gridsize / n_s) ** 2
+    return {
+        "value": 1.0 / (dt * scale),
+        "unit": "wavefronts/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"full SYN20 chain, 1 wavelength, {n_s}x{n_s} complex128, oracle/run_np.py "
+                  f"(NumPy pocketfft, single thread) took {dt:.1f} s; scaled by {scale:g}x pixels to "
+                  f"{gridsize}x{gridsize}; host has {os.cpu_count()} logical CPUs",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--grid", type=int, default=4096)
+    ap.add_argument("--batch", type=int, default=8, help="wavefronts per GPU per step")
+    ap.add_argument("--precision", default="fp64", choices=["fp64", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        args.gpus = world
+
+    dist = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch
+        import torch.distributed as dist
+
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from paos_amd import _lib
+    from paos_amd.chains import syn20_chain
+    from paos_amd.dist import broadcast_blob, max_over_ranks, shard_bounds, syn20_work
+    from paos_amd.run import run_batch
+
+    n, nb = args.grid, args.batch
+    total = nb * world
+    # rank 0 describes the whole job; one broadcast (RCCL over xGMI when N > 1)
+    work = syn20_work(total, "wavelengths") if rank == 0 else None
+    work = broadcast_blob(work, src=0)
+    lo, hi = shard_bounds(total, rank, world)
+    wavelengths = work["wavelengths"][lo:hi]
+    chains = [syn20_chain(coefficients=c) for c in work["coefficients"][lo:hi]]
+    field = {"us": 0.0, "ut": 0.0}
+
+    dev = _lib.DeviceFields(n, nb, args.precision, device=local_rank)
+
+    def step():
+        return run_batch(1.0, wavelengths, n, 4, field, chains, precision=args.precision,
+                         outputs=(), dev=dev, sync=False)
+
+    def barrier():
+        dev.sync()
+        if dist is not None:
+            dist.barrier()
+            import torch
+
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    dev.profile_begin(_lib.KERNEL_FFT_ROWS, max_launches=64 * 1024)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    launches, kern_ms = dev.profile_end()
+    elapsed = max_over_ranks(elapsed)
+
+    if rank == 0:
+        esz = 16 if args.precision == "fp64" else 8
+        value = total * args.steps / elapsed
+        n_ptp, n_stw, n_wts = chain_fft_counts(wavelengths[0], n)
+        ffts = 2 * n_ptp + n_stw + n_wts
+        # 2 passes x (read + write) per 2-D FFT + one 8 B/px intensity write
+        chain_bytes = (ffts * 4 * esz + 8) * n * n
+        pass_bytes = 2 * esz * n * n * nb  # one row pass over the batch: read + write once
+        avg_ms = kern_ms / max(launches, 1)
+        achieved = pass_bytes / (avg_ms * 1e-3) / 1e9 if launches else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath) and n == 4096 and args.precision == "fp64":
+            with open(tpath) as fh:
+                traffic = json.load(fh).get("fft_rows_bytes_per_launch")
+        out = {
+            "metric": "wavefronts/sec (4096^2 c128, 20-surface chain) + achieved HBM GB/s",
+            "value": value,
+            "unit": "wavefronts/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "c128 (f64)" if args.precision == "fp64" else "c64 (f32, f64 phases)",
+            "data": "synthetic",
+            "config": {"workload": f"SYN20 20-surface chain, {n}x{n} {args.precision}, wavelength sweep "
+                                   f"1um*(1+k/512), {nb} wavefronts/GPU/step, {ffts} 2-D FFTs per wavefront "
+                                   f"({n_ptp} ptp, {n_stw} stw, {n_wts} wts)",
+                       "grid": n, "batch_per_gpu": nb, "parallelism": f"wavefront-sharded x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "fft_pass_kernel (row pass)", "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "launches": launches, "avg_launch_ms": avg_ms,
+                         "algorithmic_bytes_per_launch": pass_bytes},
+            "chain_roofline": {"algorithmic_bytes_per_wavefront": chain_bytes,
+                               "achieved_GBps_per_gpu": chain_bytes * (value / world) / 1e9,
+                               "frac_of_hbm_peak": chain_bytes * (value / world) / 1e9 / HBM_PEAK_GBS},
+            "power_check": float(res[0][20]["power"]),
+            "build": dev.build_info(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(n)
+        print(json.dumps(out), flush=True)
+    dev.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

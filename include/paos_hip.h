@@ -1,0 +1,109 @@
+/* paos_hip.h -- C ABI of libpaoship.so, the MI355X (gfx950) wavefront-propagation core.
+ *
+ * The reference (arielmission-space/PAOS v1.2.12) is pure Python and has no FFI;
+ * the boundary this library replaces is the field arithmetic inside the methods of
+ * paos.classes.wfo.WFO (paos/classes/wfo.py) as driven by paos.core.run.run
+ * (paos/core/run.py:30-228).  Each entry point below names the reference lines it
+ * stands in for.  The scalar "pilot Gaussian beam" bookkeeping of those methods
+ * stays on the host (paos_amd/planner.py); only N x N field work crosses this ABI.
+ *
+ * Conventions
+ *   - every function returns 0 on success, a PAOS_E* code otherwise;
+ *     paos_last_error(ctx) gives the message (ctx may be NULL for create errors);
+ *   - a context owns `batch` fields of n x n complex numbers (double or float) in
+ *     HBM, one HIP stream, and all scratch; calls are enqueued on that stream and
+ *     return without waiting unless they hand data to the host;
+ *   - per-item parameter blocks are plain `double` arrays, `batch` blocks long,
+ *     borrowed for the duration of the call; block[0] is an enable flag (0 = leave
+ *     that batch item untouched) so that one launch serves wavelengths / Monte-Carlo
+ *     draws whose planners disagree on whether a step runs;
+ *   - host field buffers are row-major [y][x] complex128, like WFO._wfo;
+ *   - contexts are not thread-safe; different contexts are independent.
+ */
+#ifndef PAOS_HIP_H
+#define PAOS_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct paos_ctx paos_ctx;
+
+enum { PAOS_OK = 0, PAOS_EINVAL = 1, PAOS_EHIP = 2, PAOS_EUNSUPPORTED = 3 };
+enum { PAOS_F64 = 0, PAOS_F32 = 1 };
+enum { PAOS_SHAPE_ELLIPSE = 0, PAOS_SHAPE_RECT = 1 };
+enum { PAOS_KERNEL_FFT_ROWS = 0, PAOS_KERNEL_FFT_COLS = 1, PAOS_KERNEL_PTP_MID = 2 };
+enum { PAOS_WHAT_FIELD = 0, PAOS_WHAT_AMPLITUDE = 1, PAOS_WHAT_PHASE = 2, PAOS_WHAT_INTENSITY = 3 };
+
+/* parameter-block layouts (doubles per batch item) */
+enum { PAOS_PHASE_STRIDE = 5 };    /* enable, sx, sy, coef, sgn                         */
+enum { PAOS_APERTURE_STRIDE = 8 }; /* enable, xc, yc, a|w, b|h, theta, obscuration, subpixels */
+enum { PAOS_ZERNIKE_HEAD = 8 };    /* enable, dx, dy, radius, origin_is_y, cos_off, sin_off, 1/wl;
+                                      then coefC[(nmax+1)*kdim], coefS[(nmax+1)*kdim]           */
+
+/* ---- lifetime -------------------------------------------------------------------- */
+/* WFO.__init__ (wfo.py:99-120): allocates `batch` n x n fields (n = 2^k, 64..4096).
+ * The field content is undefined until paos_fill / paos_import. */
+int paos_ctx_create(int device, int n, int batch, int precision, paos_ctx** out);
+int paos_ctx_destroy(paos_ctx* ctx);
+const char* paos_last_error(const paos_ctx* ctx);
+int paos_sync(paos_ctx* ctx);
+/* describe the build: gfx arch, layout block, pitch padding (for logs) */
+const char* paos_build_info(void);
+/* the HIP stream handle (hipStream_t) of the context, for event timing */
+void* paos_stream(paos_ctx* ctx);
+
+/* Measurement aid (no reference counterpart): time every launch of one kernel class with
+ * HIP events on the context's stream between begin and end; end synchronises and returns
+ * the launch count and the summed durations.  Used by bench.py for the roofline figure. */
+int paos_profile_begin(paos_ctx* ctx, int kernel_kind, int max_launches);
+int paos_profile_end(paos_ctx* ctx, int* launches, double* total_ms);
+
+/* ---- field I/O ---------------------------------------------------------------------- */
+/* u[:] = re + i im for every batch item -- np.ones(..., complex128), wfo.py:118 */
+int paos_fill(paos_ctx* ctx, double re, double im);
+/* host row-major complex128 -> batch item (WFO._wfo assignment in notebooks/tests) */
+int paos_import(paos_ctx* ctx, int item, const void* host_c128);
+/* batch item -> host.  what = FIELD: complex128 copy (wfo.py:162-164); AMPLITUDE: |u|
+ * (wfo.py:166-168); PHASE: angle(u) (wfo.py:170-172); INTENSITY: |u|^2 = the PSF
+ * definition of paos/core/plot.py:125-130.  Synchronises. */
+int paos_export(paos_ctx* ctx, int item, int what, void* host_out);
+
+/* ---- operators ------------------------------------------------------------------------ */
+/* WFO.aperture (wfo.py:203-278): multiply by the exact ellipse mask
+ * (EllipticalAperture.to_mask("exact")) or the 32x32 sub-pixel rectangle mask
+ * (RectangularAperture.to_mask("subpixel", subpixels=32)); obscuration uses 1 - mask. */
+int paos_aperture(paos_ctx* ctx, int shape, const double* params);
+/* the mask alone, row-major doubles, for the aperture object's
+ * .to_mask(...).to_image(shape) used at run.py:136-141, plot.py:164-184 */
+int paos_aperture_render(paos_ctx* ctx, int shape, const double* params1, double* host_mask);
+/* WFO.make_stop (wfo.py:195-201): u /= sqrt(sum |u|^2), per enabled item.
+ * enable may be NULL (= all). */
+int paos_make_stop(paos_ctx* ctx, const double* enable);
+/* sum |u|^2 per item to the host (np.sum(np.abs(u)**2), wfo.py:200).  Synchronises. */
+int paos_norm2(paos_ctx* ctx, double* host_out);
+/* quadratic phase u *= exp(i sgn [2 pi] coef ((x sx)^2 + (y sy)^2)), x, y centred pixel
+ * indices: the field part of WFO.lens (wfo.py:359-366) with mul2pi = 1, sgn = -1,
+ * coef = 0.5 lens_phase / wl. */
+int paos_phase(paos_ctx* ctx, const double* params, int mul2pi);
+/* WFO.ptp (wfo.py:462-472): ifft2(exp(-i coef (fx^2+fy^2)) fft2(u)), ortho norms, shifts
+ * cancelled; sx, sy = 1/(n dx), 1/(n dy) (np.fft.fftfreq spacing), coef = pi wl dz. */
+int paos_ptp(paos_ctx* ctx, const double* params);
+/* WFO.stw (wfo.py:491-509): fftshift(exp(+i coef f^2) FFT(ifftshift u)); inverse != 0
+ * selects ifft2 (dz < 0).  sx, sy, coef as for ptp. */
+int paos_stw(paos_ctx* ctx, const double* params, int inverse);
+/* WFO.wts (wfo.py:528-545): fftshift(FFT(ifftshift(exp(i coef (x^2+y^2)) u))); sx, sy =
+ * dx, dy; coef = pi / (dz wl). */
+int paos_wts(paos_ctx* ctx, const double* params, int inverse);
+/* WFO.zernikes (wfo.py:620-652) with Zernike polynomials (zernike.py:85-109,245-247):
+ * u *= exp(2 pi i wfe / wl) inside rho <= 1.  `table` holds the Jacobi recurrence
+ * constants [(nmax+1)][kdim][3]; `params` the per-item blocks (PAOS_ZERNIKE_HEAD +
+ * 2 (nmax+1) kdim doubles).  If host_wfe != NULL the wfe map of item 0 is returned
+ * (row-major doubles, NaN where rho > 1 -- the masked array of wfo.py:654). */
+int paos_zernike(paos_ctx* ctx, int nmax, int kdim, const double* table, const double* params,
+                 int param_stride, double* host_wfe);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAOS_HIP_H */

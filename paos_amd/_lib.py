@@ -1,0 +1,208 @@
+"""ctypes binding of libpaoship.so (include/paos_hip.h).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` / ``make``.
+There is deliberately no fallback: if the library or a GPU is missing, creating a
+device context raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpaoship.so")
+
+PAOS_F64, PAOS_F32 = 0, 1
+SHAPE_ELLIPSE, SHAPE_RECT = 0, 1
+WHAT_FIELD, WHAT_AMPLITUDE, WHAT_PHASE, WHAT_INTENSITY = 0, 1, 2, 3
+KERNEL_FFT_ROWS, KERNEL_FFT_COLS, KERNEL_PTP_MID = 0, 1, 2
+PHASE_STRIDE = 5
+APERTURE_STRIDE = 8
+ZERNIKE_HEAD = 8
+
+# every symbol include/paos_hip.h declares: (name, restype, argtypes)
+_c_ctx = ctypes.c_void_p
+_dbl_p = ctypes.POINTER(ctypes.c_double)
+SYMBOLS = {
+    "paos_ctx_create": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(_c_ctx)]),
+    "paos_ctx_destroy": (ctypes.c_int, [_c_ctx]),
+    "paos_last_error": (ctypes.c_char_p, [_c_ctx]),
+    "paos_sync": (ctypes.c_int, [_c_ctx]),
+    "paos_build_info": (ctypes.c_char_p, []),
+    "paos_stream": (ctypes.c_void_p, [_c_ctx]),
+    "paos_profile_begin": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int]),
+    "paos_profile_end": (ctypes.c_int, [_c_ctx, ctypes.POINTER(ctypes.c_int), _dbl_p]),
+    "paos_fill": (ctypes.c_int, [_c_ctx, ctypes.c_double, ctypes.c_double]),
+    "paos_import": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_void_p]),
+    "paos_export": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+    "paos_aperture": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p]),
+    "paos_aperture_render": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p, _dbl_p]),
+    "paos_make_stop": (ctypes.c_int, [_c_ctx, _dbl_p]),
+    "paos_norm2": (ctypes.c_int, [_c_ctx, _dbl_p]),
+    "paos_phase": (ctypes.c_int, [_c_ctx, _dbl_p, ctypes.c_int]),
+    "paos_ptp": (ctypes.c_int, [_c_ctx, _dbl_p]),
+    "paos_stw": (ctypes.c_int, [_c_ctx, _dbl_p, ctypes.c_int]),
+    "paos_wts": (ctypes.c_int, [_c_ctx, _dbl_p, ctypes.c_int]),
+    "paos_zernike": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, _dbl_p, _dbl_p, ctypes.c_int, _dbl_p]),
+}
+
+_lib = None
+
+
+class PaosHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libpaoship.so once; raise if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PaosHipError(
+            f"{LIB_PATH} not found: build it with `make` or "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)"
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _dptr(arr):
+    return arr.ctypes.data_as(_dbl_p)
+
+
+def as_blocks(blocks, batch, stride):
+    arr = np.ascontiguousarray(blocks, dtype=np.float64)
+    if arr.shape != (batch, stride):
+        raise ValueError(f"expected parameter blocks of shape {(batch, stride)}, got {arr.shape}")
+    return arr
+
+
+class DeviceFields:
+    """``batch`` n x n complex fields in HBM plus the stream that owns them."""
+
+    def __init__(self, n, batch=1, precision="fp64", device=0):
+        self._lib = load()
+        self._ctx = _c_ctx()
+        self.n, self.batch = int(n), int(batch)
+        if precision not in ("fp64", "fp32"):
+            raise ValueError("precision must be 'fp64' or 'fp32'")
+        self.precision = precision
+        rc = self._lib.paos_ctx_create(int(device), self.n, self.batch,
+                                       PAOS_F64 if precision == "fp64" else PAOS_F32,
+                                       ctypes.byref(self._ctx))
+        if rc != 0:
+            msg = self._lib.paos_last_error(None).decode()
+            self._ctx = _c_ctx()
+            raise PaosHipError(f"paos_ctx_create failed ({rc}): {msg}")
+
+    # -- plumbing ---------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc != 0:
+            raise PaosHipError(f"{what} failed ({rc}): {self._lib.paos_last_error(self._ctx).decode()}")
+
+    def close(self):
+        if getattr(self, "_ctx", None) and self._ctx.value:
+            self._lib.paos_ctx_destroy(self._ctx)
+            self._ctx = _c_ctx()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._check(self._lib.paos_sync(self._ctx), "paos_sync")
+
+    @property
+    def stream(self):
+        return self._lib.paos_stream(self._ctx)
+
+    def build_info(self):
+        return self._lib.paos_build_info().decode()
+
+    def profile_begin(self, kernel_kind, max_launches=4096):
+        self._check(self._lib.paos_profile_begin(self._ctx, int(kernel_kind), int(max_launches)),
+                    "paos_profile_begin")
+
+    def profile_end(self):
+        n, ms = ctypes.c_int(0), ctypes.c_double(0.0)
+        self._check(self._lib.paos_profile_end(self._ctx, ctypes.byref(n), ctypes.byref(ms)),
+                    "paos_profile_end")
+        return n.value, ms.value
+
+    # -- field I/O ----------------------------------------------------------------
+    def fill(self, value=1.0 + 0.0j):
+        value = complex(value)
+        self._check(self._lib.paos_fill(self._ctx, value.real, value.imag), "paos_fill")
+
+    def upload(self, item, field):
+        arr = np.ascontiguousarray(field, dtype=np.complex128)
+        if arr.shape != (self.n, self.n):
+            raise ValueError(f"field must have shape {(self.n, self.n)}")
+        self._check(self._lib.paos_import(self._ctx, int(item), arr.ctypes.data_as(ctypes.c_void_p)),
+                    "paos_import")
+
+    def download(self, item=0, what=WHAT_FIELD):
+        dtype = np.complex128 if what == WHAT_FIELD else np.float64
+        out = np.empty((self.n, self.n), dtype=dtype)
+        self._check(self._lib.paos_export(self._ctx, int(item), int(what),
+                                          out.ctypes.data_as(ctypes.c_void_p)), "paos_export")
+        return out
+
+    # -- operators ------------------------------------------------------------------
+    def aperture(self, shape, blocks):
+        b = as_blocks(blocks, self.batch, APERTURE_STRIDE)
+        self._check(self._lib.paos_aperture(self._ctx, int(shape), _dptr(b)), "paos_aperture")
+
+    def aperture_mask(self, shape, block):
+        b = as_blocks([block], 1, APERTURE_STRIDE)
+        out = np.empty((self.n, self.n), dtype=np.float64)
+        self._check(self._lib.paos_aperture_render(self._ctx, int(shape), _dptr(b), _dptr(out)),
+                    "paos_aperture_render")
+        return out
+
+    def make_stop(self, enable=None):
+        if enable is None:
+            self._check(self._lib.paos_make_stop(self._ctx, None), "paos_make_stop")
+        else:
+            e = np.ascontiguousarray(enable, dtype=np.float64).reshape(self.batch)
+            self._check(self._lib.paos_make_stop(self._ctx, _dptr(e)), "paos_make_stop")
+
+    def norm2(self):
+        out = np.empty(self.batch, dtype=np.float64)
+        self._check(self._lib.paos_norm2(self._ctx, _dptr(out)), "paos_norm2")
+        return out
+
+    def phase(self, blocks, mul2pi):
+        b = as_blocks(blocks, self.batch, PHASE_STRIDE)
+        self._check(self._lib.paos_phase(self._ctx, _dptr(b), int(bool(mul2pi))), "paos_phase")
+
+    def ptp(self, blocks):
+        b = as_blocks(blocks, self.batch, PHASE_STRIDE)
+        self._check(self._lib.paos_ptp(self._ctx, _dptr(b)), "paos_ptp")
+
+    def stw(self, blocks, inverse):
+        b = as_blocks(blocks, self.batch, PHASE_STRIDE)
+        self._check(self._lib.paos_stw(self._ctx, _dptr(b), int(bool(inverse))), "paos_stw")
+
+    def wts(self, blocks, inverse):
+        b = as_blocks(blocks, self.batch, PHASE_STRIDE)
+        self._check(self._lib.paos_wts(self._ctx, _dptr(b), int(bool(inverse))), "paos_wts")
+
+    def zernike(self, nmax, kdim, table, blocks, want_wfe=False):
+        t = np.ascontiguousarray(table, dtype=np.float64).reshape(-1)
+        b = np.ascontiguousarray(blocks, dtype=np.float64)
+        if b.ndim != 2 or b.shape[0] != self.batch:
+            raise ValueError("zernike blocks must be [batch][stride]")
+        out = np.empty((self.n, self.n), dtype=np.float64) if want_wfe else None
+        self._check(self._lib.paos_zernike(self._ctx, int(nmax), int(kdim), _dptr(t), _dptr(b),
+                                           int(b.shape[1]), _dptr(out) if want_wfe else None),
+                    "paos_zernike")
+        return out

@@ -1,0 +1,308 @@
+// fft_core.h -- register-radix Stockham FFT building blocks for gfx950 (CDNA4).
+//
+// One "line" (a row or a column of the N x N field) is transformed by N/E
+// threads that hold E complex elements each in VGPRs.  Every stage is a radix-E
+// (last stage: the remaining radix) DFT done entirely in registers; between
+// stages the line is exchanged through LDS with the Stockham auto-sort index
+// map, so the result comes out in natural order and the first load / last store
+// hit global memory with unit stride across lanes.  No MFMA: a c128 FFT has
+// ~2 flop/byte, far below the machine balance, so the pass is HBM-bound and the
+// job of this file is to keep every global access a full 128-byte line.
+//
+// Replaces, on the GPU, numpy.fft.fft2 / ifft2 as called by the reference at
+// paos/classes/wfo.py:462-472 (ptp), :493-509 (stw), :535-545 (wts).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace paos {
+
+template <typename T>
+struct cx {
+  T x, y;
+};
+
+template <typename T>
+__device__ __forceinline__ cx<T> cadd(cx<T> a, cx<T> b) { return {a.x + b.x, a.y + b.y}; }
+template <typename T>
+__device__ __forceinline__ cx<T> csub(cx<T> a, cx<T> b) { return {a.x - b.x, a.y - b.y}; }
+template <typename T>
+__device__ __forceinline__ cx<T> cmul(cx<T> a, cx<T> b) {
+  return {fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x)};
+}
+template <typename T>
+__device__ __forceinline__ cx<T> cconj(cx<T> a) { return {a.x, -a.y}; }
+
+// sin and cos of a double with |a| < ~1e7 rad: three-term Cody-Waite reduction
+// by pi/2 (exact thanks to FMA) + the classic minimax kernels on [-pi/4, pi/4].
+// About 1 ulp; ~45 instructions and no data-dependent branch, unlike the
+// generic library routine whose Payne-Hanek path bloats register use when 16
+// calls are unrolled into one FFT pass.  Larger arguments take the library path.
+__device__ __forceinline__ void sincos_fast(double a, double* sn, double* cs) {
+  if (!(fabs(a) < 1.0e7)) {
+    sincos(a, sn, cs);
+    return;
+  }
+  const double n = rint(a * 0.63661977236758134308);  // 2/pi
+  double r = fma(-n, 1.57079632673412561417e+00, a);
+  r = fma(-n, 6.07710050630396597660e-11, r);
+  r = fma(-n, 2.02226624879595063154e-21, r);
+  const double z = r * r;
+  double ps = fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+  ps = fma(z, ps, 2.75573137070700676789e-06);
+  ps = fma(z, ps, -1.98412698298579493134e-04);
+  ps = fma(z, ps, 8.33333333332248946124e-03);
+  ps = fma(z, ps, -1.66666666666666324348e-01);
+  const double s = fma(r * z, ps, r);
+  double pc = fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+  pc = fma(z, pc, -2.75573143513906633035e-07);
+  pc = fma(z, pc, 2.48015872894767294178e-05);
+  pc = fma(z, pc, -1.38888888888741095749e-03);
+  pc = fma(z, pc, 4.16666666666666019037e-02);
+  const double c = fma(z * z, pc, fma(z, -0.5, 1.0));
+  const int q = (int)n & 3;
+  const double s1 = (q & 1) ? c : s;
+  const double c1 = (q & 1) ? s : c;
+  *sn = (q & 2) ? -s1 : s1;
+  *cs = ((q + 1) & 2) ? -c1 : c1;
+}
+
+// cos(2 pi m / 32), m = 0..8 (first octant pair); everything else by symmetry.
+__device__ constexpr double kCos32[9] = {
+    1.0,
+    0.98078528040323044913,
+    0.92387953251128675613,
+    0.83146961230254523708,
+    0.70710678118654752440,
+    0.55557023301960222474,
+    0.38268343236508977173,
+    0.19509032201612826785,
+    0.0};
+
+__device__ constexpr double cos32(int m) {
+  m &= 31;
+  if (m > 16) m = 32 - m;
+  return (m > 8) ? -kCos32[16 - m] : kCos32[m];
+}
+__device__ constexpr double sin32(int m) { return cos32(m - 8); }
+
+// v * W_R^m with W_R = exp(-2 pi i / R) for DIR = +1 (forward) and its
+// conjugate for DIR = -1.  m is a compile-time constant after unrolling, so
+// the trivial cases fold away.
+template <int R, int DIR, typename T>
+__device__ __forceinline__ cx<T> mulw(cx<T> v, int m) {
+  const int m32 = (m * (32 / R)) & 31;
+  if (m32 == 0) return v;
+  if (m32 == 16) return {-v.x, -v.y};
+  if (m32 == 8) return (DIR > 0) ? cx<T>{v.y, -v.x} : cx<T>{-v.y, v.x};    // * -/+ i
+  if (m32 == 24) return (DIR > 0) ? cx<T>{-v.y, v.x} : cx<T>{v.y, -v.x};   // * +/- i
+  const T c = (T)cos32(m32);
+  const T s = (T)((DIR > 0) ? -sin32(m32) : sin32(m32));
+  return {fma(v.x, c, -(v.y * s)), fma(v.x, s, v.y * c)};
+}
+
+// In-place DFT of R points held in registers, natural order in and out.
+template <int R, int DIR, typename T>
+__device__ __forceinline__ void dft(cx<T>* v) {
+  if constexpr (R == 2) {
+    cx<T> a = v[0], b = v[1];
+    v[0] = cadd(a, b);
+    v[1] = csub(a, b);
+  } else if constexpr (R == 4) {
+    cx<T> t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+    cx<T> t2 = cadd(v[1], v[3]), t3 = csub(v[1], v[3]);
+    v[0] = cadd(t0, t2);
+    v[2] = csub(t0, t2);
+    if constexpr (DIR > 0) {
+      v[1] = {t1.x + t3.y, t1.y - t3.x};
+      v[3] = {t1.x - t3.y, t1.y + t3.x};
+    } else {
+      v[1] = {t1.x - t3.y, t1.y + t3.x};
+      v[3] = {t1.x + t3.y, t1.y - t3.x};
+    }
+  } else if constexpr (R > 4) {
+    // R = A * B, n = B n1 + n2, k = k1 + A k2:
+    //   W_R^{nk} = W_A^{n1 k1} W_R^{n2 k1} W_B^{n2 k2}
+    constexpr int A = 4, B = R / 4;
+    cx<T> y[R];
+#pragma unroll
+    for (int n2 = 0; n2 < B; ++n2) {
+      cx<T> a[A];
+#pragma unroll
+      for (int n1 = 0; n1 < A; ++n1) a[n1] = v[B * n1 + n2];
+      dft<A, DIR>(a);
+#pragma unroll
+      for (int k1 = 0; k1 < A; ++k1) y[k1 * B + n2] = mulw<R, DIR>(a[k1], n2 * k1);
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < A; ++k1) {
+      cx<T> b[B];
+#pragma unroll
+      for (int n2 = 0; n2 < B; ++n2) b[n2] = y[k1 * B + n2];
+      dft<B, DIR>(b);
+#pragma unroll
+      for (int k2 = 0; k2 < B; ++k2) v[k1 + A * k2] = b[k2];
+    }
+  }
+}
+
+// LDS padding: one extra slot every 16 so that the stride-R scatter of the
+// first exchange and the stride-1 gather both stay conflict-free.
+__device__ __forceinline__ constexpr int lds_pad(int i) { return i + (i >> 4); }
+template <int N>
+constexpr int lds_line_slots() { return N + (N >> 4); }
+
+template <int N, int E, int NS>
+struct StageInfo {
+  static constexpr int REM = N / NS;               // points still to combine
+  static constexpr int R = (REM >= E) ? E : REM;   // radix of this stage
+  static constexpr int TPT = E / R;                // butterflies per thread
+  static constexpr bool LAST = (NS * R == N);
+};
+
+// radix of the final stage / butterflies per thread in it
+template <int N, int E, int NS = 1>
+constexpr int last_radix() {
+  if constexpr (StageInfo<N, E, NS>::LAST) return StageInfo<N, E, NS>::R;
+  else return last_radix<N, E, NS * StageInfo<N, E, NS>::R>();
+}
+
+// Slot k of the register file after the transform holds X[t + outslot(k) * TL]
+// (TL = N / E threads per line); before it, slot k holds x[t + k * TL].
+template <int N, int E>
+__device__ __forceinline__ constexpr int outslot(int k) {
+  constexpr int RL = last_radix<N, E>();
+  constexpr int TPTL = E / RL;
+  return (k / RL) + (k % RL) * TPTL;
+}
+
+// Twiddle powers v[r] *= w^r.  w^r = (w^4)^a * w^b keeps only five powers live
+// (w, w^2, w^3, w^4 and the running (w^4)^a) instead of R of them, and bounds
+// the product depth at R/4 + 1.
+template <int R, typename T>
+__device__ __forceinline__ void apply_twiddle_powers(cx<T>* v, cx<T> w1) {
+  v[1] = cmul(v[1], w1);
+  if constexpr (R > 2) {
+    const cx<T> w2 = cmul(w1, w1);
+    const cx<T> w3 = cmul(w2, w1);
+    v[2] = cmul(v[2], w2);
+    v[3] = cmul(v[3], w3);
+    if constexpr (R > 4) {
+      const cx<T> w4 = cmul(w2, w2);
+      cx<T> base = w4;
+#pragma unroll
+      for (int a = 1; a < R / 4; ++a) {
+        v[4 * a] = cmul(v[4 * a], base);
+        v[4 * a + 1] = cmul(v[4 * a + 1], cmul(base, w1));
+        v[4 * a + 2] = cmul(v[4 * a + 2], cmul(base, w2));
+        v[4 * a + 3] = cmul(v[4 * a + 3], cmul(base, w3));
+        if (a + 1 < R / 4) base = cmul(base, w4);
+      }
+    }
+  }
+}
+
+// All stages of one line.  ``lds`` is this line's exchange area: cx<T> slots
+// when !SPLIT, T slots (real and imaginary parts exchanged one after the other,
+// halving the LDS footprint) when SPLIT.  ``tw`` = exp(-2 pi i m / N), m < N.
+template <typename T, int N, int E, int DIR, bool SPLIT, int NS = 1>
+__device__ __forceinline__ void fft_stages(cx<T>* v, void* lds, int t,
+                                           const cx<T>* __restrict__ tw) {
+  using S = StageInfo<N, E, NS>;
+  constexpr int TL = N / E;
+  constexpr int R = S::R;
+  constexpr int TPT = S::TPT;
+
+#pragma unroll
+  for (int s = 0; s < TPT; ++s) {
+    if constexpr (NS > 1) {
+      const int j = t + s * TL;
+      const int k = j & (NS - 1);
+      cx<T> w1 = tw[k * (N / (NS * R))];
+      if constexpr (DIR < 0) w1.y = -w1.y;
+      apply_twiddle_powers<R>(v + s * R, w1);
+    }
+    dft<R, DIR>(v + s * R);
+  }
+
+  if constexpr (!S::LAST) {
+    using SN = StageInfo<N, E, NS * R>;
+    constexpr int R2 = SN::R;
+    constexpr int TPT2 = SN::TPT;
+    // Scatter/gather slots are pad(base) + a compile-time offset (no carry out of
+    // the low four bits for power-of-two radices), so each thread needs one LDS
+    // address VGPR per exchange and the ds_* immediates carry the rest.
+    constexpr bool LIN_R = (TL % 16 == 0) && ((N / R2) % 16 == 0);
+    int wb[TPT];
+#pragma unroll
+    for (int s = 0; s < TPT; ++s) {
+      const int j = t + s * TL;
+      wb[s] = lds_pad((j / NS) * (NS * R) + (j & (NS - 1)));
+    }
+    const int rb = lds_pad(t);
+    auto ridx = [&](int s, int r) -> int {
+      const int off = s * TL + r * (N / R2);
+      return LIN_R ? rb + lds_pad(off) : lds_pad(t + off);
+    };
+    if constexpr (!SPLIT) {
+      cx<T>* l = reinterpret_cast<cx<T>*>(lds);
+#pragma unroll
+      for (int s = 0; s < TPT; ++s)
+#pragma unroll
+        for (int r = 0; r < R; ++r) l[wb[s] + lds_pad(r * NS)] = v[s * R + r];
+      __syncthreads();
+#pragma unroll
+      for (int s = 0; s < TPT2; ++s)
+#pragma unroll
+        for (int r = 0; r < R2; ++r) v[s * R2 + r] = l[ridx(s, r)];
+      if constexpr (!SN::LAST) __syncthreads();
+    } else {
+      T* l = reinterpret_cast<T*>(lds);
+#pragma unroll
+      for (int part = 0; part < 2; ++part) {
+#pragma unroll
+        for (int s = 0; s < TPT; ++s)
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+            l[wb[s] + lds_pad(r * NS)] = part ? v[s * R + r].y : v[s * R + r].x;
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < TPT2; ++s)
+#pragma unroll
+          for (int r = 0; r < R2; ++r) {
+            const T val = l[ridx(s, r)];
+            if (part) v[s * R2 + r].y = val; else v[s * R2 + r].x = val;
+          }
+        if (part == 0 || !SN::LAST) __syncthreads();
+      }
+    }
+    fft_stages<T, N, E, DIR, SPLIT, NS * R>(v, lds, t, tw);
+  }
+}
+
+// Undo the output slot permutation in registers (compile-time renaming), so
+// that slot k holds X[t + k * TL] again -- lets a forward transform feed an
+// inverse one with no LDS trip in between (fused ptp column pass).
+template <int N, int E, typename T>
+__device__ __forceinline__ void unpermute_slots(cx<T>* v) {
+  cx<T> tmp[E];
+#pragma unroll
+  for (int k = 0; k < E; ++k) tmp[outslot<N, E>(k)] = v[k];
+#pragma unroll
+  for (int k = 0; k < E; ++k) v[k] = tmp[k];
+}
+
+// --------------------------------------------------------------------------
+// HBM layout of a field.  Blocks of BR rows x BC columns are contiguous, blocks
+// are ordered row-major.  BR = 1 is plain row-major.  With c128 and
+// BR x BC = 2 x 4 a block is exactly one 128-byte line in either direction, so
+// the row pass (2 rows per workgroup) and the column pass (4 columns per
+// workgroup) both move whole lines.
+// ``pitch`` = elements from one block-row to the next: n * BR when dense; the
+// context pads it by a few blocks so that the column pass (stride = pitch) does
+// not march through HBM channels with a power-of-two stride.
+template <int BR, int BC>
+__device__ __host__ __forceinline__ constexpr size_t layout_index(int row, int col, size_t pitch) {
+  return (size_t)(row / BR) * pitch + (size_t)(col / BC) * (BR * BC) + (row % BR) * BC + (col % BC);
+}
+
+}  // namespace paos

@@ -1,0 +1,555 @@
+// paos_hip.hip -- C ABI (include/paos_hip.h) over the gfx950 kernels.
+//
+// Host side of the library: context / buffer management, the per-call parameter
+// arena (pinned ring -> device), launch geometry per grid size, error mapping.
+// No PyTorch, no hipFFT, no CPU fallback: every operator is a kernel launch.
+#include "../../include/paos_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <complex>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "pointwise.h"
+
+using namespace paos;
+
+// ---- build-time layout choice -------------------------------------------------------
+// A field is stored as 128-byte blocks of 4 rows x (2 complex128 | 4 complex64) columns,
+// blocks row-major, so one cache line is a unit of work for the row pass (4 rows per
+// workgroup) and for the column pass (2|4 columns per workgroup) alike (DESIGN.md
+// section 2).  PAD_BLOCKS extra blocks per block row de-tune the power-of-two stride of
+// the column pass (measured: 3.5 -> 4.8 TB/s at 4096^2, profiles/r01_fftbench.txt).
+#ifndef PAOS_BR
+#define PAOS_BR 4
+#endif
+#ifndef PAOS_PAD_BLOCKS
+#define PAOS_PAD_BLOCKS 3
+#endif
+static constexpr int BR = PAOS_BR;
+template <typename T>
+struct Lay {
+  static constexpr int BC = 128 / (BR * (int)sizeof(cx<T>));
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+struct Arena {
+  double* host = nullptr;  // pinned
+  double* dev = nullptr;
+  size_t cap = 0, head = 0;  // in doubles
+};
+
+}  // namespace
+
+struct paos_ctx {
+  int device = 0, n = 0, batch = 0, precision = 0;
+  unsigned pitch = 0, item_stride = 0;
+  hipStream_t stream = nullptr;
+  void* field = nullptr;
+  void* tw = nullptr;
+  void* staging = nullptr;  // n*n*16 bytes, row-major
+  double* partial = nullptr;
+  double* norm2 = nullptr;
+  double* norm2_host = nullptr;  // pinned
+  int nparts = 0;
+  Arena arena;
+  std::string err;
+  // optional per-kernel-class timing with HIP events on the context's stream
+  int prof_kind = -1;
+  std::vector<hipEvent_t> prof_events;  // start/stop pairs
+  size_t prof_used = 0;
+};
+
+namespace {
+
+int fail(paos_ctx* c, int code, const std::string& msg) {
+  if (c) c->err = msg;
+  g_err = msg;
+  return code;
+}
+
+#define HIPCHK(c, call)                                                                     \
+  do {                                                                                      \
+    hipError_t e_ = (call);                                                                 \
+    if (e_ != hipSuccess)                                                                   \
+      return fail((c), PAOS_EHIP,                                                           \
+                  std::string(#call) + ": " + hipGetErrorString(e_) + " (" __FILE__ ":" +   \
+                      std::to_string(__LINE__) + ")");                                      \
+  } while (0)
+
+size_t elem_bytes(const paos_ctx* c) { return c->precision == PAOS_F64 ? 16 : 8; }
+
+// copy `count` doubles into the arena; returns the device pointer through *dev
+int arena_push(paos_ctx* c, const double* src, size_t count, const double** dev) {
+  Arena& a = c->arena;
+  if (count > a.cap) return fail(c, PAOS_EINVAL, "parameter block larger than the arena");
+  if (a.head + count > a.cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // ring wrap: earlier copies must have landed
+    a.head = 0;
+  }
+  std::memcpy(a.host + a.head, src, count * sizeof(double));
+  HIPCHK(c, hipMemcpyAsync(a.dev + a.head, a.host + a.head, count * sizeof(double),
+                           hipMemcpyHostToDevice, c->stream));
+  *dev = a.dev + a.head;
+  a.head += (count + 15) & ~size_t(15);
+  return PAOS_OK;
+}
+
+int pw_blocks(const paos_ctx* c) {
+  const size_t total = (size_t)c->item_stride;
+  size_t b = (total + kPwThreads - 1) / kPwThreads;
+  return (int)(b < 2048 ? b : 2048);
+}
+
+// ---- FFT launch geometry per grid size ----------------------------------------------
+// Row pass: LINES = BR rows per tile; column pass: LINES = BC columns per tile.
+// E elements per thread; TILES tiles per workgroup keep small grids at >= 128 threads.
+template <typename T, int N>
+struct FftCfg {
+  static constexpr int BC = Lay<T>::BC;
+  static constexpr int E = 16;
+  // rows of a block row handled by one row tile: all four, except at N = 4096 where four
+  // lines of 4096 points do not fit the register file of a spill-free workgroup
+  static constexpr int ROW_LINES = (N >= 4096) ? BR / 2 : BR;
+  static constexpr int COL_LINES = BC;
+  static constexpr int ROW_THREADS = ROW_LINES * N / E, COL_THREADS = COL_LINES * N / E;
+  static constexpr int ROW_TILES = (ROW_THREADS >= 128) ? 1 : 128 / ROW_THREADS;
+  static constexpr int COL_TILES = (COL_THREADS >= 128) ? 1 : 128 / COL_THREADS;
+  // split the LDS exchange (re, then im) when a full-complex one would exceed 64 KiB
+  static constexpr bool ROW_SPLIT = (size_t)ROW_LINES * ROW_TILES * line_lds_bytes<T, N, false>() > 72 * 1024;
+  static constexpr bool COL_SPLIT = (size_t)COL_LINES * COL_TILES * line_lds_bytes<T, N, false>() > 72 * 1024;
+  static constexpr int MINW = 1;
+};
+
+template <typename Kern>
+int launch_fft(paos_ctx* c, Kern kern, dim3 grid, dim3 block, size_t lds, const FftPassArgs& a,
+               int kind) {
+  // kernels that need more than the default 64 KiB of dynamic LDS opt in once
+  static thread_local std::unordered_set<const void*> configured;
+  if (lds > 48 * 1024 && !configured.count((const void*)kern)) {
+    HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds));
+    configured.insert((const void*)kern);
+  }
+  const bool timed = (kind == c->prof_kind) && (c->prof_used + 2 <= c->prof_events.size());
+  if (timed) HIPCHK(c, hipEventRecord(c->prof_events[c->prof_used], c->stream));
+  hipLaunchKernelGGL(kern, grid, block, lds, c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  if (timed) {
+    HIPCHK(c, hipEventRecord(c->prof_events[c->prof_used + 1], c->stream));
+    c->prof_used += 2;
+  }
+  return PAOS_OK;
+}
+
+template <typename T, int N, int AXIS, int DIR>
+int fft_pass(paos_ctx* c, const double* dparams, int pre, int post, double scale) {
+  using C = FftCfg<T, N>;
+  constexpr int BC = C::BC;
+  constexpr int LINES = AXIS == 0 ? C::ROW_LINES : C::COL_LINES;
+  constexpr int TILES = AXIS == 0 ? C::ROW_TILES : C::COL_TILES;
+  constexpr bool SPLIT = AXIS == 0 ? C::ROW_SPLIT : C::COL_SPLIT;
+  FftPassArgs a{};
+  a.field = c->field; a.tw = c->tw; a.params = dparams; a.pre_mode = pre; a.post_mode = post;
+  a.scale = scale; a.pitch = c->pitch; a.item_stride = c->item_stride;
+  const dim3 grid(N / LINES / TILES, c->batch), block(TILES * LINES * N / C::E);
+  const size_t lds = (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT>();
+  return launch_fft(c, fft_pass_kernel<T, N, C::E, LINES, TILES, AXIS, BR, BC, SPLIT, DIR, C::MINW>,
+                    grid, block, lds, a, AXIS == 0 ? PAOS_KERNEL_FFT_ROWS : PAOS_KERNEL_FFT_COLS);
+}
+
+template <typename T, int N>
+int fft_ptp_mid(paos_ctx* c, const double* dparams, double scale) {
+  using C = FftCfg<T, N>;
+  constexpr int BC = C::BC;
+  constexpr int LINES = C::COL_LINES, TILES = C::COL_TILES;
+  constexpr bool SPLIT = C::COL_SPLIT;
+  FftPassArgs a{};
+  a.field = c->field; a.tw = c->tw; a.params = dparams; a.scale = scale;
+  a.pitch = c->pitch; a.item_stride = c->item_stride;
+  const dim3 grid(N / LINES / TILES, c->batch), block(TILES * LINES * N / C::E);
+  const size_t lds = (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT>();
+  return launch_fft(c, fft_ptp_mid_kernel<T, N, C::E, LINES, TILES, 1, BR, BC, SPLIT, C::MINW>, grid,
+                    block, lds, a, PAOS_KERNEL_PTP_MID);
+}
+
+// ptp = rows fwd | columns fwd * H * columns inv | rows inv ; 1/N^2 overall (two ortho 2-D FFTs)
+template <typename T, int N>
+int do_ptp(paos_ctx* c, const double* dp) {
+  int rc = fft_pass<T, N, 0, +1>(c, dp, 0, 0, 1.0);
+  if (rc) return rc;
+  rc = fft_ptp_mid<T, N>(c, dp, 1.0 / N);
+  if (rc) return rc;
+  return fft_pass<T, N, 0, -1>(c, dp, 0, 0, 1.0 / N);
+}
+
+// stw = S Qc FFT(S u): rows (S on load), columns (S Qc / N on store)
+template <typename T, int N, int DIR>
+int do_stw(paos_ctx* c, const double* dp) {
+  int rc = fft_pass<T, N, 0, DIR>(c, dp, PW_SIGN, 0, 1.0);
+  if (rc) return rc;
+  return fft_pass<T, N, 1, DIR>(c, dp, 0, PW_SIGN | PW_PHASE, 1.0 / N);
+}
+
+// wts = S FFT(S P u): rows (P S on load), columns (S / N on store)
+template <typename T, int N, int DIR>
+int do_wts(paos_ctx* c, const double* dp) {
+  int rc = fft_pass<T, N, 0, DIR>(c, dp, PW_SIGN | PW_PHASE, 0, 1.0);
+  if (rc) return rc;
+  return fft_pass<T, N, 1, DIR>(c, dp, 0, PW_SIGN, 1.0 / N);
+}
+
+enum FftOp { OP_PTP, OP_STW_F, OP_STW_I, OP_WTS_F, OP_WTS_I };
+
+template <typename T, int N>
+int fft_op_n(paos_ctx* c, FftOp op, const double* dp) {
+  switch (op) {
+    case OP_PTP: return do_ptp<T, N>(c, dp);
+    case OP_STW_F: return do_stw<T, N, +1>(c, dp);
+    case OP_STW_I: return do_stw<T, N, -1>(c, dp);
+    case OP_WTS_F: return do_wts<T, N, +1>(c, dp);
+    case OP_WTS_I: return do_wts<T, N, -1>(c, dp);
+  }
+  return PAOS_EINVAL;
+}
+
+template <typename T>
+int fft_op_t(paos_ctx* c, FftOp op, const double* dp) {
+  switch (c->n) {
+    case 64: return fft_op_n<T, 64>(c, op, dp);
+    case 128: return fft_op_n<T, 128>(c, op, dp);
+    case 256: return fft_op_n<T, 256>(c, op, dp);
+    case 512: return fft_op_n<T, 512>(c, op, dp);
+    case 1024: return fft_op_n<T, 1024>(c, op, dp);
+    case 2048: return fft_op_n<T, 2048>(c, op, dp);
+    case 4096: return fft_op_n<T, 4096>(c, op, dp);
+  }
+  return fail(c, PAOS_EUNSUPPORTED, "grid size must be a power of two in 64..4096");
+}
+
+int fft_op(paos_ctx* c, FftOp op, const double* host_params) {
+  if (!c || !host_params) return fail(c, PAOS_EINVAL, "null argument");
+  const double* dp = nullptr;
+  int rc = arena_push(c, host_params, (size_t)c->batch * FP_STRIDE, &dp);
+  if (rc) return rc;
+  return c->precision == PAOS_F64 ? fft_op_t<double>(c, op, dp) : fft_op_t<float>(c, op, dp);
+}
+
+template <typename T>
+std::vector<std::complex<T>> twiddles(int n) {
+  std::vector<std::complex<T>> tw(n);
+  const long double two_pi = 6.283185307179586476925286766559005768L;
+  for (int m = 0; m < n; ++m) {
+    // exact octant symmetry keeps the table correctly rounded and conj-symmetric
+    const long double a = two_pi * (long double)m / (long double)n;
+    tw[m] = std::complex<T>((T)cosl(a), (T)-sinl(a));
+  }
+  return tw;
+}
+
+#define DISPATCH_T(c, expr_d, expr_f) ((c)->precision == PAOS_F64 ? (expr_d) : (expr_f))
+
+}  // namespace
+
+extern "C" {
+
+const char* paos_last_error(const paos_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+const char* paos_build_info(void) {
+  static const std::string info = std::string("libpaoship gfx950 layout=") + std::to_string(BR) + "x(" +
+                                  std::to_string(Lay<double>::BC) + "|" + std::to_string(Lay<float>::BC) +
+                                  ") pad_blocks=" + std::to_string(PAOS_PAD_BLOCKS);
+  return info.c_str();
+}
+
+void* paos_stream(paos_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int paos_ctx_create(int device, int n, int batch, int precision, paos_ctx** out) {
+  if (!out) return fail(nullptr, PAOS_EINVAL, "out is null");
+  *out = nullptr;
+  if (n < 64 || n > 4096 || (n & (n - 1))) return fail(nullptr, PAOS_EUNSUPPORTED, "grid size must be a power of two in 64..4096");
+  if (batch < 1) return fail(nullptr, PAOS_EINVAL, "batch must be >= 1");
+  if (precision != PAOS_F64 && precision != PAOS_F32) return fail(nullptr, PAOS_EINVAL, "precision must be PAOS_F64 or PAOS_F32");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(nullptr, PAOS_EHIP, "no HIP device available: libpaoship has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(nullptr, PAOS_EINVAL, "device index out of range");
+  paos_ctx* c = new paos_ctx();
+  c->device = device; c->n = n; c->batch = batch; c->precision = precision;
+  const int bc = precision == PAOS_F64 ? Lay<double>::BC : Lay<float>::BC;
+  c->pitch = (unsigned)n * BR + (unsigned)PAOS_PAD_BLOCKS * BR * bc;
+  c->item_stride = c->pitch * (unsigned)(n / BR);
+  const size_t eb = elem_bytes(c);
+  auto bail = [&](hipError_t e, const char* what) {
+    std::string msg = std::string(what) + ": " + hipGetErrorString(e);
+    paos_ctx_destroy(c);
+    return fail(nullptr, PAOS_EHIP, msg);
+  };
+  hipError_t e;
+  if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
+  if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+  if ((e = hipMalloc(&c->field, (size_t)c->item_stride * batch * eb)) != hipSuccess) return bail(e, "hipMalloc(field)");
+  if ((e = hipMemsetAsync(c->field, 0, (size_t)c->item_stride * batch * eb, c->stream)) != hipSuccess) return bail(e, "hipMemset(field)");
+  if ((e = hipMalloc(&c->tw, (size_t)n * eb)) != hipSuccess) return bail(e, "hipMalloc(tw)");
+  if ((e = hipMalloc(&c->staging, (size_t)n * n * 16)) != hipSuccess) return bail(e, "hipMalloc(staging)");
+  c->nparts = 1024;
+  if ((e = hipMalloc(&c->partial, (size_t)batch * c->nparts * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(partial)");
+  if ((e = hipMalloc(&c->norm2, (size_t)batch * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(norm2)");
+  if ((e = hipHostMalloc(&c->norm2_host, (size_t)batch * sizeof(double))) != hipSuccess) return bail(e, "hipHostMalloc(norm2)");
+  c->arena.cap = (size_t)1 << 20;  // 8 MiB of doubles
+  if (c->arena.cap < (size_t)batch * 4096) c->arena.cap = (size_t)batch * 4096;
+  if ((e = hipHostMalloc(&c->arena.host, c->arena.cap * sizeof(double))) != hipSuccess) return bail(e, "hipHostMalloc(arena)");
+  if ((e = hipMalloc(&c->arena.dev, c->arena.cap * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(arena)");
+  if (precision == PAOS_F64) {
+    auto tw = twiddles<double>(n);
+    e = hipMemcpy(c->tw, tw.data(), (size_t)n * eb, hipMemcpyHostToDevice);
+  } else {
+    auto tw = twiddles<float>(n);
+    e = hipMemcpy(c->tw, tw.data(), (size_t)n * eb, hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) return bail(e, "hipMemcpy(tw)");
+  *out = c;
+  return PAOS_OK;
+}
+
+int paos_profile_begin(paos_ctx* c, int kernel_kind, int max_launches) {
+  if (!c || max_launches < 0) return fail(c, PAOS_EINVAL, "bad profile request");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  while (c->prof_events.size() < (size_t)2 * max_launches) {
+    hipEvent_t e;
+    HIPCHK(c, hipEventCreate(&e));
+    c->prof_events.push_back(e);
+  }
+  c->prof_kind = kernel_kind;
+  c->prof_used = 0;
+  return PAOS_OK;
+}
+
+int paos_profile_end(paos_ctx* c, int* launches, double* total_ms) {
+  if (!c || !launches || !total_ms) return fail(c, PAOS_EINVAL, "null argument");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double sum = 0.0;
+  for (size_t i = 0; i + 1 < c->prof_used; i += 2) {
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->prof_events[i], c->prof_events[i + 1]));
+    sum += ms;
+  }
+  *launches = (int)(c->prof_used / 2);
+  *total_ms = sum;
+  c->prof_kind = -1;
+  c->prof_used = 0;
+  return PAOS_OK;
+}
+
+int paos_ctx_destroy(paos_ctx* c) {
+  if (!c) return PAOS_OK;
+  (void)hipSetDevice(c->device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
+  if (c->field) (void)hipFree(c->field);
+  if (c->tw) (void)hipFree(c->tw);
+  if (c->staging) (void)hipFree(c->staging);
+  if (c->partial) (void)hipFree(c->partial);
+  if (c->norm2) (void)hipFree(c->norm2);
+  if (c->norm2_host) (void)hipHostFree(c->norm2_host);
+  if (c->arena.host) (void)hipHostFree(c->arena.host);
+  if (c->arena.dev) (void)hipFree(c->arena.dev);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return PAOS_OK;
+}
+
+int paos_sync(paos_ctx* c) {
+  if (!c) return fail(c, PAOS_EINVAL, "null context");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PAOS_OK;
+}
+
+int paos_fill(paos_ctx* c, double re, double im) {
+  if (!c) return fail(c, PAOS_EINVAL, "null context");
+  const size_t total = (size_t)c->item_stride * c->batch;
+  // padding blocks are filled too; they are never read by any operator
+  if (c->precision == PAOS_F64)
+    hipLaunchKernelGGL(fill_kernel<double>, dim3(2048), dim3(kPwThreads), 0, c->stream,
+                       (cx<double>*)c->field, total, re, im);
+  else
+    hipLaunchKernelGGL(fill_kernel<float>, dim3(2048), dim3(kPwThreads), 0, c->stream,
+                       (cx<float>*)c->field, total, (float)re, (float)im);
+  HIPCHK(c, hipGetLastError());
+  return PAOS_OK;
+}
+
+int paos_import(paos_ctx* c, int item, const void* host) {
+  if (!c || !host || item < 0 || item >= c->batch) return fail(c, PAOS_EINVAL, "bad item or null buffer");
+  const size_t bytes = (size_t)c->n * c->n * 16;
+  HIPCHK(c, hipMemcpyAsync(c->staging, host, bytes, hipMemcpyHostToDevice, c->stream));
+  if (c->precision == PAOS_F64)
+    hipLaunchKernelGGL((import_kernel<double, BR, Lay<double>::BC>), dim3(pw_blocks(c)), dim3(kPwThreads), 0, c->stream,
+                       (cx<double>*)c->field + (size_t)item * c->item_stride, (const cx<double>*)c->staging,
+                       c->n, c->pitch);
+  else
+    hipLaunchKernelGGL((import_kernel<float, BR, Lay<float>::BC>), dim3(pw_blocks(c)), dim3(kPwThreads), 0, c->stream,
+                       (cx<float>*)c->field + (size_t)item * c->item_stride, (const cx<double>*)c->staging,
+                       c->n, c->pitch);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // the host buffer is only borrowed
+  return PAOS_OK;
+}
+
+int paos_export(paos_ctx* c, int item, int what, void* host_out) {
+  if (!c || !host_out || item < 0 || item >= c->batch || what < 0 || what > 3)
+    return fail(c, PAOS_EINVAL, "bad item/what or null buffer");
+  if (c->precision == PAOS_F64)
+    hipLaunchKernelGGL((export_kernel<double, BR, Lay<double>::BC>), dim3(pw_blocks(c)), dim3(kPwThreads), 0, c->stream,
+                       (const cx<double>*)c->field + (size_t)item * c->item_stride, (double*)c->staging,
+                       c->n, c->pitch, what);
+  else
+    hipLaunchKernelGGL((export_kernel<float, BR, Lay<float>::BC>), dim3(pw_blocks(c)), dim3(kPwThreads), 0, c->stream,
+                       (const cx<float>*)c->field + (size_t)item * c->item_stride, (double*)c->staging,
+                       c->n, c->pitch, what);
+  HIPCHK(c, hipGetLastError());
+  const size_t bytes = (size_t)c->n * c->n * (what == PAOS_WHAT_FIELD ? 16 : 8);
+  HIPCHK(c, hipMemcpyAsync(host_out, c->staging, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PAOS_OK;
+}
+
+static int aperture_launch(paos_ctx* c, int shape, const double* dp, int nitems, double* mask_out) {
+  const dim3 grid(pw_blocks(c), nitems), block(kPwThreads);
+#define AP_LAUNCH(T, S)                                                                          \
+  hipLaunchKernelGGL((aperture_kernel<T, BR, Lay<T>::BC, S>), grid, block, 0, c->stream,                 \
+                     mask_out ? (cx<T>*)nullptr : (cx<T>*)c->field, dp, c->n, c->pitch,           \
+                     c->item_stride, mask_out)
+  if (c->precision == PAOS_F64) {
+    if (shape == PAOS_SHAPE_ELLIPSE) AP_LAUNCH(double, 0); else AP_LAUNCH(double, 1);
+  } else {
+    if (shape == PAOS_SHAPE_ELLIPSE) AP_LAUNCH(float, 0); else AP_LAUNCH(float, 1);
+  }
+#undef AP_LAUNCH
+  HIPCHK(c, hipGetLastError());
+  return PAOS_OK;
+}
+
+int paos_aperture(paos_ctx* c, int shape, const double* params) {
+  if (!c || !params) return fail(c, PAOS_EINVAL, "null argument");
+  if (shape != PAOS_SHAPE_ELLIPSE && shape != PAOS_SHAPE_RECT) return fail(c, PAOS_EINVAL, "unknown aperture shape");
+  const double* dp = nullptr;
+  int rc = arena_push(c, params, (size_t)c->batch * AP_STRIDE, &dp);
+  if (rc) return rc;
+  return aperture_launch(c, shape, dp, c->batch, nullptr);
+}
+
+int paos_aperture_render(paos_ctx* c, int shape, const double* params1, double* host_mask) {
+  if (!c || !params1 || !host_mask) return fail(c, PAOS_EINVAL, "null argument");
+  if (shape != PAOS_SHAPE_ELLIPSE && shape != PAOS_SHAPE_RECT) return fail(c, PAOS_EINVAL, "unknown aperture shape");
+  const double* dp = nullptr;
+  int rc = arena_push(c, params1, AP_STRIDE, &dp);
+  if (rc) return rc;
+  rc = aperture_launch(c, shape, dp, 1, (double*)c->staging);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(host_mask, c->staging, (size_t)c->n * c->n * 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return PAOS_OK;
+}
+
+static int norm2_launch(paos_ctx* c, const double* den) {
+  const dim3 grid(c->nparts, c->batch), block(kPwThreads);
+  if (c->precision == PAOS_F64)
+    hipLaunchKernelGGL((norm2_partial_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream,
+                       (const cx<double>*)c->field, c->partial, c->n, c->pitch, c->item_stride, den, 1);
+  else
+    hipLaunchKernelGGL((norm2_partial_kernel<float, BR, Lay<float>::BC>), grid, block, 0, c->stream,
+                       (const cx<float>*)c->field, c->partial, c->n, c->pitch, c->item_stride, den, 1);
+  HIPCHK(c, hipGetLastError());
+  hipLaunchKernelGGL(norm2_final_kernel, dim3(c->batch), block, 0, c->stream, c->partial, c->norm2,
+                     c->nparts, den, 1);
+  HIPCHK(c, hipGetLastError());
+  return PAOS_OK;
+}
+
+int paos_make_stop(paos_ctx* c, const double* enable) {
+  if (!c) return fail(c, PAOS_EINVAL, "null context");
+  const double* den = nullptr;
+  if (enable) {
+    int rc = arena_push(c, enable, (size_t)c->batch, &den);
+    if (rc) return rc;
+  }
+  int rc = norm2_launch(c, den);
+  if (rc) return rc;
+  const dim3 grid(pw_blocks(c), c->batch), block(kPwThreads);
+  if (c->precision == PAOS_F64)
+    hipLaunchKernelGGL(stop_scale_kernel<double>, grid, block, 0, c->stream, (cx<double>*)c->field,
+                       c->norm2, c->item_stride, den, 1);
+  else
+    hipLaunchKernelGGL(stop_scale_kernel<float>, grid, block, 0, c->stream, (cx<float>*)c->field,
+                       c->norm2, c->item_stride, den, 1);
+  HIPCHK(c, hipGetLastError());
+  return PAOS_OK;
+}
+
+int paos_norm2(paos_ctx* c, double* host_out) {
+  if (!c || !host_out) return fail(c, PAOS_EINVAL, "null argument");
+  int rc = norm2_launch(c, nullptr);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->norm2_host, c->norm2, (size_t)c->batch * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::memcpy(host_out, c->norm2_host, (size_t)c->batch * sizeof(double));
+  return PAOS_OK;
+}
+
+int paos_phase(paos_ctx* c, const double* params, int mul2pi) {
+  if (!c || !params) return fail(c, PAOS_EINVAL, "null argument");
+  const double* dp = nullptr;
+  int rc = arena_push(c, params, (size_t)c->batch * FP_STRIDE, &dp);
+  if (rc) return rc;
+  const int mode = PW_PHASE | (mul2pi ? PW_MUL2PI : 0);
+  const dim3 grid(pw_blocks(c), c->batch), block(kPwThreads);
+  if (c->precision == PAOS_F64)
+    hipLaunchKernelGGL((phase_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream, (cx<double>*)c->field,
+                       dp, c->n, c->pitch, c->item_stride, mode);
+  else
+    hipLaunchKernelGGL((phase_kernel<float, BR, Lay<float>::BC>), grid, block, 0, c->stream, (cx<float>*)c->field, dp,
+                       c->n, c->pitch, c->item_stride, mode);
+  HIPCHK(c, hipGetLastError());
+  return PAOS_OK;
+}
+
+int paos_ptp(paos_ctx* c, const double* params) { return fft_op(c, OP_PTP, params); }
+int paos_stw(paos_ctx* c, const double* params, int inverse) { return fft_op(c, inverse ? OP_STW_I : OP_STW_F, params); }
+int paos_wts(paos_ctx* c, const double* params, int inverse) { return fft_op(c, inverse ? OP_WTS_I : OP_WTS_F, params); }
+
+int paos_zernike(paos_ctx* c, int nmax, int kdim, const double* table, const double* params,
+                 int param_stride, double* host_wfe) {
+  if (!c || !table || !params) return fail(c, PAOS_EINVAL, "null argument");
+  if (nmax < 0 || kdim < nmax / 2 + 1 || param_stride < ZP_HEAD + 2 * (nmax + 1) * kdim)
+    return fail(c, PAOS_EINVAL, "inconsistent Zernike table dimensions");
+  const double *dt = nullptr, *dp = nullptr;
+  int rc = arena_push(c, table, (size_t)(nmax + 1) * kdim * 3, &dt);
+  if (rc) return rc;
+  rc = arena_push(c, params, (size_t)c->batch * param_stride, &dp);
+  if (rc) return rc;
+  const dim3 grid(pw_blocks(c), c->batch), block(kPwThreads);
+  double* wfe = host_wfe ? (double*)c->staging : nullptr;
+  if (c->precision == PAOS_F64)
+    hipLaunchKernelGGL((zernike_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream, (cx<double>*)c->field,
+                       dt, dp, param_stride, c->n, c->pitch, c->item_stride, nmax, kdim, wfe);
+  else
+    hipLaunchKernelGGL((zernike_kernel<float, BR, Lay<float>::BC>), grid, block, 0, c->stream, (cx<float>*)c->field, dt,
+                       dp, param_stride, c->n, c->pitch, c->item_stride, nmax, kdim, wfe);
+  HIPCHK(c, hipGetLastError());
+  if (host_wfe) {
+    HIPCHK(c, hipMemcpyAsync(host_wfe, c->staging, (size_t)c->n * c->n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return PAOS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,385 @@
+// pointwise.h -- element-wise and reduction kernels of the wavefront operators.
+//
+// Every kernel walks the field in MEMORY order (16 B per lane, unit stride) and
+// recovers (row, col) from the blocked layout, so the access pattern is a plain
+// stream regardless of the layout chosen for the FFT passes.
+//
+//   aperture  -> paos/classes/wfo.py:203-278 (mask values: photutils semantics,
+//                restated in oracle/aperture_np.py -- same operations, same order)
+//   make_stop -> wfo.py:195-201
+//   lens      -> wfo.py:359-366 (the scalar pilot-beam part stays on the host)
+//   zernikes  -> wfo.py:620-652 + paos/classes/zernike.py:85-109,245-247
+//   amplitude / phase / intensity -> wfo.py:166-172, paos/core/plot.py:125-130
+#pragma once
+#include "fft_kernels.h"
+
+namespace paos {
+
+// memory index (inside one item) -> (row, col); false for pitch-padding slots
+template <int BR, int BC>
+__device__ __forceinline__ bool layout_unmap(size_t m, int n, unsigned pitch, int& row, int& col) {
+  const unsigned brow = (unsigned)(m / pitch), rem = (unsigned)(m % pitch);
+  if (rem >= (unsigned)n * BR) return false;
+  const unsigned in = rem % (BR * BC);
+  row = (int)(brow * BR + in / BC);
+  col = (int)((rem / (BR * BC)) * BC + in % BC);
+  return true;
+}
+
+constexpr int kPwThreads = 256;
+
+template <typename T>
+__global__ void fill_kernel(cx<T>* f, size_t total, T re, T im) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < total; i += (size_t)gridDim.x * blockDim.x) f[i] = {re, im};
+}
+
+// ---- host <-> device layout conversion (staging buffer is row-major complex128)
+template <typename T, int BR, int BC>
+__global__ void import_kernel(cx<T>* f, const cx<double>* staged, int n, unsigned pitch) {
+  const size_t total = (size_t)pitch * (n / BR);
+  size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
+    int r, c;
+    if (!layout_unmap<BR, BC>(m, n, pitch, r, c)) continue;
+    const cx<double> v = staged[(size_t)r * n + c];
+    f[m] = {(T)v.x, (T)v.y};
+  }
+}
+
+// what: 0 complex field, 1 amplitude |u| (hypot), 2 phase atan2(im, re), 3 intensity |u|^2
+template <typename T, int BR, int BC>
+__global__ void export_kernel(const cx<T>* f, double* out, int n, unsigned pitch, int what) {
+  const size_t total = (size_t)pitch * (n / BR);
+  size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
+    int r, c;
+    if (!layout_unmap<BR, BC>(m, n, pitch, r, c)) continue;
+    const size_t o = (size_t)r * n + c;
+    const double x = (double)f[m].x, y = (double)f[m].y;
+    if (what == 0) {
+      out[2 * o] = x;
+      out[2 * o + 1] = y;
+    } else if (what == 1) {
+      out[o] = hypot(x, y);
+    } else if (what == 2) {
+      out[o] = atan2(y, x);
+    } else {
+      out[o] = __dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y));
+    }
+  }
+}
+
+// ---- lens / generic quadratic phase (pointwise() of fft_kernels.h) ------------
+template <typename T, int BR, int BC>
+__global__ void phase_kernel(cx<T>* field, const double* params, int n, unsigned pitch,
+                             unsigned item_stride, int mode) {
+  const int item = blockIdx.y;
+  const double* p = params + (size_t)item * FP_STRIDE;
+  if (p[FP_ENABLE] == 0.0) return;
+  cx<T>* f = field + (size_t)item * item_stride;
+  const size_t total = item_stride;
+  size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
+    int r, c;
+    if (!layout_unmap<BR, BC>(m, n, pitch, r, c)) continue;
+    f[m] = pointwise(f[m], mode, r, c, n, p);
+  }
+}
+
+// ---- make_stop: sum |u|^2 (two deterministic stages), then scale ---------------
+__device__ __forceinline__ double block_sum(double v, double* sh) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) sh[wave] = v;
+  __syncthreads();
+  double s = 0.0;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s += sh[w];
+  return s;  // valid in thread 0
+}
+
+template <typename T, int BR, int BC>
+__global__ void norm2_partial_kernel(const cx<T>* field, double* partial, int n, unsigned pitch,
+                                     unsigned item_stride, const double* enable, int enable_stride) {
+  const int item = blockIdx.y;
+  if (enable && enable[(size_t)item * enable_stride] == 0.0) return;
+  __shared__ double sh[kPwThreads / 64];
+  const cx<T>* f = field + (size_t)item * item_stride;
+  const size_t total = item_stride;
+  double acc = 0.0;
+  size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
+    if ((unsigned)(m % pitch) >= (unsigned)n * BR) continue;  // pitch padding
+    const double x = (double)f[m].x, y = (double)f[m].y;
+    acc += __dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y));
+  }
+  const double s = block_sum(acc, sh);
+  if (threadIdx.x == 0) partial[(size_t)item * gridDim.x + blockIdx.x] = s;
+}
+
+__global__ void norm2_final_kernel(const double* partial, double* norm2, int nparts,
+                                   const double* enable, int enable_stride) {
+  const int item = blockIdx.x;
+  if (enable && enable[(size_t)item * enable_stride] == 0.0) return;
+  __shared__ double sh[kPwThreads / 64];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) acc += partial[(size_t)item * nparts + i];
+  const double s = block_sum(acc, sh);
+  if (threadIdx.x == 0) norm2[item] = s;
+}
+
+// u *= 1/sqrt(norm2[item])  (NumPy's complex /= real multiplies by the reciprocal)
+template <typename T>
+__global__ void stop_scale_kernel(cx<T>* field, const double* norm2, unsigned item_stride,
+                                  const double* enable, int enable_stride) {
+  const int item = blockIdx.y;
+  if (enable && enable[(size_t)item * enable_stride] == 0.0) return;
+  const double s = 1.0 / sqrt(norm2[item]);
+  cx<T>* f = field + (size_t)item * item_stride;
+  const size_t total = item_stride;
+  size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; m < total; m += (size_t)gridDim.x * blockDim.x)
+    f[m] = {(T)__dmul_rn((double)f[m].x, s), (T)__dmul_rn((double)f[m].y, s)};
+}
+
+// ---- apertures ------------------------------------------------------------------
+// per-item block: [enable, xc, yc, a|w, b|h, theta, obscuration, subpixels]
+enum : int { AP_ENABLE = 0, AP_XC, AP_YC, AP_A, AP_B, AP_THETA, AP_OBSC, AP_SUBPIX, AP_STRIDE };
+
+struct EdgeAcc {
+  double area;
+  bool touched;
+};
+
+// signed area of (triangle O, p, p+d) INTERSECT unit disk -- oracle/aperture_np.py:_edge_term
+__device__ __forceinline__ void edge_term(double px, double py, double dx, double dy, EdgeAcc& acc) {
+  const double cr = __dsub_rn(__dmul_rn(px, dy), __dmul_rn(py, dx));
+  const double pp = __dadd_rn(__dmul_rn(px, px), __dmul_rn(py, py));
+  const double pd = __dadd_rn(__dmul_rn(px, dx), __dmul_rn(py, dy));
+  const double dd = __dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy));
+  const double cc = __dsub_rn(pp, 1.0);
+  const double disc = __dsub_rn(__dmul_rn(pd, pd), __dmul_rn(dd, cc));
+  const bool has = disc > 0.0;
+  const double sq = sqrt(has ? disc : 0.0);
+  const double qq = -(__dadd_rn(pd, (pd >= 0.0) ? sq : -sq));
+  const double ta = qq / dd;
+  const double tb = (qq != 0.0) ? cc / qq : ta;
+  const double t1 = fmin(ta, tb), t2 = fmax(ta, tb);
+  const double t1c = fmin(fmax(t1, 0.0), 1.0), t2c = fmin(fmax(t2, 0.0), 1.0);
+  const bool part = has && (t1c < t2c);
+  double val;
+  if (part) {
+    const double a_in = atan2(__dmul_rn(t1c, cr), __dadd_rn(pp, __dmul_rn(t1c, pd)));
+    const double a_out =
+        atan2(__dmul_rn(__dsub_rn(1.0, t2c), cr),
+              __dadd_rn(__dadd_rn(pp, __dmul_rn(__dadd_rn(1.0, t2c), pd)), __dmul_rn(t2c, dd)));
+    val = __dmul_rn(0.5, __dadd_rn(__dadd_rn(a_in, __dmul_rn(__dsub_rn(t2c, t1c), cr)), a_out));
+  } else {
+    val = __dmul_rn(0.5, atan2(cr, __dadd_rn(pp, pd)));
+  }
+  acc.area = val;
+  acc.touched = part;
+}
+
+__device__ __forceinline__ double ellipse_pixel(int kx, int ky, double xc, double yc, double a,
+                                                double b, double ct, double st, double full_disk) {
+  const double x0 = __dsub_rn((double)kx - 0.5, xc), x1 = __dsub_rn((double)kx + 0.5, xc);
+  const double y0 = __dsub_rn((double)ky - 0.5, yc), y1 = __dsub_rn((double)ky + 0.5, yc);
+  auto ux = [&](double x, double y) { return __dadd_rn(__dmul_rn(x, ct), __dmul_rn(y, st)) / a; };
+  auto uy = [&](double x, double y) { return __dsub_rn(__dmul_rn(y, ct), __dmul_rn(x, st)) / b; };
+  const double c0x = ux(x0, y0), c0y = uy(x0, y0);
+  const double c1x = ux(x1, y0), c1y = uy(x1, y0);
+  const double c2x = ux(x1, y1), c2y = uy(x1, y1);
+  const double c3x = ux(x0, y1), c3y = uy(x0, y1);
+  auto inside = [](double x, double y) { return __dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y)) <= 1.0; };
+  const bool i0 = inside(c0x, c0y), i1 = inside(c1x, c1y), i2 = inside(c2x, c2y), i3 = inside(c3x, c3y);
+  if (i0 && i1 && i2 && i3) return 1.0;
+  EdgeAcc e0, e1, e2, e3;
+  edge_term(c0x, c0y, __dsub_rn(c1x, c0x), __dsub_rn(c1y, c0y), e0);
+  edge_term(c1x, c1y, __dsub_rn(c2x, c1x), __dsub_rn(c2y, c1y), e1);
+  edge_term(c2x, c2y, __dsub_rn(c3x, c2x), __dsub_rn(c3y, c2y), e2);
+  edge_term(c3x, c3y, __dsub_rn(c0x, c3x), __dsub_rn(c0y, c3y), e3);
+  const bool touched = i0 || i1 || i2 || i3 || e0.touched || e1.touched || e2.touched || e3.touched;
+  if (!touched) {
+    const bool holds = (x0 <= 0.0) && (x1 >= 0.0) && (y0 <= 0.0) && (y1 >= 0.0);
+    return holds ? full_disk : 0.0;
+  }
+  double area = __dmul_rn(__dadd_rn(__dadd_rn(e0.area, e1.area), __dadd_rn(e2.area, e3.area)),
+                          __dmul_rn(a, b));
+  return fmin(fmax(area, 0.0), 1.0);
+}
+
+// #sub-samples (1-D) of pixel k with |x| < half; positions by repeated addition
+__device__ __forceinline__ int subpixel_count_1d(int k, double centre, double half, int subpixels) {
+  const double step = 1.0 / (double)subpixels;
+  double x = __dsub_rn(__dsub_rn((double)k - 0.5, centre), __dmul_rn(0.5, step));
+  int cnt = 0;
+  for (int s = 0; s < subpixels; ++s) {
+    x = __dadd_rn(x, step);
+    cnt += (fabs(x) < half) ? 1 : 0;
+  }
+  return cnt;
+}
+
+__device__ __forceinline__ double rect_pixel(int kx, int ky, double xc, double yc, double hw,
+                                             double hh, double ct, double st, int subpixels) {
+  const double step = 1.0 / (double)subpixels;
+  int cnt = 0;
+  double x = __dsub_rn(__dsub_rn((double)kx - 0.5, xc), __dmul_rn(0.5, step));
+  for (int i = 0; i < subpixels; ++i) {
+    x = __dadd_rn(x, step);
+    double y = __dsub_rn(__dsub_rn((double)ky - 0.5, yc), __dmul_rn(0.5, step));
+    for (int j = 0; j < subpixels; ++j) {
+      y = __dadd_rn(y, step);
+      const double xt = __dadd_rn(__dmul_rn(y, st), __dmul_rn(x, ct));
+      const double yt = __dsub_rn(__dmul_rn(y, ct), __dmul_rn(x, st));
+      cnt += (fabs(xt) < hw && fabs(yt) < hh) ? 1 : 0;
+    }
+  }
+  return (double)cnt / (double)(subpixels * subpixels);
+}
+
+struct ApertureBox {
+  int ixmin, ixmax, iymin, iymax;  // photutils bounding box, max exclusive
+};
+
+__device__ __forceinline__ ApertureBox make_box(double xc, double yc, double xe, double ye) {
+  ApertureBox b;
+  b.ixmin = (int)floor(__dadd_rn(__dsub_rn(xc, xe), 0.5));
+  b.ixmax = (int)ceil(__dadd_rn(__dadd_rn(xc, xe), 0.5));
+  b.iymin = (int)floor(__dadd_rn(__dsub_rn(yc, ye), 0.5));
+  b.iymax = (int)ceil(__dadd_rn(__dadd_rn(yc, ye), 0.5));
+  return b;
+}
+
+// SHAPE 0: exact ellipse, 1: sub-pixel rectangle.  If ``mask_out`` is non-null the
+// kernel renders the mask (row-major doubles, item 0 only) instead of applying it.
+template <typename T, int BR, int BC, int SHAPE>
+__global__ void aperture_kernel(cx<T>* field, const double* params, int n, unsigned pitch,
+                                unsigned item_stride, double* mask_out) {
+  const int item = blockIdx.y;
+  const double* p = params + (size_t)item * AP_STRIDE;
+  if (p[AP_ENABLE] == 0.0) return;
+  const double xc = p[AP_XC], yc = p[AP_YC], a = p[AP_A], b = p[AP_B], theta = p[AP_THETA];
+  const bool obsc = p[AP_OBSC] != 0.0;
+  const int subpix = (int)p[AP_SUBPIX];
+  const double ct = cos(theta), st = sin(theta);
+  double xe, ye, hw = 0.0, hh = 0.0, full_disk = 0.0;
+  if (SHAPE == 0) {
+    xe = sqrt(__dadd_rn(__dmul_rn(__dmul_rn(a, ct), __dmul_rn(a, ct)),
+                        __dmul_rn(__dmul_rn(b, st), __dmul_rn(b, st))));
+    ye = sqrt(__dadd_rn(__dmul_rn(__dmul_rn(a, st), __dmul_rn(a, st)),
+                        __dmul_rn(__dmul_rn(b, ct), __dmul_rn(b, ct))));
+    full_disk = fmin(__dmul_rn(__dmul_rn(3.141592653589793, a), b), 1.0);
+  } else {
+    hw = a / 2.0;
+    hh = b / 2.0;
+    xe = fmax(fabs(__dsub_rn(__dmul_rn(hw, ct), __dmul_rn(hh, st))),
+              fabs(__dadd_rn(__dmul_rn(hw, ct), __dmul_rn(hh, st))));
+    ye = fmax(fabs(__dadd_rn(__dmul_rn(hw, st), __dmul_rn(hh, ct))),
+              fabs(__dsub_rn(__dmul_rn(hw, st), __dmul_rn(hh, ct))));
+  }
+  const ApertureBox box = make_box(xc, yc, xe, ye);
+  cx<T>* f = field ? field + (size_t)item * item_stride : nullptr;
+  const size_t total = item_stride;
+  size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
+    int r, c;
+    if (!layout_unmap<BR, BC>(m, n, pitch, r, c)) continue;
+    double mask = 0.0;
+    if (c >= box.ixmin && c < box.ixmax && r >= box.iymin && r < box.iymax) {
+      if (SHAPE == 0) {
+        mask = ellipse_pixel(c, r, xc, yc, a, b, ct, st, full_disk);
+      } else if (theta == 0.0) {
+        const int cxn = subpixel_count_1d(c, xc, hw, subpix);
+        const int cyn = subpixel_count_1d(r, yc, hh, subpix);
+        mask = (double)(cxn * cyn) / (double)(subpix * subpix);
+      } else {
+        mask = rect_pixel(c, r, xc, yc, hw, hh, ct, st, subpix);
+      }
+    }
+    if (mask_out) {
+      if (item == 0) mask_out[(size_t)r * n + c] = mask;
+      continue;
+    }
+    const double w = obsc ? __dsub_rn(1.0, mask) : mask;
+    if (w != 1.0) {
+      cx<T> v = f[m];
+      v.x = (T)__dmul_rn((double)v.x, w);
+      v.y = (T)__dmul_rn((double)v.y, w);
+      f[m] = v;
+    }
+  }
+}
+
+// ---- Zernike phase ----------------------------------------------------------------
+// shared table (doubles): [0]=nmax, then for am in 0..nmax, k in 0..KMAXP-1 the Jacobi
+// recurrence constants A, B, C of P_k^{(am,0)}:  P_k = (A x + B) P_{k-1} - C P_{k-2}.
+// per-item block: [enable, dx, dy, radius, origin_is_y, cos_off, sin_off, inv_wl,
+//                  then coefC[am][k], coefS[am][k]] with the (-1)^k norm Z product folded in.
+enum : int { ZP_ENABLE = 0, ZP_DX, ZP_DY, ZP_RADIUS, ZP_ORIGIN_Y, ZP_COS_OFF, ZP_SIN_OFF, ZP_INV_WL, ZP_HEAD };
+
+template <typename T, int BR, int BC>
+__global__ void zernike_kernel(cx<T>* field, const double* table, const double* params,
+                               int param_stride, int n, unsigned pitch, unsigned item_stride,
+                               int nmax, int kdim, double* wfe_out) {
+  const int item = blockIdx.y;
+  const double* p = params + (size_t)item * param_stride;
+  if (p[ZP_ENABLE] == 0.0) return;
+  const double dx = p[ZP_DX], dy = p[ZP_DY], radius = p[ZP_RADIUS], inv_wl = p[ZP_INV_WL];
+  const bool origin_y = p[ZP_ORIGIN_Y] != 0.0;
+  const double co = p[ZP_COS_OFF], so = p[ZP_SIN_OFF];
+  const double* coef_c = p + ZP_HEAD;
+  const double* coef_s = coef_c + (size_t)(nmax + 1) * kdim;
+  cx<T>* f = field + (size_t)item * item_stride;
+  const size_t total = item_stride;
+  size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
+    int r, c;
+    if (!layout_unmap<BR, BC>(m, n, pitch, r, c)) continue;
+    const double x = (double)(c - n / 2) * dx, y = (double)(r - n / 2) * dy;
+    const double rr = sqrt(__dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y)));
+    const double rho = rr / radius;
+    const bool masked = rho > 1.0;
+    double wfe = 0.0;
+    if (!masked) {
+      double c1 = 1.0, s1 = 0.0;
+      if (rr > 0.0) {
+        c1 = (origin_y ? y : x) / rr;
+        s1 = (origin_y ? x : y) / rr;
+      }
+      const double cr = c1 * co - s1 * so, sr = s1 * co + c1 * so;
+      const double xj = 1.0 - 2.0 * rho * rho;
+      double rho_pow = 1.0, cm = 1.0, sm = 0.0;
+      for (int am = 0; am <= nmax; ++am) {
+        const int kmax = (nmax - am) / 2;
+        double pkm1 = 0.0, pk = 1.0;
+        for (int k = 0; k <= kmax; ++k) {
+          if (k > 0) {
+            const double* abc = table + ((size_t)am * kdim + k) * 3;
+            const double pn = (abc[0] * xj + abc[1]) * pk - abc[2] * pkm1;
+            pkm1 = pk;
+            pk = pn;
+          }
+          const size_t ci = (size_t)am * kdim + k;
+          wfe += (rho_pow * pk) * (coef_c[ci] * cm + coef_s[ci] * sm);
+        }
+        rho_pow *= rho;
+        const double cn = cm * cr - sm * sr;
+        sm = sm * cr + cm * sr;
+        cm = cn;
+      }
+      const double arg = __dmul_rn(__dmul_rn(6.283185307179586, wfe), inv_wl);
+      double sn, cs;
+      sincos_fast(arg, &sn, &cs);
+      const cx<double> v = {(double)f[m].x, (double)f[m].y};
+      f[m] = {(T)__dsub_rn(__dmul_rn(v.x, cs), __dmul_rn(v.y, sn)),
+              (T)__dadd_rn(__dmul_rn(v.x, sn), __dmul_rn(v.y, cs))};
+    }
+    if (wfe_out && item == 0) wfe_out[(size_t)r * n + c] = masked ? __longlong_as_double(0x7ff8000000000000LL) : wfe;
+  }
+}
+
+}  // namespace paos

@@ -1,0 +1,229 @@
+"""Host planner: the scalar half of every WFO operator.
+
+The reference mixes, inside each ``WFO`` method, a few dozen floating-point
+operations on the pilot Gaussian beam (paos/classes/wfo.py:318-357, 386-416,
+434-443, 454-460, 483-508, 520-544, 556-572) with O(N^2) array work.  The array
+work lives on the GPU; this module keeps the scalar algebra on the host, in IEEE
+double with the reference's operation order, because it *decides* which
+propagator runs (``|z - zw0| < 2 zr``, ``|dz| < wl/1000``) and those branches
+must agree with the reference bit for bit.
+
+Each method returns what the device needs: a 5-double block
+``[enable, sx, sy, coef, sgn]`` (include/paos_hip.h, PAOS_PHASE_STRIDE) or
+``None`` when the reference would return without touching the field.
+"""
+import numpy as np
+
+
+class PilotBeam:
+    """Scalar state of one wavefront -- the attributes of wfo.py:105-120."""
+
+    def __init__(self, beam_diameter, wl, grid_size, zoom):
+        assert np.log2(grid_size).is_integer(), "Grid size should be 2**n"
+        assert zoom > 0, "zoom factor should be positive"
+        assert beam_diameter > 0, "beam diameter should be positive"
+        assert wl > 0, "a wavelength should be positive"
+        self.n = int(grid_size)
+        self.wl = wl
+        self.z = 0.0
+        self.w0 = beam_diameter / 2.0
+        self.zw0 = 0.0
+        self.zr = np.pi * self.w0**2 / wl
+        self.rayleigh_factor = 2.0
+        self.dx = beam_diameter * zoom / grid_size
+        self.dy = beam_diameter * zoom / grid_size
+        self.C = 0.0
+        self.fratio = np.inf
+        self.propagator = ""
+
+    # ---- read-outs ---------------------------------------------------------------
+    @property
+    def wz(self):
+        return self.w0 * np.sqrt(1.0 + ((self.z - self.zw0) / self.zr) ** 2)
+
+    @property
+    def distancetofocus(self):
+        return self.zw0 - self.z
+
+    @property
+    def extent(self):
+        n = self.n
+        return (-n // 2 * self.dx, (n // 2 - 1) * self.dx, -n // 2 * self.dy, (n // 2 - 1) * self.dy)
+
+    def region(self, z=None):
+        """'I' within rayleigh_factor * zr of the waist, else 'O' (wfo.py:280-302)."""
+        gap = (self.z if z is None else z) - self.zw0
+        return "I" if np.abs(gap) < self.rayleigh_factor * self.zr else "O"
+
+    # ---- operators -----------------------------------------------------------------
+    def lens(self, lens_fl):
+        """wfo.py:318-366.  Returns the phase block of
+        exp(2 pi i * (-(x^2+y^2) * (0.5 lens_phase / wl)))."""
+        wz = self.w0 * np.sqrt(1.0 + ((self.z - self.zw0) / self.zr) ** 2)
+        gap = self.z - self.zw0
+        regime = self.region()
+        curv_in = gap / (gap**2 + self.zr**2)
+        curv_out = curv_in - 1.0 / lens_fl
+        self.w0 = wz / np.sqrt(1.0 + (np.pi * wz**2 * curv_out / self.wl) ** 2)
+        self.zw0 = -curv_out / (curv_out**2 + (self.wl / (np.pi * wz**2)) ** 2) + self.z
+        self.zr = np.pi * self.w0**2 / self.wl
+        regime += self.region()
+
+        ref_in = 0.0 if (regime[0] == "I" or self.C == 0.0) else 1 / gap
+        gap = self.z - self.zw0
+        ref_out = 0.0 if regime[1] == "I" else 1 / gap
+        self.C = ref_out
+        if regime == "II":
+            power = 1.0 / lens_fl
+        elif regime == "IO":
+            power = 1 / lens_fl + ref_out
+        elif regime == "OI":
+            power = 1.0 / lens_fl - ref_in
+        else:
+            power = 1.0 / lens_fl - ref_in + ref_out
+        self.fratio = np.abs(gap) / (2 * wz)
+        return [1.0, self.dx, self.dy, 0.5 * power / self.wl, -1.0]
+
+    def magnification(self, My, Mx=None):
+        """wfo.py:386-416 (note run() passes (Mt, Ms), run.py:195)."""
+        if Mx is None:
+            Mx = My
+        assert Mx > 0.0, "Negative magnification not implemented yet."
+        assert My > 0.0, "Negative magnification not implemented yet."
+        self.dx *= Mx
+        self.dy *= My
+        if np.abs(Mx - 1.0) < 1.0e-8:
+            return
+        gap = self.z - self.zw0
+        wz = self.w0 * np.sqrt(1.0 + ((self.z - self.zw0) / self.zr) ** 2)
+        gap *= Mx**2
+        wz *= Mx
+        self.w0 *= Mx
+        self.zr *= Mx**2
+        self.zw0 = self.z - gap
+        self.fratio = np.abs(gap) / (2 * wz)
+
+    def change_medium(self, n1n2):
+        """wfo.py:434-443."""
+        gap = self.z - self.zw0
+        gap /= n1n2
+        self.zr /= n1n2
+        self.wl *= n1n2
+        self.zw0 = self.z - gap
+        self.fratio /= n1n2
+
+    def _freq_steps(self):
+        # np.fft.fftfreq(n, d): val = 1.0 / (n * d), results = integers * val
+        return 1.0 / (self.n * self.dx), 1.0 / (self.n * self.dy)
+
+    def ptp(self, dz):
+        """wfo.py:454-472: block for H = exp(-i (pi wl dz)(fx^2 + fy^2))."""
+        if np.abs(dz) < 0.001 * self.wl:
+            return None
+        if self.C != 0:
+            raise ValueError("PTP wavefront should be planar")
+        fsx, fsy = self._freq_steps()
+        block = [1.0, fsx, fsy, (np.pi * self.wl * dz), -1.0]
+        self.z = self.z + dz
+        return block
+
+    def stw(self, dz):
+        """wfo.py:483-509: (block for Q = exp(+i (pi wl dz) f^2), inverse flag)."""
+        if np.abs(dz) < 0.001 * self.wl:
+            return None
+        if self.C == 0.0:
+            raise ValueError("STW wavefront should not be planar")
+        fsx, fsy = self._freq_steps()
+        block = [1.0, fsx, fsy, (np.pi * self.wl * dz), 1.0]
+        self.z = self.z + dz
+        self.C = 0.0
+        # (fx[1] - fx[0]) * wl * |dz| with fx[1] = 1 * val, fx[0] = 0 * val
+        self.dx = (fsx - 0.0) * self.wl * np.abs(dz)
+        self.dy = (fsy - 0.0) * self.wl * np.abs(dz)
+        return block, not (dz >= 0)
+
+    def wts(self, dz):
+        """wfo.py:520-545: (block for P = exp(+i (pi/(dz wl)) (x^2+y^2)), inverse flag)."""
+        if np.abs(dz) < 0.001 * self.wl:
+            return None
+        if self.C != 0.0:
+            raise ValueError("WTS wavefront should be planar")
+        block = [1.0, self.dx, self.dy, (np.pi / (dz * self.wl)), 1.0]
+        self.z = self.z + dz
+        self.C = 1 / (self.z - self.zw0)
+        self.dx = self.wl * np.abs(dz) / (self.n * self.dx)
+        self.dy = self.wl * np.abs(dz) / (self.n * self.dy)
+        return block, not (dz >= 0)
+
+    def propagate(self, dz):
+        """wfo.py:556-572: list of ('stw'|'ptp'|'wts', block[, inverse]) steps."""
+        regime = self.region() + self.region(self.z + dz)
+        z1 = self.z
+        z2 = self.z + dz
+        steps = []
+
+        def add(kind, res):
+            if res is None:
+                return
+            if kind == "ptp":
+                steps.append((kind, res, False))
+            else:
+                steps.append((kind, res[0], res[1]))
+
+        if regime == "II":
+            add("ptp", self.ptp(dz))
+        elif regime == "OI":
+            add("stw", self.stw(self.zw0 - z1))
+            add("ptp", self.ptp(z2 - self.zw0))
+        elif regime == "IO":
+            add("ptp", self.ptp(self.zw0 - z1))
+            add("wts", self.wts(z2 - self.zw0))
+        elif regime == "OO":
+            add("stw", self.stw(self.zw0 - z1))
+            add("wts", self.wts(z2 - self.zw0))
+        self.propagator = regime
+        return steps
+
+
+# ---- Zernike tables -------------------------------------------------------------------
+def jacobi_recurrence(nmax):
+    """Constants of P_k^{(a,0)}(x) = (A x + B) P_{k-1} - C P_{k-2} for a = 0..nmax,
+    k = 0..nmax//2, shape (nmax+1, kdim, 3).  The GPU evaluates the radial
+    polynomial of the reference, (-1)^k rho^a P_k^{(a,0)}(1 - 2 rho^2)
+    (zernike.py:245-247), with this stable three-term recurrence."""
+    kdim = nmax // 2 + 1
+    tab = np.zeros((nmax + 1, kdim, 3), dtype=np.float64)
+    for a in range(nmax + 1):
+        for k in range(1, kdim):
+            if k == 1:
+                tab[a, k] = ((a + 2) / 2.0, a / 2.0, 0.0)
+                continue
+            den = 2.0 * k * (k + a) * (2 * k + a - 2)
+            tab[a, k, 0] = (2 * k + a - 1) * (2 * k + a) * (2 * k + a - 2) / den
+            tab[a, k, 1] = (2 * k + a - 1) * (a * a) / den
+            tab[a, k, 2] = 2.0 * (k + a - 1) * (k - 1) * (2 * k + a) / den
+    return tab
+
+
+def zernike_block(m, n, norm, coeffs, dx, dy, radius, wl, origin="x", offset_deg=0.0, nmax=None):
+    """Per-item parameter block of paos_zernike: header + cos / sin coefficient
+    planes indexed [|m|][k], k = (n - |m|)/2, with (-1)^k * norm * Z folded in."""
+    m = np.asarray(m, dtype=int)
+    n = np.asarray(n, dtype=int)
+    if nmax is None:
+        nmax = int(n.max())
+    kdim = nmax // 2 + 1
+    cosp = np.zeros((nmax + 1, kdim), dtype=np.float64)
+    sinp = np.zeros((nmax + 1, kdim), dtype=np.float64)
+    for mk, nk, nrm, ck in zip(m, n, norm, coeffs):
+        k = (nk - abs(mk)) // 2
+        val = (-1.0) ** k * nrm * ck
+        if mk >= 0:
+            cosp[abs(mk), k] += val
+        else:
+            sinp[abs(mk), k] += val
+    if origin not in ("x", "y"):
+        raise ValueError(f"Origin {origin} not recognised. Origin shall be either x or y")
+    off = np.deg2rad(offset_deg)
+    head = [1.0, dx, dy, radius, 1.0 if origin == "y" else 0.0, np.cos(off), np.sin(off), 1.0 / wl]
+    return np.concatenate([head, cosp.ravel(), sinp.ravel()]), nmax, kdim

@@ -1,0 +1,289 @@
+"""Propagation loop: ``run`` (drop-in) and ``run_batch`` (many wavefronts per launch).
+
+``run(pupil_diameter, wavelength, gridsize, zoom, field, opt_chain)`` keeps the
+signature, the per-surface order of operations and the returned dictionary of
+``paos.core.run.run`` (reference paos/core/run.py:30-228).  All scalar decisions
+are taken on the host exactly as there (coordinate break :81-91, aperture
+geometry :96-122, Zernike radius :131, gating of Magnification / ChangeMedium /
+lens / propagate :181-207, ray and ABCD bookkeeping :209-219); the field never
+leaves HBM except for the arrays of surfaces marked ``save``.
+
+``run_batch`` runs B independent wavefronts (wavelengths of one lens file, or
+Monte-Carlo WFE realisations -- what the reference fans out over joblib workers,
+paos/core/pipeline.py:140-150) through ONE sequence of kernel launches: every
+launch carries a per-item parameter block with an enable flag, so items whose
+planners disagree (a ptp skipped for one wavelength, II vs OI) still share
+launches.
+"""
+from copy import deepcopy
+
+import numpy as np
+
+from . import _lib
+from .abcd import ABCD
+from .aperture import EllipticalAperture, bbox_misses_grid, make_aperture
+from .coordinate_break import coordinate_break
+from .planner import PilotBeam, jacobi_recurrence, zernike_block
+from .zernike import Zernike, norm_factors
+
+_OFF_PHASE = [0.0] * _lib.PHASE_STRIDE
+_OFF_APERTURE = [0.0] * _lib.APERTURE_STRIDE
+
+
+class _Item:
+    """Host state of one wavefront while it walks the chain."""
+
+    def __init__(self, pupil_diameter, wavelength, gridsize, zoom, field):
+        self.beam = PilotBeam(pupil_diameter, wavelength, gridsize, zoom)
+        self.vt = np.array([0.0, field["ut"]])
+        self.vs = np.array([0.0, field["us"]])
+        self.acc_t = ABCD()
+        self.acc_s = ABCD()
+
+
+def _plan_surface(st, item):
+    """Host half of one loop iteration of run.py:77-224 for one wavefront.  Returns the
+    device work as a dict of slots and advances the host state."""
+    beam = st.beam
+    plan = {"aperture": None, "stop": False, "zernike": None, "lens": None, "steps": []}
+
+    if item["type"] == "Coordinate Break":
+        st.vt, st.vs = coordinate_break(st.vt, st.vs, item["xdec"], item["ydec"], item["xrot"],
+                                        item["yrot"], 0.0)
+
+    if "aperture" in item:
+        ap = item["aperture"]
+        xdec = ap["xc"] if np.isfinite(ap["xc"]) else st.vs[0]
+        ydec = ap["yc"] if np.isfinite(ap["yc"]) else st.vt[0]
+        xrad = ap["xrad"]
+        yrad = ap["yrad"]
+        xrad *= np.sqrt(1 / (st.vs[1] ** 2 + 1))
+        yrad *= np.sqrt(1 / (st.vt[1] ** 2 + 1))
+        xaper = xdec - st.vs[0]
+        yaper = ydec - st.vt[0]
+        obscuration = ap["type"] != "aperture"
+        if np.all(np.isfinite([xrad, yrad])):
+            handle = make_aperture(beam.n, beam.dx, beam.dy, xaper, yaper, hx=xrad, hy=yrad,
+                                   shape=ap["shape"])
+            if bbox_misses_grid(handle, beam.n):
+                raise TypeError("aperture does not overlap the grid (mask is None in the reference)")
+            plan["aperture"] = (handle, obscuration)
+
+    plan["stop"] = bool(item["is_stop"])
+
+    if item["type"] == "Zernike":
+        radius = item["Zradius"] if np.isfinite(item["Zradius"]) else beam.wz
+        if item["Zorthonorm"]:
+            raise NotImplementedError("Zorthonorm=True (PolyOrthoNorm) is not accelerated yet")
+        index = np.asarray(item["Zindex"])
+        assert not np.any(np.diff(index) - 1), "Zernike sequence should be continuous"
+        ordering = item["Zordering"]
+        if ordering not in ("ansi", "noll", "fringe", "standard"):
+            raise AssertionError("Unrecognised ordering scheme.")
+        m, n = Zernike.j2mn(len(index), ordering)
+        plan["zernike"] = dict(m=m, n=n, norm=norm_factors(m, n, item["Znormalize"]),
+                               Z=np.asarray(item["Z"], dtype=np.float64), dx=beam.dx, dy=beam.dy,
+                               radius=radius, wl=beam.wl, origin=item["Zorigin"])
+    if item["type"] in ("Grid Sag", "PSD"):
+        raise NotImplementedError(f"surface type {item['type']} is outside the accelerated path")
+
+    # push_results scalars (run.py:12-27) are those BEFORE magnification / lens / propagate
+    plan["scalars"] = {
+        "wz": beam.wz, "distancetofocus": beam.distancetofocus, "fratio": beam.fratio,
+        "dx": beam.dx, "dy": beam.dy, "wl": beam.wl, "extent": beam.extent,
+        "propagator": beam.propagator,
+    }
+
+    Ms = item["ABCDs"].M
+    Mt = item["ABCDt"].M
+    fl = np.inf if (item["ABCDt"].power == 0) else item["ABCDt"].cout / item["ABCDt"].power
+    T = item["ABCDt"].cout * item["ABCDt"].thickness
+    n1n2 = item["ABCDt"].n1n2
+    if Mt != 1.0 or Ms != 1.0:
+        beam.magnification(Mt, Ms)
+    if np.abs(n1n2) != 1.0:
+        beam.change_medium(n1n2)
+    if np.isfinite(fl):
+        plan["lens"] = beam.lens(fl)
+    if np.isfinite(T) and np.abs(T) > 1e-10:
+        plan["steps"] = beam.propagate(T)
+
+    st.vt = item["ABCDt"]() @ st.vt
+    st.vs = item["ABCDs"]() @ st.vs
+    st.acc_t = item["ABCDt"] * st.acc_t
+    st.acc_s = item["ABCDs"] * st.acc_s
+    plan["ABCDt"] = st.acc_t
+    plan["ABCDs"] = st.acc_s
+    return plan
+
+
+def _launch_apertures(dev, plans):
+    for code, cls_is_ellipse in ((_lib.SHAPE_ELLIPSE, True), (_lib.SHAPE_RECT, False)):
+        blocks, any_on = [], False
+        for p in plans:
+            ap = p["aperture"]
+            if ap is not None and isinstance(ap[0], EllipticalAperture) == cls_is_ellipse:
+                blocks.append(ap[0].block(obscuration=ap[1]))
+                any_on = True
+            else:
+                blocks.append(_OFF_APERTURE)
+        if any_on:
+            dev.aperture(code, blocks)
+
+
+def _launch_zernike(dev, plans, want_wfe=False):
+    zs = [p["zernike"] for p in plans]
+    if not any(z is not None for z in zs):
+        return None
+    nmax = max(int(z["n"].max()) for z in zs if z is not None)
+    kdim = nmax // 2 + 1
+    stride = _lib.ZERNIKE_HEAD + 2 * (nmax + 1) * kdim
+    blocks = np.zeros((len(plans), stride), dtype=np.float64)
+    for i, z in enumerate(zs):
+        if z is not None:
+            blocks[i], _, _ = zernike_block(z["m"], z["n"], z["norm"], z["Z"], z["dx"], z["dy"],
+                                            z["radius"], z["wl"], origin=z["origin"], nmax=nmax)
+    return dev.zernike(nmax, kdim, jacobi_recurrence(nmax), blocks, want_wfe=want_wfe)
+
+
+def _launch_steps(dev, plans):
+    """stw / ptp / wts in the fixed slot order every regime respects (OI: stw, ptp;
+    IO: ptp, wts; OO: stw, wts; II: ptp -- wfo.py:560-570)."""
+    for kind in ("stw", "ptp", "wts"):
+        for inverse in ((False,) if kind == "ptp" else (False, True)):
+            blocks, any_on = [], False
+            for p in plans:
+                hit = [s for s in p["steps"] if s[0] == kind and bool(s[2]) == inverse]
+                if hit:
+                    blocks.append(hit[0][1])
+                    any_on = True
+                else:
+                    blocks.append(_OFF_PHASE)
+            if not any_on:
+                continue
+            if kind == "ptp":
+                dev.ptp(blocks)
+            elif kind == "stw":
+                dev.stw(blocks, inverse)
+            else:
+                dev.wts(blocks, inverse)
+
+
+def _walk(dev, states, chains, on_saved):
+    """Drive all items through their chains in lock-step, one surface at a time."""
+    keys = [list(c.keys()) for c in chains]
+    if any(k != keys[0] for k in keys[1:]):
+        raise ValueError("batched chains must list the same surfaces (same keys, same order)")
+    for key in keys[0]:
+        items = [c[key] for c in chains]
+        plans = [_plan_surface(st, it) for st, it in zip(states, items)]
+        _launch_apertures(dev, plans)
+        if any(p["stop"] for p in plans):
+            dev.make_stop([1.0 if p["stop"] else 0.0 for p in plans])
+        want_wfe = len(plans) == 1 and bool(items[0]["save"])
+        wfe = _launch_zernike(dev, plans, want_wfe=want_wfe)
+        if any(it["save"] for it in items):
+            on_saved(key, items, plans, wfe)
+        if any(p["lens"] is not None for p in plans):
+            dev.phase([p["lens"] if p["lens"] is not None else _OFF_PHASE for p in plans],
+                      mul2pi=True)
+        _launch_steps(dev, plans)
+
+
+def run(pupil_diameter, wavelength, gridsize, zoom, field, opt_chain, precision="fp64", device=0):
+    """Drop-in for ``paos.core.run.run``: same arguments, same returned dict
+    ``{num: {aperture, [wfe], amplitude, wz, distancetofocus, fratio, phase, dx, dy, wfo,
+    wl, extent, propagator, ABCDt, ABCDs}}`` for surfaces with ``save`` set."""
+    assert isinstance(opt_chain, dict), "opt_chain must be a dict"
+    retval = {}
+    state = _Item(pupil_diameter, wavelength, gridsize, zoom, field)
+    dev = _lib.DeviceFields(int(gridsize), 1, precision, device)
+    dev.fill(1.0 + 0.0j)
+
+    def on_saved(key, items, plans, wfe):
+        item, plan = items[0], plans[0]
+        rec = {"aperture": plan["aperture"][0] if plan["aperture"] else None}
+        if wfe is not None:
+            outside = np.isnan(wfe)
+            rec["wfe"] = np.ma.MaskedArray(data=np.where(outside, 0.0, wfe), mask=outside,
+                                           fill_value=0.0)
+        s = plan["scalars"]
+        rec.update({
+            "amplitude": dev.download(0, _lib.WHAT_AMPLITUDE),
+            "wz": s["wz"], "distancetofocus": s["distancetofocus"], "fratio": s["fratio"],
+            "phase": dev.download(0, _lib.WHAT_PHASE),
+            "dx": s["dx"], "dy": s["dy"],
+            "wfo": dev.download(0, _lib.WHAT_FIELD),
+            "wl": s["wl"], "extent": s["extent"], "propagator": s["propagator"],
+        })
+        rec["_plan"] = plan  # ABCDs are attached once the surface is fully processed
+        retval[item["num"]] = rec
+
+    try:
+        _walk(dev, [state], [opt_chain], on_saved)
+        dev.sync()
+    finally:
+        dev.close()
+    for rec in retval.values():
+        plan = rec.pop("_plan")
+        rec["ABCDt"] = deepcopy(plan["ABCDt"])
+        rec["ABCDs"] = deepcopy(plan["ABCDs"])
+    return retval
+
+
+def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, precision="fp64",
+              device=0, outputs=("psf",), dev=None, sync=True):
+    """Propagate ``B = len(opt_chains)`` wavefronts together on one GPU.
+
+    ``wavelengths[i]`` / ``opt_chains[i]`` describe wavefront ``i`` (chains must
+    contain the same surfaces).  Returns a list of ``B`` dicts
+    ``{num: {scalars..., 'power': sum|u|^2, ['psf'], ['wfo'], ['amplitude'], ['phase']}}``
+    for saved surfaces.  ``outputs`` picks which N x N arrays are copied back to the
+    host per saved surface and item ('psf' = |u|^2, plot.py:125-130); ``()`` keeps
+    every array on the GPU and returns scalars and the power only -- the mode the
+    throughput benchmark uses.  ``dev`` may pass a pre-allocated
+    ``DeviceFields(gridsize, B)`` to reuse across calls.
+    """
+    nb = len(opt_chains)
+    if len(wavelengths) != nb:
+        raise ValueError("one wavelength per chain is required")
+    unknown = set(outputs) - {"psf", "wfo", "amplitude", "phase"}
+    if unknown:
+        raise ValueError(f"unknown outputs {sorted(unknown)}")
+    states = [_Item(pupil_diameter, wl, gridsize, zoom, field) for wl in wavelengths]
+    own = dev is None
+    if own:
+        dev = _lib.DeviceFields(int(gridsize), nb, precision, device)
+    elif dev.batch != nb or dev.n != int(gridsize):
+        raise ValueError("supplied DeviceFields does not match the batch")
+    dev.fill(1.0 + 0.0j)
+    results = [dict() for _ in range(nb)]
+    what = {"psf": _lib.WHAT_INTENSITY, "wfo": _lib.WHAT_FIELD, "amplitude": _lib.WHAT_AMPLITUDE,
+            "phase": _lib.WHAT_PHASE}
+
+    def on_saved(key, items, plans, wfe):
+        power = dev.norm2()
+        for i, (item, plan) in enumerate(zip(items, plans)):
+            if not item["save"]:
+                continue
+            rec = dict(plan["scalars"])
+            rec["aperture"] = plan["aperture"][0] if plan["aperture"] else None
+            rec["power"] = float(power[i])
+            for name in outputs:
+                rec[name] = dev.download(i, what[name])
+            rec["_plan"] = plan
+            results[i][item["num"]] = rec
+
+    try:
+        _walk(dev, states, list(opt_chains), on_saved)
+        if sync:
+            dev.sync()
+    finally:
+        if own:
+            dev.close()
+    for res in results:
+        for rec in res.values():
+            plan = rec.pop("_plan")
+            rec["ABCDt"] = plan["ABCDt"]
+            rec["ABCDs"] = plan["ABCDs"]
+    return results

@@ -1,0 +1,157 @@
+"""Device-backed wavefront object with the PAOS ``WFO`` interface.
+
+Same constructor, read-only properties and methods as ``paos.classes.wfo.WFO``
+(reference paos/classes/wfo.py:12-654).  The N x N complex field lives in HBM
+(``_lib.DeviceFields``); every method below runs the scalar pilot-beam part on
+the host (``planner.PilotBeam``) and the field part as HIP kernels.  ``grid_sag``
+and ``psd`` (wfo.py:656-949) are outside the accelerated path and raise.
+"""
+import numpy as np
+
+from . import _lib
+from .aperture import bbox_misses_grid, make_aperture, EllipticalAperture
+from .planner import PilotBeam, jacobi_recurrence, zernike_block
+from .zernike import Zernike, norm_factors
+
+
+class _FieldView:
+    """What ``wfo._wfo`` hands out: has ``.shape``/``.dtype`` (read by run.py:139 and
+    notebooks) and converts to a NumPy array on demand (one device download)."""
+
+    def __init__(self, owner):
+        self._owner = owner
+        self.shape = (owner._beam.n, owner._beam.n)
+        self.dtype = np.dtype(np.complex128)
+
+    def __array__(self, dtype=None, copy=None):
+        arr = self._owner._dev.download(0, _lib.WHAT_FIELD)
+        return arr if dtype is None else arr.astype(dtype)
+
+    def copy(self):
+        return np.asarray(self)
+
+
+class WFO:
+    def __init__(self, beam_diameter, wl, grid_size, zoom, precision="fp64", device=0):
+        self._beam = PilotBeam(beam_diameter, wl, grid_size, zoom)
+        self._zoom = zoom
+        self._dev = _lib.DeviceFields(int(grid_size), 1, precision, device)
+        self._dev.fill(1.0 + 0.0j)  # np.ones(..., complex128), wfo.py:118
+
+    # ---- scalar read-outs (wfo.py:122-160,174-193) ----------------------------------
+    wl = property(lambda self: self._beam.wl)
+    z = property(lambda self: self._beam.z)
+    w0 = property(lambda self: self._beam.w0)
+    zw0 = property(lambda self: self._beam.zw0)
+    zr = property(lambda self: self._beam.zr)
+    rayleigh_factor = property(lambda self: self._beam.rayleigh_factor)
+    dx = property(lambda self: self._beam.dx)
+    dy = property(lambda self: self._beam.dy)
+    C = property(lambda self: self._beam.C)
+    fratio = property(lambda self: self._beam.fratio)
+    wz = property(lambda self: self._beam.wz)
+    distancetofocus = property(lambda self: self._beam.distancetofocus)
+    propagator = property(lambda self: self._beam.propagator)
+    extent = property(lambda self: self._beam.extent)
+
+    # ---- field read-outs (wfo.py:162-172) ----------------------------------------------
+    @property
+    def wfo(self):
+        return self._dev.download(0, _lib.WHAT_FIELD)
+
+    @property
+    def amplitude(self):
+        return self._dev.download(0, _lib.WHAT_AMPLITUDE)
+
+    @property
+    def phase(self):
+        return self._dev.download(0, _lib.WHAT_PHASE)
+
+    @property
+    def intensity(self):
+        """|u|^2 -- the PSF as the reference's callers define it (plot.py:125-130)."""
+        return self._dev.download(0, _lib.WHAT_INTENSITY)
+
+    @property
+    def _wfo(self):
+        return _FieldView(self)
+
+    @_wfo.setter
+    def _wfo(self, value):
+        self._dev.upload(0, value)
+
+    # ---- operators ------------------------------------------------------------------------
+    def make_stop(self):
+        self._dev.make_stop()
+
+    def aperture(self, xc, yc, hx=None, hy=None, r=None, shape="elliptical", tilt=None,
+                 obscuration=False):
+        b = self._beam
+        ap = make_aperture(b.n, b.dx, b.dy, xc, yc, hx=hx, hy=hy, r=r, shape=shape, tilt=tilt)
+        if bbox_misses_grid(ap, b.n):
+            # photutils' to_image() gives None here and the reference dies on u *= None
+            raise TypeError("aperture does not overlap the grid (mask is None in the reference)")
+        code = _lib.SHAPE_ELLIPSE if isinstance(ap, EllipticalAperture) else _lib.SHAPE_RECT
+        self._dev.aperture(code, [ap.block(obscuration=obscuration)])
+        return ap
+
+    def insideout(self, z=None):
+        return self._beam.region(z)
+
+    def lens(self, lens_fl):
+        self._dev.phase([self._beam.lens(lens_fl)], mul2pi=True)
+
+    def Magnification(self, My, Mx=None):
+        self._beam.magnification(My, Mx)
+
+    def ChangeMedium(self, n1n2):
+        self._beam.change_medium(n1n2)
+
+    def ptp(self, dz):
+        block = self._beam.ptp(dz)
+        if block is not None:
+            self._dev.ptp([block])
+
+    def stw(self, dz):
+        res = self._beam.stw(dz)
+        if res is not None:
+            self._dev.stw([res[0]], res[1])
+
+    def wts(self, dz):
+        res = self._beam.wts(dz)
+        if res is not None:
+            self._dev.wts([res[0]], res[1])
+
+    def propagate(self, dz):
+        for kind, block, inverse in self._beam.propagate(dz):
+            if kind == "ptp":
+                self._dev.ptp([block])
+            elif kind == "stw":
+                self._dev.stw([block], inverse)
+            else:
+                self._dev.wts([block], inverse)
+
+    def zernikes(self, index, Z, ordering, normalize, radius, offset=0.0, origin="x",
+                 orthonorm=False, mask=False):
+        """wfo.py:574-654.  Returns the masked wfe map like the reference."""
+        index = np.asarray(index)
+        assert not np.any(np.diff(index) - 1), "Zernike sequence should be continuous"
+        if orthonorm:
+            raise NotImplementedError("PolyOrthoNorm (Zorthonorm=True) is not accelerated yet")
+        if mask is not False and np.any(mask):
+            raise NotImplementedError("an explicit pupil mask is only used with orthonorm=True")
+        if ordering not in ("ansi", "noll", "fringe", "standard"):
+            raise AssertionError("Unrecognised ordering scheme.")
+        m, n = Zernike.j2mn(len(index), ordering)
+        b = self._beam
+        block, nmax, kdim = zernike_block(m, n, norm_factors(m, n, normalize), np.asarray(Z, float),
+                                          b.dx, b.dy, radius, b.wl, origin=origin, offset_deg=offset)
+        wfe = self._dev.zernike(nmax, kdim, jacobi_recurrence(nmax), [block], want_wfe=True)
+        outside = np.isnan(wfe)
+        return np.ma.MaskedArray(data=np.where(outside, 0.0, wfe), mask=outside, fill_value=0.0)
+
+    def grid_sag(self, *args, **kwargs):
+        raise NotImplementedError("grid_sag is outside the accelerated path (SURVEY.md section 2)")
+
+    def psd(self, *args, **kwargs):
+        raise NotImplementedError("psd is outside the accelerated path (SURVEY.md section 2)")

@@ -1,0 +1,345 @@
+"""GPU parity: HIP path (through the C ABI) vs the reference's own golden vectors
+and vs the CPU oracle on the same seeded inputs.  Run with ``-m gpu`` on an MI355X.
+
+Tolerances: the north star asks |PSF_gpu - PSF_ref| / |PSF_ref| < 1e-10 in fp64
+(BASELINE.json); fields are checked at 1e-11 of max|u| (observed ~1e-14), aperture
+classification {0, partial, 1} bit-exactly, fp32 mode at 2e-5 (c64 FFT chain).
+"""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+FIELD_TOL = 1e-11
+PSF_TOL = 1e-10
+ORDERINGS = ("ansi", "noll", "fringe", "standard")
+DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
+
+
+@pytest.fixture(scope="module")
+def WFO():
+    from paos_amd.wfo import WFO as cls
+
+    return cls
+
+
+def scalars(w):
+    return np.array([w.wl, w.z, w.w0, w.zw0, w.zr, w.dx, w.dy, w.C, w.fratio, w.wz,
+                     w.distancetofocus])
+
+
+def fresh(WFO, g, wl=3.0e-6, anam=False, n=64):
+    w = WFO(1.0, wl, n, 4)
+    if anam:
+        w.Magnification(1.25, 0.8)
+    w._wfo = g["u0"]
+    return w
+
+
+def check(g, tag, w, before=None):
+    if before is not None:
+        assert np.array_equal(before, g[tag + "_before"]), tag
+    assert np.array_equal(scalars(w), g[tag + "_after"]), tag
+    assert rel_err(w.wfo, g[tag + "_u"]) < FIELD_TOL, (tag, rel_err(w.wfo, g[tag + "_u"]))
+
+
+def test_library_loaded_is_in_tree():
+    from paos_amd import _lib
+
+    lib = _lib.load()
+    assert os.path.dirname(_lib.LIB_PATH).endswith("paos_amd")
+    assert b"gfx950" in lib.paos_build_info()
+
+
+def test_upload_download_roundtrip(WFO):
+    g = load_golden("primitives.npz")
+    w = fresh(WFO, g)
+    assert np.array_equal(w.wfo, g["u0"])
+    assert np.array_equal(np.asarray(w._wfo), g["u0"]) and w._wfo.shape == (64, 64)
+    assert rel_err(w.amplitude, np.abs(g["u0"])) < 1e-15
+    assert rel_err(w.phase, np.angle(g["u0"])) < 1e-15
+    w2 = WFO(1.0, 1e-6, 128, 4)
+    assert np.array_equal(w2.wfo, np.ones((128, 128), dtype=complex))
+
+
+@pytest.mark.parametrize("anam", [False, True])
+def test_primitives_vs_reference_vectors(WFO, anam):
+    """Every field primitive against outputs of the reference's own wfo.py."""
+    g = load_golden("primitives.npz")
+    sfx = "_anam" if anam else ""
+    w = fresh(WFO, g, anam=anam)
+    b = scalars(w)
+    w.make_stop()
+    check(g, "make_stop" + sfx, w, b)
+    for fl in (10.0, -3.0, 0.4):
+        w = fresh(WFO, g, anam=anam)
+        b = scalars(w)
+        w.lens(fl)
+        check(g, f"lens_{fl}{sfx}", w, b)
+    for dz in (0.5, -0.25, 1.0e-8):
+        w = fresh(WFO, g, anam=anam)
+        b = scalars(w)
+        w.ptp(dz)
+        check(g, f"ptp_{dz}{sfx}", w, b)
+    for fl in (10.0, -7.0):
+        w = fresh(WFO, g, anam=anam)
+        w.lens(fl)
+        w._wfo = g["u0"]
+        b = scalars(w)
+        dz = w.zw0 - w.z
+        assert dz == g[f"stw_{fl}{sfx}_dz"]
+        w.stw(dz)
+        check(g, f"stw_{fl}{sfx}", w, b)
+    for dz in (2.0, -1.5):
+        w = fresh(WFO, g, anam=anam)
+        b = scalars(w)
+        w.wts(dz)
+        check(g, f"wts_{dz}{sfx}", w, b)
+
+
+def test_propagate_regimes(WFO):
+    g = load_golden("primitives.npz")
+    for tag, (fl, dist) in {"II": (None, 1.0), "OI": (10.0, 10.0), "IO": (None, 4.0e6),
+                            "OO": (10.0, 20.0)}.items():
+        w = WFO(1.0, 3.0e-6, 64, 4)
+        if fl is not None:
+            w.lens(fl)
+        w._wfo = g["u0"]
+        b = scalars(w)
+        w.propagate(dist)
+        assert w.propagator == tag
+        check(g, "propagate_" + tag, w, b)
+    w = fresh(WFO, g)
+    w.lens(5.0)
+    w.Magnification(1.3, 0.7)
+    assert np.array_equal(scalars(w), g["magnification_after"])
+    w = fresh(WFO, g)
+    w.lens(5.0)
+    w.ChangeMedium(0.66)
+    assert np.array_equal(scalars(w), g["changemedium_after"])
+
+
+def test_guards_mirror_reference(WFO):
+    w = WFO(1.0, 3.0e-6, 64, 4)
+    u = w.wfo
+    w.ptp(1e-10)
+    assert np.array_equal(w.wfo, u) and w.z == 0.0
+    w.lens(10.0)
+    with pytest.raises(ValueError):
+        w.ptp(1.0)
+    with pytest.raises(ValueError):
+        WFO(1.0, 3.0e-6, 64, 4).stw(1.0)
+    with pytest.raises(AssertionError):
+        WFO(1.0, 3.0e-6, 100, 4)
+    with pytest.raises(ValueError):
+        w.aperture(0, 0, hx=1, hy=1, shape="hexagonal")
+
+
+@pytest.mark.parametrize("ordering", ORDERINGS)
+def test_zernike_vs_reference_vectors(WFO, ordering):
+    g = load_golden("zernike_maps.npz")
+    for norm in (True, False):
+        for origin in ("x", "y"):
+            w = WFO(1.0, 1.0e-6, 64, 2)
+            wfe = w.zernikes(np.arange(36), g["coef"], ordering, norm, 0.5, origin=origin)
+            key = f"{ordering}_{int(norm)}_{origin}"
+            assert np.array_equal(np.ma.getmaskarray(wfe), g[key + "_mask"]), key
+            assert rel_err(wfe.filled(0.0), g[key + "_wfe"]) < 1e-13, key
+            assert rel_err(w.wfo, g[key + "_u"]) < FIELD_TOL, key
+
+
+def test_zernike_anamorphic_and_kat(WFO):
+    g = load_golden("zernike_maps.npz")
+    w = WFO(1.0, 2.0e-6, 64, 2)
+    w.Magnification(1.5, 0.75)
+    wfe = w.zernikes(np.arange(15), g["coef"][:15], "noll", True, 0.62, origin="x")
+    assert rel_err(wfe.filled(0.0), g["anam_wfe"]) < 1e-13
+    assert rel_err(w.wfo, g["anam_u"]) < FIELD_TOL
+    # the reference's notebook pin (notebook/ComputeGridSag.ipynb:131)
+    w2 = WFO(1.1, 0.55e-6, 1024, 4)
+    wfe = w2.zernikes(np.arange(6), np.array([0, 10, 0, -30, 20, 0]) * 1e-9, "noll", True, 0.55)
+    assert abs(np.std(wfe) - 3.7394904478041395e-08) < 1e-20
+
+
+def test_aperture_masks_vs_oracle(WFO):
+    """Mask VALUES are parity-unpinned (photutils absent); the GPU must at least
+    agree with the CPU restatement: classification bit-exact, values to 1e-14."""
+    from oracle import aperture_np
+    from paos_amd.aperture import EllipticalAperture, RectangularAperture
+
+    cases = [
+        (EllipticalAperture((128.0, 128.0), 32.0, 32.0), aperture_np.ellipse_mask, (128.0, 128.0, 32.0, 32.0, 0.0)),
+        (EllipticalAperture((120.3, 131.1), 40.7, 25.2, 0.6), aperture_np.ellipse_mask, (120.3, 131.1, 40.7, 25.2, 0.6)),
+        (EllipticalAperture((30.2, 250.9), 40.7, 25.2), aperture_np.ellipse_mask, (30.2, 250.9, 40.7, 25.2, 0.0)),
+        (EllipticalAperture((100.2, 99.9), 0.3, 0.2, 0.3), aperture_np.ellipse_mask, (100.2, 99.9, 0.3, 0.2, 0.3)),
+        (RectangularAperture((128.0, 128.0), 80.5, 33.25), aperture_np.rectangle_mask, (128.0, 128.0, 80.5, 33.25, 0.0)),
+        (RectangularAperture((127.6, 130.2), 50.5, 21.25, 0.3), aperture_np.rectangle_mask, (127.6, 130.2, 50.5, 21.25, 0.3)),
+    ]
+    for ap, fn, args in cases:
+        got = ap.to_mask(method="exact" if isinstance(ap, EllipticalAperture) else "subpixel").to_image((256, 256))
+        ref = fn((256, 256), *args)
+        assert np.array_equal(got == 0.0, ref == 0.0), ap
+        assert np.array_equal(got == 1.0, ref == 1.0), ap
+        assert np.max(np.abs(got - ref)) < 1e-14, (ap, np.max(np.abs(got - ref)))
+    g = load_golden("primitives.npz")
+    w = fresh(WFO, g)
+    w.aperture(0.1, -0.2, hx=0.9, hy=0.6, shape="elliptical")
+    assert rel_err(w.wfo, g["aperture_ell_u"]) < 1e-14
+    w = fresh(WFO, g)
+    w.aperture(0.0, 0.0, hx=0.7, hy=0.3, shape="rectangular", obscuration=True)
+    assert rel_err(w.wfo, g["aperture_rect_obsc_u"]) < 1e-14
+
+
+CHAINS = {"Hubble_simple": 128, "Excite_TEL": 64, "Ariel_AIRS-CH0": 64, "Ariel_FGS-FGS1": 64}
+
+
+def _spec(name):
+    from paos_amd.chains import syn20_chain
+    from paos_amd.parse_config import parse_config
+
+    if name == "SYN20":
+        return dict(pup=1.0, wl=1.0e-6, zoom=4, field={"us": 0.0, "ut": 0.0}, chain=syn20_chain()), 128
+    pup, par, wls, fields, chains = parse_config(os.path.join(DATA, "lens", name + ".ini"))
+    return dict(pup=pup, wl=1.0e-6 * wls[0], zoom=par["zoom"], field=fields[0], chain=chains[0]), CHAINS[name]
+
+
+@pytest.mark.parametrize("name", list(CHAINS) + ["SYN20"])
+def test_run_vs_reference_vectors(name):
+    """run() end to end against the reference's run() outputs (tests/golden)."""
+    from paos_amd.run import run
+
+    spec, n = _spec(name)
+    gs = load_golden(f"scalars_{name}.npz")
+    chain = copy.deepcopy(spec["chain"])
+    for item in chain.values():
+        item["save"] = True
+    ret = run(spec["pup"], spec["wl"], 64, spec["zoom"], spec["field"], chain)
+    assert np.array_equal(sorted(ret), gs["nums"])
+    for row, k in zip(gs["table"], gs["nums"]):
+        r = ret[k]
+        got = [r["wl"], r["dx"], r["dy"], r["wz"], r["distancetofocus"], r["fratio"]]
+        assert np.array_equal(got, row), (name, k, got, row)
+    assert [ret[k]["propagator"] for k in gs["nums"]] == list(gs["propagator"])
+    assert np.array_equal(np.array([ret[k]["ABCDt"]() for k in gs["nums"]]), gs["ABCDt"])
+    assert np.array_equal(np.array([ret[k]["extent"] for k in gs["nums"]]), gs["extent"])
+
+    gr = load_golden(f"run_{name}.npz")
+    ret = run(spec["pup"], spec["wl"], n, spec["zoom"], spec["field"], spec["chain"])
+    assert np.array_equal(sorted(ret), gr["nums"])
+    for k in gr["nums"]:
+        ref = gr[f"S{k:02d}_wfo"]
+        assert rel_err(ret[k]["wfo"], ref) < FIELD_TOL, (name, k, rel_err(ret[k]["wfo"], ref))
+        assert rel_err(ret[k]["amplitude"] ** 2, np.abs(ref) ** 2) < PSF_TOL
+        assert rel_err(ret[k]["amplitude"], np.abs(ref)) < FIELD_TOL
+        if f"S{k:02d}_wfe" in gr:
+            assert rel_err(ret[k]["wfe"].filled(0.0), gr[f"S{k:02d}_wfe"]) < 1e-13
+
+
+@pytest.mark.parametrize("n", [256, 512])
+def test_run_vs_oracle_mid_sizes(n):
+    """SYN20 and the anamorphic AIRS-CH0 chain against the oracle at sizes it finishes in seconds."""
+    from oracle.run_np import run as oracle_run
+    from paos_amd.run import run
+
+    for name in ("SYN20", "Ariel_AIRS-CH0"):
+        spec, _ = _spec(name)
+        got = run(spec["pup"], spec["wl"], n, spec["zoom"], spec["field"], spec["chain"])
+        ref = oracle_run(spec["pup"], spec["wl"], n, spec["zoom"], spec["field"], spec["chain"], light=True)
+        assert sorted(got) == sorted(ref)
+        for k in ref:
+            assert rel_err(got[k]["wfo"], ref[k]["wfo"]) < FIELD_TOL, (name, n, k)
+            assert rel_err(got[k]["amplitude"] ** 2, ref[k]["amplitude"] ** 2) < PSF_TOL
+            for key in ("dx", "dy", "wl", "fratio", "wz", "distancetofocus", "propagator"):
+                assert got[k][key] == ref[k][key], (name, k, key)
+            # phase only where the amplitude is significant (atan2 of noise elsewhere)
+            sig = ref[k]["amplitude"] > 1e-6 * ref[k]["amplitude"].max()
+            dphi = np.angle(np.exp(1j * (got[k]["phase"] - ref[k]["phase"])))
+            assert np.max(np.abs(dphi[sig])) < 1e-8
+
+
+def test_wfe_injection_vs_reference_vectors():
+    from paos_amd.chains import inject_wfe, syn20_chain
+    from paos_amd.run import run
+
+    for col in (0, 1):
+        g = load_golden(f"run_SYN20_wfe{col}.npz")
+        ret = run(1.0, 1.0e-6, 64, 4, {"us": 0.0, "ut": 0.0}, inject_wfe(syn20_chain(), g["draw_nm"]))
+        assert rel_err(ret[20]["wfo"], g["wfo"]) < FIELD_TOL
+        assert np.array_equal([ret[20]["dx"], ret[20]["dy"], ret[20]["fratio"]], g["scal"])
+
+
+def test_run_batch_matches_single_runs():
+    """Wavelength sweep + WFE draws in one batch == item-by-item run() (bitwise: same kernels)."""
+    from paos_amd.chains import inject_wfe, read_wfe_table, syn20_chain, syn20_wavelength
+    from paos_amd.run import run, run_batch
+
+    _, _, _, table = read_wfe_table(os.path.join(DATA, "wfe", "wfe_realization_SN20210914.csv"))
+    field = {"us": 0.0, "ut": 0.0}
+    wls = [syn20_wavelength(k * 100) for k in range(3)]
+    chains = [inject_wfe(syn20_chain(), table[:, k]) for k in range(3)]
+    batch = run_batch(1.0, wls, 128, 4, field, chains, outputs=("psf", "wfo"))
+    for i in range(3):
+        single = run(1.0, wls[i], 128, 4, field, chains[i])
+        assert sorted(batch[i]) == sorted(single)
+        for k in single:
+            assert np.array_equal(batch[i][k]["wfo"], single[k]["wfo"])
+            assert rel_err(batch[i][k]["psf"], single[k]["amplitude"] ** 2) < 1e-15
+            assert batch[i][k]["dx"] == single[k]["dx"] and batch[i][k]["fratio"] == single[k]["fratio"]
+            assert abs(batch[i][k]["power"] - np.sum(single[k]["amplitude"] ** 2)) < 1e-12
+
+
+def test_fp32_mode_tolerance():
+    """c64 storage / FFT arithmetic with fp64 phase arguments: expected ~3e-6."""
+    from paos_amd.chains import syn20_chain
+    from paos_amd.run import run
+
+    field = {"us": 0.0, "ut": 0.0}
+    r64 = run(1.0, 1.0e-6, 256, 4, field, syn20_chain())
+    r32 = run(1.0, 1.0e-6, 256, 4, field, syn20_chain(), precision="fp32")
+    e = rel_err(r32[20]["amplitude"] ** 2, r64[20]["amplitude"] ** 2)
+    assert 1e-9 < e < 2e-5, e
+
+
+@pytest.mark.parametrize("n", [1024, 2048, 4096])
+def test_full_size_properties(WFO, n):
+    """Size-independent checks at BASELINE grid sizes: unit power after make_stop is
+    conserved by ptp/stw/wts (ortho FFTs + unimodular phases); ptp(dz) o ptp(-dz) and
+    stw o its inverse return the input field."""
+    w = WFO(1.0, 1.0e-6, n, 4)
+    w.aperture(0.0, 0.0, hx=0.5, hy=0.5, shape="elliptical")
+    w.make_stop()
+    dev = w._dev
+    assert abs(dev.norm2()[0] - 1.0) < 1e-13
+    u0 = w.wfo
+    w.ptp(3.0)
+    assert abs(dev.norm2()[0] - 1.0) < 1e-12
+    w.ptp(-3.0)
+    assert rel_err(w.wfo, u0) < 1e-12
+    w.lens(10.0)
+    w.propagate(10.0)  # OI: stw + ptp
+    assert w.propagator == "OI" and abs(dev.norm2()[0] - 1.0) < 1e-12
+    # Airy pattern: the peak of a uniform circular pupil's PSF sits at the grid centre
+    psf = w.intensity
+    assert np.unravel_index(np.argmax(psf), psf.shape) == (n // 2, n // 2)
+    assert np.allclose(psf, psf[::-1, ::-1][np.ix_(np.r_[n - 1, 0:n - 1], np.r_[n - 1, 0:n - 1])], atol=1e-18)
+
+
+def test_full_size_4096_vs_oracle_single_ptp(WFO):
+    """One 4096^2 ptp (the headline step) against NumPy on the same seeded input."""
+    n = 4096
+    rng = np.random.default_rng(5)
+    u0 = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    from oracle.pop_numpy import RefWFO
+
+    w = WFO(1.0, 1.0e-6, n, 4)
+    w._wfo = u0
+    w.ptp(2.5)
+    r = RefWFO(1.0, 1.0e-6, n, 4)
+    r._wfo = u0.copy()
+    r.ptp(2.5)
+    assert rel_err(w.wfo, r._wfo) < FIELD_TOL
