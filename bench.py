@@ -10,8 +10,8 @@ lambda_k = 1 um (1 + k/512)) per GPU through all 20 surfaces on the HIP path; fi
 are created and stay in HBM.  With N GPUs every rank gets its own contiguous block of
 the sweep (weak scaling) after ONE broadcast of the work description from rank 0.
 Rank 0 prints one JSON line (contract in the task statement) with two extra objects:
-``roofline`` (dominant kernel: the FFT row pass, HIP-event timed inside the timed
-region) and ``cpu_baseline`` (the NumPy oracle on a bounded sample, rank 0, N=1 only).
+``roofline`` (dominant kernel: the fused FFT pass, every launch HIP-event timed inside the
+timed region) and ``cpu_baseline`` (the NumPy oracle on a bounded sample, rank 0, N=1 only).
 """
 import argparse
 import json
@@ -109,9 +109,11 @@ def main():
 
     dev = _lib.DeviceFields(n, nb, args.precision, device=local_rank)
 
+    stats = {}
+
     def step():
         return run_batch(1.0, wavelengths, n, 4, field, chains, precision=args.precision,
-                         outputs=(), dev=dev, sync=False)
+                         outputs=(), dev=dev, sync=False, stats=stats)
 
     def barrier():
         dev.sync()
@@ -124,7 +126,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    dev.profile_begin(_lib.KERNEL_FFT_ROWS, max_launches=64 * 1024)
+    dev.profile_begin(_lib.KERNEL_PASS_ANY, max_launches=64 * 1024)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
@@ -140,14 +142,14 @@ def main():
         ffts = 2 * n_ptp + n_stw + n_wts
         # 2 passes x (read + write) per 2-D FFT + one 8 B/px intensity write
         chain_bytes = (ffts * 4 * esz + 8) * n * n
-        pass_bytes = 2 * esz * n * n * nb  # one row pass over the batch: read + write once
+        pass_bytes = 2 * esz * n * n * nb  # one pass over the batch: every element read + written once
         avg_ms = kern_ms / max(launches, 1)
         achieved = pass_bytes / (avg_ms * 1e-3) / 1e9 if launches else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(tpath) and n == 4096 and args.precision == "fp64":
             with open(tpath) as fh:
-                traffic = json.load(fh).get("fft_rows_bytes_per_launch")
+                traffic = json.load(fh).get("fused_pass_bytes_per_launch")
         out = {
             "metric": "wavefronts/sec (4096^2 c128, 20-surface chain) + achieved HBM GB/s",
             "value": value,
@@ -165,10 +167,11 @@ def main():
                                    f"1um*(1+k/512), {nb} wavefronts/GPU/step, {ffts} 2-D FFTs per wavefront "
                                    f"({n_ptp} ptp, {n_stw} stw, {n_wts} wts)",
                        "grid": n, "batch_per_gpu": nb, "parallelism": f"wavefront-sharded x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "fft_pass_kernel (row pass)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "fused_pass_kernel (rows and columns)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "launches": launches, "avg_launch_ms": avg_ms,
-                         "algorithmic_bytes_per_launch": pass_bytes},
+                         "algorithmic_bytes_per_launch": pass_bytes,
+                         "fused_passes_per_wavefront": stats.get("fused_passes")},
             "chain_roofline": {"algorithmic_bytes_per_wavefront": chain_bytes,
                                "achieved_GBps_per_gpu": chain_bytes * (value / world) / 1e9,
                                "frac_of_hbm_peak": chain_bytes * (value / world) / 1e9 / HBM_PEAK_GBS},

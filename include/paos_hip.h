@@ -32,7 +32,11 @@ typedef struct paos_ctx paos_ctx;
 enum { PAOS_OK = 0, PAOS_EINVAL = 1, PAOS_EHIP = 2, PAOS_EUNSUPPORTED = 3 };
 enum { PAOS_F64 = 0, PAOS_F32 = 1 };
 enum { PAOS_SHAPE_ELLIPSE = 0, PAOS_SHAPE_RECT = 1 };
-enum { PAOS_KERNEL_FFT_ROWS = 0, PAOS_KERNEL_FFT_COLS = 1, PAOS_KERNEL_PTP_MID = 2 };
+enum { PAOS_KERNEL_PASS_ROWS = 0, PAOS_KERNEL_PASS_COLS = 1, PAOS_KERNEL_PASS_ANY = 2 };
+/* pointwise operators that ride on an FFT pass (paos_run_passes) */
+enum { PAOS_PW_SIGN = 1, PAOS_PW_QPHASE_CENTRED = 2, PAOS_PW_QPHASE_NATURAL = 3, PAOS_PW_SCALE = 4 };
+enum { PAOS_PWF_MUL2PI = 1 };
+enum { PAOS_MAX_PW = 6 };
 enum { PAOS_WHAT_FIELD = 0, PAOS_WHAT_AMPLITUDE = 1, PAOS_WHAT_PHASE = 2, PAOS_WHAT_INTENSITY = 3 };
 
 /* parameter-block layouts (doubles per batch item) */
@@ -40,6 +44,20 @@ enum { PAOS_PHASE_STRIDE = 5 };    /* enable, sx, sy, coef, sgn                 
 enum { PAOS_APERTURE_STRIDE = 8 }; /* enable, xc, yc, a|w, b|h, theta, obscuration, subpixels */
 enum { PAOS_ZERNIKE_HEAD = 8 };    /* enable, dx, dy, radius, origin_is_y, cos_off, sin_off, 1/wl;
                                       then coefC[(nmax+1)*kdim], coefS[(nmax+1)*kdim]           */
+
+/* One HBM pass over every field of the batch:
+ *   load -> pre operators -> [1-D FFTs along `axis`] -> mid operators -> [1-D FFTs] -> post -> store.
+ * `block` / `fft1` / `fft2` index parameter block sets of PAOS_PHASE_STRIDE doubles per batch
+ * item: operators read [enable, sx, sy, coef, sgn] (SIGN uses enable only, SCALE multiplies by
+ * coef); a transform control block reads [enable, inverse].  axis = -1: no transform, the
+ * operators of `pre` are applied in a stand-alone pass. */
+typedef struct { int kind, flags, block; } paos_pw_op;
+typedef struct {
+  int axis;                    /* 0 = along rows, 1 = along columns, -1 = no transform */
+  int fft1, fft2;              /* control block index, or -1 for "no transform here"  */
+  int n_pre, n_mid, n_post;
+  paos_pw_op pre[PAOS_MAX_PW], mid[PAOS_MAX_PW], post[PAOS_MAX_PW];
+} paos_pass;
 
 /* ---- lifetime -------------------------------------------------------------------- */
 /* WFO.__init__ (wfo.py:99-120): allocates `batch` n x n fields (n = 2^k, 64..4096).
@@ -95,6 +113,15 @@ int paos_stw(paos_ctx* ctx, const double* params, int inverse);
 /* WFO.wts (wfo.py:528-545): fftshift(FFT(ifftshift(exp(i coef (x^2+y^2)) u))); sx, sy =
  * dx, dy; coef = pi / (dz wl). */
 int paos_wts(paos_ctx* ctx, const double* params, int inverse);
+/* A whole stretch of the propagation loop (run.py:193-207 over consecutive surfaces) as a
+ * program of passes: lens phases (wfo.py:359-366), the checkerboard signs that replace
+ * fftshift/ifftshift, the quadratic phases and ortho scalings of ptp / stw / wts
+ * (wfo.py:462-545) ride on the FFT passes, and the last pass of one propagator merges with the
+ * first pass of the next because a 2-D FFT may run rows-then-columns or columns-then-rows.
+ * `blocks` = n_blocks sets of [batch][PAOS_PHASE_STRIDE] doubles.  paos_ptp / paos_stw /
+ * paos_wts / paos_phase above are one-operator programs of the same machinery. */
+int paos_run_passes(paos_ctx* ctx, const paos_pass* passes, int n_passes, const double* blocks,
+                    int n_blocks);
 /* WFO.zernikes (wfo.py:620-652) with Zernike polynomials (zernike.py:85-109,245-247):
  * u *= exp(2 pi i wfe / wl) inside rho <= 1.  `table` holds the Jacobi recurrence
  * constants [(nmax+1)][kdim][3]; `params` the per-item blocks (PAOS_ZERNIKE_HEAD +

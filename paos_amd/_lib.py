@@ -15,7 +15,23 @@ LIB_PATH = os.path.join(_HERE, "libpaoship.so")
 PAOS_F64, PAOS_F32 = 0, 1
 SHAPE_ELLIPSE, SHAPE_RECT = 0, 1
 WHAT_FIELD, WHAT_AMPLITUDE, WHAT_PHASE, WHAT_INTENSITY = 0, 1, 2, 3
-KERNEL_FFT_ROWS, KERNEL_FFT_COLS, KERNEL_PTP_MID = 0, 1, 2
+KERNEL_PASS_ROWS, KERNEL_PASS_COLS, KERNEL_PASS_ANY = 0, 1, 2
+PW_SIGN, PW_QPHASE_CENTRED, PW_QPHASE_NATURAL, PW_SCALE = 1, 2, 3, 4
+PWF_MUL2PI = 1
+MAX_PW = 6
+
+
+class PwOp(ctypes.Structure):
+    """paos_pw_op of include/paos_hip.h"""
+    _fields_ = [("kind", ctypes.c_int), ("flags", ctypes.c_int), ("block", ctypes.c_int)]
+
+
+class Pass(ctypes.Structure):
+    """paos_pass of include/paos_hip.h"""
+    _fields_ = [("axis", ctypes.c_int), ("fft1", ctypes.c_int), ("fft2", ctypes.c_int),
+                ("n_pre", ctypes.c_int), ("n_mid", ctypes.c_int), ("n_post", ctypes.c_int),
+                ("pre", PwOp * MAX_PW), ("mid", PwOp * MAX_PW), ("post", PwOp * MAX_PW)]
+
 PHASE_STRIDE = 5
 APERTURE_STRIDE = 8
 ZERNIKE_HEAD = 8
@@ -43,6 +59,7 @@ SYMBOLS = {
     "paos_ptp": (ctypes.c_int, [_c_ctx, _dbl_p]),
     "paos_stw": (ctypes.c_int, [_c_ctx, _dbl_p, ctypes.c_int]),
     "paos_wts": (ctypes.c_int, [_c_ctx, _dbl_p, ctypes.c_int]),
+    "paos_run_passes": (ctypes.c_int, [_c_ctx, ctypes.POINTER(Pass), ctypes.c_int, _dbl_p, ctypes.c_int]),
     "paos_zernike": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, _dbl_p, _dbl_p, ctypes.c_int, _dbl_p]),
 }
 
@@ -195,6 +212,26 @@ class DeviceFields:
     def wts(self, blocks, inverse):
         b = as_blocks(blocks, self.batch, PHASE_STRIDE)
         self._check(self._lib.paos_wts(self._ctx, _dptr(b), int(bool(inverse))), "paos_wts")
+
+    def run_passes(self, passes, blocks):
+        """passes: list of dicts {axis, fft1, fft2, pre, mid, post} with operator tuples
+        (kind, flags, block); blocks: array [n_blocks][batch][PHASE_STRIDE]."""
+        b = np.ascontiguousarray(blocks, dtype=np.float64)
+        if b.ndim != 3 or b.shape[1:] != (self.batch, PHASE_STRIDE):
+            raise ValueError("blocks must be [n_blocks][batch][5]")
+        arr = (Pass * len(passes))()
+        for dst, src in zip(arr, passes):
+            dst.axis, dst.fft1, dst.fft2 = src["axis"], src.get("fft1", -1), src.get("fft2", -1)
+            for name in ("pre", "mid", "post"):
+                ops = src.get(name, ())
+                if len(ops) > MAX_PW:
+                    raise ValueError("too many operators in one pass slot")
+                setattr(dst, "n_" + name, len(ops))
+                lst = getattr(dst, name)
+                for i, (kind, flags, block) in enumerate(ops):
+                    lst[i].kind, lst[i].flags, lst[i].block = kind, flags, block
+        self._check(self._lib.paos_run_passes(self._ctx, arr, len(passes), _dptr(b), b.shape[0]),
+                    "paos_run_passes")
 
     def zernike(self, nmax, kdim, table, blocks, want_wfe=False):
         t = np.ascontiguousarray(table, dtype=np.float64).reshape(-1)

@@ -38,8 +38,8 @@ __device__ __forceinline__ cx<T> cconj(cx<T> a) { return {a.x, -a.y}; }
 // generic library routine whose Payne-Hanek path bloats register use when 16
 // calls are unrolled into one FFT pass.  Larger arguments take the library path.
 __device__ __forceinline__ void sincos_fast(double a, double* sn, double* cs) {
-  if (!(fabs(a) < 1.0e7)) {
-    sincos(a, sn, cs);
+  if (__builtin_expect(!(fabs(a) < 1.0e7), 0)) {
+    sincos(a, sn, cs);  // cold: generic library path (Payne-Hanek) for absurdly large arguments
     return;
   }
   const double n = rint(a * 0.63661977236758134308);  // 2/pi

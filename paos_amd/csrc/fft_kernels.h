@@ -19,23 +19,37 @@
 
 namespace paos {
 
+// ---- pointwise operators that ride on an FFT pass ----------------------------------
+// A pass applies up to three short lists of diagonal operators -- before the first
+// transform, between the two transforms, after the second -- each operator with a
+// per-item parameter block [enable, sx, sy, coef, sgn] (doubles, device memory).
 enum : int {
-  PW_SIGN = 1,     // multiply by (-1)^(row+col)
-  PW_PHASE = 2,    // multiply by exp(i sgn coef ((gx sx)^2 + (gy sy)^2)), centred coords
-  PW_MUL2PI = 4,   // argument gets an extra factor 2 pi (lens form, wfo.py:363-366)
+  PWK_SIGN = 1,       // (-1)^(row+col): the fftshift / ifftshift pair folded into the data
+  PWK_QPHASE_C = 2,   // exp(i sgn coef ((gx sx)^2 + (gy sy)^2)), g = index - N/2 (centred)
+  PWK_QPHASE_N = 3,   // same with g = natural-order signed frequency index (np.fft.fftfreq)
+  PWK_SCALE = 4,      // multiply by block[FP_COEF] (exact power of two: the ortho 1/N)
+};
+enum : int { PWF_MUL2PI = 1 };  // argument gets an extra factor 2 pi (lens form, wfo.py:363-366)
+enum : int { FP_ENABLE = 0, FP_SX = 1, FP_SY = 2, FP_COEF = 3, FP_SGN = 4, FP_STRIDE = 5 };
+// FFT control block: [enable, inverse, -, -, -]
+enum : int { FC_ENABLE = 0, FC_INVERSE = 1 };
+constexpr int kMaxPw = 6;
+
+struct PwOp {
+  int kind;
+  int flags;
+  int block;  // index of the [batch][FP_STRIDE] parameter block set
 };
 
-// per-item parameter block of an FFT pass (doubles, device memory)
-enum : int { FP_ENABLE = 0, FP_SX = 1, FP_SY = 2, FP_COEF = 3, FP_SGN = 4, FP_STRIDE = 5 };
-
-struct FftPassArgs {
-  void* field;            // batch of N*N complex<T>
+struct PassArgs {
+  void* field;            // batch of fields, complex<T>, blocked layout
   const void* tw;         // exp(-2 pi i m / N), m < N, complex<T>
-  const double* params;   // [item][FP_STRIDE] or nullptr (all items enabled, no phase)
-  int pre_mode;           // PW_* flags applied on load
-  int post_mode;          // PW_* flags applied on store
-  double scale;           // applied on store (exact power of two)
-  unsigned pitch;         // elements between block rows of the layout (>= N * BR)
+  const double* blocks;   // parameter block sets: [block][item][FP_STRIDE]
+  int batch;
+  int fft1, fft2;         // control block index of the first / second transform, -1 = none
+  int n_pre, n_mid, n_post;
+  PwOp pre[kMaxPw], mid[kMaxPw], post[kMaxPw];
+  unsigned pitch;         // elements between block rows of the layout
   unsigned item_stride;   // elements between batch items
 };
 
@@ -54,19 +68,26 @@ __device__ __forceinline__ cx<double> quad_phase(int gx, int gy, double sx, doub
 }
 
 template <typename T>
-__device__ __forceinline__ cx<T> pointwise(cx<T> v, int mode, int row, int col, int n,
-                                           const double* p) {
-  if (mode & PW_SIGN) {
+__device__ __forceinline__ cx<T> apply_pw(cx<T> v, const PwOp& op, const double* p, int row, int col,
+                                          int n) {
+  if (op.kind == PWK_SIGN) {
     if ((row + col) & 1) { v.x = -v.x; v.y = -v.y; }
-  }
-  if (mode & PW_PHASE) {
-    const cx<double> f = quad_phase(col - n / 2, row - n / 2, p[FP_SX], p[FP_SY], p[FP_COEF],
-                                    p[FP_SGN], (mode & PW_MUL2PI) != 0);
+  } else if (op.kind == PWK_SCALE) {
+    const T sc = (T)p[FP_COEF];
+    v.x *= sc; v.y *= sc;
+  } else {
+    int gx, gy;
+    if (op.kind == PWK_QPHASE_C) {
+      gx = col - n / 2; gy = row - n / 2;
+    } else {
+      gx = (col < n / 2) ? col : col - n;
+      gy = (row < n / 2) ? row : row - n;
+    }
+    const cx<double> f = quad_phase(gx, gy, p[FP_SX], p[FP_SY], p[FP_COEF], p[FP_SGN],
+                                    (op.flags & PWF_MUL2PI) != 0);
     const cx<double> vd = {(double)v.x, (double)v.y};
-    const cx<double> r = {__dsub_rn(__dmul_rn(vd.x, f.x), __dmul_rn(vd.y, f.y)),
-                          __dadd_rn(__dmul_rn(vd.x, f.y), __dmul_rn(vd.y, f.x))};
-    v.x = (T)r.x;
-    v.y = (T)r.y;
+    v.x = (T)__dsub_rn(__dmul_rn(vd.x, f.x), __dmul_rn(vd.y, f.y));
+    v.y = (T)__dadd_rn(__dmul_rn(vd.x, f.y), __dmul_rn(vd.y, f.x));
   }
   return v;
 }
@@ -77,10 +98,16 @@ __device__ __forceinline__ cx<T> pointwise(cx<T> v, int mode, int row, int col, 
 // rows, 64 contiguous bytes per block); the sibling tile that owns the other rows
 // is then placed 8 workgroups away so that both land on the same XCD/L2 under the
 // round-robin dispatch (a speed hint only -- any placement is correct).
-template <int N, int E, int LINES, int TILES, int AXIS, int BR, int BC>
+// SEQ > 1: the tile still spans LINES lines, but only LINES / SEQ of them are processed at a
+// time -- each thread owns the same position of SEQ lines and walks them one after the other
+// (smaller workgroups, two of them resident per CU, and the loads of line s+1 are in flight
+// while line s is transformed).
+template <int N, int E, int LINES, int TILES, int AXIS, int BR, int BC, int SEQ = 1>
 struct TileMap {
   static constexpr int TL = N / E;
-  static constexpr int TILE_THREADS = LINES * TL;
+  static constexpr int PAR = LINES / SEQ;            // lines processed concurrently
+  static constexpr int TILE_THREADS = PAR * TL;
+  unsigned seq_stride;  // element offset from line s to line s+1 of the same thread
   int line, t;      // which line of the tile / position inside the line
   int lds_line;     // line slot inside the workgroup's LDS
   int row0, col0;   // first row (AXIS 0) or column (AXIS 1) of the tile
@@ -95,6 +122,7 @@ struct TileMap {
       if constexpr (BR == 1) {
         row0 = tile * LINES;
         line = tid / TL; t = tid % TL;
+        static_assert(SEQ == 1 || PAR == 1, "canonical rows: sequential lines need PAR == 1");
       } else {
         static_assert(BR % LINES == 0, "row tiles cover whole or 1/2^k block rows");
         static_assert((N / E) % BC == 0, "threads per line must cover whole blocks");
@@ -104,11 +132,12 @@ struct TileMap {
           tile = (grp * 8 + in % 8) * SUB + in / 8;
         }
         row0 = tile * LINES;
-        const int bc = tid % BC, br = (tid / BC) % LINES, q = tid / (BC * LINES);
+        const int bc = tid % BC, br = (tid / BC) % PAR, q = tid / (BC * PAR);
         line = br; t = q * BC + bc;
       }
       base = (unsigned)layout_index<BR, BC>(row0 + line, t, pitch);
       stride = (unsigned)TL * BR;
+      seq_stride = (BR == 1) ? (unsigned)PAR * pitch : (unsigned)PAR * BC;  // next rows of the block
     } else {
       row0 = 0; col0 = tile * LINES;
       if constexpr (BR == 1) {
@@ -116,17 +145,18 @@ struct TileMap {
       } else {
         static_assert(LINES == BC, "column tiles span exactly one block column");
         static_assert((N / E) % BR == 0, "threads per line must cover whole blocks");
-        const int bc = tid % BC, br = (tid / BC) % BR, q = tid / (BC * BR);
+        const int bc = tid % PAR, br = (tid / PAR) % BR, q = tid / (PAR * BR);
         line = bc; t = q * BR + br;
       }
       base = (unsigned)layout_index<BR, BC>(t, col0 + line, pitch);
       stride = (unsigned)(TL / BR) * pitch;
+      seq_stride = (unsigned)PAR;  // next columns of the block
     }
-    lds_line = (tid_wg / TILE_THREADS) * LINES + line;
+    lds_line = (tid_wg / TILE_THREADS) * PAR + line;
   }
-  // (row, col) of the element at position t + kp*TL along the line
-  __device__ __forceinline__ int row(int kp) const { return AXIS == 0 ? row0 + line : t + kp * TL; }
-  __device__ __forceinline__ int col(int kp) const { return AXIS == 0 ? t + kp * TL : col0 + line; }
+  // (row, col) of the element at position t + kp*TL along the line (sequential line s)
+  __device__ __forceinline__ int row(int kp, int s = 0) const { return AXIS == 0 ? row0 + line + s * PAR : t + kp * TL; }
+  __device__ __forceinline__ int col(int kp, int s = 0) const { return AXIS == 0 ? t + kp * TL : col0 + line + s * PAR; }
 };
 
 template <typename T, int N, bool SPLIT>
@@ -134,85 +164,93 @@ constexpr size_t line_lds_bytes() {
   return (size_t)lds_line_slots<N>() * (SPLIT ? sizeof(T) : 2 * sizeof(T));
 }
 
-// One FFT per line.  DIR = +1 forward, -1 inverse (unnormalised; ``scale`` carries 1/N).
-template <typename T, int N, int E, int LINES, int TILES, int AXIS, int BR, int BC, bool SPLIT,
-          int DIR, int MINW>
-__global__ void __launch_bounds__(TILES* LINES* N / E, MINW)
-    fft_pass_kernel(FftPassArgs a) {
-  const int item = blockIdx.y;
-  const double* p = a.params ? a.params + (size_t)item * FP_STRIDE : nullptr;
-  if (p && p[FP_ENABLE] == 0.0) return;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  const TileMap<N, E, LINES, TILES, AXIS, BR, BC> m(blockIdx.x, threadIdx.x, a.pitch);
-  cx<T>* f = reinterpret_cast<cx<T>*>(a.field) + (size_t)item * a.item_stride;  // wave-uniform
-  void* lds = smem + (size_t)m.lds_line * line_lds_bytes<T, N, SPLIT>();
-
-  cx<T> v[E];
+template <typename T, int E, typename Map>
+__device__ __forceinline__ void apply_list(cx<T>* v, const PwOp* list, int count, const PassArgs& a,
+                                           int item, const Map& m, int n, int sq = 0) {
+  for (int o = 0; o < count; ++o) {
+    const PwOp op = list[o];
+    const double* p = a.blocks + ((size_t)op.block * a.batch + item) * FP_STRIDE;
+    if (p[FP_ENABLE] == 0.0) continue;
 #pragma unroll
-  for (int k = 0; k < E; ++k) v[k] = f[m.base + (unsigned)k * m.stride];
-  if (a.pre_mode) {
-#pragma unroll
-    for (int k = 0; k < E; ++k) v[k] = pointwise(v[k], a.pre_mode, m.row(k), m.col(k), N, p);
-  }
-
-  fft_stages<T, N, E, DIR, SPLIT>(v, lds, m.t, reinterpret_cast<const cx<T>*>(a.tw));
-
-  const T sc = (T)a.scale;
-#pragma unroll
-  for (int k = 0; k < E; ++k) {
-    const int kp = outslot<N, E>(k);
-    cx<T> o = v[k];
-    if (a.post_mode) o = pointwise(o, a.post_mode, m.row(kp), m.col(kp), N, p);
-    o.x *= sc; o.y *= sc;
-    f[m.base + (unsigned)kp * m.stride] = o;
+    for (int k = 0; k < E; ++k) {
+      v[k] = apply_pw(v[k], op, p, m.row(k, sq), m.col(k, sq), n);
+    }
   }
 }
 
-// Fused middle pass of ptp: forward FFT along the line, multiply by
-// H = exp(-i coef (fx^2 + fy^2)) (natural-order signed frequencies,
-// wfo.py:464-468), inverse FFT along the line.
-template <typename T, int N, int E, int LINES, int TILES, int AXIS, int BR, int BC, bool SPLIT,
-          int MINW>
-__global__ void __launch_bounds__(TILES* LINES* N / E, MINW)
-    fft_ptp_mid_kernel(FftPassArgs a) {
-  const int item = blockIdx.y;
-  const double* p = a.params + (size_t)item * FP_STRIDE;
-  if (p[FP_ENABLE] == 0.0) return;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// Forward transform of the thread's line slots, natural slot order in and out; the
+// inverse is conj(FFT(conj x)) so the direction is a per-item runtime flag.
+template <typename T, int N, int E, bool SPLIT>
+__device__ __forceinline__ void line_fft(cx<T>* v, void* lds, int t, const cx<T>* tw, bool inverse) {
+  if (inverse) {
+#pragma unroll
+    for (int k = 0; k < E; ++k) v[k].y = -v[k].y;
+  }
+  fft_stages<T, N, E, +1, SPLIT>(v, lds, t, tw);
+  unpermute_slots<N, E>(v);
+  if (inverse) {
+#pragma unroll
+    for (int k = 0; k < E; ++k) v[k].y = -v[k].y;
+  }
+}
 
-  const TileMap<N, E, LINES, TILES, AXIS, BR, BC> m(blockIdx.x, threadIdx.x, a.pitch);
-  cx<T>* f = reinterpret_cast<cx<T>*>(a.field) + (size_t)item * a.item_stride;
+// THE pass kernel: load tile -> pre ops -> [FFT] -> mid ops -> [FFT] -> post ops -> store,
+// in place.  Which transforms run, their direction and every operator are per-item
+// runtime data, so one launch serves a batch whose items disagree (wavelengths whose
+// planners skip a step, Monte-Carlo draws).  Examples (wfo.py lines in the header):
+//   stw   = rows[pre S | FFT] , cols[FFT | mid S Qc 1/N]
+//   wts   = rows[pre S P | FFT] , cols[FFT | mid S 1/N]
+//   ptp   = rows[FFT] , cols[FFT | mid H 1/N | IFFT] , rows[IFFT | mid 1/N]
+// and, because a 2-D transform may equally run columns first, the last pass of one
+// operator and the first pass of the next share an axis and are emitted as ONE pass:
+//   ... ptp | lens | ptp ... = rows[IFFT | mid 1/N, lens | FFT].
+template <typename T, int N, int E, int LINES, int TILES, int AXIS, int BR, int BC, bool SPLIT,
+          int MINW, int SEQ = 1>
+__global__ void __launch_bounds__(TILES* LINES* N / E / SEQ, MINW)
+    fused_pass_kernel(PassArgs a) {
+  const int item = blockIdx.y;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const TileMap<N, E, LINES, TILES, AXIS, BR, BC, SEQ> m(blockIdx.x, threadIdx.x, a.pitch);
+  const double* c1 = a.fft1 >= 0 ? a.blocks + ((size_t)a.fft1 * a.batch + item) * FP_STRIDE : nullptr;
+  const double* c2 = a.fft2 >= 0 ? a.blocks + ((size_t)a.fft2 * a.batch + item) * FP_STRIDE : nullptr;
+  const bool do1 = c1 && c1[FC_ENABLE] != 0.0, do2 = c2 && c2[FC_ENABLE] != 0.0;
+  // an item with nothing enabled in this pass is left untouched (no load, no store)
+  bool any = do1 || do2;
+  for (int o = 0; o < a.n_pre && !any; ++o) any = a.blocks[((size_t)a.pre[o].block * a.batch + item) * FP_STRIDE] != 0.0;
+  for (int o = 0; o < a.n_mid && !any; ++o) any = a.blocks[((size_t)a.mid[o].block * a.batch + item) * FP_STRIDE] != 0.0;
+  for (int o = 0; o < a.n_post && !any; ++o) any = a.blocks[((size_t)a.post[o].block * a.batch + item) * FP_STRIDE] != 0.0;
+  if (!any) return;
+
+  cx<T>* f = reinterpret_cast<cx<T>*>(a.field) + (size_t)item * a.item_stride;  // wave-uniform
   void* lds = smem + (size_t)m.lds_line * line_lds_bytes<T, N, SPLIT>();
   const cx<T>* tw = reinterpret_cast<const cx<T>*>(a.tw);
 
-  cx<T> v[E];
+  static_assert(SEQ == 1 || SEQ == 2, "one or two sequential lines");
+  // Two separately named register files (a 2-D array would be demoted to scratch).
+  cx<T> va[E], vb[E];
 #pragma unroll
-  for (int k = 0; k < E; ++k) v[k] = f[m.base + (unsigned)k * m.stride];
-
-  fft_stages<T, N, E, +1, SPLIT>(v, lds, m.t, tw);
-  unpermute_slots<N, E>(v);
-
-  const double sx = p[FP_SX], sy = p[FP_SY], coef = p[FP_COEF];
+  for (int k = 0; k < E; ++k) va[k] = f[m.base + (unsigned)k * m.stride];
+  if constexpr (SEQ == 2) {
 #pragma unroll
-  for (int k = 0; k < E; ++k) {
-    const int r = m.row(k), c = m.col(k);
-    const int gy = (r < N / 2) ? r : r - N;
-    const int gx = (c < N / 2) ? c : c - N;
-    const cx<double> h = quad_phase(gx, gy, sx, sy, coef, -1.0, false);
-    const cx<double> vd = {(double)v[k].x, (double)v[k].y};
-    v[k].x = (T)__dsub_rn(__dmul_rn(vd.x, h.x), __dmul_rn(vd.y, h.y));
-    v[k].y = (T)__dadd_rn(__dmul_rn(vd.x, h.y), __dmul_rn(vd.y, h.x));
+    for (int k = 0; k < E; ++k) vb[k] = f[m.base + m.seq_stride + (unsigned)k * m.stride];
   }
 
-  __syncthreads();  // the forward transform's last LDS reads precede the next writes
-  fft_stages<T, N, E, -1, SPLIT>(v, lds, m.t, tw);
-
-  const T sc = (T)a.scale;
+  auto process = [&](cx<T>* v, int sq) __attribute__((always_inline)) {
+    apply_list<T, E>(v, a.pre, a.n_pre, a, item, m, N, sq);
+    if (do1) line_fft<T, N, E, SPLIT>(v, lds, m.t, tw, c1[FC_INVERSE] != 0.0);
+    apply_list<T, E>(v, a.mid, a.n_mid, a, item, m, N, sq);
+    if (do2) {
+      if (do1) __syncthreads();  // the first transform's last LDS reads precede new writes
+      line_fft<T, N, E, SPLIT>(v, lds, m.t, tw, c2[FC_INVERSE] != 0.0);
+    }
+    apply_list<T, E>(v, a.post, a.n_post, a, item, m, N, sq);
 #pragma unroll
-  for (int k = 0; k < E; ++k) {
-    const int kp = outslot<N, E>(k);
-    f[m.base + (unsigned)kp * m.stride] = {v[k].x * sc, v[k].y * sc};
+    for (int k = 0; k < E; ++k) f[m.base + (unsigned)sq * m.seq_stride + (unsigned)k * m.stride] = v[k];
+  };
+  process(va, 0);
+  if constexpr (SEQ == 2) {
+    __syncthreads();  // line 0 is done with the exchange area
+    process(vb, 1);
   }
 }
 

@@ -118,20 +118,22 @@ struct FftCfg {
   static constexpr int E = 16;
   // rows of a block row handled by one row tile: all four, except at N = 4096 where four
   // lines of 4096 points do not fit the register file of a spill-free workgroup
-  static constexpr int ROW_LINES = (N >= 4096) ? BR / 2 : BR;
+  static constexpr int ROW_LINES = (N >= 2048) ? BR / 2 : BR;  // 256-thread tiles at 2048 measured +29 %
   static constexpr int COL_LINES = BC;
   static constexpr int ROW_THREADS = ROW_LINES * N / E, COL_THREADS = COL_LINES * N / E;
   static constexpr int ROW_TILES = (ROW_THREADS >= 128) ? 1 : 128 / ROW_THREADS;
   static constexpr int COL_TILES = (COL_THREADS >= 128) ? 1 : 128 / COL_THREADS;
-  // split the LDS exchange (re, then im) when a full-complex one would exceed 64 KiB
-  static constexpr bool ROW_SPLIT = (size_t)ROW_LINES * ROW_TILES * line_lds_bytes<T, N, false>() > 72 * 1024;
-  static constexpr bool COL_SPLIT = (size_t)COL_LINES * COL_TILES * line_lds_bytes<T, N, false>() > 72 * 1024;
+  // Exchange whole complex numbers through LDS (two barriers per exchange) whenever the
+  // tile fits; otherwise real and imaginary parts take turns in half the space.  Register
+  // pressure (~230 VGPRs) already limits these kernels to 8 waves per CU, so using up to
+  // 144 KiB of the 160 KiB LDS costs no occupancy (measured +3..7 %, profiles/r01_fftbench_v4).
+  static constexpr bool ROW_SPLIT = (size_t)ROW_LINES * ROW_TILES * line_lds_bytes<T, N, false>() > 144 * 1024;
+  static constexpr bool COL_SPLIT = (size_t)COL_LINES * COL_TILES * line_lds_bytes<T, N, false>() > 144 * 1024;
   static constexpr int MINW = 1;
 };
 
 template <typename Kern>
-int launch_fft(paos_ctx* c, Kern kern, dim3 grid, dim3 block, size_t lds, const FftPassArgs& a,
-               int kind) {
+int launch_pass(paos_ctx* c, Kern kern, dim3 grid, dim3 block, size_t lds, const PassArgs& a, int kind) {
   // kernels that need more than the default 64 KiB of dynamic LDS opt in once
   static thread_local std::unordered_set<const void*> configured;
   if (lds > 48 * 1024 && !configured.count((const void*)kern)) {
@@ -139,7 +141,8 @@ int launch_fft(paos_ctx* c, Kern kern, dim3 grid, dim3 block, size_t lds, const 
                                   (int)lds));
     configured.insert((const void*)kern);
   }
-  const bool timed = (kind == c->prof_kind) && (c->prof_used + 2 <= c->prof_events.size());
+  const bool timed = (c->prof_kind == kind || c->prof_kind == PAOS_KERNEL_PASS_ANY) &&
+                     (c->prof_used + 2 <= c->prof_events.size());
   if (timed) HIPCHK(c, hipEventRecord(c->prof_events[c->prof_used], c->stream));
   hipLaunchKernelGGL(kern, grid, block, lds, c->stream, a);
   HIPCHK(c, hipGetLastError());
@@ -150,97 +153,135 @@ int launch_fft(paos_ctx* c, Kern kern, dim3 grid, dim3 block, size_t lds, const 
   return PAOS_OK;
 }
 
-template <typename T, int N, int AXIS, int DIR>
-int fft_pass(paos_ctx* c, const double* dparams, int pre, int post, double scale) {
+template <typename T, int N, int AXIS>
+int pass_launch(paos_ctx* c, const PassArgs& a) {
   using C = FftCfg<T, N>;
   constexpr int BC = C::BC;
   constexpr int LINES = AXIS == 0 ? C::ROW_LINES : C::COL_LINES;
   constexpr int TILES = AXIS == 0 ? C::ROW_TILES : C::COL_TILES;
   constexpr bool SPLIT = AXIS == 0 ? C::ROW_SPLIT : C::COL_SPLIT;
-  FftPassArgs a{};
-  a.field = c->field; a.tw = c->tw; a.params = dparams; a.pre_mode = pre; a.post_mode = post;
-  a.scale = scale; a.pitch = c->pitch; a.item_stride = c->item_stride;
   const dim3 grid(N / LINES / TILES, c->batch), block(TILES * LINES * N / C::E);
   const size_t lds = (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT>();
-  return launch_fft(c, fft_pass_kernel<T, N, C::E, LINES, TILES, AXIS, BR, BC, SPLIT, DIR, C::MINW>,
-                    grid, block, lds, a, AXIS == 0 ? PAOS_KERNEL_FFT_ROWS : PAOS_KERNEL_FFT_COLS);
+  return launch_pass(c, fused_pass_kernel<T, N, C::E, LINES, TILES, AXIS, BR, BC, SPLIT, C::MINW>, grid,
+                     block, lds, a, AXIS == 0 ? PAOS_KERNEL_PASS_ROWS : PAOS_KERNEL_PASS_COLS);
 }
 
 template <typename T, int N>
-int fft_ptp_mid(paos_ctx* c, const double* dparams, double scale) {
-  using C = FftCfg<T, N>;
-  constexpr int BC = C::BC;
-  constexpr int LINES = C::COL_LINES, TILES = C::COL_TILES;
-  constexpr bool SPLIT = C::COL_SPLIT;
-  FftPassArgs a{};
-  a.field = c->field; a.tw = c->tw; a.params = dparams; a.scale = scale;
-  a.pitch = c->pitch; a.item_stride = c->item_stride;
-  const dim3 grid(N / LINES / TILES, c->batch), block(TILES * LINES * N / C::E);
-  const size_t lds = (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT>();
-  return launch_fft(c, fft_ptp_mid_kernel<T, N, C::E, LINES, TILES, 1, BR, BC, SPLIT, C::MINW>, grid,
-                    block, lds, a, PAOS_KERNEL_PTP_MID);
-}
-
-// ptp = rows fwd | columns fwd * H * columns inv | rows inv ; 1/N^2 overall (two ortho 2-D FFTs)
-template <typename T, int N>
-int do_ptp(paos_ctx* c, const double* dp) {
-  int rc = fft_pass<T, N, 0, +1>(c, dp, 0, 0, 1.0);
-  if (rc) return rc;
-  rc = fft_ptp_mid<T, N>(c, dp, 1.0 / N);
-  if (rc) return rc;
-  return fft_pass<T, N, 0, -1>(c, dp, 0, 0, 1.0 / N);
-}
-
-// stw = S Qc FFT(S u): rows (S on load), columns (S Qc / N on store)
-template <typename T, int N, int DIR>
-int do_stw(paos_ctx* c, const double* dp) {
-  int rc = fft_pass<T, N, 0, DIR>(c, dp, PW_SIGN, 0, 1.0);
-  if (rc) return rc;
-  return fft_pass<T, N, 1, DIR>(c, dp, 0, PW_SIGN | PW_PHASE, 1.0 / N);
-}
-
-// wts = S FFT(S P u): rows (P S on load), columns (S / N on store)
-template <typename T, int N, int DIR>
-int do_wts(paos_ctx* c, const double* dp) {
-  int rc = fft_pass<T, N, 0, DIR>(c, dp, PW_SIGN | PW_PHASE, 0, 1.0);
-  if (rc) return rc;
-  return fft_pass<T, N, 1, DIR>(c, dp, 0, PW_SIGN, 1.0 / N);
-}
-
-enum FftOp { OP_PTP, OP_STW_F, OP_STW_I, OP_WTS_F, OP_WTS_I };
-
-template <typename T, int N>
-int fft_op_n(paos_ctx* c, FftOp op, const double* dp) {
-  switch (op) {
-    case OP_PTP: return do_ptp<T, N>(c, dp);
-    case OP_STW_F: return do_stw<T, N, +1>(c, dp);
-    case OP_STW_I: return do_stw<T, N, -1>(c, dp);
-    case OP_WTS_F: return do_wts<T, N, +1>(c, dp);
-    case OP_WTS_I: return do_wts<T, N, -1>(c, dp);
-  }
-  return PAOS_EINVAL;
+int pass_n(paos_ctx* c, int axis, const PassArgs& a) {
+  return axis == 0 ? pass_launch<T, N, 0>(c, a) : pass_launch<T, N, 1>(c, a);
 }
 
 template <typename T>
-int fft_op_t(paos_ctx* c, FftOp op, const double* dp) {
+int pass_t(paos_ctx* c, int axis, const PassArgs& a) {
   switch (c->n) {
-    case 64: return fft_op_n<T, 64>(c, op, dp);
-    case 128: return fft_op_n<T, 128>(c, op, dp);
-    case 256: return fft_op_n<T, 256>(c, op, dp);
-    case 512: return fft_op_n<T, 512>(c, op, dp);
-    case 1024: return fft_op_n<T, 1024>(c, op, dp);
-    case 2048: return fft_op_n<T, 2048>(c, op, dp);
-    case 4096: return fft_op_n<T, 4096>(c, op, dp);
+    case 64: return pass_n<T, 64>(c, axis, a);
+    case 128: return pass_n<T, 128>(c, axis, a);
+    case 256: return pass_n<T, 256>(c, axis, a);
+    case 512: return pass_n<T, 512>(c, axis, a);
+    case 1024: return pass_n<T, 1024>(c, axis, a);
+    case 2048: return pass_n<T, 2048>(c, axis, a);
+    case 4096: return pass_n<T, 4096>(c, axis, a);
   }
   return fail(c, PAOS_EUNSUPPORTED, "grid size must be a power of two in 64..4096");
 }
 
-int fft_op(paos_ctx* c, FftOp op, const double* host_params) {
-  if (!c || !host_params) return fail(c, PAOS_EINVAL, "null argument");
-  const double* dp = nullptr;
-  int rc = arena_push(c, host_params, (size_t)c->batch * FP_STRIDE, &dp);
+int check_ops(paos_ctx* c, const paos_pw_op* ops, int count, int n_blocks) {
+  if (count < 0 || count > PAOS_MAX_PW) return fail(c, PAOS_EINVAL, "too many pointwise operators in a pass");
+  for (int o = 0; o < count; ++o) {
+    if (ops[o].kind < PAOS_PW_SIGN || ops[o].kind > PAOS_PW_SCALE) return fail(c, PAOS_EINVAL, "unknown pointwise operator");
+    if (ops[o].block < 0 || ops[o].block >= n_blocks) return fail(c, PAOS_EINVAL, "operator block index out of range");
+  }
+  return PAOS_OK;
+}
+
+int run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks, int n_blocks) {
+  if (!c || !passes || !blocks || n_passes < 0 || n_blocks < 1) return fail(c, PAOS_EINVAL, "bad pass program");
+  const double* dblocks = nullptr;
+  int rc = arena_push(c, blocks, (size_t)n_blocks * c->batch * FP_STRIDE, &dblocks);
   if (rc) return rc;
-  return c->precision == PAOS_F64 ? fft_op_t<double>(c, op, dp) : fft_op_t<float>(c, op, dp);
+  for (int i = 0; i < n_passes; ++i) {
+    const paos_pass& p = passes[i];
+    if ((rc = check_ops(c, p.pre, p.n_pre, n_blocks))) return rc;
+    if ((rc = check_ops(c, p.mid, p.n_mid, n_blocks))) return rc;
+    if ((rc = check_ops(c, p.post, p.n_post, n_blocks))) return rc;
+    if (p.fft1 >= n_blocks || p.fft2 >= n_blocks) return fail(c, PAOS_EINVAL, "transform control block out of range");
+    PassArgs a{};
+    a.field = c->field; a.tw = c->tw; a.blocks = dblocks; a.batch = c->batch;
+    a.fft1 = p.fft1; a.fft2 = p.fft2; a.n_pre = p.n_pre; a.n_mid = p.n_mid; a.n_post = p.n_post;
+    static_assert(sizeof(PwOp) == sizeof(paos_pw_op), "ABI op layout");
+    std::memcpy(a.pre, p.pre, sizeof(a.pre));
+    std::memcpy(a.mid, p.mid, sizeof(a.mid));
+    std::memcpy(a.post, p.post, sizeof(a.post));
+    a.pitch = c->pitch; a.item_stride = c->item_stride;
+    if (p.axis == 0 || p.axis == 1) {
+      rc = c->precision == PAOS_F64 ? pass_t<double>(c, p.axis, a) : pass_t<float>(c, p.axis, a);
+      if (rc) return rc;
+    } else if (p.axis == -1) {
+      if (p.fft1 >= 0 || p.fft2 >= 0 || p.n_mid || p.n_post)
+        return fail(c, PAOS_EINVAL, "a transform-free pass carries its operators in the pre list");
+      const dim3 grid(pw_blocks(c), c->batch), block(kPwThreads);
+      if (c->precision == PAOS_F64)
+        hipLaunchKernelGGL((pointwise_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream, a, c->n);
+      else
+        hipLaunchKernelGGL((pointwise_kernel<float, BR, Lay<float>::BC>), grid, block, 0, c->stream, a, c->n);
+      HIPCHK(c, hipGetLastError());
+    } else {
+      return fail(c, PAOS_EINVAL, "pass axis must be 0, 1 or -1");
+    }
+  }
+  return PAOS_OK;
+}
+
+// ---- the reference's primitives as pass programs --------------------------------------
+struct Program {
+  std::vector<paos_pass> passes;
+  std::vector<double> blocks;
+  int batch;
+  explicit Program(int b) : batch(b) {}
+  // block set with the enable flags of `src` (stride FP_STRIDE) and the given payload
+  int add_block(const double* src, double v1, double v2, double v3, double v4, bool copy) {
+    const int id = (int)(blocks.size() / ((size_t)batch * FP_STRIDE));
+    for (int i = 0; i < batch; ++i) {
+      const double* s = src + (size_t)i * FP_STRIDE;
+      if (copy) blocks.insert(blocks.end(), s, s + FP_STRIDE);
+      else blocks.insert(blocks.end(), {s[FP_ENABLE], v1, v2, v3, v4});
+    }
+    return id;
+  }
+  paos_pass& add_pass(int axis, int fft1, int fft2) {
+    paos_pass p{};
+    p.axis = axis; p.fft1 = fft1; p.fft2 = fft2;
+    passes.push_back(p);
+    return passes.back();
+  }
+};
+void push(paos_pw_op* list, int& count, int kind, int block, int flags = 0) { list[count++] = {kind, flags, block}; }
+
+enum FftOp { OP_PTP, OP_STW, OP_WTS };
+
+int fft_op(paos_ctx* c, FftOp op, const double* params, int inverse) {
+  if (!c || !params) return fail(c, PAOS_EINVAL, "null argument");
+  Program g(c->batch);
+  const double inv_n = 1.0 / c->n;
+  const int par = g.add_block(params, 0, 0, 0, 0, true);
+  const int scl = g.add_block(params, 0, 0, inv_n, 0, false);
+  if (op == OP_PTP) {
+    const int fwd = g.add_block(params, 0, 0, 0, 0, false), inv = g.add_block(params, 1, 0, 0, 0, false);
+    g.add_pass(0, fwd, -1);
+    { paos_pass& p = g.add_pass(1, fwd, inv); push(p.mid, p.n_mid, PAOS_PW_QPHASE_NATURAL, par); push(p.mid, p.n_mid, PAOS_PW_SCALE, scl); }
+    { paos_pass& p = g.add_pass(0, inv, -1); push(p.mid, p.n_mid, PAOS_PW_SCALE, scl); }
+  } else {
+    const int ctl = g.add_block(params, inverse ? 1.0 : 0.0, 0, 0, 0, false);
+    paos_pass& r = g.add_pass(0, ctl, -1);
+    push(r.pre, r.n_pre, PAOS_PW_SIGN, par);
+    if (op == OP_WTS) push(r.pre, r.n_pre, PAOS_PW_QPHASE_CENTRED, par);
+    paos_pass& q = g.add_pass(1, ctl, -1);
+    push(q.mid, q.n_mid, PAOS_PW_SIGN, par);
+    if (op == OP_STW) push(q.mid, q.n_mid, PAOS_PW_QPHASE_CENTRED, par);
+    push(q.mid, q.n_mid, PAOS_PW_SCALE, scl);
+  }
+  return run_passes(c, g.passes.data(), (int)g.passes.size(), g.blocks.data(),
+                    (int)(g.blocks.size() / ((size_t)c->batch * FP_STRIDE)));
 }
 
 template <typename T>
@@ -507,24 +548,20 @@ int paos_norm2(paos_ctx* c, double* host_out) {
 
 int paos_phase(paos_ctx* c, const double* params, int mul2pi) {
   if (!c || !params) return fail(c, PAOS_EINVAL, "null argument");
-  const double* dp = nullptr;
-  int rc = arena_push(c, params, (size_t)c->batch * FP_STRIDE, &dp);
-  if (rc) return rc;
-  const int mode = PW_PHASE | (mul2pi ? PW_MUL2PI : 0);
-  const dim3 grid(pw_blocks(c), c->batch), block(kPwThreads);
-  if (c->precision == PAOS_F64)
-    hipLaunchKernelGGL((phase_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream, (cx<double>*)c->field,
-                       dp, c->n, c->pitch, c->item_stride, mode);
-  else
-    hipLaunchKernelGGL((phase_kernel<float, BR, Lay<float>::BC>), grid, block, 0, c->stream, (cx<float>*)c->field, dp,
-                       c->n, c->pitch, c->item_stride, mode);
-  HIPCHK(c, hipGetLastError());
-  return PAOS_OK;
+  Program g(c->batch);
+  const int par = g.add_block(params, 0, 0, 0, 0, true);
+  paos_pass& p = g.add_pass(-1, -1, -1);
+  push(p.pre, p.n_pre, PAOS_PW_QPHASE_CENTRED, par, mul2pi ? PAOS_PWF_MUL2PI : 0);
+  return run_passes(c, g.passes.data(), 1, g.blocks.data(), 1);
 }
 
-int paos_ptp(paos_ctx* c, const double* params) { return fft_op(c, OP_PTP, params); }
-int paos_stw(paos_ctx* c, const double* params, int inverse) { return fft_op(c, inverse ? OP_STW_I : OP_STW_F, params); }
-int paos_wts(paos_ctx* c, const double* params, int inverse) { return fft_op(c, inverse ? OP_WTS_I : OP_WTS_F, params); }
+int paos_run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks, int n_blocks) {
+  return run_passes(c, passes, n_passes, blocks, n_blocks);
+}
+
+int paos_ptp(paos_ctx* c, const double* params) { return fft_op(c, OP_PTP, params, 0); }
+int paos_stw(paos_ctx* c, const double* params, int inverse) { return fft_op(c, OP_STW, params, inverse); }
+int paos_wts(paos_ctx* c, const double* params, int inverse) { return fft_op(c, OP_WTS, params, inverse); }
 
 int paos_zernike(paos_ctx* c, int nmax, int kdim, const double* table, const double* params,
                  int param_stride, double* host_wfe) {

@@ -70,20 +70,26 @@ __global__ void export_kernel(const cx<T>* f, double* out, int n, unsigned pitch
   }
 }
 
-// ---- lens / generic quadratic phase (pointwise() of fft_kernels.h) ------------
+// ---- stand-alone pointwise pass (op list without a transform) --------------------
+// Used when a lens (wfo.py:359-366) is not adjacent to an FFT pass it could ride on.
 template <typename T, int BR, int BC>
-__global__ void phase_kernel(cx<T>* field, const double* params, int n, unsigned pitch,
-                             unsigned item_stride, int mode) {
+__global__ void pointwise_kernel(PassArgs a, int n) {
   const int item = blockIdx.y;
-  const double* p = params + (size_t)item * FP_STRIDE;
-  if (p[FP_ENABLE] == 0.0) return;
-  cx<T>* f = field + (size_t)item * item_stride;
-  const size_t total = item_stride;
+  bool any = false;
+  for (int o = 0; o < a.n_pre && !any; ++o) any = a.blocks[((size_t)a.pre[o].block * a.batch + item) * FP_STRIDE] != 0.0;
+  if (!any) return;
+  cx<T>* f = reinterpret_cast<cx<T>*>(a.field) + (size_t)item * a.item_stride;
+  const size_t total = a.item_stride;
   size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
     int r, c;
-    if (!layout_unmap<BR, BC>(m, n, pitch, r, c)) continue;
-    f[m] = pointwise(f[m], mode, r, c, n, p);
+    if (!layout_unmap<BR, BC>(m, n, a.pitch, r, c)) continue;
+    cx<T> v = f[m];
+    for (int o = 0; o < a.n_pre; ++o) {
+      const double* p = a.blocks + ((size_t)a.pre[o].block * a.batch + item) * FP_STRIDE;
+      if (p[FP_ENABLE] != 0.0) v = apply_pw(v, a.pre[o], p, r, c, n);
+    }
+    f[m] = v;
   }
 }
 

@@ -1,0 +1,147 @@
+"""Pass compiler: turn a run of lens / stw / ptp / wts operators into fused HBM passes.
+
+Every operator of the reference between two "breakers" (aperture, stop, Zernike,
+saving a surface) is a chain of diagonal multiplications and 1-D transforms along
+the rows or the columns of the field:
+
+    lens : diag(exp(-2 pi i c (x^2+y^2)))                       wfo.py:359-366
+    stw  : S . Qc . F_B F_A . S          (F = fft or ifft)        wfo.py:491-509
+    wts  : S . F_B F_A . S . P                                    wfo.py:528-545
+    ptp  : F_A^-1 F_B^-1 . H . F_B F_A                            wfo.py:462-472
+
+where {A, B} = {rows, columns} in EITHER order (a 2-D transform is separable), S is the
+checkerboard that replaces the fftshift / ifftshift pair and Qc / P / H are quadratic
+phases.  One GPU pass can do ``diag, F_A, diag, F_A', diag`` on a resident tile, so the
+compiler picks A for each operator = the axis the previous operator ended on and glues
+the boundary transforms of neighbours into one pass.  Cost per 2-D transform drops from
+two passes (plus one per lens) to about one.
+
+The compiler is batch-aware: every operator carries one parameter block per batch item
+whose first entry is an enable flag, so items whose planners disagree (a ptp skipped
+below wl/1000, II vs OI regimes) still share the pass sequence.
+"""
+import numpy as np
+
+from . import _lib
+
+_OFF = [0.0, 0.0, 0.0, 0.0, 0.0]
+
+
+class PassCompiler:
+    def __init__(self, batch, n):
+        self.batch, self.n = int(batch), int(n)
+        self._reset()
+
+    def _reset(self):
+        self.blocks = []    # each: list of `batch` 5-double rows
+        self.passes = []    # emitted, in order
+        self.open = None    # last pass, if its second transform slot is still free
+        self.tail = []      # pointwise operators not yet attached to a pass
+
+    # ---- helpers -------------------------------------------------------------------
+    def _block(self, rows):
+        self.blocks.append([list(r) if r is not None else _OFF for r in rows])
+        return len(self.blocks) - 1
+
+    def _derived(self, rows, v1=0.0, v2=0.0, v3=0.0, v4=0.0):
+        """Block with the enable flags of ``rows`` and a fixed payload."""
+        return self._block([[1.0, v1, v2, v3, v4] if (r is not None and r[0] != 0.0) else None
+                            for r in rows])
+
+    def _standalone(self, ops):
+        for i in range(0, len(ops), _lib.MAX_PW):
+            self.passes.append({"axis": -1, "pre": list(ops[i:i + _lib.MAX_PW])})
+
+    def _close_open(self):
+        """Attach pending pointwise work to the open pass (or emit it alone)."""
+        if self.open is not None:
+            if len(self.open["mid"]) + len(self.tail) <= _lib.MAX_PW:
+                self.open["mid"] += self.tail
+                self.tail = []
+            self.open = None
+        if self.tail:
+            self._standalone(self.tail)
+            self.tail = []
+
+    def _first_pass(self, pre_ops, ctl):
+        """First 1-D pass of an operator: glue onto the open pass when there is one."""
+        o = self.open
+        if o is not None and len(o["mid"]) + len(self.tail) + len(pre_ops) <= _lib.MAX_PW:
+            o["mid"] += self.tail + pre_ops
+            o["fft2"] = ctl
+            self.tail = []
+            self.open = None
+            return o["axis"]
+        if o is not None:
+            self._close_open()
+        pre = list(pre_ops)
+        if len(self.tail) + len(pre) <= _lib.MAX_PW:
+            pre = self.tail + pre  # pending lens phases ride on this pass's load
+            self.tail = []
+        else:
+            self._close_open()
+        self.passes.append({"axis": 0, "fft1": ctl, "pre": pre, "mid": [], "post": []})
+        return 0
+
+    def _open_pass(self, axis, ctl, mid_ops):
+        p = {"axis": axis, "fft1": ctl, "fft2": -1, "pre": [], "mid": list(mid_ops), "post": []}
+        self.passes.append(p)
+        self.open = p
+
+    # ---- operators (rows = one 5-double block or None per batch item) --------------------
+    def lens(self, rows):
+        if all(r is None for r in rows):
+            return
+        self.tail.append((_lib.PW_QPHASE_CENTRED, _lib.PWF_MUL2PI, self._block(rows)))
+
+    def _single(self, rows, inverse, kind):
+        if all(r is None for r in rows):
+            return
+        par = self._block(rows)
+        ctl = self._block([[1.0, 1.0 if inv else 0.0, 0, 0, 0] if r is not None else None
+                           for r, inv in zip(rows, inverse)])
+        scl = self._derived(rows, v3=1.0 / self.n)
+        sign = (_lib.PW_SIGN, 0, par)
+        phase = (_lib.PW_QPHASE_CENTRED, 0, par)
+        pre = [phase, sign] if kind == "wts" else [sign]
+        post = [sign, phase] if kind == "stw" else [sign]
+        axis = self._first_pass(pre, ctl)
+        self._open_pass(1 - axis, ctl, post + [(_lib.PW_SCALE, 0, scl)])
+
+    def stw(self, rows, inverse):
+        self._single(rows, inverse, "stw")
+
+    def wts(self, rows, inverse):
+        self._single(rows, inverse, "wts")
+
+    def ptp(self, rows):
+        if all(r is None for r in rows):
+            return
+        par = self._block(rows)
+        fwd = self._derived(rows, v1=0.0)
+        inv = self._derived(rows, v1=1.0)
+        scl = self._derived(rows, v3=1.0 / self.n)
+        axis = self._first_pass([], fwd)
+        self.passes.append({"axis": 1 - axis, "fft1": fwd, "fft2": inv, "pre": [], "post": [],
+                            "mid": [(_lib.PW_QPHASE_NATURAL, 0, par), (_lib.PW_SCALE, 0, scl)]})
+        self.open = None
+        self._open_pass(axis, inv, [(_lib.PW_SCALE, 0, scl)])
+
+    # ---- execution -----------------------------------------------------------------------
+    def pending(self):
+        return bool(self.passes or self.tail or self.open)
+
+    def program(self):
+        """Finish the current stretch; returns (passes, blocks[n][batch][5])."""
+        self._close_open()
+        passes, blocks = self.passes, np.asarray(self.blocks, dtype=np.float64).reshape(-1, self.batch, 5)
+        self._reset()
+        return passes, blocks
+
+    def flush(self, dev):
+        if not self.pending():
+            return 0
+        passes, blocks = self.program()
+        if passes:
+            dev.run_passes(passes, blocks)
+        return len(passes)

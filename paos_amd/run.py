@@ -23,6 +23,7 @@ from . import _lib
 from .abcd import ABCD
 from .aperture import EllipticalAperture, bbox_misses_grid, make_aperture
 from .coordinate_break import coordinate_break
+from .passes import PassCompiler
 from .planner import PilotBeam, jacobi_recurrence, zernike_block
 from .zernike import Zernike, norm_factors
 
@@ -146,48 +147,51 @@ def _launch_zernike(dev, plans, want_wfe=False):
     return dev.zernike(nmax, kdim, jacobi_recurrence(nmax), blocks, want_wfe=want_wfe)
 
 
-def _launch_steps(dev, plans):
-    """stw / ptp / wts in the fixed slot order every regime respects (OI: stw, ptp;
-    IO: ptp, wts; OO: stw, wts; II: ptp -- wfo.py:560-570)."""
+def _queue_steps(comp, plans):
+    """Lens and stw / ptp / wts of one surface go to the pass compiler, in the fixed slot
+    order every regime respects (OI: stw, ptp; IO: ptp, wts; OO: stw, wts; II: ptp --
+    wfo.py:560-570).  Nothing is launched here: consecutive surfaces fuse (passes.py)."""
+    comp.lens([p["lens"] for p in plans])
     for kind in ("stw", "ptp", "wts"):
-        for inverse in ((False,) if kind == "ptp" else (False, True)):
-            blocks, any_on = [], False
-            for p in plans:
-                hit = [s for s in p["steps"] if s[0] == kind and bool(s[2]) == inverse]
-                if hit:
-                    blocks.append(hit[0][1])
-                    any_on = True
-                else:
-                    blocks.append(_OFF_PHASE)
-            if not any_on:
-                continue
-            if kind == "ptp":
-                dev.ptp(blocks)
-            elif kind == "stw":
-                dev.stw(blocks, inverse)
-            else:
-                dev.wts(blocks, inverse)
+        rows, inverse = [], []
+        for p in plans:
+            hit = [s for s in p["steps"] if s[0] == kind]
+            rows.append(hit[0][1] if hit else None)
+            inverse.append(bool(hit[0][2]) if hit else False)
+        if kind == "ptp":
+            comp.ptp(rows)
+        elif kind == "stw":
+            comp.stw(rows, inverse)
+        else:
+            comp.wts(rows, inverse)
 
 
-def _walk(dev, states, chains, on_saved):
+def _walk(dev, states, chains, on_saved, stats=None):
     """Drive all items through their chains in lock-step, one surface at a time."""
     keys = [list(c.keys()) for c in chains]
     if any(k != keys[0] for k in keys[1:]):
         raise ValueError("batched chains must list the same surfaces (same keys, same order)")
+    comp = PassCompiler(len(states), dev.n)
+    npass = 0
     for key in keys[0]:
         items = [c[key] for c in chains]
         plans = [_plan_surface(st, it) for st, it in zip(states, items)]
+        saved = any(it["save"] for it in items)
+        breaker = saved or any(p["aperture"] is not None or p["stop"] or p["zernike"] is not None
+                               for p in plans)
+        if breaker:
+            npass += comp.flush(dev)  # the field must be current before a non-fusable operator
         _launch_apertures(dev, plans)
         if any(p["stop"] for p in plans):
             dev.make_stop([1.0 if p["stop"] else 0.0 for p in plans])
         want_wfe = len(plans) == 1 and bool(items[0]["save"])
         wfe = _launch_zernike(dev, plans, want_wfe=want_wfe)
-        if any(it["save"] for it in items):
+        if saved:
             on_saved(key, items, plans, wfe)
-        if any(p["lens"] is not None for p in plans):
-            dev.phase([p["lens"] if p["lens"] is not None else _OFF_PHASE for p in plans],
-                      mul2pi=True)
-        _launch_steps(dev, plans)
+        _queue_steps(comp, plans)
+    npass += comp.flush(dev)
+    if stats is not None:
+        stats["fused_passes"] = npass
 
 
 def run(pupil_diameter, wavelength, gridsize, zoom, field, opt_chain, precision="fp64", device=0):
@@ -232,7 +236,7 @@ def run(pupil_diameter, wavelength, gridsize, zoom, field, opt_chain, precision=
 
 
 def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, precision="fp64",
-              device=0, outputs=("psf",), dev=None, sync=True):
+              device=0, outputs=("psf",), dev=None, sync=True, stats=None):
     """Propagate ``B = len(opt_chains)`` wavefronts together on one GPU.
 
     ``wavelengths[i]`` / ``opt_chains[i]`` describe wavefront ``i`` (chains must
@@ -275,7 +279,7 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
             results[i][item["num"]] = rec
 
     try:
-        _walk(dev, states, list(opt_chains), on_saved)
+        _walk(dev, states, list(opt_chains), on_saved, stats=stats)
         if sync:
             dev.sync()
     finally:

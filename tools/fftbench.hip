@@ -62,8 +62,9 @@ struct Timer {
 };
 
 template <typename T, int N, int E, int LINES, int AXIS, int BR, int BC, bool SPLIT, int MINW = 1,
-          int TILES = 1>
+          int TILES = 1, int PW = 0, int SEQ = 1>
 void bench_variant(const char* name, int batch, int reps, int pad_blocks = 0) {
+  if (batch == 0) return;
   const unsigned pitch = (unsigned)N * BR + (unsigned)pad_blocks * BR * BC;
   const unsigned item_stride = pitch * (N / BR);
   const size_t elems = (size_t)N * N * batch;
@@ -83,21 +84,31 @@ void bench_variant(const char* name, int batch, int reps, int pad_blocks = 0) {
   CK(hipMalloc(&dtw, N * sizeof(cx<T>)));
   CK(hipMemcpy(dtw, tw.data(), N * sizeof(cx<T>), hipMemcpyHostToDevice));
 
-  FftPassArgs a{};
-  a.field = d; a.tw = dtw; a.params = nullptr; a.pre_mode = 0; a.post_mode = 0; a.scale = 1.0;
+  // block sets: 0 = forward control, 1 = inverse control, 2 = scale 1/N, 3 = scale 1/64, 4 = H phase
+  const int NB = 5;
+  std::vector<double> hb((size_t)NB * batch * FP_STRIDE, 0.0);
+  for (int i = 0; i < batch; ++i) {
+    double* p0 = &hb[((size_t)0 * batch + i) * FP_STRIDE]; p0[0] = 1; p0[1] = 0;
+    double* p1 = &hb[((size_t)1 * batch + i) * FP_STRIDE]; p1[0] = 1; p1[1] = 1;
+    double* p2 = &hb[((size_t)2 * batch + i) * FP_STRIDE]; p2[0] = 1; p2[3] = 1.0 / N;
+    double* p3 = &hb[((size_t)3 * batch + i) * FP_STRIDE]; p3[0] = 1; p3[3] = 1.0 / 64;
+    double* p4 = &hb[((size_t)4 * batch + i) * FP_STRIDE]; p4[0] = 1; p4[1] = 0.01; p4[2] = 0.01; p4[3] = 0.37; p4[4] = -1;
+  }
+  double* dblk;
+  CK(hipMalloc(&dblk, hb.size() * sizeof(double)));
+  CK(hipMemcpy(dblk, hb.data(), hb.size() * sizeof(double), hipMemcpyHostToDevice));
+  PassArgs a{};
+  a.field = d; a.tw = dtw; a.blocks = dblk; a.batch = batch; a.fft1 = 0; a.fft2 = -1;
   a.pitch = pitch; a.item_stride = item_stride;
-  const dim3 grid(N / LINES / TILES, batch), block(TILES * LINES * N / E);
-  const size_t lds = TILES * LINES * line_lds_bytes<T, N, SPLIT>();
-  auto kf = fft_pass_kernel<T, N, E, LINES, TILES, AXIS, BR, BC, SPLIT, +1, MINW>;
-  auto ki = fft_pass_kernel<T, N, E, LINES, TILES, AXIS, BR, BC, SPLIT, -1, MINW>;
+  const dim3 grid(N / LINES / TILES, batch), block(TILES * LINES * N / E / SEQ);
+  const size_t lds = TILES * LINES / SEQ * line_lds_bytes<T, N, SPLIT>();
+  auto kf = fused_pass_kernel<T, N, E, LINES, TILES, AXIS, BR, BC, SPLIT, MINW, SEQ>;
   CK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  CK(hipFuncSetAttribute((const void*)ki, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
 
-  // round trip on item 0
-  a.scale = 1.0;
+  // round trip on item 0: forward, then inverse with the 1/N scale
   hipLaunchKernelGGL(kf, dim3(N / LINES / TILES, 1), block, lds, 0, a);
-  a.scale = 1.0 / N;
-  hipLaunchKernelGGL(ki, dim3(N / LINES / TILES, 1), block, lds, 0, a);
+  { PassArgs bk = a; bk.fft1 = 1; bk.n_mid = 1; bk.mid[0] = {PWK_SCALE, 0, 2};
+    hipLaunchKernelGGL(kf, dim3(N / LINES / TILES, 1), block, lds, 0, bk); }
   CK(hipDeviceSynchronize());
   std::vector<std::complex<T>> back((size_t)N * N);
   for (int r = 0; r < N / BR; ++r)
@@ -106,34 +117,25 @@ void bench_variant(const char* name, int batch, int reps, int pad_blocks = 0) {
   double err = 0;
   for (size_t i = 0; i < back.size(); ++i) err = fmax(err, (double)std::abs(back[i] - h[i]));
 
-  a.scale = 1.0 / 64;  // keep magnitudes bounded over repeated launches
+  a.n_mid = 1; a.mid[0] = {PWK_SCALE, 0, 3};  // keep magnitudes bounded over repeated launches
   Timer tm;
   float ms = tm.run([&] { hipLaunchKernelGGL(kf, grid, block, lds, 0, a); }, reps);
   const double bytes = 2.0 * elems * sizeof(cx<T>);
   int nb = 0;
   CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kf, block.x, lds));
-  printf("%-30s N=%d b=%d E=%d L=%dx%d ax=%d blk=%dx%d pad=%d split=%d minw=%d thr=%d lds=%zuK occ=%d  %8.3f ms  %7.1f GB/s  rt_err=%.2e\n",
-         name, N, batch, E, LINES, TILES, AXIS, BR, BC, pad_blocks, (int)SPLIT, MINW, block.x, lds / 1024, nb, ms,
+  printf("%-30s N=%d b=%d E=%d SEQ=%d L=%dx%d ax=%d blk=%dx%d pad=%d split=%d minw=%d pw=%d thr=%d lds=%zuK occ=%d  %8.3f ms  %7.1f GB/s  rt_err=%.2e\n",
+         name, N, batch, E, SEQ, LINES, TILES, AXIS, BR, BC, pad_blocks, (int)SPLIT, MINW, PW, block.x, lds / 1024, nb, ms,
          bytes / ms * 1e-6, err);
   fflush(stdout);
 
-  if (AXIS == 1) {  // fused ptp middle pass on the same shape
-    std::vector<double> hp(batch * FP_STRIDE);
-    for (int b = 0; b < batch; ++b) {
-      hp[b * FP_STRIDE + FP_ENABLE] = 1; hp[b * FP_STRIDE + FP_SX] = 0.01; hp[b * FP_STRIDE + FP_SY] = 0.01;
-      hp[b * FP_STRIDE + FP_COEF] = 0.37; hp[b * FP_STRIDE + FP_SGN] = -1;
-    }
-    double* dp;
-    CK(hipMalloc(&dp, hp.size() * sizeof(double)));
-    CK(hipMemcpy(dp, hp.data(), hp.size() * sizeof(double), hipMemcpyHostToDevice));
-    auto km = fft_ptp_mid_kernel<T, N, E, LINES, TILES, AXIS, BR, BC, SPLIT, MINW>;
-    CK(hipFuncSetAttribute((const void*)km, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    a.params = dp; a.scale = 1.0 / N;
-    float ms2 = tm.run([&] { hipLaunchKernelGGL(km, grid, block, lds, 0, a); }, reps);
-    printf("%-34s   fused fwd*H*inv            %8.3f ms  %7.1f GB/s\n", name, ms2, bytes / ms2 * 1e-6);
+  if (PW) {  // double pass: fwd | H, 1/N | inv  (the ptp middle pass)
+    PassArgs m2 = a;
+    m2.fft1 = 0; m2.fft2 = 1; m2.n_mid = 2; m2.mid[0] = {PWK_QPHASE_N, 0, 4}; m2.mid[1] = {PWK_SCALE, 0, 2};
+    float ms2 = tm.run([&] { hipLaunchKernelGGL(kf, grid, block, lds, 0, m2); }, reps);
+    printf("%-30s     double pass fwd|H|inv      %8.3f ms  %7.1f GB/s\n", name, ms2, bytes / ms2 * 1e-6);
     fflush(stdout);
-    CK(hipFree(dp));
   }
+  CK(hipFree(dblk));
   CK(hipFree(d));
   CK(hipFree(dtw));
 }
@@ -154,41 +156,20 @@ void bench_copy(int n, int batch, int reps) {
 
 int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 10;
-  const int b4 = 4, b2 = 16, b1 = 64;
+  const int b4 = 8;
+  const int pad = 3;
   bench_copy<double>(4096, b4, reps);
-  // ---- 4096 rows
-  bench_variant<double, 4096, 16, 1, 0, 1, 1, false>("4096 rows canon", b4, reps);
-  bench_variant<double, 4096, 16, 2, 0, 2, 4, true>("4096 rows blk2x4", b4, reps, 0);
-  bench_variant<double, 4096, 16, 2, 0, 2, 4, true>("4096 rows blk2x4", b4, reps, 1);
-  bench_variant<double, 4096, 16, 2, 0, 2, 4, true, 4>("4096 rows blk2x4", b4, reps, 1);
-  bench_variant<double, 4096, 16, 4, 0, 4, 2, true, 4>("4096 rows blk4x2", b4, reps, 1);
-  // ---- 4096 cols, pad sweep
-  for (int pad : {0, 1, 2, 3, 8, 33}) {
-    bench_variant<double, 4096, 32, 4, 1, 2, 4, true>("4096 cols blk2x4 E32", b4, reps, pad);
-  }
-  for (int pad : {0, 1, 3, 33}) {
-    bench_variant<double, 4096, 16, 2, 1, 4, 2, true>("4096 cols blk4x2 E16", b4, reps, pad);
-    bench_variant<double, 4096, 16, 2, 1, 4, 2, true, 4>("4096 cols blk4x2 E16", b4, reps, pad);
-  }
-  bench_variant<double, 4096, 16, 4, 1, 2, 4, true, 4>("4096 cols blk2x4 E16", b4, reps, 1);
-  bench_variant<double, 4096, 16, 2, 1, 1, 1, true, 4>("4096 cols canon W2", b4, reps, 0);
-  // ---- 2048
-  bench_variant<double, 2048, 16, 2, 0, 2, 4, false>("2048 rows blk2x4", b2, reps, 1);
-  for (int pad : {0, 1, 3, 33}) {
-    bench_variant<double, 2048, 16, 4, 1, 2, 4, false>("2048 cols blk2x4", b2, reps, pad);
-  }
-  bench_variant<double, 2048, 16, 4, 1, 2, 4, true, 4>("2048 cols blk2x4", b2, reps, 1);
-  // ---- 1024
-  bench_variant<double, 1024, 16, 2, 0, 2, 4, false>("1024 rows blk2x4", b1, reps, 1);
-  bench_variant<double, 1024, 16, 2, 0, 2, 4, false, 1, 2>("1024 rows blk2x4 T2", b1, reps, 1);
-  for (int pad : {0, 1, 3}) {
-    bench_variant<double, 1024, 16, 4, 1, 2, 4, false>("1024 cols blk2x4", b1, reps, pad);
-  }
-  bench_variant<double, 1024, 16, 4, 1, 2, 4, false, 4>("1024 cols blk2x4", b1, reps, 1);
-  // ---- fp32
-  bench_copy<float>(4096, b4, reps);
-  bench_variant<float, 4096, 16, 2, 0, 2, 4, false>("4096 f32 rows blk2x4", b4, reps, 1);
-  bench_variant<float, 4096, 16, 4, 1, 2, 4, false>("4096 f32 cols blk2x4", b4, reps, 1);
-  bench_variant<float, 4096, 16, 4, 1, 2, 4, true, 4>("4096 f32 cols blk2x4", b4, reps, 1);
+  bench_variant<double, 4096, 16, 2, 0, 4, 2, true, 1, 1, 1, 1>("blk4x2 rows L2 512thr", b4, reps, pad);
+  bench_variant<double, 4096, 16, 2, 0, 4, 2, false, 1, 1, 1, 1>("blk4x2 rows L2 512thr full", b4, reps, pad);
+  bench_variant<double, 4096, 16, 2, 0, 4, 2, true, 2, 1, 1, 2>("blk4x2 rows L2 SEQ2 256thr mw2", b4, reps, pad);
+  bench_variant<double, 4096, 16, 2, 0, 4, 2, false, 2, 1, 1, 2>("blk4x2 rows L2 SEQ2 256thr mw2 full", b4, reps, pad);
+  bench_variant<double, 4096, 16, 2, 1, 4, 2, true, 1, 1, 1, 1>("blk4x2 cols L2 512thr", b4, reps, pad);
+  bench_variant<double, 4096, 16, 2, 1, 4, 2, false, 1, 1, 1, 1>("blk4x2 cols L2 512thr full", b4, reps, pad);
+  bench_variant<double, 4096, 16, 2, 1, 4, 2, true, 2, 1, 1, 2>("blk4x2 cols L2 SEQ2 256thr mw2", b4, reps, pad);
+  bench_variant<double, 4096, 16, 2, 1, 4, 2, false, 2, 1, 1, 2>("blk4x2 cols L2 SEQ2 256thr mw2 full", b4, reps, pad);
+  bench_variant<double, 2048, 16, 4, 0, 4, 2, false, 2, 1, 1, 2>("2048 rows L4 SEQ2 256thr mw2", 16, reps, pad);
+  bench_variant<double, 2048, 16, 2, 0, 4, 2, false, 1, 1, 1, 1>("2048 rows L2 256thr", 16, reps, pad);
+  bench_variant<double, 2048, 16, 4, 0, 4, 2, true, 1, 1, 1, 1>("2048 rows L4 512thr", 16, reps, pad);
+  bench_variant<double, 2048, 16, 2, 1, 4, 2, false, 1, 1, 1, 1>("2048 cols L2 256thr", 16, reps, pad);
   return 0;
 }
