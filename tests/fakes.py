@@ -1,0 +1,173 @@
+"""CPU stand-ins used by the ``not gpu`` tests.
+
+``ModelDevice`` mimics ``paos_amd._lib.DeviceFields`` with NumPy arrays and executes
+pass programs by the documented semantics of include/paos_hip.h (operators, per-item
+enable flags, transform control blocks).  It is a *model of the device contract* for
+testing the host logic (planner, pass compiler, batching) without a GPU -- test
+infrastructure only, never imported by the product.  Aperture masks and Zernike maps
+come from the oracle.
+"""
+import numpy as np
+
+from oracle import aperture_np
+from paos_amd import _lib
+
+
+class ModelDevice:
+    def __init__(self, n, batch=1, precision="fp64", device=0):
+        self.n, self.batch, self.precision = int(n), int(batch), precision
+        self.u = np.zeros((self.batch, self.n, self.n), dtype=np.complex128)
+        self.log = []  # (name, detail) per launch
+        self.pass_count = 0
+
+    def close(self):
+        pass
+
+    def sync(self):
+        pass
+
+    def build_info(self):
+        return "numpy model"
+
+    def fill(self, value=1.0 + 0.0j):
+        self.u[:] = value
+
+    def upload(self, item, field):
+        self.u[item] = field
+
+    def download(self, item=0, what=_lib.WHAT_FIELD):
+        u = self.u[item]
+        if what == _lib.WHAT_FIELD:
+            return u.copy()
+        if what == _lib.WHAT_AMPLITUDE:
+            return np.abs(u)
+        if what == _lib.WHAT_PHASE:
+            return np.angle(u)
+        return u.real**2 + u.imag**2
+
+    def norm2(self):
+        return np.array([np.sum(np.abs(u) ** 2) for u in self.u])
+
+    def make_stop(self, enable=None):
+        self.log.append(("make_stop", None))
+        for i in range(self.batch):
+            if enable is None or enable[i]:
+                self.u[i] /= np.sqrt(np.sum(np.abs(self.u[i]) ** 2))
+
+    def aperture(self, shape, blocks):
+        self.log.append(("aperture", shape))
+        for i, b in enumerate(blocks):
+            if not b[0]:
+                continue
+            _, xc, yc, a, bb, theta, obsc, _sub = b
+            if shape == _lib.SHAPE_ELLIPSE:
+                mask = aperture_np.ellipse_mask((self.n, self.n), xc, yc, a, bb, theta)
+            else:
+                mask = aperture_np.rectangle_mask((self.n, self.n), xc, yc, a, bb, theta)
+            self.u[i] *= (1 - mask) if obsc else mask
+
+    def zernike(self, nmax, kdim, table, blocks, want_wfe=False):
+        """Mirror of csrc/pointwise.h zernike_kernel (same recurrences, NumPy)."""
+        self.log.append(("zernike", nmax))
+        table = np.asarray(table).reshape(nmax + 1, kdim, 3)
+        n = self.n
+        wfe0 = None
+        for i, b in enumerate(np.asarray(blocks)):
+            if not b[0]:
+                continue
+            _, dx, dy, radius, origin_y, co, so, inv_wl = b[:8]
+            cc = b[8:8 + (nmax + 1) * kdim].reshape(nmax + 1, kdim)
+            ss = b[8 + (nmax + 1) * kdim:8 + 2 * (nmax + 1) * kdim].reshape(nmax + 1, kdim)
+            x = (np.arange(n) - n // 2) * dx
+            y = (np.arange(n) - n // 2) * dy
+            xx, yy = np.meshgrid(x, y)
+            rr = np.sqrt(xx**2 + yy**2)
+            rho = rr / radius
+            with np.errstate(invalid="ignore", divide="ignore"):
+                c1 = np.where(rr > 0, (yy if origin_y else xx) / rr, 1.0)
+                s1 = np.where(rr > 0, (xx if origin_y else yy) / rr, 0.0)
+            cr, sr = c1 * co - s1 * so, s1 * co + c1 * so
+            xj = 1.0 - 2.0 * rho * rho
+            wfe = np.zeros_like(rho)
+            rho_pow, cm, sm = np.ones_like(rho), np.ones_like(rho), np.zeros_like(rho)
+            for am in range(nmax + 1):
+                pkm1, pk = np.zeros_like(rho), np.ones_like(rho)
+                for k in range((nmax - am) // 2 + 1):
+                    if k > 0:
+                        a_, b_, c_ = table[am, k]
+                        pkm1, pk = pk, (a_ * xj + b_) * pk - c_ * pkm1
+                    wfe += (rho_pow * pk) * (cc[am, k] * cm + ss[am, k] * sm)
+                rho_pow = rho_pow * rho
+                cm, sm = cm * cr - sm * sr, sm * cr + cm * sr
+            masked = rho > 1.0
+            wfe = np.where(masked, 0.0, wfe)
+            self.u[i] = self.u[i] * np.exp(1j * ((6.283185307179586 * wfe) * inv_wl))
+            if i == 0:
+                wfe0 = np.where(masked, np.nan, wfe)
+        return wfe0 if want_wfe else None
+
+    # ---- pass programs -----------------------------------------------------------------
+    def _apply(self, u, op, p):
+        kind, flags, _ = op
+        n = self.n
+        if kind == _lib.PW_SIGN:
+            i = np.arange(n)
+            return u * np.where((i[:, None] + i[None, :]) & 1, -1.0, 1.0)
+        if kind == _lib.PW_SCALE:
+            return u * p[3]
+        i = np.arange(n)
+        g = (i - n // 2) if kind == _lib.PW_QPHASE_CENTRED else np.where(i < n // 2, i, i - n)
+        x, y = g * p[1], g * p[2]
+        xx, yy = np.meshgrid(x, y)
+        q = p[3] * (xx**2 + yy**2)
+        if flags & _lib.PWF_MUL2PI:
+            q = 6.283185307179586 * q
+        return u * (np.cos(q) + 1j * p[4] * np.sin(q))
+
+    def run_passes(self, passes, blocks):
+        blocks = np.asarray(blocks, dtype=np.float64)
+        assert blocks.ndim == 3 and blocks.shape[1:] == (self.batch, 5)
+        for ps in passes:
+            self.pass_count += 1
+            self.log.append(("pass", ps["axis"]))
+            for i in range(self.batch):
+                u = self.u[i]
+                for slot, ctl in (("pre", ps.get("fft1", -1)), ("mid", ps.get("fft2", -1)), ("post", -1)):
+                    for op in ps.get(slot, ()):
+                        p = blocks[op[2], i]
+                        if p[0] != 0.0:
+                            u = self._apply(u, op, p)
+                    if ctl is not None and ctl >= 0 and blocks[ctl, i, 0] != 0.0:
+                        assert ps["axis"] in (0, 1)
+                        ax = 1 if ps["axis"] == 0 else 0  # "along rows" = NumPy axis 1
+                        u = np.fft.ifft(u, axis=ax) * self.n if blocks[ctl, i, 1] else np.fft.fft(u, axis=ax)
+                self.u[i] = u
+
+    # one-operator programs, as csrc/paos_hip.hip builds them
+    def _single(self, blocks, inverse, kind):
+        from paos_amd.passes import PassCompiler
+
+        comp = PassCompiler(self.batch, self.n)
+        rows = [list(b) if b[0] else None for b in blocks]
+        if kind == "ptp":
+            comp.ptp(rows)
+        elif kind == "stw":
+            comp.stw(rows, [inverse] * self.batch)
+        elif kind == "wts":
+            comp.wts(rows, [inverse] * self.batch)
+        else:
+            comp.lens(rows)
+        comp.flush(self)
+
+    def ptp(self, blocks):
+        self._single(blocks, False, "ptp")
+
+    def stw(self, blocks, inverse):
+        self._single(blocks, inverse, "stw")
+
+    def wts(self, blocks, inverse):
+        self._single(blocks, inverse, "wts")
+
+    def phase(self, blocks, mul2pi):
+        assert mul2pi
+        self._single(blocks, False, "lens")

@@ -293,6 +293,27 @@ def test_run_batch_matches_single_runs():
             assert abs(batch[i][k]["power"] - np.sum(single[k]["amplitude"] ** 2)) < 1e-12
 
 
+def test_batch_with_divergent_propagator_regimes():
+    """One batch, two wavelengths whose planners pick different primitives for the same
+    surface (OO = stw + wts vs OI = stw + ptp): per-item enable flags keep them correct."""
+    from oracle.run_np import run as oracle_run
+    from paos_amd.run import run_batch
+    from test_host_logic import _two_regime_chain
+
+    field = {"us": 0.0, "ut": 0.0}
+    wls = [1.0e-6, 1.0e-5]
+    chains = [_two_regime_chain(), _two_regime_chain()]
+    got = run_batch(1.0, wls, 256, 4, field, chains, outputs=("wfo",))
+    props = []
+    for i in range(2):
+        ref = oracle_run(1.0, wls[i], 256, 4, field, chains[i], light=True)
+        props.append(ref[3]["propagator"])
+        for k in ref:
+            assert rel_err(got[i][k]["wfo"], ref[k]["wfo"]) < FIELD_TOL, (i, k)
+            assert got[i][k]["propagator"] == ref[k]["propagator"] and got[i][k]["dx"] == ref[k]["dx"]
+    assert props == ["OO", "OI"]
+
+
 def test_fp32_mode_tolerance():
     """c64 storage / FFT arithmetic with fp64 phase arguments: expected ~3e-6."""
     from paos_amd.chains import syn20_chain

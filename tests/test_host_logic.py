@@ -1,0 +1,208 @@
+"""Host logic without a GPU: the planner, the pass compiler and the batched run loop are
+driven against a NumPy model of the device contract (tests/fakes.py) and compared with the
+reference's golden vectors and the oracle."""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+from fakes import ModelDevice
+from oracle.run_np import run as oracle_run
+from paos_amd import _lib
+from paos_amd.chains import inject_wfe, read_wfe_table, syn20_chain, syn20_wavelength
+from paos_amd.parse_config import parse_config
+from paos_amd.planner import PilotBeam, jacobi_recurrence
+from paos_amd.run import _Item, _walk
+
+DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
+FIELD = {"us": 0.0, "ut": 0.0}
+
+
+def beam_scalars(b):
+    return np.array([b.wl, b.z, b.w0, b.zw0, b.zr, b.dx, b.dy, b.C, b.fratio, b.wz, b.distancetofocus])
+
+
+def test_pilot_beam_matches_reference_scalars():
+    """PilotBeam vs the before/after scalars recorded from the reference's WFO."""
+    g = load_golden("primitives.npz")
+    for anam in (False, True):
+        sfx = "_anam" if anam else ""
+
+        def fresh():
+            b = PilotBeam(1.0, 3.0e-6, 64, 4)
+            if anam:
+                b.magnification(1.25, 0.8)
+            return b
+
+        for fl in (10.0, -3.0, 0.4):
+            b = fresh()
+            assert np.array_equal(beam_scalars(b), g[f"lens_{fl}{sfx}_before"])
+            b.lens(fl)
+            assert np.array_equal(beam_scalars(b), g[f"lens_{fl}{sfx}_after"])
+        for dz in (0.5, -0.25, 1.0e-8):
+            b = fresh()
+            b.ptp(dz)
+            assert np.array_equal(beam_scalars(b), g[f"ptp_{dz}{sfx}_after"])
+        for fl in (10.0, -7.0):
+            b = fresh()
+            b.lens(fl)
+            blk, inv = b.stw(b.zw0 - b.z)
+            assert np.array_equal(beam_scalars(b), g[f"stw_{fl}{sfx}_after"])
+            assert inv == (g[f"stw_{fl}{sfx}_dz"] < 0) and blk[0] == 1.0
+        for dz in (2.0, -1.5):
+            b = fresh()
+            blk, inv = b.wts(dz)
+            assert np.array_equal(beam_scalars(b), g[f"wts_{dz}{sfx}_after"]) and inv == (dz < 0)
+    b = PilotBeam(1.0, 3.0e-6, 64, 4)
+    assert b.ptp(1e-10) is None and b.z == 0.0  # below wl/1000: reference returns early
+    b.lens(10.0)
+    with pytest.raises(ValueError):
+        b.ptp(1.0)
+    with pytest.raises(ValueError):
+        PilotBeam(1.0, 3.0e-6, 64, 4).stw(1.0)
+    for tag, (fl, dist) in {"II": (None, 1.0), "OI": (10.0, 10.0), "IO": (None, 4.0e6), "OO": (10.0, 20.0)}.items():
+        b = PilotBeam(1.0, 3.0e-6, 64, 4)
+        if fl:
+            b.lens(fl)
+        steps = b.propagate(dist)
+        assert b.propagator == tag
+        # IO from the waist itself: the leading ptp(0) is below wl/1000 and is skipped (wfo.py:454)
+        assert [s[0] for s in steps] == {"II": ["ptp"], "OI": ["stw", "ptp"], "IO": ["wts"], "OO": ["stw", "wts"]}[tag]
+        assert np.array_equal(beam_scalars(b), g["propagate_" + tag + "_after"])
+
+
+def _model_run(spec, n, chains=None, wls=None):
+    chains = chains or [spec["chain"]]
+    wls = wls or [spec["wl"]]
+    dev = ModelDevice(n, len(chains))
+    dev.fill(1.0)
+    states = [_Item(spec["pup"], wl, n, spec["zoom"], spec["field"]) for wl in wls]
+    saved = {}
+
+    def on_saved(key, items, plans, wfe):
+        for i, (it, pl) in enumerate(zip(items, plans)):
+            if it["save"]:
+                saved.setdefault(i, {})[it["num"]] = dict(pl["scalars"], wfo=dev.download(i), wfe=wfe)
+
+    stats = {}
+    _walk(dev, states, chains, on_saved, stats=stats)
+    return saved, dev, stats
+
+
+def _spec(name):
+    if name == "SYN20":
+        return dict(pup=1.0, wl=1.0e-6, zoom=4, field=FIELD, chain=syn20_chain())
+    pup, par, wls, fields, chains = parse_config(os.path.join(DATA, "lens", name + ".ini"))
+    return dict(pup=pup, wl=1.0e-6 * wls[0], zoom=par["zoom"], field=fields[0], chain=chains[0])
+
+
+@pytest.mark.parametrize("name", ["SYN20", "Hubble_simple", "Excite_TEL", "Ariel_AIRS-CH0", "Ariel_FGS-FGS1"])
+def test_fused_pass_programs_reproduce_reference(name):
+    """Planner + pass compiler + NumPy model of the pass semantics == the reference's run()
+    outputs: validates the operator fusion and axis alternation logic on the CPU."""
+    spec = _spec(name)
+    gs = load_golden(f"scalars_{name}.npz")
+    chain = copy.deepcopy(spec["chain"])
+    for item in chain.values():
+        item["save"] = True
+    saved, _, _ = _model_run(dict(spec, chain=chain), 64)
+    for row, k in zip(gs["table"], gs["nums"]):
+        s = saved[0][k]
+        got = [s["wl"], s["dx"], s["dy"], s["wz"], s["distancetofocus"], s["fratio"]]
+        assert np.array_equal(got, row), (name, k)
+    assert [saved[0][k]["propagator"] for k in gs["nums"]] == list(gs["propagator"])
+
+    gr = load_golden(f"run_{name}.npz")
+    n = int(gr["gridsize"])
+    saved, dev, stats = _model_run(spec, n)
+    for k in gr["nums"]:
+        assert rel_err(saved[0][k]["wfo"], gr[f"S{k:02d}_wfo"]) < 1e-12, (name, k)
+    assert stats["fused_passes"] == dev.pass_count
+
+
+def test_syn20_pass_budget():
+    """SURVEY 8d counts 43 2-D FFTs for SYN20 (16 ptp, 6 stw, 5 wts); fused they take 49
+    HBM passes (was 70 transform passes + 11 lens passes unfused)."""
+    _, dev, stats = _model_run(_spec("SYN20"), 64)
+    assert stats["fused_passes"] == 49
+    kinds = [name for name, _ in dev.log]
+    assert kinds.count("aperture") == 7 and kinds.count("make_stop") == 1 and kinds.count("zernike") == 1
+    axes = [d for name, d in dev.log if name == "pass"]
+    assert -1 not in axes  # every lens phase rides on a transform pass
+
+
+def _two_regime_chain():
+    """lens f = 10 m, stop 0.5 mm short of focus, then on to focus: the first hop is OO at
+    1 um (2 zr = 0.25 mm) but OI at 10 um (2 zr = 2.5 mm)."""
+    from paos_amd.abcd import ABCD
+
+    def item(num, kind, name, thickness=0.0, curvature=0.0, **extra):
+        d = {"num": num, "type": kind, "name": name, "is_stop": False, "save": False,
+             "ABCDt": ABCD(thickness=thickness, curvature=curvature),
+             "ABCDs": ABCD(thickness=thickness, curvature=curvature)}
+        d.update(extra)
+        return d
+
+    pupil = {"shape": "elliptical", "type": "aperture", "xrad": 0.5, "yrad": 0.5, "xc": 0.0, "yc": 0.0}
+    return {1: item(1, "Standard", "STOP", is_stop=True, aperture=pupil),
+            2: item(2, "Paraxial Lens", "L", thickness=10.0 - 5.0e-4, curvature=0.1),
+            3: item(3, "Standard", "NEAR", thickness=5.0e-4, save=True),
+            4: item(4, "Standard", "IMAGE_PLANE", save=True)}
+
+
+def test_batched_walk_matches_itemwise_oracle():
+    """Batches whose items disagree share one pass sequence: different wavelengths and WFE
+    draws through SYN20, and a chain whose propagator regime flips with wavelength (one
+    item runs stw+wts where the other runs stw+ptp in the same launches)."""
+    _, _, _, table = read_wfe_table(os.path.join(DATA, "wfe", "wfe_realization_SN20210914.csv"))
+    wls = [syn20_wavelength(0), syn20_wavelength(300), 7.0e-6]
+    chains = [inject_wfe(syn20_chain(), table[:, k]) for k in range(3)]
+    spec = dict(pup=1.0, zoom=4, field=FIELD)
+    saved, _, _ = _model_run(spec, 64, chains=chains, wls=wls)
+    for i in range(3):
+        ref = oracle_run(1.0, wls[i], 64, 4, FIELD, chains[i], light=True)
+        for k in ref:
+            assert rel_err(saved[i][k]["wfo"], ref[k]["wfo"]) < 1e-12, (i, k)
+            assert saved[i][k]["dx"] == ref[k]["dx"] and saved[i][k]["propagator"] == ref[k]["propagator"]
+
+    wls = [1.0e-6, 1.0e-5]
+    chains = [_two_regime_chain(), _two_regime_chain()]
+    saved, _, _ = _model_run(spec, 64, chains=chains, wls=wls)
+    props = []
+    for i in range(2):
+        ref = oracle_run(1.0, wls[i], 64, 4, FIELD, chains[i], light=True)
+        props.append(ref[3]["propagator"])
+        for k in ref:
+            assert rel_err(saved[i][k]["wfo"], ref[k]["wfo"]) < 1e-12, (i, k)
+            assert saved[i][k]["propagator"] == ref[k]["propagator"] and saved[i][k]["dx"] == ref[k]["dx"]
+    assert props == ["OO", "OI"]
+
+
+def test_jacobi_recurrence_matches_scipy():
+    from scipy.special import eval_jacobi
+
+    tab = jacobi_recurrence(12)
+    x = np.linspace(-1, 1, 41)
+    for a in range(13):
+        pkm1, pk = np.zeros_like(x), np.ones_like(x)
+        for k in range(0, (12 - a) // 2 + 1):
+            if k > 0:
+                A, B, C = tab[a, k]
+                pkm1, pk = pk, (A * x + B) * pk - C * pkm1
+            assert np.max(np.abs(pk - eval_jacobi(k, a, 0.0, x))) < 1e-12 * max(1.0, np.max(np.abs(pk)))
+
+
+def test_run_passes_rejects_oversized_slots():
+    from paos_amd.passes import PassCompiler
+
+    comp = PassCompiler(1, 64)
+    blk = [[1.0, 1e-3, 1e-3, 0.5, -1.0]]
+    for _ in range(9):  # many lenses in a row overflow one pass slot -> extra stand-alone passes
+        comp.lens(blk)
+    comp.ptp([[1.0, 1.0, 1.0, 1e-3, -1.0]])
+    passes, blocks = comp.program()
+    assert all(len(p.get(s, ())) <= _lib.MAX_PW for p in passes for s in ("pre", "mid", "post"))
+    assert sum(1 for p in passes if p["axis"] == -1) >= 1
+    assert blocks.shape[1:] == (1, 5)
