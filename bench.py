@@ -135,6 +135,21 @@ def main():
     launches, kern_ms = dev.profile_end()
     elapsed = max_over_ranks(elapsed)
 
+    # The north star's headline step: one ptp (fft2 -> H -> ifft2, wfo.py:462-472) on the
+    # whole batch, timed alone with the pass timer (3 launches: rows | cols x2 fused | rows).
+    ptp_ms = None
+    if rank == 0:
+        from paos_amd.planner import PilotBeam
+
+        blk = [PilotBeam(1.0, wl, n, 4).ptp(2.5) for wl in wavelengths]
+        for _ in range(2):
+            dev.ptp(blk)
+        dev.profile_begin(_lib.KERNEL_PASS_ANY, max_launches=64)
+        for _ in range(5):
+            dev.ptp(blk)
+        nl, tot = dev.profile_end()
+        ptp_ms = tot / 5.0
+
     if rank == 0:
         esz = 16 if args.precision == "fp64" else 8
         value = total * args.steps / elapsed
@@ -175,6 +190,11 @@ def main():
             "chain_roofline": {"algorithmic_bytes_per_wavefront": chain_bytes,
                                "achieved_GBps_per_gpu": chain_bytes * (value / world) / 1e9,
                                "frac_of_hbm_peak": chain_bytes * (value / world) / 1e9 / HBM_PEAK_GBS},
+            "ptp_step": {"what": "one ptp over the batch: 2 2-D FFTs + H, 3 fused passes",
+                         "ms_per_wavefront": ptp_ms / nb,
+                         "algorithmic_GBps": 8 * esz * n * n * nb / (ptp_ms * 1e-3) / 1e9,
+                         "frac_of_hbm_peak": 8 * esz * n * n * nb / (ptp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "note": "SURVEY 8d prices a ptp at 128 B/px (4 passes); the fused path moves 96 B/px"},
             "power_check": float(res[0][20]["power"]),
             "build": dev.build_info(),
         }

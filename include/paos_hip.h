@@ -34,7 +34,8 @@ enum { PAOS_F64 = 0, PAOS_F32 = 1 };
 enum { PAOS_SHAPE_ELLIPSE = 0, PAOS_SHAPE_RECT = 1 };
 enum { PAOS_KERNEL_PASS_ROWS = 0, PAOS_KERNEL_PASS_COLS = 1, PAOS_KERNEL_PASS_ANY = 2 };
 /* pointwise operators that ride on an FFT pass (paos_run_passes) */
-enum { PAOS_PW_SIGN = 1, PAOS_PW_QPHASE_CENTRED = 2, PAOS_PW_QPHASE_NATURAL = 3, PAOS_PW_SCALE = 4 };
+enum { PAOS_PW_SIGN = 1, PAOS_PW_QPHASE_CENTRED = 2, PAOS_PW_QPHASE_NATURAL = 3, PAOS_PW_SCALE = 4,
+       PAOS_PW_MASK = 5 };
 enum { PAOS_PWF_MUL2PI = 1 };
 enum { PAOS_MAX_PW = 6 };
 enum { PAOS_WHAT_FIELD = 0, PAOS_WHAT_AMPLITUDE = 1, PAOS_WHAT_PHASE = 2, PAOS_WHAT_INTENSITY = 3 };
@@ -49,8 +50,9 @@ enum { PAOS_ZERNIKE_HEAD = 8 };    /* enable, dx, dy, radius, origin_is_y, cos_o
  *   load -> pre operators -> [1-D FFTs along `axis`] -> mid operators -> [1-D FFTs] -> post -> store.
  * `block` / `fft1` / `fft2` index parameter block sets of PAOS_PHASE_STRIDE doubles per batch
  * item: operators read [enable, sx, sy, coef, sgn] (SIGN uses enable only, SCALE multiplies by
- * coef); a transform control block reads [enable, inverse].  axis = -1: no transform, the
- * operators of `pre` are applied in a stand-alone pass. */
+ * coef); a transform control block reads [enable, inverse].  MASK (WFO.aperture, wfo.py:236-276,
+ * riding on a pass) reads two consecutive block sets: `block` = [enable, xc, yc, a|w, b|h] and
+ * `block`+1 = [theta, obscuration, subpixels, shape, 0]; at most one MASK per pass.  axis = -1: no transform, the operators of `pre` are applied in a stand-alone pass. */
 typedef struct { int kind, flags, block; } paos_pw_op;
 typedef struct {
   int axis;                    /* 0 = along rows, 1 = along columns, -1 = no transform */

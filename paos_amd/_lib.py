@@ -16,7 +16,7 @@ PAOS_F64, PAOS_F32 = 0, 1
 SHAPE_ELLIPSE, SHAPE_RECT = 0, 1
 WHAT_FIELD, WHAT_AMPLITUDE, WHAT_PHASE, WHAT_INTENSITY = 0, 1, 2, 3
 KERNEL_PASS_ROWS, KERNEL_PASS_COLS, KERNEL_PASS_ANY = 0, 1, 2
-PW_SIGN, PW_QPHASE_CENTRED, PW_QPHASE_NATURAL, PW_SCALE = 1, 2, 3, 4
+PW_SIGN, PW_QPHASE_CENTRED, PW_QPHASE_NATURAL, PW_SCALE, PW_MASK = 1, 2, 3, 4, 5
 PWF_MUL2PI = 1
 MAX_PW = 6
 

@@ -201,6 +201,13 @@ __device__ __forceinline__ void apply_twiddle_powers(cx<T>* v, cx<T> w1) {
   }
 }
 
+// PAOS_DIAG (microbench timing builds only; results are wrong): bit 0 drops the barriers,
+// bit 1 drops the LDS traffic of the exchanges.
+#ifndef PAOS_DIAG
+#define PAOS_DIAG 0
+#endif
+#define PAOS_SYNC() do { if (!(PAOS_DIAG & 1)) __syncthreads(); } while (0)
+
 // All stages of one line.  ``lds`` is this line's exchange area: cx<T> slots
 // when !SPLIT, T slots (real and imaginary parts exchanged one after the other,
 // halving the LDS footprint) when SPLIT.  ``tw`` = exp(-2 pi i m / N), m < N.
@@ -248,13 +255,13 @@ __device__ __forceinline__ void fft_stages(cx<T>* v, void* lds, int t,
 #pragma unroll
       for (int s = 0; s < TPT; ++s)
 #pragma unroll
-        for (int r = 0; r < R; ++r) l[wb[s] + lds_pad(r * NS)] = v[s * R + r];
-      __syncthreads();
+        for (int r = 0; r < R; ++r) if (!(PAOS_DIAG & 2)) l[wb[s] + lds_pad(r * NS)] = v[s * R + r];
+      PAOS_SYNC();
 #pragma unroll
       for (int s = 0; s < TPT2; ++s)
 #pragma unroll
-        for (int r = 0; r < R2; ++r) v[s * R2 + r] = l[ridx(s, r)];
-      if constexpr (!SN::LAST) __syncthreads();
+        for (int r = 0; r < R2; ++r) if (!(PAOS_DIAG & 2)) v[s * R2 + r] = l[ridx(s, r)];
+      if constexpr (!SN::LAST) PAOS_SYNC();
     } else {
       T* l = reinterpret_cast<T*>(lds);
 #pragma unroll
@@ -263,16 +270,18 @@ __device__ __forceinline__ void fft_stages(cx<T>* v, void* lds, int t,
         for (int s = 0; s < TPT; ++s)
 #pragma unroll
           for (int r = 0; r < R; ++r)
-            l[wb[s] + lds_pad(r * NS)] = part ? v[s * R + r].y : v[s * R + r].x;
-        __syncthreads();
+            if (!(PAOS_DIAG & 2)) l[wb[s] + lds_pad(r * NS)] = part ? v[s * R + r].y : v[s * R + r].x;
+        PAOS_SYNC();
 #pragma unroll
         for (int s = 0; s < TPT2; ++s)
 #pragma unroll
           for (int r = 0; r < R2; ++r) {
-            const T val = l[ridx(s, r)];
-            if (part) v[s * R2 + r].y = val; else v[s * R2 + r].x = val;
+            if (!(PAOS_DIAG & 2)) {
+              const T val = l[ridx(s, r)];
+              if (part) v[s * R2 + r].y = val; else v[s * R2 + r].x = val;
+            }
           }
-        if (part == 0 || !SN::LAST) __syncthreads();
+        if (part == 0 || !SN::LAST) PAOS_SYNC();
       }
     }
     fft_stages<T, N, E, DIR, SPLIT, NS * R>(v, lds, t, tw);

@@ -28,8 +28,12 @@ enum : int {
   PWK_QPHASE_C = 2,   // exp(i sgn coef ((gx sx)^2 + (gy sy)^2)), g = index - N/2 (centred)
   PWK_QPHASE_N = 3,   // same with g = natural-order signed frequency index (np.fft.fftfreq)
   PWK_SCALE = 4,      // multiply by block[FP_COEF] (exact power of two: the ortho 1/N)
+  PWK_MASK = 5,       // multiply by the aperture weight map rendered just before the pass
 };
 enum : int { PWF_MUL2PI = 1 };  // argument gets an extra factor 2 pi (lens form, wfo.py:363-366)
+// Bits 8.. of PwOp::flags: 1 + index of this operator's separable phase table (0 = no table:
+// the phase is evaluated per pixel with sincos).
+constexpr int kTableShift = 8;
 enum : int { FP_ENABLE = 0, FP_SX = 1, FP_SY = 2, FP_COEF = 3, FP_SGN = 4, FP_STRIDE = 5 };
 // FFT control block: [enable, inverse, -, -, -]
 enum : int { FC_ENABLE = 0, FC_INVERSE = 1 };
@@ -45,6 +49,8 @@ struct PassArgs {
   void* field;            // batch of fields, complex<T>, blocked layout
   const void* tw;         // exp(-2 pi i m / N), m < N, complex<T>
   const double* blocks;   // parameter block sets: [block][item][FP_STRIDE]
+  const cx<double>* tables;  // phase tables: [table][item][2][N] = exp(i sgn A_x(col)), exp(i sgn A_y(row))
+  const double* mask;     // aperture weights in the field's own layout: [item][item_stride]
   int batch;
   int fft1, fft2;         // control block index of the first / second transform, -1 = none
   int n_pre, n_mid, n_post;
@@ -67,10 +73,41 @@ __device__ __forceinline__ cx<double> quad_phase(int gx, int gy, double sx, doub
   return {cs, sgn * sn};
 }
 
+// The quadratic phase of one pixel from the separable tables plus an exact correction.
+// Reference value: exp(i sgn a), a = fl([2 pi] fl(coef fl(X + Y))), X = fl(x^2), Y = fl(y^2).
+// The tables hold exp(i sgn [2 pi] coef X) and exp(i sgn [2 pi] coef Y) for the EXACT real
+// products, so   a = [2 pi] coef (X + Y) + delta   with a delta of a few ulp(a) that is
+// recovered exactly with error-free transformations (TwoSum, FMA residuals):
+//   s + e1 = X + Y,  q + e2 = coef s,  [a + e3 = 2 pi q]
+//   delta = -(e2 + coef e1)            [delta' = 2 pi delta - e3]
+// and exp(i a) = Ex Ey (1 + i sgn delta) to 1e-20.  ~25 fp64 instructions instead of ~65.
+__device__ __forceinline__ cx<double> table_phase(double x, double y, double coef, double sgn,
+                                                  bool mul2pi, cx<double> ex, cx<double> ey) {
+  const double X = __dmul_rn(x, x), Y = __dmul_rn(y, y);
+  const double s = __dadd_rn(X, Y);
+  const double bb = __dsub_rn(s, X);
+  const double e1 = __dadd_rn(__dsub_rn(X, __dsub_rn(s, bb)), __dsub_rn(Y, bb));
+  const double q = __dmul_rn(coef, s);
+  const double e2 = fma(coef, s, -q);
+  double delta = -fma(coef, e1, e2);
+  if (mul2pi) {
+    const double a = __dmul_rn(6.283185307179586, q);
+    const double e3 = fma(6.283185307179586, q, -a);
+    delta = fma(6.283185307179586, delta, -e3);
+  }
+  delta *= sgn;
+  const cx<double> w = {fma(ex.x, ey.x, -(ex.y * ey.y)), fma(ex.x, ey.y, ex.y * ey.x)};
+  return {fma(-delta, w.y, w.x), fma(delta, w.x, w.y)};
+}
+
 template <typename T>
 __device__ __forceinline__ cx<T> apply_pw(cx<T> v, const PwOp& op, const double* p, int row, int col,
-                                          int n) {
-  if (op.kind == PWK_SIGN) {
+                                          int n, const cx<double>* tab, const double* mask_at) {
+  if (op.kind == PWK_MASK) {
+    const double w = *mask_at;
+    v.x = (T)__dmul_rn((double)v.x, w);
+    v.y = (T)__dmul_rn((double)v.y, w);
+  } else if (op.kind == PWK_SIGN) {
     if ((row + col) & 1) { v.x = -v.x; v.y = -v.y; }
   } else if (op.kind == PWK_SCALE) {
     const T sc = (T)p[FP_COEF];
@@ -83,13 +120,59 @@ __device__ __forceinline__ cx<T> apply_pw(cx<T> v, const PwOp& op, const double*
       gx = (col < n / 2) ? col : col - n;
       gy = (row < n / 2) ? row : row - n;
     }
-    const cx<double> f = quad_phase(gx, gy, p[FP_SX], p[FP_SY], p[FP_COEF], p[FP_SGN],
-                                    (op.flags & PWF_MUL2PI) != 0);
+    cx<double> f;
+    if (tab) {
+      f = table_phase((double)gx * p[FP_SX], (double)gy * p[FP_SY], p[FP_COEF], p[FP_SGN],
+                      (op.flags & PWF_MUL2PI) != 0, tab[col], tab[n + row]);
+    } else {
+      f = quad_phase(gx, gy, p[FP_SX], p[FP_SY], p[FP_COEF], p[FP_SGN], (op.flags & PWF_MUL2PI) != 0);
+    }
     const cx<double> vd = {(double)v.x, (double)v.y};
     v.x = (T)__dsub_rn(__dmul_rn(vd.x, f.x), __dmul_rn(vd.y, f.y));
     v.y = (T)__dadd_rn(__dmul_rn(vd.x, f.y), __dmul_rn(vd.y, f.x));
   }
   return v;
+}
+
+// Fills the tables of one pass program: grid = (ceil(2N / 256), items, tables).  Entry j < N is
+// the column factor exp(i sgn A_x(j)), entry N + i the row factor; A = [2 pi] coef fl((g s)^2) as
+// an exact double-double product, reduced by the library sincos on the head plus a first-order
+// correction for the tail (|tail| <= ulp(head), second order 1e-20).
+struct TableJob {
+  int block;   // parameter block set
+  int kind;    // PWK_QPHASE_C or PWK_QPHASE_N
+  int flags;
+};
+constexpr int kMaxTables = 32;
+struct TableArgs {
+  const double* blocks;
+  cx<double>* tables;
+  int batch, n, count;
+  TableJob jobs[kMaxTables];
+};
+
+__global__ void phase_table_kernel(TableArgs a) {
+  const int item = blockIdx.y, tb = blockIdx.z;
+  const TableJob job = a.jobs[tb];
+  const double* p = a.blocks + ((size_t)job.block * a.batch + item) * FP_STRIDE;
+  if (p[FP_ENABLE] == 0.0) return;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= 2 * a.n) return;
+  const int idx = j < a.n ? j : j - a.n;
+  const int g = job.kind == PWK_QPHASE_C ? idx - a.n / 2 : (idx < a.n / 2 ? idx : idx - a.n);
+  const double w = (double)g * (j < a.n ? p[FP_SX] : p[FP_SY]);
+  const double X = __dmul_rn(w, w);
+  double hi = __dmul_rn(p[FP_COEF], X);
+  double lo = fma(p[FP_COEF], X, -hi);
+  if (job.flags & PWF_MUL2PI) {
+    const double h2 = __dmul_rn(6.283185307179586, hi);
+    lo = fma(6.283185307179586, hi, -h2) + 6.283185307179586 * lo;
+    hi = h2;
+  }
+  double sn, cs;
+  sincos(hi, &sn, &cs);
+  const double c2 = fma(-lo, sn, cs), s2 = fma(lo, cs, sn);
+  a.tables[((size_t)tb * a.batch + item) * 2 * a.n + j] = {c2, p[FP_SGN] * s2};
 }
 
 // Which elements a thread owns.  A workgroup handles TILES tiles of LINES lines;
@@ -171,9 +254,12 @@ __device__ __forceinline__ void apply_list(cx<T>* v, const PwOp* list, int count
     const PwOp op = list[o];
     const double* p = a.blocks + ((size_t)op.block * a.batch + item) * FP_STRIDE;
     if (p[FP_ENABLE] == 0.0) continue;
+    const int ti = (op.flags >> kTableShift) - 1;
+    const cx<double>* tab = ti >= 0 ? a.tables + ((size_t)ti * a.batch + item) * 2 * n : nullptr;
+    const double* mk = a.mask + (size_t)item * a.item_stride + m.base + (unsigned)sq * m.seq_stride;
 #pragma unroll
     for (int k = 0; k < E; ++k) {
-      v[k] = apply_pw(v[k], op, p, m.row(k, sq), m.col(k, sq), n);
+      v[k] = apply_pw(v[k], op, p, m.row(k, sq), m.col(k, sq), n, tab, mk + (unsigned)k * m.stride);
     }
   }
 }
@@ -240,7 +326,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E / SEQ, MINW)
     if (do1) line_fft<T, N, E, SPLIT>(v, lds, m.t, tw, c1[FC_INVERSE] != 0.0);
     apply_list<T, E>(v, a.mid, a.n_mid, a, item, m, N, sq);
     if (do2) {
-      if (do1) __syncthreads();  // the first transform's last LDS reads precede new writes
+      if (do1) PAOS_SYNC();  // the first transform's last LDS reads precede new writes
       line_fft<T, N, E, SPLIT>(v, lds, m.t, tw, c2[FC_INVERSE] != 0.0);
     }
     apply_list<T, E>(v, a.post, a.n_post, a, item, m, N, sq);
@@ -249,7 +335,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E / SEQ, MINW)
   };
   process(va, 0);
   if constexpr (SEQ == 2) {
-    __syncthreads();  // line 0 is done with the exchange area
+    PAOS_SYNC();  // line 0 is done with the exchange area
     process(vb, 1);
   }
 }

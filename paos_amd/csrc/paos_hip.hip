@@ -10,6 +10,7 @@
 #include <cmath>
 #include <complex>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_set>
@@ -56,6 +57,8 @@ struct paos_ctx {
   void* field = nullptr;
   void* tw = nullptr;
   void* staging = nullptr;  // n*n*16 bytes, row-major
+  cx<double>* tables = nullptr;  // kMaxTables x batch x 2n separable phase factors
+  double* mask = nullptr;        // batch x item_stride aperture weights (allocated on first use)
   double* partial = nullptr;
   double* norm2 = nullptr;
   double* norm2_host = nullptr;  // pinned
@@ -188,9 +191,77 @@ int pass_t(paos_ctx* c, int axis, const PassArgs& a) {
 int check_ops(paos_ctx* c, const paos_pw_op* ops, int count, int n_blocks) {
   if (count < 0 || count > PAOS_MAX_PW) return fail(c, PAOS_EINVAL, "too many pointwise operators in a pass");
   for (int o = 0; o < count; ++o) {
-    if (ops[o].kind < PAOS_PW_SIGN || ops[o].kind > PAOS_PW_SCALE) return fail(c, PAOS_EINVAL, "unknown pointwise operator");
+    if (ops[o].kind < PAOS_PW_SIGN || ops[o].kind > PAOS_PW_MASK) return fail(c, PAOS_EINVAL, "unknown pointwise operator");
     if (ops[o].block < 0 || ops[o].block >= n_blocks) return fail(c, PAOS_EINVAL, "operator block index out of range");
+    if (ops[o].kind == PAOS_PW_MASK && ops[o].block + 1 >= n_blocks) return fail(c, PAOS_EINVAL, "an aperture operator needs two parameter blocks");
   }
+  return PAOS_OK;
+}
+
+// Separable phase tables with an exact rounding correction (fft_kernels.h: table_phase) replace
+// the per-pixel sincos by ~25 fp64 instructions + one L2-resident 16-byte load.  Measured on
+// MI355X (round 1) the extra loads cost more than the arithmetic they save at 2 waves/SIMD
+// (90 vs 97 wavefronts/s), so the path is opt-in: PAOS_PHASE_TABLES=1.
+bool use_tables() {
+  static const bool on = [] { const char* e = getenv("PAOS_PHASE_TABLES"); return e && e[0] == '1'; }();
+  return on;
+}
+
+int launch_one_pass(paos_ctx* c, const paos_pass& p, const double* dblocks, int n_blocks,
+                    const int* table_of_op /* [3][PAOS_MAX_PW], -1 = none */) {
+  int rc;
+  if ((rc = check_ops(c, p.pre, p.n_pre, n_blocks))) return rc;
+  if ((rc = check_ops(c, p.mid, p.n_mid, n_blocks))) return rc;
+  if ((rc = check_ops(c, p.post, p.n_post, n_blocks))) return rc;
+  if (p.fft1 >= n_blocks || p.fft2 >= n_blocks) return fail(c, PAOS_EINVAL, "transform control block out of range");
+  {  // at most one aperture operator per pass: its weight map is rendered right before it
+    const paos_pw_op* lists3[3] = {p.pre, p.mid, p.post};
+    const int counts3[3] = {p.n_pre, p.n_mid, p.n_post};
+    int nmask = 0;
+    for (int l = 0; l < 3; ++l)
+      for (int o = 0; o < counts3[l]; ++o)
+        if (lists3[l][o].kind == PAOS_PW_MASK) {
+          if (++nmask > 1) return fail(c, PAOS_EINVAL, "one aperture operator per pass");
+          if (!c->mask) HIPCHK(c, hipMalloc(&c->mask, (size_t)c->batch * c->item_stride * sizeof(double)));
+          const double* ap = dblocks + (size_t)lists3[l][o].block * c->batch * FP_STRIDE;
+          const dim3 grid(pw_blocks(c), c->batch), block(kPwThreads);
+          const double* ap2 = ap + (size_t)c->batch * FP_STRIDE;  // the next block set
+          if (c->precision == PAOS_F64) {
+            hipLaunchKernelGGL((aperture_kernel<double, BR, Lay<double>::BC, 0>), grid, block, 0, c->stream, (cx<double>*)nullptr, ap, ap2, FP_STRIDE, c->n, c->pitch, c->item_stride, c->mask, 1);
+            hipLaunchKernelGGL((aperture_kernel<double, BR, Lay<double>::BC, 1>), grid, block, 0, c->stream, (cx<double>*)nullptr, ap, ap2, FP_STRIDE, c->n, c->pitch, c->item_stride, c->mask, 1);
+          } else {
+            hipLaunchKernelGGL((aperture_kernel<float, BR, Lay<float>::BC, 0>), grid, block, 0, c->stream, (cx<float>*)nullptr, ap, ap2, FP_STRIDE, c->n, c->pitch, c->item_stride, c->mask, 1);
+            hipLaunchKernelGGL((aperture_kernel<float, BR, Lay<float>::BC, 1>), grid, block, 0, c->stream, (cx<float>*)nullptr, ap, ap2, FP_STRIDE, c->n, c->pitch, c->item_stride, c->mask, 1);
+          }
+          HIPCHK(c, hipGetLastError());
+        }
+  }
+  PassArgs a{};
+  a.field = c->field; a.tw = c->tw; a.blocks = dblocks; a.tables = c->tables; a.mask = c->mask; a.batch = c->batch;
+  a.fft1 = p.fft1; a.fft2 = p.fft2; a.n_pre = p.n_pre; a.n_mid = p.n_mid; a.n_post = p.n_post;
+  static_assert(sizeof(PwOp) == sizeof(paos_pw_op), "ABI op layout");
+  std::memcpy(a.pre, p.pre, sizeof(a.pre));
+  std::memcpy(a.mid, p.mid, sizeof(a.mid));
+  std::memcpy(a.post, p.post, sizeof(a.post));
+  PwOp* lists[3] = {a.pre, a.mid, a.post};
+  for (int l = 0; l < 3; ++l)
+    for (int o = 0; o < PAOS_MAX_PW; ++o) {
+      lists[l][o].flags &= (1 << kTableShift) - 1;
+      const int t = table_of_op[l * PAOS_MAX_PW + o];
+      if (t >= 0) lists[l][o].flags |= (t + 1) << kTableShift;
+    }
+  a.pitch = c->pitch; a.item_stride = c->item_stride;
+  if (p.axis == 0 || p.axis == 1)
+    return c->precision == PAOS_F64 ? pass_t<double>(c, p.axis, a) : pass_t<float>(c, p.axis, a);
+  if (p.axis != -1) return fail(c, PAOS_EINVAL, "pass axis must be 0, 1 or -1");
+  if (p.fft1 >= 0 || p.fft2 >= 0 || p.n_mid || p.n_post)
+    return fail(c, PAOS_EINVAL, "a transform-free pass carries its operators in the pre list");
+  const dim3 grid(pw_blocks(c), c->batch), block(kPwThreads);
+  if (c->precision == PAOS_F64)
+    hipLaunchKernelGGL((pointwise_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream, a, c->n);
+  else
+    hipLaunchKernelGGL((pointwise_kernel<float, BR, Lay<float>::BC>), grid, block, 0, c->stream, a, c->n);
+  HIPCHK(c, hipGetLastError());
   return PAOS_OK;
 }
 
@@ -199,35 +270,46 @@ int run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double*
   const double* dblocks = nullptr;
   int rc = arena_push(c, blocks, (size_t)n_blocks * c->batch * FP_STRIDE, &dblocks);
   if (rc) return rc;
-  for (int i = 0; i < n_passes; ++i) {
-    const paos_pass& p = passes[i];
-    if ((rc = check_ops(c, p.pre, p.n_pre, n_blocks))) return rc;
-    if ((rc = check_ops(c, p.mid, p.n_mid, n_blocks))) return rc;
-    if ((rc = check_ops(c, p.post, p.n_post, n_blocks))) return rc;
-    if (p.fft1 >= n_blocks || p.fft2 >= n_blocks) return fail(c, PAOS_EINVAL, "transform control block out of range");
-    PassArgs a{};
-    a.field = c->field; a.tw = c->tw; a.blocks = dblocks; a.batch = c->batch;
-    a.fft1 = p.fft1; a.fft2 = p.fft2; a.n_pre = p.n_pre; a.n_mid = p.n_mid; a.n_post = p.n_post;
-    static_assert(sizeof(PwOp) == sizeof(paos_pw_op), "ABI op layout");
-    std::memcpy(a.pre, p.pre, sizeof(a.pre));
-    std::memcpy(a.mid, p.mid, sizeof(a.mid));
-    std::memcpy(a.post, p.post, sizeof(a.post));
-    a.pitch = c->pitch; a.item_stride = c->item_stride;
-    if (p.axis == 0 || p.axis == 1) {
-      rc = c->precision == PAOS_F64 ? pass_t<double>(c, p.axis, a) : pass_t<float>(c, p.axis, a);
-      if (rc) return rc;
-    } else if (p.axis == -1) {
-      if (p.fft1 >= 0 || p.fft2 >= 0 || p.n_mid || p.n_post)
-        return fail(c, PAOS_EINVAL, "a transform-free pass carries its operators in the pre list");
-      const dim3 grid(pw_blocks(c), c->batch), block(kPwThreads);
-      if (c->precision == PAOS_F64)
-        hipLaunchKernelGGL((pointwise_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream, a, c->n);
-      else
-        hipLaunchKernelGGL((pointwise_kernel<float, BR, Lay<float>::BC>), grid, block, 0, c->stream, a, c->n);
-      HIPCHK(c, hipGetLastError());
-    } else {
-      return fail(c, PAOS_EINVAL, "pass axis must be 0, 1 or -1");
+  // Walk the program in chunks whose phase operators fit the table store: fill the tables of
+  // a chunk with one small launch, then run its passes.
+  int i = 0;
+  while (i < n_passes) {
+    TableArgs ta{};
+    ta.blocks = dblocks; ta.tables = c->tables; ta.batch = c->batch; ta.n = c->n; ta.count = 0;
+    std::vector<int> assign;  // per pass of the chunk: [3][PAOS_MAX_PW]
+    int j = i;
+    for (; j < n_passes; ++j) {
+      const paos_pass& p = passes[j];
+      const paos_pw_op* lists[3] = {p.pre, p.mid, p.post};
+      const int counts[3] = {p.n_pre, p.n_mid, p.n_post};
+      int need = 0;
+      for (int l = 0; l < 3; ++l)
+        for (int o = 0; o < counts[l] && o < PAOS_MAX_PW; ++o)
+          need += (lists[l][o].kind == PAOS_PW_QPHASE_CENTRED || lists[l][o].kind == PAOS_PW_QPHASE_NATURAL);
+      if (use_tables() && ta.count + need > kMaxTables) {
+        if (j == i) return fail(c, PAOS_EINVAL, "one pass needs more phase tables than the store holds");
+        break;
+      }
+      const size_t base = assign.size();
+      assign.resize(base + 3 * PAOS_MAX_PW, -1);
+      if (!use_tables()) continue;
+      for (int l = 0; l < 3; ++l)
+        for (int o = 0; o < counts[l] && o < PAOS_MAX_PW; ++o) {
+          const paos_pw_op& op = lists[l][o];
+          if (op.kind != PAOS_PW_QPHASE_CENTRED && op.kind != PAOS_PW_QPHASE_NATURAL) continue;
+          if (op.block < 0 || op.block >= n_blocks) return fail(c, PAOS_EINVAL, "operator block index out of range");
+          ta.jobs[ta.count] = {op.block, op.kind, op.flags & PAOS_PWF_MUL2PI};
+          assign[base + l * PAOS_MAX_PW + o] = ta.count++;
+        }
     }
+    if (ta.count > 0) {
+      const dim3 grid((2 * c->n + 255) / 256, c->batch, ta.count);
+      hipLaunchKernelGGL(phase_table_kernel, grid, dim3(256), 0, c->stream, ta);
+      HIPCHK(c, hipGetLastError());
+    }
+    for (int q = i; q < j; ++q)
+      if ((rc = launch_one_pass(c, passes[q], dblocks, n_blocks, &assign[(size_t)(q - i) * 3 * PAOS_MAX_PW]))) return rc;
+    i = j;
   }
   return PAOS_OK;
 }
@@ -341,6 +423,7 @@ int paos_ctx_create(int device, int n, int batch, int precision, paos_ctx** out)
   if ((e = hipMemsetAsync(c->field, 0, (size_t)c->item_stride * batch * eb, c->stream)) != hipSuccess) return bail(e, "hipMemset(field)");
   if ((e = hipMalloc(&c->tw, (size_t)n * eb)) != hipSuccess) return bail(e, "hipMalloc(tw)");
   if ((e = hipMalloc(&c->staging, (size_t)n * n * 16)) != hipSuccess) return bail(e, "hipMalloc(staging)");
+  if ((e = hipMalloc(&c->tables, (size_t)kMaxTables * batch * 2 * n * sizeof(cx<double>))) != hipSuccess) return bail(e, "hipMalloc(tables)");
   c->nparts = 1024;
   if ((e = hipMalloc(&c->partial, (size_t)batch * c->nparts * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(partial)");
   if ((e = hipMalloc(&c->norm2, (size_t)batch * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(norm2)");
@@ -398,6 +481,8 @@ int paos_ctx_destroy(paos_ctx* c) {
   if (c->field) (void)hipFree(c->field);
   if (c->tw) (void)hipFree(c->tw);
   if (c->staging) (void)hipFree(c->staging);
+  if (c->tables) (void)hipFree(c->tables);
+  if (c->mask) (void)hipFree(c->mask);
   if (c->partial) (void)hipFree(c->partial);
   if (c->norm2) (void)hipFree(c->norm2);
   if (c->norm2_host) (void)hipHostFree(c->norm2_host);
@@ -467,8 +552,8 @@ static int aperture_launch(paos_ctx* c, int shape, const double* dp, int nitems,
   const dim3 grid(pw_blocks(c), nitems), block(kPwThreads);
 #define AP_LAUNCH(T, S)                                                                          \
   hipLaunchKernelGGL((aperture_kernel<T, BR, Lay<T>::BC, S>), grid, block, 0, c->stream,                 \
-                     mask_out ? (cx<T>*)nullptr : (cx<T>*)c->field, dp, c->n, c->pitch,           \
-                     c->item_stride, mask_out)
+                     mask_out ? (cx<T>*)nullptr : (cx<T>*)c->field, dp, (const double*)nullptr,    \
+                     AP_STRIDE, c->n, c->pitch, c->item_stride, mask_out, 0)
   if (c->precision == PAOS_F64) {
     if (shape == PAOS_SHAPE_ELLIPSE) AP_LAUNCH(double, 0); else AP_LAUNCH(double, 1);
   } else {

@@ -87,7 +87,12 @@ __global__ void pointwise_kernel(PassArgs a, int n) {
     cx<T> v = f[m];
     for (int o = 0; o < a.n_pre; ++o) {
       const double* p = a.blocks + ((size_t)a.pre[o].block * a.batch + item) * FP_STRIDE;
-      if (p[FP_ENABLE] != 0.0) v = apply_pw(v, a.pre[o], p, r, c, n);
+      if (p[FP_ENABLE] != 0.0) {
+        const int ti = (a.pre[o].flags >> kTableShift) - 1;
+        v = apply_pw(v, a.pre[o], p, r, c, n,
+                     ti >= 0 ? a.tables + ((size_t)ti * a.batch + item) * 2 * n : nullptr,
+                     a.mask + (size_t)item * a.item_stride + m);
+      }
     }
     f[m] = v;
   }
@@ -152,7 +157,7 @@ __global__ void stop_scale_kernel(cx<T>* field, const double* norm2, unsigned it
 
 // ---- apertures ------------------------------------------------------------------
 // per-item block: [enable, xc, yc, a|w, b|h, theta, obscuration, subpixels]
-enum : int { AP_ENABLE = 0, AP_XC, AP_YC, AP_A, AP_B, AP_THETA, AP_OBSC, AP_SUBPIX, AP_STRIDE };
+enum : int { AP_ENABLE = 0, AP_XC, AP_YC, AP_A, AP_B, AP_THETA, AP_OBSC, AP_SUBPIX, AP_STRIDE, AP_SHAPE = 8 };
 
 struct EdgeAcc {
   double area;
@@ -260,17 +265,24 @@ __device__ __forceinline__ ApertureBox make_box(double xc, double yc, double xe,
   return b;
 }
 
-// SHAPE 0: exact ellipse, 1: sub-pixel rectangle.  If ``mask_out`` is non-null the
-// kernel renders the mask (row-major doubles, item 0 only) instead of applying it.
+// SHAPE 0: exact ellipse, 1: sub-pixel rectangle.  ``mask_out`` non-null: render instead of
+// apply -- row-major mask of item 0 (weights_out == 0, for the aperture object's to_image) or,
+// with weights_out != 0, the multiplicative weight (mask, or 1 - mask for an obscuration) of
+// EVERY item in the field's own layout, for a PWK_MASK operator riding on an FFT pass.
 template <typename T, int BR, int BC, int SHAPE>
-__global__ void aperture_kernel(cx<T>* field, const double* params, int n, unsigned pitch,
-                                unsigned item_stride, double* mask_out) {
+__global__ void aperture_kernel(cx<T>* field, const double* params, const double* params2,
+                                int param_stride, int n, unsigned pitch, unsigned item_stride,
+                                double* mask_out, int weights_out) {
   const int item = blockIdx.y;
-  const double* p = params + (size_t)item * AP_STRIDE;
+  const double* p = params + (size_t)item * param_stride;
+  // second half of the record [theta, obscuration, subpixels, shape]: contiguous for the
+  // 8-double blocks of paos_aperture, in the next block set for a pass-program operator
+  const double* p2 = params2 ? params2 + (size_t)item * param_stride : p + AP_THETA;
   if (p[AP_ENABLE] == 0.0) return;
-  const double xc = p[AP_XC], yc = p[AP_YC], a = p[AP_A], b = p[AP_B], theta = p[AP_THETA];
-  const bool obsc = p[AP_OBSC] != 0.0;
-  const int subpix = (int)p[AP_SUBPIX];
+  if (weights_out && SHAPE != (int)p2[3]) return;
+  const double xc = p[AP_XC], yc = p[AP_YC], a = p[AP_A], b = p[AP_B], theta = p2[0];
+  const bool obsc = p2[1] != 0.0;
+  const int subpix = (int)p2[2];
   const double ct = cos(theta), st = sin(theta);
   double xe, ye, hw = 0.0, hh = 0.0, full_disk = 0.0;
   if (SHAPE == 0) {
@@ -306,11 +318,12 @@ __global__ void aperture_kernel(cx<T>* field, const double* params, int n, unsig
         mask = rect_pixel(c, r, xc, yc, hw, hh, ct, st, subpix);
       }
     }
+    const double w = obsc ? __dsub_rn(1.0, mask) : mask;
     if (mask_out) {
-      if (item == 0) mask_out[(size_t)r * n + c] = mask;
+      if (weights_out) mask_out[(size_t)item * item_stride + m] = w;
+      else if (item == 0) mask_out[(size_t)r * n + c] = mask;
       continue;
     }
-    const double w = obsc ? __dsub_rn(1.0, mask) : mask;
     if (w != 1.0) {
       cx<T> v = f[m];
       v.x = (T)__dmul_rn((double)v.x, w);

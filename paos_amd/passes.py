@@ -89,6 +89,20 @@ class PassCompiler:
         self.open = p
 
     # ---- operators (rows = one 5-double block or None per batch item) --------------------
+    def aperture(self, records):
+        """records: per item None or the 8-double aperture block of paos_aperture
+        [enable, xc, yc, a|w, b|h, theta, obscuration, subpixels] plus the shape code.  The
+        mask rides on the next pass (its weight map is rendered right before it)."""
+        if all(r is None for r in records):
+            return
+        if any(op[0] == _lib.PW_MASK for op in self.tail) or (
+                self.open is not None and any(op[0] == _lib.PW_MASK for op in self.open["mid"])):
+            self._close_open()  # one aperture per pass
+        first = self._block([r[0][:5] if r is not None else None for r in records])
+        self._block([[r[0][5], r[0][6], r[0][7], float(r[1]), 0.0] if r is not None else None
+                     for r in records])
+        self.tail.append((_lib.PW_MASK, 0, first))
+
     def lens(self, rows):
         if all(r is None for r in rows):
             return

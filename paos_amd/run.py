@@ -27,6 +27,13 @@ from .passes import PassCompiler
 from .planner import PilotBeam, jacobi_recurrence, zernike_block
 from .zernike import Zernike, norm_factors
 
+# Apertures can ride on FFT passes as PW_MASK operators (their weight map is rendered right
+# before the pass).  On MI355X round 1 this is a net loss -- the fused passes are compute-bound
+# and a stand-alone aperture pass runs at HBM speed -- so it is opt-in: PAOS_FUSE_APERTURES=1.
+import os as _os
+
+FUSE_APERTURES = _os.environ.get("PAOS_FUSE_APERTURES", "0") == "1"
+
 _OFF_PHASE = [0.0] * _lib.PHASE_STRIDE
 _OFF_APERTURE = [0.0] * _lib.APERTURE_STRIDE
 
@@ -147,6 +154,20 @@ def _launch_zernike(dev, plans, want_wfe=False):
     return dev.zernike(nmax, kdim, jacobi_recurrence(nmax), blocks, want_wfe=want_wfe)
 
 
+def _queue_apertures(comp, plans):
+    """Apertures as pass operators (their weight maps are rendered right before the pass
+    they ride on, csrc/paos_hip.hip: launch_one_pass)."""
+    recs = []
+    for p in plans:
+        ap = p["aperture"]
+        if ap is None:
+            recs.append(None)
+        else:
+            code = _lib.SHAPE_ELLIPSE if isinstance(ap[0], EllipticalAperture) else _lib.SHAPE_RECT
+            recs.append((ap[0].block(obscuration=ap[1]), code))
+    comp.aperture(recs)
+
+
 def _queue_steps(comp, plans):
     """Lens and stw / ptp / wts of one surface go to the pass compiler, in the fixed slot
     order every regime respects (OI: stw, ptp; IO: ptp, wts; OO: stw, wts; II: ptp --
@@ -177,11 +198,15 @@ def _walk(dev, states, chains, on_saved, stats=None):
         items = [c[key] for c in chains]
         plans = [_plan_surface(st, it) for st, it in zip(states, items)]
         saved = any(it["save"] for it in items)
-        breaker = saved or any(p["aperture"] is not None or p["stop"] or p["zernike"] is not None
-                               for p in plans)
+        fuse_ap = FUSE_APERTURES
+        if fuse_ap:
+            _queue_apertures(comp, plans)
+        breaker = saved or any(p["stop"] or p["zernike"] is not None or
+                               (p["aperture"] is not None and not fuse_ap) for p in plans)
         if breaker:
             npass += comp.flush(dev)  # the field must be current before a non-fusable operator
-        _launch_apertures(dev, plans)
+        if not fuse_ap:
+            _launch_apertures(dev, plans)
         if any(p["stop"] for p in plans):
             dev.make_stop([1.0 if p["stop"] else 0.0 for p in plans])
         want_wfe = len(plans) == 1 and bool(items[0]["save"])

@@ -115,6 +115,8 @@ class ModelDevice:
             return u * np.where((i[:, None] + i[None, :]) & 1, -1.0, 1.0)
         if kind == _lib.PW_SCALE:
             return u * p[3]
+        if kind == _lib.PW_MASK:
+            raise AssertionError("handled by the caller (needs two blocks)")
         i = np.arange(n)
         g = (i - n // 2) if kind == _lib.PW_QPHASE_CENTRED else np.where(i < n // 2, i, i - n)
         x, y = g * p[1], g * p[2]
@@ -127,6 +129,7 @@ class ModelDevice:
     def run_passes(self, passes, blocks):
         blocks = np.asarray(blocks, dtype=np.float64)
         assert blocks.ndim == 3 and blocks.shape[1:] == (self.batch, 5)
+        n_ = self.n
         for ps in passes:
             self.pass_count += 1
             self.log.append(("pass", ps["axis"]))
@@ -135,7 +138,14 @@ class ModelDevice:
                 for slot, ctl in (("pre", ps.get("fft1", -1)), ("mid", ps.get("fft2", -1)), ("post", -1)):
                     for op in ps.get(slot, ()):
                         p = blocks[op[2], i]
-                        if p[0] != 0.0:
+                        if p[0] == 0.0:
+                            continue
+                        if op[0] == _lib.PW_MASK:
+                            theta, obsc, _sub, shape, _ = blocks[op[2] + 1, i]
+                            fn = aperture_np.ellipse_mask if shape == _lib.SHAPE_ELLIPSE else aperture_np.rectangle_mask
+                            mask = fn((n_, n_), p[1], p[2], p[3], p[4], theta)
+                            u = u * ((1 - mask) if obsc else mask)
+                        else:
                             u = self._apply(u, op, p)
                     if ctl is not None and ctl >= 0 and blocks[ctl, i, 0] != 0.0:
                         assert ps["axis"] in (0, 1)

@@ -314,6 +314,20 @@ def test_batch_with_divergent_propagator_regimes():
     assert props == ["OO", "OI"]
 
 
+def test_optional_paths_keep_parity(monkeypatch):
+    """Opt-in variants measured slower in round 1 but kept for later rounds: apertures riding
+    on passes (PAOS_FUSE_APERTURES) -- same results as the default path."""
+    import paos_amd.run as prun
+    from paos_amd.chains import syn20_chain
+
+    field = {"us": 0.0, "ut": 0.0}
+    base = prun.run(1.0, 1.0e-6, 256, 4, field, syn20_chain())
+    monkeypatch.setattr(prun, "FUSE_APERTURES", True)
+    fused = prun.run(1.0, 1.0e-6, 256, 4, field, syn20_chain())
+    for k in base:
+        assert rel_err(fused[k]["wfo"], base[k]["wfo"]) < 1e-13
+
+
 def test_fp32_mode_tolerance():
     """c64 storage / FFT arithmetic with fp64 phase arguments: expected ~3e-6."""
     from paos_amd.chains import syn20_chain

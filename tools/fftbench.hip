@@ -158,18 +158,9 @@ int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 10;
   const int b4 = 8;
   const int pad = 3;
-  bench_copy<double>(4096, b4, reps);
-  bench_variant<double, 4096, 16, 2, 0, 4, 2, true, 1, 1, 1, 1>("blk4x2 rows L2 512thr", b4, reps, pad);
+  printf("PAOS_DIAG=%d\n", PAOS_DIAG);
   bench_variant<double, 4096, 16, 2, 0, 4, 2, false, 1, 1, 1, 1>("blk4x2 rows L2 512thr full", b4, reps, pad);
-  bench_variant<double, 4096, 16, 2, 0, 4, 2, true, 2, 1, 1, 2>("blk4x2 rows L2 SEQ2 256thr mw2", b4, reps, pad);
-  bench_variant<double, 4096, 16, 2, 0, 4, 2, false, 2, 1, 1, 2>("blk4x2 rows L2 SEQ2 256thr mw2 full", b4, reps, pad);
-  bench_variant<double, 4096, 16, 2, 1, 4, 2, true, 1, 1, 1, 1>("blk4x2 cols L2 512thr", b4, reps, pad);
   bench_variant<double, 4096, 16, 2, 1, 4, 2, false, 1, 1, 1, 1>("blk4x2 cols L2 512thr full", b4, reps, pad);
-  bench_variant<double, 4096, 16, 2, 1, 4, 2, true, 2, 1, 1, 2>("blk4x2 cols L2 SEQ2 256thr mw2", b4, reps, pad);
-  bench_variant<double, 4096, 16, 2, 1, 4, 2, false, 2, 1, 1, 2>("blk4x2 cols L2 SEQ2 256thr mw2 full", b4, reps, pad);
-  bench_variant<double, 2048, 16, 4, 0, 4, 2, false, 2, 1, 1, 2>("2048 rows L4 SEQ2 256thr mw2", 16, reps, pad);
-  bench_variant<double, 2048, 16, 2, 0, 4, 2, false, 1, 1, 1, 1>("2048 rows L2 256thr", 16, reps, pad);
-  bench_variant<double, 2048, 16, 4, 0, 4, 2, true, 1, 1, 1, 1>("2048 rows L4 512thr", 16, reps, pad);
-  bench_variant<double, 2048, 16, 2, 1, 4, 2, false, 1, 1, 1, 1>("2048 cols L2 256thr", 16, reps, pad);
+  bench_variant<double, 4096, 16, 1, 0, 1, 1, false, 1, 1, 1, 1>("canon rows L1 256thr full", b4, reps, 0);
   return 0;
 }
