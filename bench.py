@@ -84,7 +84,8 @@ def main():
         args.gpus = world
 
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("PAOS_BENCH_FORCE_DIST") == "1":  # the flag exercises the
+        # process-group path with a single rank (what a 1-GPU box can test)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch
         import torch.distributed as dist
@@ -195,7 +196,7 @@ def main():
                          "algorithmic_GBps": 8 * esz * n * n * nb / (ptp_ms * 1e-3) / 1e9,
                          "frac_of_hbm_peak": 8 * esz * n * n * nb / (ptp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "note": "SURVEY 8d prices a ptp at 128 B/px (4 passes); the fused path moves 96 B/px"},
-            "power_check": float(res[0][20]["power"]),
+            "power_check": float(dev.norm2_fetch(res[0][20]["power_ticket"])[0]),
             "build": dev.build_info(),
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -102,6 +102,10 @@ int paos_aperture_render(paos_ctx* ctx, int shape, const double* params1, double
 int paos_make_stop(paos_ctx* ctx, const double* enable);
 /* sum |u|^2 per item to the host (np.sum(np.abs(u)**2), wfo.py:200).  Synchronises. */
 int paos_norm2(paos_ctx* ctx, double* host_out);
+/* The same without stalling the host: enqueue the reduction and its copy to pinned memory,
+ * get a ticket (up to 64 outstanding), fetch after the work was synchronised. */
+int paos_norm2_enqueue(paos_ctx* ctx, int* ticket);
+int paos_norm2_fetch(paos_ctx* ctx, int ticket, double* host_out);
 /* quadratic phase u *= exp(i sgn [2 pi] coef ((x sx)^2 + (y sy)^2)), x, y centred pixel
  * indices: the field part of WFO.lens (wfo.py:359-366) with mul2pi = 1, sgn = -1,
  * coef = 0.5 lens_phase / wl. */

@@ -55,6 +55,8 @@ SYMBOLS = {
     "paos_aperture_render": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p, _dbl_p]),
     "paos_make_stop": (ctypes.c_int, [_c_ctx, _dbl_p]),
     "paos_norm2": (ctypes.c_int, [_c_ctx, _dbl_p]),
+    "paos_norm2_enqueue": (ctypes.c_int, [_c_ctx, ctypes.POINTER(ctypes.c_int)]),
+    "paos_norm2_fetch": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p]),
     "paos_phase": (ctypes.c_int, [_c_ctx, _dbl_p, ctypes.c_int]),
     "paos_ptp": (ctypes.c_int, [_c_ctx, _dbl_p]),
     "paos_stw": (ctypes.c_int, [_c_ctx, _dbl_p, ctypes.c_int]),
@@ -195,6 +197,16 @@ class DeviceFields:
     def norm2(self):
         out = np.empty(self.batch, dtype=np.float64)
         self._check(self._lib.paos_norm2(self._ctx, _dptr(out)), "paos_norm2")
+        return out
+
+    def norm2_enqueue(self):
+        t = ctypes.c_int(-1)
+        self._check(self._lib.paos_norm2_enqueue(self._ctx, ctypes.byref(t)), "paos_norm2_enqueue")
+        return t.value
+
+    def norm2_fetch(self, ticket):
+        out = np.empty(self.batch, dtype=np.float64)
+        self._check(self._lib.paos_norm2_fetch(self._ctx, int(ticket), _dptr(out)), "paos_norm2_fetch")
         return out
 
     def phase(self, blocks, mul2pi):

@@ -31,6 +31,7 @@ class ABCD:
         self._mat = _compose(thickness, curvature, n1, n2, M)
         self._cin = np.sign(n1)
         self._cout = np.sign(n2)
+        self._cache = {}  # read-outs of the factorisation, filled on first use
 
     # matrix access ---------------------------------------------------------
     def __call__(self):
@@ -43,6 +44,7 @@ class ABCD:
     @ABCD.setter
     def ABCD(self, value):
         self._mat = value.copy()
+        self._cache = {}
 
     # direction of travel (+1 left-to-right, -1 right-to-left) ---------------
     @property
@@ -62,22 +64,36 @@ class ABCD:
         self._cout = value
 
     # factorisation read-outs (abcd.py:98-116,142-144) ------------------------
+    def _readout(self, name):
+        val = self._cache.get(name)
+        if val is None:
+            m = self._mat
+            if name == "thickness":
+                val = m[0, 1] / m[1, 1]
+            elif name == "M":
+                val = (m[0, 0] * m[1, 1] - m[0, 1] * m[1, 0]) / m[1, 1]
+            elif name == "n1n2":
+                val = m[1, 1] * self._readout("M")
+            else:  # power
+                val = -m[1, 0] / self._readout("M")
+            self._cache[name] = val
+        return val
+
     @property
     def thickness(self):
-        return self._mat[0, 1] / self._mat[1, 1]
+        return self._readout("thickness")
 
     @property
     def M(self):
-        m = self._mat
-        return (m[0, 0] * m[1, 1] - m[0, 1] * m[1, 0]) / m[1, 1]
+        return self._readout("M")
 
     @property
     def n1n2(self):
-        return self._mat[1, 1] * self.M
+        return self._readout("n1n2")
 
     @property
     def power(self):
-        return -self._mat[1, 0] / self.M
+        return self._readout("power")
 
     @property
     def f_eff(self):
@@ -86,10 +102,11 @@ class ABCD:
     def __mul__(self, other):
         """self after other: matrix product, direction flags taken from
         ``other`` (abcd.py:157-164)."""
-        res = ABCD()
-        res.ABCD = self._mat @ other()
-        res.cin = other.cin
-        res.cout = other.cout
+        res = ABCD.__new__(ABCD)  # skip the constructor's three 2x2 products
+        res._mat = self._mat @ other()
+        res._cin = other.cin
+        res._cout = other.cout
+        res._cache = {}
         return res
 
     def __repr__(self):

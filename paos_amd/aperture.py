@@ -92,15 +92,19 @@ def make_aperture(n, dx, dy, xc, yc, hx=None, hy=None, r=None, shape="elliptical
 def bbox_misses_grid(ap, n):
     """photutils' ``to_image`` returns None when the mask's bounding box does not
     overlap the image; the reference then fails on ``u *= None``."""
-    ct, st = np.cos(ap.theta), np.sin(ap.theta)
+    import math
+
+    ct, st = math.cos(ap.theta), math.sin(ap.theta)
     if isinstance(ap, EllipticalAperture):
-        xe = np.sqrt((ap.a * ct) ** 2 + (ap.b * st) ** 2)
-        ye = np.sqrt((ap.a * st) ** 2 + (ap.b * ct) ** 2)
+        xe = math.sqrt((ap.a * ct) ** 2 + (ap.b * st) ** 2)
+        ye = math.sqrt((ap.a * st) ** 2 + (ap.b * ct) ** 2)
     else:
         hw, hh = ap.w / 2.0, ap.h / 2.0
         xe = max(abs(hw * ct - hh * st), abs(hw * ct + hh * st))
         ye = max(abs(hw * st + hh * ct), abs(hw * st - hh * ct))
-    xc, yc = ap.positions
-    x0, x1 = np.floor(xc - xe + 0.5), np.ceil(xc + xe + 0.5)
-    y0, y1 = np.floor(yc - ye + 0.5), np.ceil(yc + ye + 0.5)
+    xc, yc = float(ap.positions[0]), float(ap.positions[1])
+    if not (math.isfinite(xc) and math.isfinite(yc) and math.isfinite(xe) and math.isfinite(ye)):
+        return True
+    x0, x1 = math.floor(xc - xe + 0.5), math.ceil(xc + xe + 0.5)
+    y0, y1 = math.floor(yc - ye + 0.5), math.ceil(yc + ye + 0.5)
     return max(x0, 0) >= min(x1, n) or max(y0, 0) >= min(y1, n)

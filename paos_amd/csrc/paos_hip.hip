@@ -33,6 +33,7 @@ using namespace paos;
 #define PAOS_PAD_BLOCKS 3
 #endif
 static constexpr int BR = PAOS_BR;
+static constexpr int kNormSlots = 64;  // outstanding paos_norm2_enqueue results
 template <typename T>
 struct Lay {
   static constexpr int BC = 128 / (BR * (int)sizeof(cx<T>));
@@ -61,7 +62,8 @@ struct paos_ctx {
   double* mask = nullptr;        // batch x item_stride aperture weights (allocated on first use)
   double* partial = nullptr;
   double* norm2 = nullptr;
-  double* norm2_host = nullptr;  // pinned
+  double* norm2_host = nullptr;  // pinned, kNormSlots x batch
+  int norm_slot = 0;
   int nparts = 0;
   Arena arena;
   std::string err;
@@ -118,6 +120,8 @@ int pw_blocks(const paos_ctx* c) {
 template <typename T, int N>
 struct FftCfg {
   static constexpr int BC = Lay<T>::BC;
+  // 16 points per thread.  (32 points of complex64 fill the same 64 data VGPRs, but the
+  // radix-32 butterflies spill: 256 VGPRs + 60-70 AGPRs measured, so E stays 16 for both types.)
   static constexpr int E = 16;
   // rows of a block row handled by one row tile: all four, except at N = 4096 where four
   // lines of 4096 points do not fit the register file of a spill-free workgroup
@@ -427,7 +431,7 @@ int paos_ctx_create(int device, int n, int batch, int precision, paos_ctx** out)
   c->nparts = 1024;
   if ((e = hipMalloc(&c->partial, (size_t)batch * c->nparts * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(partial)");
   if ((e = hipMalloc(&c->norm2, (size_t)batch * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(norm2)");
-  if ((e = hipHostMalloc(&c->norm2_host, (size_t)batch * sizeof(double))) != hipSuccess) return bail(e, "hipHostMalloc(norm2)");
+  if ((e = hipHostMalloc(&c->norm2_host, (size_t)kNormSlots * batch * sizeof(double))) != hipSuccess) return bail(e, "hipHostMalloc(norm2)");
   c->arena.cap = (size_t)1 << 20;  // 8 MiB of doubles
   if (c->arena.cap < (size_t)batch * 4096) c->arena.cap = (size_t)batch * 4096;
   if ((e = hipHostMalloc(&c->arena.host, c->arena.cap * sizeof(double))) != hipSuccess) return bail(e, "hipHostMalloc(arena)");
@@ -618,6 +622,25 @@ int paos_make_stop(paos_ctx* c, const double* enable) {
     hipLaunchKernelGGL(stop_scale_kernel<float>, grid, block, 0, c->stream, (cx<float>*)c->field,
                        c->norm2, c->item_stride, den, 1);
   HIPCHK(c, hipGetLastError());
+  return PAOS_OK;
+}
+
+int paos_norm2_enqueue(paos_ctx* c, int* ticket) {
+  if (!c || !ticket) return fail(c, PAOS_EINVAL, "null argument");
+  int rc = norm2_launch(c, nullptr);
+  if (rc) return rc;
+  const int slot = c->norm_slot;
+  c->norm_slot = (slot + 1) % kNormSlots;
+  HIPCHK(c, hipMemcpyAsync(c->norm2_host + (size_t)slot * c->batch, c->norm2, (size_t)c->batch * sizeof(double),
+                           hipMemcpyDeviceToHost, c->stream));
+  *ticket = slot;
+  return PAOS_OK;
+}
+
+int paos_norm2_fetch(paos_ctx* c, int ticket, double* host_out) {
+  if (!c || !host_out || ticket < 0 || ticket >= kNormSlots) return fail(c, PAOS_EINVAL, "bad ticket");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::memcpy(host_out, c->norm2_host + (size_t)ticket * c->batch, (size_t)c->batch * sizeof(double));
   return PAOS_OK;
 }
 

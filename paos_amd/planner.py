@@ -12,7 +12,15 @@ Each method returns what the device needs: a 5-double block
 ``[enable, sx, sy, coef, sgn]`` (include/paos_hip.h, PAOS_PHASE_STRIDE) or
 ``None`` when the reference would return without touching the field.
 """
+import math
+
 import numpy as np
+
+
+def _sqrt(x):
+    # math.sqrt == np.sqrt bit for bit (both correctly rounded); this one skips NumPy's
+    # scalar dispatch.  Negative / nan inputs keep NumPy's nan instead of raising.
+    return math.sqrt(x) if x >= 0.0 else np.sqrt(x)
 
 
 class PilotBeam:
@@ -39,7 +47,7 @@ class PilotBeam:
     # ---- read-outs ---------------------------------------------------------------
     @property
     def wz(self):
-        return self.w0 * np.sqrt(1.0 + ((self.z - self.zw0) / self.zr) ** 2)
+        return self.w0 * _sqrt(1.0 + ((self.z - self.zw0) / self.zr) ** 2)
 
     @property
     def distancetofocus(self):
@@ -53,18 +61,18 @@ class PilotBeam:
     def region(self, z=None):
         """'I' within rayleigh_factor * zr of the waist, else 'O' (wfo.py:280-302)."""
         gap = (self.z if z is None else z) - self.zw0
-        return "I" if np.abs(gap) < self.rayleigh_factor * self.zr else "O"
+        return "I" if abs(gap) < self.rayleigh_factor * self.zr else "O"
 
     # ---- operators -----------------------------------------------------------------
     def lens(self, lens_fl):
         """wfo.py:318-366.  Returns the phase block of
         exp(2 pi i * (-(x^2+y^2) * (0.5 lens_phase / wl)))."""
-        wz = self.w0 * np.sqrt(1.0 + ((self.z - self.zw0) / self.zr) ** 2)
+        wz = self.w0 * _sqrt(1.0 + ((self.z - self.zw0) / self.zr) ** 2)
         gap = self.z - self.zw0
         regime = self.region()
         curv_in = gap / (gap**2 + self.zr**2)
         curv_out = curv_in - 1.0 / lens_fl
-        self.w0 = wz / np.sqrt(1.0 + (np.pi * wz**2 * curv_out / self.wl) ** 2)
+        self.w0 = wz / _sqrt(1.0 + (np.pi * wz**2 * curv_out / self.wl) ** 2)
         self.zw0 = -curv_out / (curv_out**2 + (self.wl / (np.pi * wz**2)) ** 2) + self.z
         self.zr = np.pi * self.w0**2 / self.wl
         regime += self.region()
@@ -81,7 +89,7 @@ class PilotBeam:
             power = 1.0 / lens_fl - ref_in
         else:
             power = 1.0 / lens_fl - ref_in + ref_out
-        self.fratio = np.abs(gap) / (2 * wz)
+        self.fratio = abs(gap) / (2 * wz)
         return [1.0, self.dx, self.dy, 0.5 * power / self.wl, -1.0]
 
     def magnification(self, My, Mx=None):
@@ -118,7 +126,7 @@ class PilotBeam:
 
     def ptp(self, dz):
         """wfo.py:454-472: block for H = exp(-i (pi wl dz)(fx^2 + fy^2))."""
-        if np.abs(dz) < 0.001 * self.wl:
+        if abs(dz) < 0.001 * self.wl:
             return None
         if self.C != 0:
             raise ValueError("PTP wavefront should be planar")
@@ -129,7 +137,7 @@ class PilotBeam:
 
     def stw(self, dz):
         """wfo.py:483-509: (block for Q = exp(+i (pi wl dz) f^2), inverse flag)."""
-        if np.abs(dz) < 0.001 * self.wl:
+        if abs(dz) < 0.001 * self.wl:
             return None
         if self.C == 0.0:
             raise ValueError("STW wavefront should not be planar")
@@ -138,21 +146,21 @@ class PilotBeam:
         self.z = self.z + dz
         self.C = 0.0
         # (fx[1] - fx[0]) * wl * |dz| with fx[1] = 1 * val, fx[0] = 0 * val
-        self.dx = (fsx - 0.0) * self.wl * np.abs(dz)
-        self.dy = (fsy - 0.0) * self.wl * np.abs(dz)
+        self.dx = (fsx - 0.0) * self.wl * abs(dz)
+        self.dy = (fsy - 0.0) * self.wl * abs(dz)
         return block, not (dz >= 0)
 
     def wts(self, dz):
         """wfo.py:520-545: (block for P = exp(+i (pi/(dz wl)) (x^2+y^2)), inverse flag)."""
-        if np.abs(dz) < 0.001 * self.wl:
+        if abs(dz) < 0.001 * self.wl:
             return None
         if self.C != 0.0:
             raise ValueError("WTS wavefront should be planar")
         block = [1.0, self.dx, self.dy, (np.pi / (dz * self.wl)), 1.0]
         self.z = self.z + dz
         self.C = 1 / (self.z - self.zw0)
-        self.dx = self.wl * np.abs(dz) / (self.n * self.dx)
-        self.dy = self.wl * np.abs(dz) / (self.n * self.dy)
+        self.dx = self.wl * abs(dz) / (self.n * self.dx)
+        self.dy = self.wl * abs(dz) / (self.n * self.dy)
         return block, not (dz >= 0)
 
     def propagate(self, dz):

@@ -15,6 +15,7 @@ launch carries a per-item parameter block with an enable flag, so items whose
 planners disagree (a ptp skipped for one wavelength, II vs OI) still share
 launches.
 """
+import math
 from copy import deepcopy
 
 import numpy as np
@@ -61,16 +62,16 @@ def _plan_surface(st, item):
 
     if "aperture" in item:
         ap = item["aperture"]
-        xdec = ap["xc"] if np.isfinite(ap["xc"]) else st.vs[0]
-        ydec = ap["yc"] if np.isfinite(ap["yc"]) else st.vt[0]
+        xdec = ap["xc"] if math.isfinite(ap["xc"]) else st.vs[0]
+        ydec = ap["yc"] if math.isfinite(ap["yc"]) else st.vt[0]
         xrad = ap["xrad"]
         yrad = ap["yrad"]
-        xrad *= np.sqrt(1 / (st.vs[1] ** 2 + 1))
-        yrad *= np.sqrt(1 / (st.vt[1] ** 2 + 1))
+        xrad *= math.sqrt(1 / (st.vs[1] ** 2 + 1))  # sqrt is correctly rounded either way
+        yrad *= math.sqrt(1 / (st.vt[1] ** 2 + 1))
         xaper = xdec - st.vs[0]
         yaper = ydec - st.vt[0]
         obscuration = ap["type"] != "aperture"
-        if np.all(np.isfinite([xrad, yrad])):
+        if math.isfinite(xrad) and math.isfinite(yrad):
             handle = make_aperture(beam.n, beam.dx, beam.dy, xaper, yaper, hx=xrad, hy=yrad,
                                    shape=ap["shape"])
             if bbox_misses_grid(handle, beam.n):
@@ -80,7 +81,7 @@ def _plan_surface(st, item):
     plan["stop"] = bool(item["is_stop"])
 
     if item["type"] == "Zernike":
-        radius = item["Zradius"] if np.isfinite(item["Zradius"]) else beam.wz
+        radius = item["Zradius"] if math.isfinite(item["Zradius"]) else beam.wz
         if item["Zorthonorm"]:
             raise NotImplementedError("Zorthonorm=True (PolyOrthoNorm) is not accelerated yet")
         index = np.asarray(item["Zindex"])
@@ -109,11 +110,11 @@ def _plan_surface(st, item):
     n1n2 = item["ABCDt"].n1n2
     if Mt != 1.0 or Ms != 1.0:
         beam.magnification(Mt, Ms)
-    if np.abs(n1n2) != 1.0:
+    if abs(n1n2) != 1.0:
         beam.change_medium(n1n2)
-    if np.isfinite(fl):
+    if math.isfinite(fl):
         plan["lens"] = beam.lens(fl)
-    if np.isfinite(T) and np.abs(T) > 1e-10:
+    if math.isfinite(T) and abs(T) > 1e-10:
         plan["steps"] = beam.propagate(T)
 
     st.vt = item["ABCDt"]() @ st.vt
@@ -267,7 +268,8 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
     ``wavelengths[i]`` / ``opt_chains[i]`` describe wavefront ``i`` (chains must
     contain the same surfaces).  Returns a list of ``B`` dicts
     ``{num: {scalars..., 'power': sum|u|^2, ['psf'], ['wfo'], ['amplitude'], ['phase']}}``
-    for saved surfaces.  ``outputs`` picks which N x N arrays are copied back to the
+    for saved surfaces (with ``sync=False`` the power is left as ``'power_ticket'`` for
+    ``dev.norm2_fetch``).  ``outputs`` picks which N x N arrays are copied back to the
     host per saved surface and item ('psf' = |u|^2, plot.py:125-130); ``()`` keeps
     every array on the GPU and returns scalars and the power only -- the mode the
     throughput benchmark uses.  ``dev`` may pass a pre-allocated
@@ -290,23 +292,34 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
     what = {"psf": _lib.WHAT_INTENSITY, "wfo": _lib.WHAT_FIELD, "amplitude": _lib.WHAT_AMPLITUDE,
             "phase": _lib.WHAT_PHASE}
 
+    tickets = []  # (ticket, [(item index, record)]): powers are fetched after the walk, so the
+    # host keeps planning while the GPU works (no mid-chain synchronisation)
+
     def on_saved(key, items, plans, wfe):
-        power = dev.norm2()
+        pending = []
         for i, (item, plan) in enumerate(zip(items, plans)):
             if not item["save"]:
                 continue
             rec = dict(plan["scalars"])
             rec["aperture"] = plan["aperture"][0] if plan["aperture"] else None
-            rec["power"] = float(power[i])
             for name in outputs:
                 rec[name] = dev.download(i, what[name])
             rec["_plan"] = plan
             results[i][item["num"]] = rec
+            pending.append((i, rec))
+        tickets.append((dev.norm2_enqueue(), pending))
 
     try:
         _walk(dev, states, list(opt_chains), on_saved, stats=stats)
-        if sync:
-            dev.sync()
+        if sync or own:
+            for ticket, pending in tickets:
+                power = dev.norm2_fetch(ticket)
+                for i, rec in pending:
+                    rec["power"] = float(power[i])
+        else:  # caller synchronises later: hand out the tickets
+            for ticket, pending in tickets:
+                for i, rec in pending:
+                    rec["power_ticket"] = ticket
     finally:
         if own:
             dev.close()

@@ -48,6 +48,14 @@ class ModelDevice:
     def norm2(self):
         return np.array([np.sum(np.abs(u) ** 2) for u in self.u])
 
+    def norm2_enqueue(self):
+        self._tickets = getattr(self, "_tickets", [])
+        self._tickets.append(self.norm2())
+        return len(self._tickets) - 1
+
+    def norm2_fetch(self, ticket):
+        return self._tickets[ticket]
+
     def make_stop(self, enable=None):
         self.log.append(("make_stop", None))
         for i in range(self.batch):
