@@ -10,7 +10,10 @@
 * :func:`read_wfe_table` -- reader for ``wfe data/wfe_realization_*.csv``
   (3 comment lines, then rows J, N, M, WFE000..WFE999).
 """
+import configparser
 import copy
+import os
+import tempfile
 
 import numpy as np
 
@@ -102,3 +105,30 @@ def inject_wfe(opt_chain, draw_nm, surface_name="Z1"):
     if not hit:
         raise KeyError(f"no surface named {surface_name!r} in the chain (is it 'Ignore = True'?)")
     return out
+
+
+def parse_config_variant(path, wavelengths_um=None, unignore=()):
+    """``parse_config`` on a lens file with (a) the ``[wavelengths]`` section replaced by
+    ``wavelengths_um`` (wavelength sweeps beyond the handful a shipped file lists) and (b)
+    ``Ignore`` cleared on the surfaces whose ``Comment`` is in ``unignore`` (the shipped
+    Ariel_FGS-FGS1.ini keeps the Monte-Carlo surface ``Z1`` ignored).  The file
+    on disk is not touched: a temporary copy is parsed."""
+    from .parse_config import parse_config
+
+    cfg = configparser.ConfigParser()
+    cfg.read(os.path.expanduser(path))
+    if wavelengths_um is not None:
+        cfg.remove_section("wavelengths")
+        cfg.add_section("wavelengths")
+        for k, wl in enumerate(wavelengths_um, start=1):
+            cfg["wavelengths"][f"w{k}"] = repr(float(wl))
+    for name in cfg.sections():
+        if name.startswith("lens_") and cfg[name].get("Comment", "") in unignore:
+            cfg[name]["Ignore"] = "False"
+    with tempfile.NamedTemporaryFile("w", suffix=".ini", delete=False) as fh:
+        cfg.write(fh)
+        tmp = fh.name
+    try:
+        return parse_config(tmp)
+    finally:
+        os.unlink(tmp)

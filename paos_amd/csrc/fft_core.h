@@ -32,16 +32,14 @@ __device__ __forceinline__ cx<T> cmul(cx<T> a, cx<T> b) {
 template <typename T>
 __device__ __forceinline__ cx<T> cconj(cx<T> a) { return {a.x, -a.y}; }
 
-// sin and cos of a double with |a| < ~1e7 rad: three-term Cody-Waite reduction
-// by pi/2 (exact thanks to FMA) + the classic minimax kernels on [-pi/4, pi/4].
-// About 1 ulp; ~45 instructions and no data-dependent branch, unlike the
-// generic library routine whose Payne-Hanek path bloats register use when 16
-// calls are unrolled into one FFT pass.  Larger arguments take the library path.
+// sin and cos of a double: three-term Cody-Waite reduction by pi/2 + the classic minimax
+// kernels on [-pi/4, pi/4].  With FMA the first reduction step a - n*pio2_1 is exact for any
+// n (the difference needs <= 34 bits), the later steps round at 1e-16 of |r| <= 1, and the
+// three-term pi/2 is good to 8.5e-32 * n, so the result is ~1 ulp for |a| up to 2^40; the
+// library validates on the host that no phase argument exceeds kMaxPhaseArg (paos_hip.hip)
+// so the kernels carry no Payne-Hanek fallback.  ~45 instructions, branch-free.
+constexpr double kMaxPhaseArg = 1.0e12;
 __device__ __forceinline__ void sincos_fast(double a, double* sn, double* cs) {
-  if (__builtin_expect(!(fabs(a) < 1.0e7), 0)) {
-    sincos(a, sn, cs);  // cold: generic library path (Payne-Hanek) for absurdly large arguments
-    return;
-  }
   const double n = rint(a * 0.63661977236758134308);  // 2/pi
   double r = fma(-n, 1.57079632673412561417e+00, a);
   r = fma(-n, 6.07710050630396597660e-11, r);
@@ -59,7 +57,7 @@ __device__ __forceinline__ void sincos_fast(double a, double* sn, double* cs) {
   pc = fma(z, pc, -1.38888888888741095749e-03);
   pc = fma(z, pc, 4.16666666666666019037e-02);
   const double c = fma(z * z, pc, fma(z, -0.5, 1.0));
-  const int q = (int)n & 3;
+  const int q = (int)((long long)n & 3);  // n may exceed 2^31 near kMaxPhaseArg
   const double s1 = (q & 1) ? c : s;
   const double c1 = (q & 1) ? s : c;
   *sn = (q & 2) ? -s1 : s1;
@@ -201,6 +199,18 @@ __device__ __forceinline__ void apply_twiddle_powers(cx<T>* v, cx<T> w1) {
   }
 }
 
+// Register-frugal twiddle powers: a running product, two twiddles live (vs five above).
+// Error grows linearly (<= R roundings, ~2e-15 for R = 16): well inside the parity budget.
+template <int R, typename T>
+__device__ __forceinline__ void apply_twiddle_chain(cx<T>* v, cx<T> w1) {
+  cx<T> w = w1;
+#pragma unroll
+  for (int r = 1; r < R; ++r) {
+    v[r] = cmul(v[r], w);
+    if (r + 1 < R) w = cmul(w, w1);
+  }
+}
+
 // PAOS_DIAG (microbench timing builds only; results are wrong): bit 0 drops the barriers,
 // bit 1 drops the LDS traffic of the exchanges.
 #ifndef PAOS_DIAG
@@ -211,7 +221,11 @@ __device__ __forceinline__ void apply_twiddle_powers(cx<T>* v, cx<T> w1) {
 // All stages of one line.  ``lds`` is this line's exchange area: cx<T> slots
 // when !SPLIT, T slots (real and imaginary parts exchanged one after the other,
 // halving the LDS footprint) when SPLIT.  ``tw`` = exp(-2 pi i m / N), m < N.
-template <typename T, int N, int E, int DIR, bool SPLIT, int NS = 1>
+// FR (frugal): sequential twiddle chain and scheduling fences between the phases of a stage,
+// which keeps a 4096-point c128 pass at ~118 VGPRs -- four waves per SIMD, i.e. two 512-thread
+// workgroups per CU whose load / compute / store phases overlap (profiles/r01_vgpr_experiments.txt).
+#define PAOS_FENCE() do { if constexpr (FR != 0) __builtin_amdgcn_sched_barrier(0); } while (0)
+template <typename T, int N, int E, int DIR, bool SPLIT, int NS = 1, int FR = 0>
 __device__ __forceinline__ void fft_stages(cx<T>* v, void* lds, int t,
                                            const cx<T>* __restrict__ tw) {
   using S = StageInfo<N, E, NS>;
@@ -226,9 +240,12 @@ __device__ __forceinline__ void fft_stages(cx<T>* v, void* lds, int t,
       const int k = j & (NS - 1);
       cx<T> w1 = tw[k * (N / (NS * R))];
       if constexpr (DIR < 0) w1.y = -w1.y;
-      apply_twiddle_powers<R>(v + s * R, w1);
+      if constexpr (FR != 0) apply_twiddle_chain<R>(v + s * R, w1);
+      else apply_twiddle_powers<R>(v + s * R, w1);
+      PAOS_FENCE();
     }
     dft<R, DIR>(v + s * R);
+    PAOS_FENCE();
   }
 
   if constexpr (!S::LAST) {
@@ -284,7 +301,8 @@ __device__ __forceinline__ void fft_stages(cx<T>* v, void* lds, int t,
         if (part == 0 || !SN::LAST) PAOS_SYNC();
       }
     }
-    fft_stages<T, N, E, DIR, SPLIT, NS * R>(v, lds, t, tw);
+    PAOS_FENCE();
+    fft_stages<T, N, E, DIR, SPLIT, NS * R, FR>(v, lds, t, tw);
   }
 }
 

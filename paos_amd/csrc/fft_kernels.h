@@ -100,38 +100,41 @@ __device__ __forceinline__ cx<double> table_phase(double x, double y, double coe
   return {fma(-delta, w.y, w.x), fma(delta, w.x, w.y)};
 }
 
-template <typename T>
+// FEAT selects the optional operators compiled into a kernel: bit 0 = separable phase tables,
+// bit 1 = aperture weight maps.  The default kernels carry neither (they cost registers even
+// when idle); the dispatcher picks the FEAT = 3 build only for programs that use them.
+//
+// Every operator is expressed as ONE complex factor per pixel (sign: +-1, scale: c, mask: w,
+// phase: cos + i sgn sin) and a single multiply, so the branches on the operator kind merge
+// four registers instead of the whole register file of the line (which cost 2x the VGPRs).
+// v * (c + 0i) computed as (x c - y 0, x 0 + y c) is exact, so sign/scale/mask keep their
+// plain-multiplication results.
+template <int FEAT>
+__device__ __forceinline__ cx<double> pw_factor(const PwOp& op, const double* p, int row, int col,
+                                                int n, const cx<double>* tab, const double* mask_at) {
+  if ((FEAT & 2) && op.kind == PWK_MASK) return {*mask_at, 0.0};
+  if (op.kind == PWK_SIGN) return {((row + col) & 1) ? -1.0 : 1.0, 0.0};
+  if (op.kind == PWK_SCALE) return {p[FP_COEF], 0.0};
+  int gx, gy;
+  if (op.kind == PWK_QPHASE_C) {
+    gx = col - n / 2; gy = row - n / 2;
+  } else {
+    gx = (col < n / 2) ? col : col - n;
+    gy = (row < n / 2) ? row : row - n;
+  }
+  if ((FEAT & 1) && tab)
+    return table_phase((double)gx * p[FP_SX], (double)gy * p[FP_SY], p[FP_COEF], p[FP_SGN],
+                       (op.flags & PWF_MUL2PI) != 0, tab[col], tab[n + row]);
+  return quad_phase(gx, gy, p[FP_SX], p[FP_SY], p[FP_COEF], p[FP_SGN], (op.flags & PWF_MUL2PI) != 0);
+}
+
+template <typename T, int FEAT>
 __device__ __forceinline__ cx<T> apply_pw(cx<T> v, const PwOp& op, const double* p, int row, int col,
                                           int n, const cx<double>* tab, const double* mask_at) {
-  if (op.kind == PWK_MASK) {
-    const double w = *mask_at;
-    v.x = (T)__dmul_rn((double)v.x, w);
-    v.y = (T)__dmul_rn((double)v.y, w);
-  } else if (op.kind == PWK_SIGN) {
-    if ((row + col) & 1) { v.x = -v.x; v.y = -v.y; }
-  } else if (op.kind == PWK_SCALE) {
-    const T sc = (T)p[FP_COEF];
-    v.x *= sc; v.y *= sc;
-  } else {
-    int gx, gy;
-    if (op.kind == PWK_QPHASE_C) {
-      gx = col - n / 2; gy = row - n / 2;
-    } else {
-      gx = (col < n / 2) ? col : col - n;
-      gy = (row < n / 2) ? row : row - n;
-    }
-    cx<double> f;
-    if (tab) {
-      f = table_phase((double)gx * p[FP_SX], (double)gy * p[FP_SY], p[FP_COEF], p[FP_SGN],
-                      (op.flags & PWF_MUL2PI) != 0, tab[col], tab[n + row]);
-    } else {
-      f = quad_phase(gx, gy, p[FP_SX], p[FP_SY], p[FP_COEF], p[FP_SGN], (op.flags & PWF_MUL2PI) != 0);
-    }
-    const cx<double> vd = {(double)v.x, (double)v.y};
-    v.x = (T)__dsub_rn(__dmul_rn(vd.x, f.x), __dmul_rn(vd.y, f.y));
-    v.y = (T)__dadd_rn(__dmul_rn(vd.x, f.y), __dmul_rn(vd.y, f.x));
-  }
-  return v;
+  const cx<double> f = pw_factor<FEAT>(op, p, row, col, n, tab, mask_at);
+  const cx<double> vd = {(double)v.x, (double)v.y};
+  return {(T)__dsub_rn(__dmul_rn(vd.x, f.x), __dmul_rn(vd.y, f.y)),
+          (T)__dadd_rn(__dmul_rn(vd.x, f.y), __dmul_rn(vd.y, f.x))};
 }
 
 // Fills the tables of one pass program: grid = (ceil(2N / 256), items, tables).  Entry j < N is
@@ -247,32 +250,33 @@ constexpr size_t line_lds_bytes() {
   return (size_t)lds_line_slots<N>() * (SPLIT ? sizeof(T) : 2 * sizeof(T));
 }
 
-template <typename T, int E, typename Map>
+template <typename T, int E, int FR, int FEAT, typename Map>
 __device__ __forceinline__ void apply_list(cx<T>* v, const PwOp* list, int count, const PassArgs& a,
                                            int item, const Map& m, int n, int sq = 0) {
   for (int o = 0; o < count; ++o) {
     const PwOp op = list[o];
     const double* p = a.blocks + ((size_t)op.block * a.batch + item) * FP_STRIDE;
     if (p[FP_ENABLE] == 0.0) continue;
-    const int ti = (op.flags >> kTableShift) - 1;
+    const int ti = (FEAT & 1) ? (op.flags >> kTableShift) - 1 : -1;
     const cx<double>* tab = ti >= 0 ? a.tables + ((size_t)ti * a.batch + item) * 2 * n : nullptr;
-    const double* mk = a.mask + (size_t)item * a.item_stride + m.base + (unsigned)sq * m.seq_stride;
+    const double* mk = (FEAT & 2) ? a.mask + (size_t)item * a.item_stride + m.base + (unsigned)sq * m.seq_stride : nullptr;
 #pragma unroll
     for (int k = 0; k < E; ++k) {
-      v[k] = apply_pw(v[k], op, p, m.row(k, sq), m.col(k, sq), n, tab, mk + (unsigned)k * m.stride);
+      v[k] = apply_pw<T, FEAT>(v[k], op, p, m.row(k, sq), m.col(k, sq), n, tab, (FEAT & 2) ? mk + (unsigned)k * m.stride : nullptr);
+      if constexpr (FR != 0) __builtin_amdgcn_sched_barrier(0);  // one phase factor at a time
     }
   }
 }
 
 // Forward transform of the thread's line slots, natural slot order in and out; the
 // inverse is conj(FFT(conj x)) so the direction is a per-item runtime flag.
-template <typename T, int N, int E, bool SPLIT>
+template <typename T, int N, int E, bool SPLIT, int FR>
 __device__ __forceinline__ void line_fft(cx<T>* v, void* lds, int t, const cx<T>* tw, bool inverse) {
   if (inverse) {
 #pragma unroll
     for (int k = 0; k < E; ++k) v[k].y = -v[k].y;
   }
-  fft_stages<T, N, E, +1, SPLIT>(v, lds, t, tw);
+  fft_stages<T, N, E, +1, SPLIT, 1, FR>(v, lds, t, tw);
   unpermute_slots<N, E>(v);
   if (inverse) {
 #pragma unroll
@@ -291,7 +295,7 @@ __device__ __forceinline__ void line_fft(cx<T>* v, void* lds, int t, const cx<T>
 // operator and the first pass of the next share an axis and are emitted as ONE pass:
 //   ... ptp | lens | ptp ... = rows[IFFT | mid 1/N, lens | FFT].
 template <typename T, int N, int E, int LINES, int TILES, int AXIS, int BR, int BC, bool SPLIT,
-          int MINW, int SEQ = 1>
+          int MINW, int SEQ = 1, int FR = 0, int FEAT = 0>
 __global__ void __launch_bounds__(TILES* LINES* N / E / SEQ, MINW)
     fused_pass_kernel(PassArgs a) {
   const int item = blockIdx.y;
@@ -322,14 +326,14 @@ __global__ void __launch_bounds__(TILES* LINES* N / E / SEQ, MINW)
   }
 
   auto process = [&](cx<T>* v, int sq) __attribute__((always_inline)) {
-    apply_list<T, E>(v, a.pre, a.n_pre, a, item, m, N, sq);
-    if (do1) line_fft<T, N, E, SPLIT>(v, lds, m.t, tw, c1[FC_INVERSE] != 0.0);
-    apply_list<T, E>(v, a.mid, a.n_mid, a, item, m, N, sq);
+    apply_list<T, E, FR, FEAT>(v, a.pre, a.n_pre, a, item, m, N, sq);
+    if (do1) line_fft<T, N, E, SPLIT, FR>(v, lds, m.t, tw, c1[FC_INVERSE] != 0.0);
+    apply_list<T, E, FR, FEAT>(v, a.mid, a.n_mid, a, item, m, N, sq);
     if (do2) {
       if (do1) PAOS_SYNC();  // the first transform's last LDS reads precede new writes
-      line_fft<T, N, E, SPLIT>(v, lds, m.t, tw, c2[FC_INVERSE] != 0.0);
+      line_fft<T, N, E, SPLIT, FR>(v, lds, m.t, tw, c2[FC_INVERSE] != 0.0);
     }
-    apply_list<T, E>(v, a.post, a.n_post, a, item, m, N, sq);
+    apply_list<T, E, FR, FEAT>(v, a.post, a.n_post, a, item, m, N, sq);
 #pragma unroll
     for (int k = 0; k < E; ++k) f[m.base + (unsigned)sq * m.seq_stride + (unsigned)k * m.stride] = v[k];
   };

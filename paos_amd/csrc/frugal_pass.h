@@ -1,0 +1,124 @@
+// frugal_pass.h -- the register-frugal pass kernel (<= 128 VGPRs: two 512-thread workgroups
+// per CU, so the load / compute / store phases of neighbouring tiles overlap).
+//
+// Same contract as fused_pass_kernel, but the shape of the work is a compile-time constant:
+//   load -> slot(KPRE) -> FFT -> slot(KMID) -> [FFT] -> store
+// where a slot multiplies every pixel by  s * scale * prod_{j<K} exp(i sgn_j q_j):
+//   s      = (-1)^(row+col) if the item's sign flag is set, else 1 (fftshift folding)
+//   scale  = exact power of two (ortho 1/N), 1 when unused
+//   q_j    = m2_j * fl(coef_j * fl(x^2 + y^2)), centred or natural-order coordinates,
+//            m2_j in {1, 2 pi}  (fl(1 * q) == q, so the reference's rounding is kept)
+// Everything that varies per batch item is DATA (a disabled phase has coef = 0 -> factor 1,
+// exactly), so the instruction stream has no branches on operator kinds -- those branches are
+// what pushes the generic interpreter to ~230 VGPRs (profiles/r01_vgpr_experiments.txt).
+#pragma once
+#include "fft_kernels.h"
+
+#ifndef PAOS_FENCE_EVERY
+#define PAOS_FENCE_EVERY 2
+#endif
+
+namespace paos {
+
+constexpr int kFrugalMaxPre = 2, kFrugalMaxMid = 3;
+
+struct FrugalPhase {
+  double sx, sy, coef, sgn, m2, natural;  // natural != 0: np.fft.fftfreq index order
+};
+struct FrugalSlot {
+  double sign_on, scale;
+};
+// per-item record, doubles: [fft1_on, fft1_inv, fft2_on, fft2_inv, pre slot, pre phases[2],
+// mid slot, mid phases[3]]
+struct FrugalItem {
+  double active;  // 0: the item takes no part in this pass (no load, no store)
+  double fft1_on, fft1_inv, fft2_on, fft2_inv;
+  FrugalSlot pre;
+  FrugalPhase pre_ph[kFrugalMaxPre];
+  FrugalSlot mid;
+  FrugalPhase mid_ph[kFrugalMaxMid];
+};
+
+struct FrugalArgs {
+  void* field;
+  const void* tw;
+  const FrugalItem* items;  // [batch]
+  unsigned pitch, item_stride;
+};
+
+template <typename T, int N, int E, int K, typename Map>
+__device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, const FrugalPhase* ph,
+                                            const Map& m) {
+  const double sc = sl.scale;
+  const bool sign_on = sl.sign_on != 0.0;
+#pragma unroll
+  for (int k = 0; k < E; ++k) {
+    const int row = m.row(k), col = m.col(k);
+    cx<double> vd = {(double)v[k].x, (double)v[k].y};
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const bool nat = ph[j].natural != 0.0;
+      const int gx = nat ? ((col < N / 2) ? col : col - N) : col - N / 2;
+      const int gy = nat ? ((row < N / 2) ? row : row - N) : row - N / 2;
+      const double x = (double)gx * ph[j].sx, y = (double)gy * ph[j].sy;
+      const double s = __dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y));
+      const double q = __dmul_rn(ph[j].m2, __dmul_rn(ph[j].coef, s));
+      double sn, cs;
+      sincos_fast(q, &sn, &cs);
+      sn *= ph[j].sgn;
+      vd = {__dsub_rn(__dmul_rn(vd.x, cs), __dmul_rn(vd.y, sn)),
+            __dadd_rn(__dmul_rn(vd.x, sn), __dmul_rn(vd.y, cs))};
+    }
+    const double f = (sign_on && ((row + col) & 1)) ? -sc : sc;
+    v[k] = {(T)(vd.x * f), (T)(vd.y * f)};
+    if ((k + 1) % PAOS_FENCE_EVERY == 0) __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// direction as data: conj(FFT(conj x)) with the conjugations as multiplications by +-1
+template <typename T, int N, int E, bool SPLIT>
+__device__ __forceinline__ void frugal_fft(cx<T>* v, void* lds, int t, const cx<T>* tw, double inv) {
+  const T s = inv != 0.0 ? (T)-1 : (T)1;
+#pragma unroll
+  for (int k = 0; k < E; ++k) v[k].y *= s;
+  __builtin_amdgcn_sched_barrier(0);
+  fft_stages<T, N, E, +1, SPLIT, 1, 1>(v, lds, t, tw);
+  unpermute_slots<N, E>(v);
+#pragma unroll
+  for (int k = 0; k < E; ++k) v[k].y *= s;
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <typename T, int N, int E, int LINES, int TILES, int AXIS, int BR, int BC, bool SPLIT,
+          int KPRE, int KMID, int NFFT>
+__global__ void __launch_bounds__(TILES* LINES* N / E, 4)
+    frugal_pass_kernel(FrugalArgs a) {
+  const int item = blockIdx.y;
+  const FrugalItem& it = a.items[item];
+  if (it.active == 0.0) return;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const TileMap<N, E, LINES, TILES, AXIS, BR, BC> m(blockIdx.x, threadIdx.x, a.pitch);
+  cx<T>* f = reinterpret_cast<cx<T>*>(a.field) + (size_t)item * a.item_stride;
+  void* lds = smem + (size_t)m.lds_line * line_lds_bytes<T, N, SPLIT>();
+  const cx<T>* tw = reinterpret_cast<const cx<T>*>(a.tw);
+
+  cx<T> v[E];
+#pragma unroll
+  for (int k = 0; k < E; ++k) v[k] = f[m.base + (unsigned)k * m.stride];
+  __builtin_amdgcn_sched_barrier(0);
+
+  frugal_slot<T, N, E, KPRE>(v, it.pre, it.pre_ph, m);
+  const bool ran1 = it.fft1_on != 0.0;
+  if (ran1) frugal_fft<T, N, E, SPLIT>(v, lds, m.t, tw, it.fft1_inv);
+  frugal_slot<T, N, E, KMID>(v, it.mid, it.mid_ph, m);
+  if constexpr (NFFT == 2) {
+    if (it.fft2_on != 0.0) {
+      if (ran1) __syncthreads();
+      frugal_fft<T, N, E, SPLIT>(v, lds, m.t, tw, it.fft2_inv);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < E; ++k) f[m.base + (unsigned)k * m.stride] = v[k];
+}
+
+}  // namespace paos

@@ -16,6 +16,7 @@
 #include <unordered_set>
 #include <vector>
 
+#include "frugal_pass.h"
 #include "pointwise.h"
 
 using namespace paos;
@@ -160,7 +161,7 @@ int launch_pass(paos_ctx* c, Kern kern, dim3 grid, dim3 block, size_t lds, const
   return PAOS_OK;
 }
 
-template <typename T, int N, int AXIS>
+template <typename T, int N, int AXIS, int FEAT>
 int pass_launch(paos_ctx* c, const PassArgs& a) {
   using C = FftCfg<T, N>;
   constexpr int BC = C::BC;
@@ -169,25 +170,27 @@ int pass_launch(paos_ctx* c, const PassArgs& a) {
   constexpr bool SPLIT = AXIS == 0 ? C::ROW_SPLIT : C::COL_SPLIT;
   const dim3 grid(N / LINES / TILES, c->batch), block(TILES * LINES * N / C::E);
   const size_t lds = (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT>();
-  return launch_pass(c, fused_pass_kernel<T, N, C::E, LINES, TILES, AXIS, BR, BC, SPLIT, C::MINW>, grid,
-                     block, lds, a, AXIS == 0 ? PAOS_KERNEL_PASS_ROWS : PAOS_KERNEL_PASS_COLS);
+  return launch_pass(c, fused_pass_kernel<T, N, C::E, LINES, TILES, AXIS, BR, BC, SPLIT, C::MINW, 1, 0, FEAT>,
+                     grid, block, lds, a, AXIS == 0 ? PAOS_KERNEL_PASS_ROWS : PAOS_KERNEL_PASS_COLS);
 }
 
+// feat != 0: the build with the optional operators (phase tables, aperture weight maps)
 template <typename T, int N>
-int pass_n(paos_ctx* c, int axis, const PassArgs& a) {
-  return axis == 0 ? pass_launch<T, N, 0>(c, a) : pass_launch<T, N, 1>(c, a);
+int pass_n(paos_ctx* c, int axis, const PassArgs& a, int feat) {
+  if (feat) return axis == 0 ? pass_launch<T, N, 0, 3>(c, a) : pass_launch<T, N, 1, 3>(c, a);
+  return axis == 0 ? pass_launch<T, N, 0, 0>(c, a) : pass_launch<T, N, 1, 0>(c, a);
 }
 
 template <typename T>
-int pass_t(paos_ctx* c, int axis, const PassArgs& a) {
+int pass_t(paos_ctx* c, int axis, const PassArgs& a, int feat) {
   switch (c->n) {
-    case 64: return pass_n<T, 64>(c, axis, a);
-    case 128: return pass_n<T, 128>(c, axis, a);
-    case 256: return pass_n<T, 256>(c, axis, a);
-    case 512: return pass_n<T, 512>(c, axis, a);
-    case 1024: return pass_n<T, 1024>(c, axis, a);
-    case 2048: return pass_n<T, 2048>(c, axis, a);
-    case 4096: return pass_n<T, 4096>(c, axis, a);
+    case 64: return pass_n<T, 64>(c, axis, a, feat);
+    case 128: return pass_n<T, 128>(c, axis, a, feat);
+    case 256: return pass_n<T, 256>(c, axis, a, feat);
+    case 512: return pass_n<T, 512>(c, axis, a, feat);
+    case 1024: return pass_n<T, 1024>(c, axis, a, feat);
+    case 2048: return pass_n<T, 2048>(c, axis, a, feat);
+    case 4096: return pass_n<T, 4096>(c, axis, a, feat);
   }
   return fail(c, PAOS_EUNSUPPORTED, "grid size must be a power of two in 64..4096");
 }
@@ -209,6 +212,130 @@ int check_ops(paos_ctx* c, const paos_pw_op* ops, int count, int n_blocks) {
 bool use_tables() {
   static const bool on = [] { const char* e = getenv("PAOS_PHASE_TABLES"); return e && e[0] == '1'; }();
   return on;
+}
+
+// ---- frugal path (N = 4096, complex128): compile-time pass shapes, 2 workgroups per CU -------
+// PAOS_NO_FRUGAL=1 keeps every pass on the generic kernel (A/B tests).
+bool use_frugal() {
+  static const bool on = [] { const char* e = getenv("PAOS_NO_FRUGAL"); return !(e && e[0] == '1'); }();
+  return on;
+}
+
+// Express pass p as   load | sign*scale*K phases | FFT | sign*scale*K phases | [FFT] | store.
+bool lower_frugal(const paos_ctx* c, const paos_pass& p, const double* blocks /*host*/, std::vector<FrugalItem>& items,
+                  int& kpre, int& kmid, int& nfft) {
+  if (p.axis != 0 && p.axis != 1) return false;
+  if (p.fft1 < 0 || p.n_post != 0) return false;
+  const paos_pw_op* lists[2] = {p.pre, p.mid};
+  const int counts[2] = {p.n_pre, p.n_mid};
+  int k[2] = {0, 0};
+  for (int l = 0; l < 2; ++l)
+    for (int o = 0; o < counts[l]; ++o) {
+      const int kind = lists[l][o].kind;
+      if (kind == PAOS_PW_QPHASE_CENTRED || kind == PAOS_PW_QPHASE_NATURAL) ++k[l];
+      else if (kind != PAOS_PW_SIGN && kind != PAOS_PW_SCALE) return false;
+    }
+  if (k[0] > kFrugalMaxPre || k[1] > kFrugalMaxMid) return false;
+  kpre = k[0]; kmid = k[1]; nfft = p.fft2 >= 0 ? 2 : 1;
+  items.assign(c->batch, FrugalItem{});
+  auto blk = [&](int b, int it) { return blocks + ((size_t)b * c->batch + it) * FP_STRIDE; };
+  for (int it = 0; it < c->batch; ++it) {
+    FrugalItem& fi = items[it];
+    const double* c1 = blk(p.fft1, it);
+    fi.fft1_on = c1[FC_ENABLE] != 0.0; fi.fft1_inv = c1[FC_INVERSE] != 0.0;
+    if (p.fft2 >= 0) { const double* c2 = blk(p.fft2, it); fi.fft2_on = c2[FC_ENABLE] != 0.0; fi.fft2_inv = c2[FC_INVERSE] != 0.0; }
+    bool active = fi.fft1_on != 0.0 || fi.fft2_on != 0.0;
+    FrugalSlot* slots[2] = {&fi.pre, &fi.mid};
+    FrugalPhase* phases[2] = {fi.pre_ph, fi.mid_ph};
+    for (int l = 0; l < 2; ++l) {
+      slots[l]->sign_on = 0.0; slots[l]->scale = 1.0;
+      int j = 0;
+      for (int o = 0; o < counts[l]; ++o) {
+        const paos_pw_op& op = lists[l][o];
+        const double* q = blk(op.block, it);
+        const bool on = q[FP_ENABLE] != 0.0;
+        active = active || on;
+        if (op.kind == PAOS_PW_SIGN) { if (on) slots[l]->sign_on = slots[l]->sign_on != 0.0 ? 0.0 : 1.0; }
+        else if (op.kind == PAOS_PW_SCALE) { if (on) slots[l]->scale *= q[FP_COEF]; }
+        else {
+          FrugalPhase& ph = phases[l][j++];
+          ph.natural = op.kind == PAOS_PW_QPHASE_NATURAL ? 1.0 : 0.0;
+          if (on) { ph.sx = q[FP_SX]; ph.sy = q[FP_SY]; ph.coef = q[FP_COEF]; ph.sgn = q[FP_SGN]; ph.m2 = (op.flags & PAOS_PWF_MUL2PI) ? 6.283185307179586 : 1.0; }
+          else { ph.sx = ph.sy = 0.0; ph.coef = 0.0; ph.sgn = 1.0; ph.m2 = 1.0; }  // exp(i 0) = 1 exactly
+        }
+      }
+    }
+    fi.active = active ? 1.0 : 0.0;
+  }
+  return true;
+}
+
+template <int AXIS, int KPRE, int KMID, int NFFT>
+int frugal_launch(paos_ctx* c, const FrugalArgs& a) {
+  using T = double;
+  constexpr int N = 4096;
+  using C = FftCfg<T, N>;
+  constexpr int LINES = AXIS == 0 ? C::ROW_LINES : C::COL_LINES;
+  constexpr bool SPLIT = true;  // two workgroups share the 160 KiB of LDS
+  const dim3 grid(N / LINES, c->batch), block(LINES * N / C::E);
+  const size_t lds = (size_t)LINES * line_lds_bytes<T, N, SPLIT>();
+  auto kern = frugal_pass_kernel<T, N, C::E, LINES, 1, AXIS, BR, C::BC, SPLIT, KPRE, KMID, NFFT>;
+  static thread_local bool configured = false;
+  if (!configured) {
+    HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    configured = true;
+  }
+  const int kind = AXIS == 0 ? PAOS_KERNEL_PASS_ROWS : PAOS_KERNEL_PASS_COLS;
+  const bool timed = (c->prof_kind == kind || c->prof_kind == PAOS_KERNEL_PASS_ANY) &&
+                     (c->prof_used + 2 <= c->prof_events.size());
+  if (timed) HIPCHK(c, hipEventRecord(c->prof_events[c->prof_used], c->stream));
+  hipLaunchKernelGGL(kern, grid, block, lds, c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  if (timed) {
+    HIPCHK(c, hipEventRecord(c->prof_events[c->prof_used + 1], c->stream));
+    c->prof_used += 2;
+  }
+  return PAOS_OK;
+}
+
+template <int AXIS, int KPRE, int KMID>
+int frugal_nfft(paos_ctx* c, const FrugalArgs& a, int nfft) {
+  return nfft == 2 ? frugal_launch<AXIS, KPRE, KMID, 2>(c, a) : frugal_launch<AXIS, KPRE, KMID, 1>(c, a);
+}
+template <int AXIS, int KPRE>
+int frugal_kmid(paos_ctx* c, const FrugalArgs& a, int kmid, int nfft) {
+  switch (kmid) {
+    case 0: return frugal_nfft<AXIS, KPRE, 0>(c, a, nfft);
+    case 1: return frugal_nfft<AXIS, KPRE, 1>(c, a, nfft);
+    case 2: return frugal_nfft<AXIS, KPRE, 2>(c, a, nfft);
+    default: return frugal_nfft<AXIS, KPRE, 3>(c, a, nfft);
+  }
+}
+template <int AXIS>
+int frugal_kpre(paos_ctx* c, const FrugalArgs& a, int kpre, int kmid, int nfft) {
+  switch (kpre) {
+    case 0: return frugal_kmid<AXIS, 0>(c, a, kmid, nfft);
+    case 1: return frugal_kmid<AXIS, 1>(c, a, kmid, nfft);
+    default: return frugal_kmid<AXIS, 2>(c, a, kmid, nfft);
+  }
+}
+
+// returns PAOS_OK and sets *done when the pass ran on the frugal path
+int try_frugal(paos_ctx* c, const paos_pass& p, const double* host_blocks, bool* done) {
+  *done = false;
+  if (!use_frugal() || c->precision != PAOS_F64 || c->n != 4096) return PAOS_OK;
+  std::vector<FrugalItem> items;
+  int kpre = 0, kmid = 0, nfft = 1;
+  if (!lower_frugal(c, p, host_blocks, items, kpre, kmid, nfft)) return PAOS_OK;
+  const double* ditems = nullptr;
+  static_assert(sizeof(FrugalItem) % sizeof(double) == 0, "record of doubles");
+  int rc = arena_push(c, reinterpret_cast<const double*>(items.data()),
+                      items.size() * sizeof(FrugalItem) / sizeof(double), &ditems);
+  if (rc) return rc;
+  FrugalArgs a{c->field, c->tw, reinterpret_cast<const FrugalItem*>(ditems), c->pitch, c->item_stride};
+  rc = p.axis == 0 ? frugal_kpre<0>(c, a, kpre, kmid, nfft) : frugal_kpre<1>(c, a, kpre, kmid, nfft);
+  if (rc == PAOS_OK) *done = true;
+  return rc;
 }
 
 int launch_one_pass(paos_ctx* c, const paos_pass& p, const double* dblocks, int n_blocks,
@@ -248,15 +375,18 @@ int launch_one_pass(paos_ctx* c, const paos_pass& p, const double* dblocks, int 
   std::memcpy(a.mid, p.mid, sizeof(a.mid));
   std::memcpy(a.post, p.post, sizeof(a.post));
   PwOp* lists[3] = {a.pre, a.mid, a.post};
+  const int counts[3] = {a.n_pre, a.n_mid, a.n_post};
+  int feat = 0;
   for (int l = 0; l < 3; ++l)
     for (int o = 0; o < PAOS_MAX_PW; ++o) {
       lists[l][o].flags &= (1 << kTableShift) - 1;
       const int t = table_of_op[l * PAOS_MAX_PW + o];
-      if (t >= 0) lists[l][o].flags |= (t + 1) << kTableShift;
+      if (t >= 0) { lists[l][o].flags |= (t + 1) << kTableShift; feat = 3; }
+      if (o < counts[l] && lists[l][o].kind == PWK_MASK) feat = 3;
     }
   a.pitch = c->pitch; a.item_stride = c->item_stride;
   if (p.axis == 0 || p.axis == 1)
-    return c->precision == PAOS_F64 ? pass_t<double>(c, p.axis, a) : pass_t<float>(c, p.axis, a);
+    return c->precision == PAOS_F64 ? pass_t<double>(c, p.axis, a, feat) : pass_t<float>(c, p.axis, a, feat);
   if (p.axis != -1) return fail(c, PAOS_EINVAL, "pass axis must be 0, 1 or -1");
   if (p.fft1 >= 0 || p.fft2 >= 0 || p.n_mid || p.n_post)
     return fail(c, PAOS_EINVAL, "a transform-free pass carries its operators in the pre list");
@@ -271,6 +401,26 @@ int launch_one_pass(paos_ctx* c, const paos_pass& p, const double* dblocks, int 
 
 int run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks, int n_blocks) {
   if (!c || !passes || !blocks || n_passes < 0 || n_blocks < 1) return fail(c, PAOS_EINVAL, "bad pass program");
+  // The device sincos has no huge-argument path: bound every enabled phase operator here.
+  for (int i = 0; i < n_passes; ++i) {
+    const paos_pw_op* lists[3] = {passes[i].pre, passes[i].mid, passes[i].post};
+    const int counts[3] = {passes[i].n_pre, passes[i].n_mid, passes[i].n_post};
+    for (int l = 0; l < 3; ++l)
+      for (int o = 0; o < counts[l] && o < PAOS_MAX_PW; ++o) {
+        const paos_pw_op& op = lists[l][o];
+        if (op.kind != PAOS_PW_QPHASE_CENTRED && op.kind != PAOS_PW_QPHASE_NATURAL) continue;
+        if (op.block < 0 || op.block >= n_blocks) return fail(c, PAOS_EINVAL, "operator block index out of range");
+        for (int it = 0; it < c->batch; ++it) {
+          const double* p = blocks + ((size_t)op.block * c->batch + it) * FP_STRIDE;
+          if (p[FP_ENABLE] == 0.0) continue;
+          const double hx = 0.5 * c->n * p[FP_SX], hy = 0.5 * c->n * p[FP_SY];
+          double arg = std::fabs(p[FP_COEF]) * (hx * hx + hy * hy);
+          if (op.flags & PAOS_PWF_MUL2PI) arg *= 6.283185307179586;
+          if (!(arg < kMaxPhaseArg))
+            return fail(c, PAOS_EUNSUPPORTED, "quadratic phase exceeds 1e12 rad at the grid corner (or is not finite)");
+        }
+      }
+  }
   const double* dblocks = nullptr;
   int rc = arena_push(c, blocks, (size_t)n_blocks * c->batch * FP_STRIDE, &dblocks);
   if (rc) return rc;
@@ -311,8 +461,12 @@ int run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double*
       hipLaunchKernelGGL(phase_table_kernel, grid, dim3(256), 0, c->stream, ta);
       HIPCHK(c, hipGetLastError());
     }
-    for (int q = i; q < j; ++q)
+    for (int q = i; q < j; ++q) {
+      bool done = false;
+      if (!use_tables() && (rc = try_frugal(c, passes[q], blocks, &done))) return rc;
+      if (done) continue;
       if ((rc = launch_one_pass(c, passes[q], dblocks, n_blocks, &assign[(size_t)(q - i) * 3 * PAOS_MAX_PW]))) return rc;
+    }
     i = j;
   }
   return PAOS_OK;

@@ -89,7 +89,7 @@ __global__ void pointwise_kernel(PassArgs a, int n) {
       const double* p = a.blocks + ((size_t)a.pre[o].block * a.batch + item) * FP_STRIDE;
       if (p[FP_ENABLE] != 0.0) {
         const int ti = (a.pre[o].flags >> kTableShift) - 1;
-        v = apply_pw(v, a.pre[o], p, r, c, n,
+        v = apply_pw<T, 3>(v, a.pre[o], p, r, c, n,
                      ti >= 0 ? a.tables + ((size_t)ti * a.batch + item) * 2 * n : nullptr,
                      a.mask + (size_t)item * a.item_stride + m);
       }

@@ -8,9 +8,10 @@
 #include <complex>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
-#include "fft_kernels.h"
+#include "frugal_pass.h"
 
 using namespace paos;
 
@@ -140,6 +141,53 @@ void bench_variant(const char* name, int batch, int reps, int pad_blocks = 0) {
   CK(hipFree(dtw));
 }
 
+template <typename T, int N, int AXIS, int KPRE, int KMID, int NFFT>
+void bench_frugal(const char* name, int batch, int reps, int pad_blocks) {
+  constexpr int E = 16, LINES = 2, BR = 4, BC = 2;
+  const unsigned pitch = (unsigned)N * BR + (unsigned)pad_blocks * BR * BC;
+  const unsigned item_stride = pitch * (N / BR);
+  cx<T>* d;
+  CK(hipMalloc(&d, (size_t)item_stride * batch * sizeof(cx<T>)));
+  CK(hipMemset(d, 0, (size_t)item_stride * batch * sizeof(cx<T>)));
+  std::vector<std::complex<T>> h((size_t)N * N);
+  srand(1);
+  for (auto& z : h) z = std::complex<T>((T)(rand() / (double)RAND_MAX - 0.5), (T)(rand() / (double)RAND_MAX - 0.5));
+  for (int b = 0; b < batch; ++b)
+    for (int r = 0; r < N / BR; ++r)
+      CK(hipMemcpy(d + (size_t)b * item_stride + (size_t)r * pitch, h.data() + (size_t)r * N * BR,
+                   (size_t)N * BR * sizeof(cx<T>), hipMemcpyHostToDevice));
+  auto tw = make_twiddles<T, N>();
+  cx<T>* dtw;
+  CK(hipMalloc(&dtw, N * sizeof(cx<T>)));
+  CK(hipMemcpy(dtw, tw.data(), N * sizeof(cx<T>), hipMemcpyHostToDevice));
+  std::vector<FrugalItem> items(batch);
+  for (auto& it : items) {
+    std::memset(&it, 0, sizeof(it));
+    it.fft1_on = 1; it.fft1_inv = 0; it.fft2_on = 1; it.fft2_inv = 1;
+    it.pre.scale = 1.0; it.mid.scale = 1.0 / N; it.mid.sign_on = 0;
+    for (int j = 0; j < kFrugalMaxPre; ++j) it.pre_ph[j] = {0.01, 0.01, 0.21, 1.0, 1.0, 0.0};
+    for (int j = 0; j < kFrugalMaxMid; ++j) it.mid_ph[j] = {0.01, 0.01, 0.37, -1.0, 1.0, 1.0};
+  }
+  FrugalItem* ditems;
+  CK(hipMalloc(&ditems, items.size() * sizeof(FrugalItem)));
+  CK(hipMemcpy(ditems, items.data(), items.size() * sizeof(FrugalItem), hipMemcpyHostToDevice));
+  FrugalArgs a{d, dtw, ditems, pitch, item_stride};
+  const dim3 grid(N / LINES, batch), block(LINES * N / E);
+  constexpr bool SPLIT = true;
+  const size_t lds = LINES * line_lds_bytes<T, N, SPLIT>();
+  auto kf = frugal_pass_kernel<T, N, E, LINES, 1, AXIS, BR, BC, SPLIT, KPRE, KMID, NFFT>;
+  CK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  Timer tm;
+  float ms = tm.run([&] { hipLaunchKernelGGL(kf, grid, block, lds, 0, a); }, reps);
+  int nb = 0;
+  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kf, block.x, lds));
+  const double bytes = 2.0 * (double)N * N * batch * sizeof(cx<T>);
+  printf("%-34s N=%d b=%d ax=%d kpre=%d kmid=%d nfft=%d thr=%d lds=%zuK occ=%d  %8.3f ms  %7.1f GB/s\n", name, N, batch,
+         AXIS, KPRE, KMID, NFFT, block.x, lds / 1024, nb, ms, bytes / ms * 1e-6);
+  fflush(stdout);
+  CK(hipFree(d)); CK(hipFree(dtw)); CK(hipFree(ditems));
+}
+
 template <typename T>
 void bench_copy(int n, int batch, int reps) {
   const size_t elems = (size_t)n * n * batch;
@@ -156,11 +204,14 @@ void bench_copy(int n, int batch, int reps) {
 
 int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 10;
-  const int b4 = 8;
-  const int pad = 3;
-  printf("PAOS_DIAG=%d\n", PAOS_DIAG);
-  bench_variant<double, 4096, 16, 2, 0, 4, 2, false, 1, 1, 1, 1>("blk4x2 rows L2 512thr full", b4, reps, pad);
-  bench_variant<double, 4096, 16, 2, 1, 4, 2, false, 1, 1, 1, 1>("blk4x2 cols L2 512thr full", b4, reps, pad);
-  bench_variant<double, 4096, 16, 1, 0, 1, 1, false, 1, 1, 1, 1>("canon rows L1 256thr full", b4, reps, 0);
+  const int b4 = 8, pad = 3;
+  bench_variant<double, 4096, 16, 2, 0, 4, 2, false, 1, 1, 1, 1>("generic rows 512thr full", b4, reps, pad);
+  bench_variant<double, 4096, 16, 2, 1, 4, 2, false, 1, 1, 1, 1>("generic cols 512thr full", b4, reps, pad);
+  bench_frugal<double, 4096, 0, 0, 0, 1>("frugal rows single", b4, reps, pad);
+  bench_frugal<double, 4096, 1, 0, 0, 1>("frugal cols single", b4, reps, pad);
+  bench_frugal<double, 4096, 0, 0, 1, 2>("frugal rows double 1 phase", b4, reps, pad);
+  bench_frugal<double, 4096, 1, 0, 1, 2>("frugal cols double 1 phase", b4, reps, pad);
+  bench_frugal<double, 4096, 0, 1, 2, 2>("frugal rows double 1+2 phases", b4, reps, pad);
+  bench_frugal<double, 4096, 0, 2, 3, 2>("frugal rows double 2+3 phases", b4, reps, pad);
   return 0;
 }
