@@ -214,7 +214,7 @@ bool use_tables() {
   return on;
 }
 
-// ---- frugal path (N = 4096, complex128): compile-time pass shapes, 2 workgroups per CU -------
+// ---- frugal path (N >= 1024, complex128): compile-time pass shapes, <= 128 VGPRs ---------------
 // PAOS_NO_FRUGAL=1 keeps every pass on the generic kernel (A/B tests).
 bool use_frugal() {
   static const bool on = [] { const char* e = getenv("PAOS_NO_FRUGAL"); return !(e && e[0] == '1'); }();
@@ -270,16 +270,16 @@ bool lower_frugal(const paos_ctx* c, const paos_pass& p, const double* blocks /*
   return true;
 }
 
-template <int AXIS, int KPRE, int KMID, int NFFT>
+template <int N, int AXIS, int KPRE, int KMID, int NFFT>
 int frugal_launch(paos_ctx* c, const FrugalArgs& a) {
   using T = double;
-  constexpr int N = 4096;
   using C = FftCfg<T, N>;
   constexpr int LINES = AXIS == 0 ? C::ROW_LINES : C::COL_LINES;
-  constexpr bool SPLIT = true;  // two workgroups share the 160 KiB of LDS
-  const dim3 grid(N / LINES, c->batch), block(LINES * N / C::E);
-  const size_t lds = (size_t)LINES * line_lds_bytes<T, N, SPLIT>();
-  auto kern = frugal_pass_kernel<T, N, C::E, LINES, 1, AXIS, BR, C::BC, SPLIT, KPRE, KMID, NFFT>;
+  constexpr int TILES = AXIS == 0 ? C::ROW_TILES : C::COL_TILES;
+  constexpr bool SPLIT = true;  // several workgroups share the 160 KiB of LDS
+  const dim3 grid(N / LINES / TILES, c->batch), block(TILES * LINES * N / C::E);
+  const size_t lds = (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT>();
+  auto kern = frugal_pass_kernel<T, N, C::E, LINES, TILES, AXIS, BR, C::BC, SPLIT, KPRE, KMID, NFFT>;
   static thread_local bool configured = false;
   if (!configured) {
     HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -298,32 +298,36 @@ int frugal_launch(paos_ctx* c, const FrugalArgs& a) {
   return PAOS_OK;
 }
 
-template <int AXIS, int KPRE, int KMID>
+template <int N, int AXIS, int KPRE, int KMID>
 int frugal_nfft(paos_ctx* c, const FrugalArgs& a, int nfft) {
-  return nfft == 2 ? frugal_launch<AXIS, KPRE, KMID, 2>(c, a) : frugal_launch<AXIS, KPRE, KMID, 1>(c, a);
+  return nfft == 2 ? frugal_launch<N, AXIS, KPRE, KMID, 2>(c, a) : frugal_launch<N, AXIS, KPRE, KMID, 1>(c, a);
 }
-template <int AXIS, int KPRE>
+template <int N, int AXIS, int KPRE>
 int frugal_kmid(paos_ctx* c, const FrugalArgs& a, int kmid, int nfft) {
   switch (kmid) {
-    case 0: return frugal_nfft<AXIS, KPRE, 0>(c, a, nfft);
-    case 1: return frugal_nfft<AXIS, KPRE, 1>(c, a, nfft);
-    case 2: return frugal_nfft<AXIS, KPRE, 2>(c, a, nfft);
-    default: return frugal_nfft<AXIS, KPRE, 3>(c, a, nfft);
+    case 0: return frugal_nfft<N, AXIS, KPRE, 0>(c, a, nfft);
+    case 1: return frugal_nfft<N, AXIS, KPRE, 1>(c, a, nfft);
+    case 2: return frugal_nfft<N, AXIS, KPRE, 2>(c, a, nfft);
+    default: return frugal_nfft<N, AXIS, KPRE, 3>(c, a, nfft);
   }
 }
-template <int AXIS>
+template <int N, int AXIS>
 int frugal_kpre(paos_ctx* c, const FrugalArgs& a, int kpre, int kmid, int nfft) {
   switch (kpre) {
-    case 0: return frugal_kmid<AXIS, 0>(c, a, kmid, nfft);
-    case 1: return frugal_kmid<AXIS, 1>(c, a, kmid, nfft);
-    default: return frugal_kmid<AXIS, 2>(c, a, kmid, nfft);
+    case 0: return frugal_kmid<N, AXIS, 0>(c, a, kmid, nfft);
+    case 1: return frugal_kmid<N, AXIS, 1>(c, a, kmid, nfft);
+    default: return frugal_kmid<N, AXIS, 2>(c, a, kmid, nfft);
   }
+}
+template <int N>
+int frugal_axis(paos_ctx* c, const FrugalArgs& a, int axis, int kpre, int kmid, int nfft) {
+  return axis == 0 ? frugal_kpre<N, 0>(c, a, kpre, kmid, nfft) : frugal_kpre<N, 1>(c, a, kpre, kmid, nfft);
 }
 
 // returns PAOS_OK and sets *done when the pass ran on the frugal path
 int try_frugal(paos_ctx* c, const paos_pass& p, const double* host_blocks, bool* done) {
   *done = false;
-  if (!use_frugal() || c->precision != PAOS_F64 || c->n != 4096) return PAOS_OK;
+  if (!use_frugal() || c->precision != PAOS_F64 || c->n < 1024) return PAOS_OK;
   std::vector<FrugalItem> items;
   int kpre = 0, kmid = 0, nfft = 1;
   if (!lower_frugal(c, p, host_blocks, items, kpre, kmid, nfft)) return PAOS_OK;
@@ -333,7 +337,11 @@ int try_frugal(paos_ctx* c, const paos_pass& p, const double* host_blocks, bool*
                       items.size() * sizeof(FrugalItem) / sizeof(double), &ditems);
   if (rc) return rc;
   FrugalArgs a{c->field, c->tw, reinterpret_cast<const FrugalItem*>(ditems), c->pitch, c->item_stride};
-  rc = p.axis == 0 ? frugal_kpre<0>(c, a, kpre, kmid, nfft) : frugal_kpre<1>(c, a, kpre, kmid, nfft);
+  switch (c->n) {
+    case 1024: rc = frugal_axis<1024>(c, a, p.axis, kpre, kmid, nfft); break;
+    case 2048: rc = frugal_axis<2048>(c, a, p.axis, kpre, kmid, nfft); break;
+    default: rc = frugal_axis<4096>(c, a, p.axis, kpre, kmid, nfft); break;
+  }
   if (rc == PAOS_OK) *done = true;
   return rc;
 }

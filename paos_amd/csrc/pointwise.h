@@ -324,7 +324,12 @@ __global__ void aperture_kernel(cx<T>* field, const double* params, const double
       else if (item == 0) mask_out[(size_t)r * n + c] = mask;
       continue;
     }
-    if (w != 1.0) {
+    // w == 1: untouched (no traffic).  w == 0: the pixel becomes +0 without being read -- most
+    // of the grid lies outside a pupil, so this halves the kernel's HBM traffic.  (The
+    // reference multiplies, so a non-finite value out there would turn into NaN instead.)
+    if (w == 0.0) {
+      f[m] = {(T)0, (T)0};
+    } else if (w != 1.0) {
       cx<T> v = f[m];
       v.x = (T)__dmul_rn((double)v.x, w);
       v.y = (T)__dmul_rn((double)v.y, w);
