@@ -190,6 +190,7 @@ __global__ void phase_table_kernel(TableArgs a) {
 // while line s is transformed).
 template <int N, int E, int LINES, int TILES, int AXIS, int BR, int BC, int SEQ = 1>
 struct TileMap {
+  static constexpr int kAxis = AXIS;
   static constexpr int TL = N / E;
   static constexpr int PAR = LINES / SEQ;            // lines processed concurrently
   static constexpr int TILE_THREADS = PAR * TL;

@@ -25,9 +25,24 @@ constexpr int kFrugalMaxPre = 2, kFrugalMaxMid = 3;
 struct FrugalPhase {
   double sx, sy, coef, sgn, m2, natural;  // natural != 0: np.fft.fftfreq index order
 };
+// A convex aperture along one line (a row for row passes, a column for column passes):
+//   pos < p0: w_out | p0 <= pos < p1: vals[pos-p0] | p1 <= pos < p2: w_in |
+//   p2 <= pos < p3: vals[kMaskW + pos-p2] | pos >= p3: w_out          (times the line factor lm)
+// rendered by mask_lines_kernel (pointwise.h) with the same per-pixel functions the stand-alone
+// aperture kernel uses, so values and the {0, partial, 1} classification are identical.
+constexpr int kMaskW = 192;  // longest partial run per side the records can hold
+struct MaskLine {
+  int p0, p1, p2, p3;
+  double lm;  // line multiplier (rectangles: the separable count of the other axis / 32)
+  double pad;
+};
 struct FrugalSlot {
   double sign_on, scale;
+  double mask_on, w_in, w_out;   // aperture riding on this slot (0/1), interior / exterior weight
+  const MaskLine* lines;          // [N] records of THIS item for the pass axis
+  const double* vals;             // [N][2 * kMaskW]
 };
+static_assert(sizeof(FrugalSlot) == 7 * sizeof(double), "record of 8-byte fields");
 // per-item record, doubles: [fft1_on, fft1_inv, fft2_on, fft2_inv, pre slot, pre phases[2],
 // mid slot, mid phases[3]]
 struct FrugalItem {
@@ -51,6 +66,21 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
                                             const Map& m) {
   const double sc = sl.scale;
   const bool sign_on = sl.sign_on != 0.0;
+  if (sl.mask_on != 0.0) {  // wave-uniform: an aperture rides on this slot
+    const int line = Map::kAxis == 0 ? m.row(0) : m.col(0);  // constant per thread
+    const MaskLine ml = sl.lines[line];
+    const double* vals = sl.vals + (size_t)line * (2 * kMaskW);
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+      const int pos = Map::kAxis == 0 ? m.col(k) : m.row(k);
+      double w = (pos >= ml.p1 && pos < ml.p2) ? sl.w_in : sl.w_out;
+      if (pos >= ml.p0 && pos < ml.p1) w = vals[pos - ml.p0];
+      if (pos >= ml.p2 && pos < ml.p3) w = vals[kMaskW + pos - ml.p2];
+      w *= ml.lm;
+      v[k] = {(T)__dmul_rn((double)v[k].x, w), (T)__dmul_rn((double)v[k].y, w)};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
 #pragma unroll
   for (int k = 0; k < E; ++k) {
     const int row = m.row(k), col = m.col(k);

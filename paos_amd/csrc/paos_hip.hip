@@ -61,6 +61,9 @@ struct paos_ctx {
   void* staging = nullptr;  // n*n*16 bytes, row-major
   cx<double>* tables = nullptr;  // kMaxTables x batch x 2n separable phase factors
   double* mask = nullptr;        // batch x item_stride aperture weights (allocated on first use)
+  MaskLine* mask_lines = nullptr;  // batch x n line records of the aperture riding on a frugal pass
+  double* mask_vals = nullptr;     // batch x n x 2 kMaskW partial weights
+  int* mask_overflow = nullptr;    // device counter: partial runs that did not fit (must stay 0)
   double* partial = nullptr;
   double* norm2 = nullptr;
   double* norm2_host = nullptr;  // pinned, kNormSlots x batch
@@ -223,19 +226,40 @@ bool use_frugal() {
 
 // Express pass p as   load | sign*scale*K phases | FFT | sign*scale*K phases | [FFT] | store.
 bool lower_frugal(const paos_ctx* c, const paos_pass& p, const double* blocks /*host*/, std::vector<FrugalItem>& items,
-                  int& kpre, int& kmid, int& nfft) {
+                  int& kpre, int& kmid, int& nfft, int& mask_block, int& mask_slot) {
   if (p.axis != 0 && p.axis != 1) return false;
   if (p.fft1 < 0 || p.n_post != 0) return false;
   const paos_pw_op* lists[2] = {p.pre, p.mid};
   const int counts[2] = {p.n_pre, p.n_mid};
   int k[2] = {0, 0};
+  mask_block = -1; mask_slot = -1;
   for (int l = 0; l < 2; ++l)
     for (int o = 0; o < counts[l]; ++o) {
       const int kind = lists[l][o].kind;
       if (kind == PAOS_PW_QPHASE_CENTRED || kind == PAOS_PW_QPHASE_NATURAL) ++k[l];
-      else if (kind != PAOS_PW_SIGN && kind != PAOS_PW_SCALE) return false;
+      else if (kind == PAOS_PW_MASK) {
+        if (mask_block >= 0) return false;  // one aperture per pass (one set of line records)
+        mask_block = lists[l][o].block; mask_slot = l;
+      } else if (kind != PAOS_PW_SIGN && kind != PAOS_PW_SCALE) return false;
     }
   if (k[0] > kFrugalMaxPre || k[1] > kFrugalMaxMid) return false;
+  if (mask_block >= 0) {  // can this aperture be held as per-line records along the pass axis?
+    for (int it = 0; it < c->batch; ++it) {
+      const double* q = blocks + ((size_t)mask_block * c->batch + it) * FP_STRIDE;
+      const double* q2 = blocks + ((size_t)(mask_block + 1) * c->batch + it) * FP_STRIDE;
+      if (q[0] == 0.0) continue;
+      const double a = q[3], b = q[4], theta = q2[0], obsc = q2[1], subpix = q2[2], shape = q2[3];
+      if (theta != 0.0 || !(a > 0.0) || !(b > 0.0)) return false;
+      if (shape == PAOS_SHAPE_ELLIPSE) {
+        // longest partial run near the tips of the ellipse: ~ 2 a sqrt(3 / b) along rows
+        const double along = p.axis == 0 ? a : b, across = p.axis == 0 ? b : a;
+        if (!(across >= 2.0) || 2.0 * along * std::sqrt(3.0 / across) + 8.0 > kMaskW) return false;
+      } else {
+        const int sp = (int)subpix;
+        if (obsc != 0.0 || sp <= 0 || (sp & (sp - 1)) != 0) return false;
+      }
+    }
+  }
   kpre = k[0]; kmid = k[1]; nfft = p.fft2 >= 0 ? 2 : 1;
   items.assign(c->batch, FrugalItem{});
   auto blk = [&](int b, int it) { return blocks + ((size_t)b * c->batch + it) * FP_STRIDE; };
@@ -249,13 +273,22 @@ bool lower_frugal(const paos_ctx* c, const paos_pass& p, const double* blocks /*
     FrugalPhase* phases[2] = {fi.pre_ph, fi.mid_ph};
     for (int l = 0; l < 2; ++l) {
       slots[l]->sign_on = 0.0; slots[l]->scale = 1.0;
+      slots[l]->mask_on = 0.0; slots[l]->w_in = 1.0; slots[l]->w_out = 0.0;
+      slots[l]->lines = nullptr; slots[l]->vals = nullptr;
       int j = 0;
       for (int o = 0; o < counts[l]; ++o) {
         const paos_pw_op& op = lists[l][o];
         const double* q = blk(op.block, it);
         const bool on = q[FP_ENABLE] != 0.0;
         active = active || on;
-        if (op.kind == PAOS_PW_SIGN) { if (on) slots[l]->sign_on = slots[l]->sign_on != 0.0 ? 0.0 : 1.0; }
+        if (op.kind == PAOS_PW_MASK) {
+          const double* q2 = blk(op.block + 1, it);
+          slots[l]->mask_on = on ? 1.0 : 0.0;
+          const bool obsc = q2[1] != 0.0 && q2[3] == PAOS_SHAPE_ELLIPSE;
+          slots[l]->w_in = obsc ? 0.0 : 1.0; slots[l]->w_out = obsc ? 1.0 : 0.0;
+          slots[l]->lines = c->mask_lines + (size_t)it * c->n;
+          slots[l]->vals = c->mask_vals + (size_t)it * c->n * 2 * kMaskW;
+        } else if (op.kind == PAOS_PW_SIGN) { if (on) slots[l]->sign_on = slots[l]->sign_on != 0.0 ? 0.0 : 1.0; }
         else if (op.kind == PAOS_PW_SCALE) { if (on) slots[l]->scale *= q[FP_COEF]; }
         else {
           FrugalPhase& ph = phases[l][j++];
@@ -325,12 +358,28 @@ int frugal_axis(paos_ctx* c, const FrugalArgs& a, int axis, int kpre, int kmid, 
 }
 
 // returns PAOS_OK and sets *done when the pass ran on the frugal path
-int try_frugal(paos_ctx* c, const paos_pass& p, const double* host_blocks, bool* done) {
+int try_frugal(paos_ctx* c, const paos_pass& p, const double* host_blocks, const double* dblocks, bool* done) {
   *done = false;
   if (!use_frugal() || c->precision != PAOS_F64 || c->n < 1024) return PAOS_OK;
   std::vector<FrugalItem> items;
-  int kpre = 0, kmid = 0, nfft = 1;
-  if (!lower_frugal(c, p, host_blocks, items, kpre, kmid, nfft)) return PAOS_OK;
+  int kpre = 0, kmid = 0, nfft = 1, mask_block = -1, mask_slot = -1;
+  if (!c->mask_lines) {  // line-record store of an aperture riding on a pass (lazily)
+    HIPCHK(c, hipMalloc(&c->mask_lines, (size_t)c->batch * c->n * sizeof(MaskLine)));
+    HIPCHK(c, hipMalloc(&c->mask_vals, (size_t)c->batch * c->n * 2 * kMaskW * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->mask_overflow, sizeof(int)));
+    HIPCHK(c, hipMemsetAsync(c->mask_overflow, 0, sizeof(int), c->stream));
+  }
+  if (!lower_frugal(c, p, host_blocks, items, kpre, kmid, nfft, mask_block, mask_slot)) return PAOS_OK;
+  if (mask_block >= 0) {  // render the records along the pass axis, right before the pass
+    const double* ap = dblocks + (size_t)mask_block * c->batch * FP_STRIDE;
+    const double* ap2 = ap + (size_t)c->batch * FP_STRIDE;
+    const dim3 grid((c->n + 3) / 4, c->batch), block(256);
+    hipLaunchKernelGGL(mask_lines_kernel<0>, grid, block, 0, c->stream, ap, ap2, (int)FP_STRIDE, c->n, p.axis,
+                       c->mask_lines, c->mask_vals, c->mask_overflow);
+    hipLaunchKernelGGL(mask_lines_kernel<1>, grid, block, 0, c->stream, ap, ap2, (int)FP_STRIDE, c->n, p.axis,
+                       c->mask_lines, c->mask_vals, c->mask_overflow);
+    HIPCHK(c, hipGetLastError());
+  }
   const double* ditems = nullptr;
   static_assert(sizeof(FrugalItem) % sizeof(double) == 0, "record of doubles");
   int rc = arena_push(c, reinterpret_cast<const double*>(items.data()),
@@ -471,7 +520,7 @@ int run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double*
     }
     for (int q = i; q < j; ++q) {
       bool done = false;
-      if (!use_tables() && (rc = try_frugal(c, passes[q], blocks, &done))) return rc;
+      if (!use_tables() && (rc = try_frugal(c, passes[q], blocks, dblocks, &done))) return rc;
       if (done) continue;
       if ((rc = launch_one_pass(c, passes[q], dblocks, n_blocks, &assign[(size_t)(q - i) * 3 * PAOS_MAX_PW]))) return rc;
     }
@@ -547,6 +596,8 @@ std::vector<std::complex<T>> twiddles(int n) {
 #define DISPATCH_T(c, expr_d, expr_f) ((c)->precision == PAOS_F64 ? (expr_d) : (expr_f))
 
 }  // namespace
+
+static int check_mask_overflow(paos_ctx* c);
 
 extern "C" {
 
@@ -649,6 +700,9 @@ int paos_ctx_destroy(paos_ctx* c) {
   if (c->staging) (void)hipFree(c->staging);
   if (c->tables) (void)hipFree(c->tables);
   if (c->mask) (void)hipFree(c->mask);
+  if (c->mask_lines) (void)hipFree(c->mask_lines);
+  if (c->mask_vals) (void)hipFree(c->mask_vals);
+  if (c->mask_overflow) (void)hipFree(c->mask_overflow);
   if (c->partial) (void)hipFree(c->partial);
   if (c->norm2) (void)hipFree(c->norm2);
   if (c->norm2_host) (void)hipHostFree(c->norm2_host);
@@ -659,10 +713,22 @@ int paos_ctx_destroy(paos_ctx* c) {
   return PAOS_OK;
 }
 
+// after a synchronisation: did an aperture's partial run overflow its line records?
+static int check_mask_overflow(paos_ctx* c) {
+  if (!c->mask_overflow) return PAOS_OK;
+  int n = 0;
+  HIPCHK(c, hipMemcpy(&n, c->mask_overflow, sizeof(int), hipMemcpyDeviceToHost));
+  if (n != 0) {
+    (void)hipMemset(c->mask_overflow, 0, sizeof(int));
+    return fail(c, PAOS_EUNSUPPORTED, "aperture line records overflowed (partial run longer than kMaskW): results are invalid");
+  }
+  return PAOS_OK;
+}
+
 int paos_sync(paos_ctx* c) {
   if (!c) return fail(c, PAOS_EINVAL, "null context");
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return PAOS_OK;
+  return check_mask_overflow(c);
 }
 
 int paos_fill(paos_ctx* c, double re, double im) {
@@ -711,7 +777,7 @@ int paos_export(paos_ctx* c, int item, int what, void* host_out) {
   const size_t bytes = (size_t)c->n * c->n * (what == PAOS_WHAT_FIELD ? 16 : 8);
   HIPCHK(c, hipMemcpyAsync(host_out, c->staging, bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  return PAOS_OK;
+  return check_mask_overflow(c);
 }
 
 static int aperture_launch(paos_ctx* c, int shape, const double* dp, int nitems, double* mask_out) {
@@ -803,7 +869,7 @@ int paos_norm2_fetch(paos_ctx* c, int ticket, double* host_out) {
   if (!c || !host_out || ticket < 0 || ticket >= kNormSlots) return fail(c, PAOS_EINVAL, "bad ticket");
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::memcpy(host_out, c->norm2_host + (size_t)ticket * c->batch, (size_t)c->batch * sizeof(double));
-  return PAOS_OK;
+  return check_mask_overflow(c);
 }
 
 int paos_norm2(paos_ctx* c, double* host_out) {

@@ -11,7 +11,7 @@
 //   zernikes  -> wfo.py:620-652 + paos/classes/zernike.py:85-109,245-247
 //   amplitude / phase / intensity -> wfo.py:166-172, paos/core/plot.py:125-130
 #pragma once
-#include "fft_kernels.h"
+#include "frugal_pass.h"
 
 namespace paos {
 
@@ -336,6 +336,90 @@ __global__ void aperture_kernel(cx<T>* field, const double* params, const double
       f[m] = v;
     }
   }
+}
+
+// ---- aperture line records for the frugal pass (frugal_pass.h: MaskLine) -------------------
+// One wave per line (axis 0: a row, positions = columns; axis 1: a column, positions = rows).
+// The wave walks the line 64 pixels at a time, evaluates the SAME per-pixel functions as
+// aperture_kernel, and records where the weight leaves w_out / reaches w_in.  theta must be 0
+// (the only case run() produces, run.py:114-121); the host checks that the partial runs fit.
+//   ellipse:   w(row, col) = ellipse_pixel(...) [1 - ... for an obscuration], lm = 1
+//   rectangle: mask = (cx(col)/S)(cy(row)/S) is separable, so along a row the record holds
+//              cx(col)/S and lm = cy(row)/S (and vice versa); obscurations of rectangles are not
+//              separable as 1 - mask and stay on the stand-alone kernel.
+template <int SHAPE>
+__global__ void mask_lines_kernel(const double* params, const double* params2, int param_stride, int n,
+                                  int axis, MaskLine* lines, double* vals, int* overflow) {
+  const int item = blockIdx.y;
+  const int line = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (line >= n) return;
+  const double* p = params + (size_t)item * param_stride;
+  const double* p2 = params2 + (size_t)item * param_stride;
+  MaskLine* out = lines + (size_t)item * n + line;
+  double* vout = vals + ((size_t)item * n + line) * (2 * kMaskW);
+  if (p[AP_ENABLE] == 0.0 || SHAPE != (int)p2[3]) return;
+  const double xc = p[AP_XC], yc = p[AP_YC], a = p[AP_A], b = p[AP_B];
+  const bool obsc = p2[1] != 0.0;
+  const int subpix = (int)p2[2];
+  const double w_in = obsc ? 0.0 : 1.0, w_out = obsc ? 1.0 : 0.0;
+  double xe, ye, hw = 0.0, hh = 0.0, full_disk = 0.0, lm = 1.0;
+  if (SHAPE == 0) {
+    xe = sqrt(__dmul_rn(a, a));  // cos 0 = 1, sin 0 = 0: the theta = 0 form of aperture_kernel's extents
+    ye = sqrt(__dmul_rn(b, b));
+    full_disk = fmin(__dmul_rn(__dmul_rn(3.141592653589793, a), b), 1.0);
+  } else {
+    hw = a / 2.0; hh = b / 2.0;
+    xe = fabs(hw); ye = fabs(hh);
+  }
+  const ApertureBox box = make_box(xc, yc, xe, ye);
+  if (SHAPE == 1) {
+    const int c_other = axis == 0 ? subpixel_count_1d(line, yc, hh, subpix) : subpixel_count_1d(line, xc, hw, subpix);
+    const bool in_box = axis == 0 ? (line >= box.iymin && line < box.iymax) : (line >= box.ixmin && line < box.ixmax);
+    lm = in_box ? (double)c_other / (double)subpix : 0.0;
+  }
+  int p0 = n, p1 = -1, p2i = -1, p3 = 0;  // first non-out, first in, last in + 1, last non-out + 1
+  // pass 1: extents
+  for (int base = 0; base < n; base += 64) {
+    const int pos = base + lane;
+    const int c = axis == 0 ? pos : line, r = axis == 0 ? line : pos;
+    double mask = 0.0;
+    if (c >= box.ixmin && c < box.ixmax && r >= box.iymin && r < box.iymax) {
+      if (SHAPE == 0) mask = ellipse_pixel(c, r, xc, yc, a, b, 1.0, 0.0, full_disk);
+      else mask = (double)(axis == 0 ? subpixel_count_1d(c, xc, hw, subpix) : subpixel_count_1d(r, yc, hh, subpix)) / (double)subpix;
+    }
+    const double w = (SHAPE == 0 && obsc) ? __dsub_rn(1.0, mask) : mask;
+    const double wi = SHAPE == 0 ? w_in : 1.0, wo = SHAPE == 0 ? w_out : 0.0;
+    const unsigned long long not_out = __ballot(w != wo), is_in = __ballot(w == wi);
+    if (not_out) {
+      p0 = min(p0, base + (int)__ffsll((long long)not_out) - 1);
+      p3 = max(p3, base + 64 - (int)__clzll((long long)not_out));
+    }
+    if (is_in) {
+      if (p1 < 0) p1 = base + (int)__ffsll((long long)is_in) - 1;
+      p2i = base + 64 - (int)__clzll((long long)is_in);
+    }
+  }
+  if (p3 <= p0) { p0 = p1 = p2i = p3 = 0; }           // the line never leaves w_out
+  else if (p1 < 0) { p1 = p2i = p3; }                  // no interior: one partial run [p0, p3)
+  if (p1 - p0 > kMaskW || p3 - p2i > kMaskW) {
+    if (lane == 0) atomicAdd(overflow, 1);
+    p0 = p1 = p2i = p3 = 0;
+  }
+  // pass 2: partial values
+  for (int side = 0; side < 2; ++side) {
+    const int lo = side == 0 ? p0 : p2i, hi = side == 0 ? p1 : p3;
+    for (int pos = lo + lane; pos < hi; pos += 64) {
+      const int c = axis == 0 ? pos : line, r = axis == 0 ? line : pos;
+      double mask = 0.0;
+      if (c >= box.ixmin && c < box.ixmax && r >= box.iymin && r < box.iymax) {
+        if (SHAPE == 0) mask = ellipse_pixel(c, r, xc, yc, a, b, 1.0, 0.0, full_disk);
+        else mask = (double)(axis == 0 ? subpixel_count_1d(c, xc, hw, subpix) : subpixel_count_1d(r, yc, hh, subpix)) / (double)subpix;
+      }
+      vout[side * kMaskW + pos - lo] = (SHAPE == 0 && obsc) ? __dsub_rn(1.0, mask) : mask;
+    }
+  }
+  if (lane == 0) *out = {p0, p1, p2i, p3, lm, 0.0};
 }
 
 // ---- Zernike phase ----------------------------------------------------------------

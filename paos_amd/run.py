@@ -28,12 +28,27 @@ from .passes import PassCompiler
 from .planner import PilotBeam, jacobi_recurrence, zernike_block
 from .zernike import Zernike, norm_factors
 
-# Apertures can ride on FFT passes as PW_MASK operators (their weight map is rendered right
-# before the pass).  On MI355X round 1 this is a net loss -- the fused passes are compute-bound
-# and a stand-alone aperture pass runs at HBM speed -- so it is opt-in: PAOS_FUSE_APERTURES=1.
+# Apertures ride on FFT passes as PW_MASK operators when the library can hold them as per-line
+# records (csrc/frugal_pass.h: MaskLine; complex128, N >= 1024, untilted ellipse whose partial
+# runs fit, or untilted rectangular aperture): no stand-alone pass and the fusion chain does
+# not break.  PAOS_FUSE_APERTURES=0 turns it off, =1 forces it for every aperture (the generic
+# kernel then uses a rendered weight map, which measured slower than a stand-alone pass).
 import os as _os
 
-FUSE_APERTURES = _os.environ.get("PAOS_FUSE_APERTURES", "0") == "1"
+FUSE_APERTURES = {"0": False, "1": True}.get(_os.environ.get("PAOS_FUSE_APERTURES", "auto"), "auto")
+_MASK_RUN = 192  # kMaskW of csrc/frugal_pass.h
+
+
+def _aperture_fits_line_records(handle, obscuration, n, precision):
+    if precision != "fp64" or n < 1024 or handle.theta != 0.0:
+        return False
+    if isinstance(handle, EllipticalAperture):
+        a, b = handle.a, handle.b
+        if not (a >= 2.0 and b >= 2.0):
+            return False
+        return (2.0 * a * math.sqrt(3.0 / b) + 8.0 <= _MASK_RUN and
+                2.0 * b * math.sqrt(3.0 / a) + 8.0 <= _MASK_RUN)
+    return not obscuration and handle.w > 0.0 and handle.h > 0.0
 
 _OFF_PHASE = [0.0] * _lib.PHASE_STRIDE
 _OFF_APERTURE = [0.0] * _lib.APERTURE_STRIDE
@@ -200,6 +215,9 @@ def _walk(dev, states, chains, on_saved, stats=None):
         plans = [_plan_surface(st, it) for st, it in zip(states, items)]
         saved = any(it["save"] for it in items)
         fuse_ap = FUSE_APERTURES
+        if fuse_ap == "auto":
+            aps = [p["aperture"] for p in plans if p["aperture"] is not None]
+            fuse_ap = bool(aps) and all(_aperture_fits_line_records(h, o, dev.n, dev.precision) for h, o in aps)
         if fuse_ap:
             _queue_apertures(comp, plans)
         breaker = saved or any(p["stop"] or p["zernike"] is not None or

@@ -314,18 +314,27 @@ def test_batch_with_divergent_propagator_regimes():
     assert props == ["OO", "OI"]
 
 
-def test_optional_paths_keep_parity(monkeypatch):
-    """Opt-in variants measured slower in round 1 but kept for later rounds: apertures riding
-    on passes (PAOS_FUSE_APERTURES) -- same results as the default path."""
+def test_aperture_fusion_variants_agree(monkeypatch):
+    """Apertures as stand-alone kernels, as per-line records riding on frugal passes (the
+    default at N >= 1024), and as rendered weight maps in the generic kernel (forced at 256)
+    give the same fields; the Hubble chain adds obscurations and off-centre pads, the field
+    stop of SYN20 a rectangle."""
     import paos_amd.run as prun
     from paos_amd.chains import syn20_chain
+    from paos_amd.parse_config import parse_config
 
     field = {"us": 0.0, "ut": 0.0}
-    base = prun.run(1.0, 1.0e-6, 256, 4, field, syn20_chain())
-    monkeypatch.setattr(prun, "FUSE_APERTURES", True)
-    fused = prun.run(1.0, 1.0e-6, 256, 4, field, syn20_chain())
-    for k in base:
-        assert rel_err(fused[k]["wfo"], base[k]["wfo"]) < 1e-13
+    pup, par, wls, fields, chains = parse_config(os.path.join(DATA, "lens", "Hubble_simple.ini"))
+    cases = [((1.0, 1.0e-6, 1024, 4, field), syn20_chain), ((pup, 1e-6 * wls[0], 1024, par["zoom"], fields[0]), lambda: chains[0]),
+             ((1.0, 1.0e-6, 256, 4, field), syn20_chain)]
+    for args, chain in cases:
+        monkeypatch.setattr(prun, "FUSE_APERTURES", False)
+        base = prun.run(*args, chain())
+        for mode in ("auto", True):
+            monkeypatch.setattr(prun, "FUSE_APERTURES", mode)
+            fused = prun.run(*args, chain())
+            for k in base:
+                assert rel_err(fused[k]["wfo"], base[k]["wfo"]) < 1e-13, (args[2], mode, k)
 
 
 def test_fp32_mode_tolerance():

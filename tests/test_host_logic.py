@@ -128,7 +128,11 @@ def test_syn20_pass_budget():
     45 passes in all when the apertures ride on passes too (PAOS_FUSE_APERTURES=1)."""
     import paos_amd.run as prun
 
-    _, dev, stats = _model_run(_spec("SYN20"), 64)
+    prun.FUSE_APERTURES = False
+    try:
+        _, dev, stats = _model_run(_spec("SYN20"), 64)
+    finally:
+        prun.FUSE_APERTURES = "auto"
     assert stats["fused_passes"] == dev.pass_count == 49
     kinds = [name for name, _ in dev.log]
     assert kinds.count("aperture") == 7 and kinds.count("make_stop") == 1 and kinds.count("zernike") == 1
@@ -137,7 +141,7 @@ def test_syn20_pass_budget():
     try:
         saved, dev, stats = _model_run(_spec("SYN20"), 64)
     finally:
-        prun.FUSE_APERTURES = False
+        prun.FUSE_APERTURES = "auto"
     kinds = [name for name, _ in dev.log]
     assert kinds.count("aperture") == 0 and stats["fused_passes"] == 45
     gr = load_golden("run_SYN20.npz")
@@ -146,7 +150,7 @@ def test_syn20_pass_budget():
     try:
         fused, _, _ = _model_run(_spec("SYN20"), 128)
     finally:
-        prun.FUSE_APERTURES = False
+        prun.FUSE_APERTURES = "auto"
     for k in gr["nums"]:
         assert rel_err(fused[0][k]["wfo"], gr[f"S{k:02d}_wfo"]) < 1e-12
         assert rel_err(fused[0][k]["wfo"], saved[0][k]["wfo"]) < 1e-13
