@@ -37,7 +37,10 @@ static constexpr int BR = PAOS_BR;
 static constexpr int kNormSlots = 64;  // outstanding paos_norm2_enqueue results
 template <typename T>
 struct Lay {
-  static constexpr int BC = 128 / (BR * (int)sizeof(cx<T>));
+  // 2 columns for both types: a block is 128 B of complex128 or 64 B of complex64.  (4 columns
+  // of complex64 would fill the line but make the column tile 4 lines = 1024 threads, which
+  // spills; measured 126 wavefronts/s vs the 2-column shape below.)
+  static constexpr int BC = 2;
 };
 
 namespace {
@@ -303,9 +306,8 @@ bool lower_frugal(const paos_ctx* c, const paos_pass& p, const double* blocks /*
   return true;
 }
 
-template <int N, int AXIS, int KPRE, int KMID, int NFFT>
+template <typename T, int N, int AXIS, int KPRE, int KMID, int NFFT>
 int frugal_launch(paos_ctx* c, const FrugalArgs& a) {
-  using T = double;
   using C = FftCfg<T, N>;
   constexpr int LINES = AXIS == 0 ? C::ROW_LINES : C::COL_LINES;
   constexpr int TILES = AXIS == 0 ? C::ROW_TILES : C::COL_TILES;
@@ -331,36 +333,37 @@ int frugal_launch(paos_ctx* c, const FrugalArgs& a) {
   return PAOS_OK;
 }
 
-template <int N, int AXIS, int KPRE, int KMID>
+template <typename T, int N, int AXIS, int KPRE, int KMID>
 int frugal_nfft(paos_ctx* c, const FrugalArgs& a, int nfft) {
-  return nfft == 2 ? frugal_launch<N, AXIS, KPRE, KMID, 2>(c, a) : frugal_launch<N, AXIS, KPRE, KMID, 1>(c, a);
+  return nfft == 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1>(c, a);
 }
-template <int N, int AXIS, int KPRE>
+template <typename T, int N, int AXIS, int KPRE>
 int frugal_kmid(paos_ctx* c, const FrugalArgs& a, int kmid, int nfft) {
   switch (kmid) {
-    case 0: return frugal_nfft<N, AXIS, KPRE, 0>(c, a, nfft);
-    case 1: return frugal_nfft<N, AXIS, KPRE, 1>(c, a, nfft);
-    case 2: return frugal_nfft<N, AXIS, KPRE, 2>(c, a, nfft);
-    default: return frugal_nfft<N, AXIS, KPRE, 3>(c, a, nfft);
+    case 0: return frugal_nfft<T, N, AXIS, KPRE, 0>(c, a, nfft);
+    case 1: return frugal_nfft<T, N, AXIS, KPRE, 1>(c, a, nfft);
+    case 2: return frugal_nfft<T, N, AXIS, KPRE, 2>(c, a, nfft);
+    default: return frugal_nfft<T, N, AXIS, KPRE, 3>(c, a, nfft);
   }
 }
-template <int N, int AXIS>
+template <typename T, int N, int AXIS>
 int frugal_kpre(paos_ctx* c, const FrugalArgs& a, int kpre, int kmid, int nfft) {
   switch (kpre) {
-    case 0: return frugal_kmid<N, AXIS, 0>(c, a, kmid, nfft);
-    case 1: return frugal_kmid<N, AXIS, 1>(c, a, kmid, nfft);
-    default: return frugal_kmid<N, AXIS, 2>(c, a, kmid, nfft);
+    case 0: return frugal_kmid<T, N, AXIS, 0>(c, a, kmid, nfft);
+    case 1: return frugal_kmid<T, N, AXIS, 1>(c, a, kmid, nfft);
+    default: return frugal_kmid<T, N, AXIS, 2>(c, a, kmid, nfft);
   }
 }
-template <int N>
+template <typename T, int N>
 int frugal_axis(paos_ctx* c, const FrugalArgs& a, int axis, int kpre, int kmid, int nfft) {
-  return axis == 0 ? frugal_kpre<N, 0>(c, a, kpre, kmid, nfft) : frugal_kpre<N, 1>(c, a, kpre, kmid, nfft);
+  return axis == 0 ? frugal_kpre<T, N, 0>(c, a, kpre, kmid, nfft) : frugal_kpre<T, N, 1>(c, a, kpre, kmid, nfft);
 }
 
 // returns PAOS_OK and sets *done when the pass ran on the frugal path
 int try_frugal(paos_ctx* c, const paos_pass& p, const double* host_blocks, const double* dblocks, bool* done) {
   *done = false;
-  if (!use_frugal() || c->precision != PAOS_F64 || c->n < 1024) return PAOS_OK;
+  // instantiated for complex128 at N >= 1024 and complex64 at N >= 2048
+  if (!use_frugal() || c->n < (c->precision == PAOS_F64 ? 1024 : 2048)) return PAOS_OK;
   std::vector<FrugalItem> items;
   int kpre = 0, kmid = 0, nfft = 1, mask_block = -1, mask_slot = -1;
   if (!c->mask_lines) {  // line-record store of an aperture riding on a pass (lazily)
@@ -386,10 +389,17 @@ int try_frugal(paos_ctx* c, const paos_pass& p, const double* host_blocks, const
                       items.size() * sizeof(FrugalItem) / sizeof(double), &ditems);
   if (rc) return rc;
   FrugalArgs a{c->field, c->tw, reinterpret_cast<const FrugalItem*>(ditems), c->pitch, c->item_stride};
-  switch (c->n) {
-    case 1024: rc = frugal_axis<1024>(c, a, p.axis, kpre, kmid, nfft); break;
-    case 2048: rc = frugal_axis<2048>(c, a, p.axis, kpre, kmid, nfft); break;
-    default: rc = frugal_axis<4096>(c, a, p.axis, kpre, kmid, nfft); break;
+  if (c->precision == PAOS_F64) {
+    switch (c->n) {
+      case 1024: rc = frugal_axis<double, 1024>(c, a, p.axis, kpre, kmid, nfft); break;
+      case 2048: rc = frugal_axis<double, 2048>(c, a, p.axis, kpre, kmid, nfft); break;
+      default: rc = frugal_axis<double, 4096>(c, a, p.axis, kpre, kmid, nfft); break;
+    }
+  } else {
+    switch (c->n) {
+      case 2048: rc = frugal_axis<float, 2048>(c, a, p.axis, kpre, kmid, nfft); break;
+      default: rc = frugal_axis<float, 4096>(c, a, p.axis, kpre, kmid, nfft); break;
+    }
   }
   if (rc == PAOS_OK) *done = true;
   return rc;

@@ -40,7 +40,7 @@ _MASK_RUN = 192  # kMaskW of csrc/frugal_pass.h
 
 
 def _aperture_fits_line_records(handle, obscuration, n, precision):
-    if precision != "fp64" or n < 1024 or handle.theta != 0.0:
+    if n < (1024 if precision == "fp64" else 2048) or handle.theta != 0.0:
         return False
     if isinstance(handle, EllipticalAperture):
         a, b = handle.a, handle.b
