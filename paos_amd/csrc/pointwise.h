@@ -379,8 +379,13 @@ __global__ void mask_lines_kernel(const double* params, const double* params2, i
     lm = in_box ? (double)c_other / (double)subpix : 0.0;
   }
   int p0 = n, p1 = -1, p2i = -1, p3 = 0;  // first non-out, first in, last in + 1, last non-out + 1
+  // Only the part of the line inside the bounding box can differ from w_out: lines that miss
+  // the box are done, the others are scanned over the box's extent along the line only.
+  const bool line_in_box = axis == 0 ? (line >= box.iymin && line < box.iymax) : (line >= box.ixmin && line < box.ixmax);
+  const int scan_lo = line_in_box ? max(0, (axis == 0 ? box.ixmin : box.iymin)) & ~63 : 0;
+  const int scan_hi = line_in_box ? min(n, axis == 0 ? box.ixmax : box.iymax) : 0;
   // pass 1: extents
-  for (int base = 0; base < n; base += 64) {
+  for (int base = scan_lo; base < scan_hi; base += 64) {
     const int pos = base + lane;
     const int c = axis == 0 ? pos : line, r = axis == 0 ? line : pos;
     double mask = 0.0;

@@ -215,9 +215,13 @@ def _walk(dev, states, chains, on_saved, stats=None):
         plans = [_plan_surface(st, it) for st, it in zip(states, items)]
         saved = any(it["save"] for it in items)
         fuse_ap = FUSE_APERTURES
+        own_breaker = saved or any(p["stop"] or p["zernike"] is not None for p in plans)
         if fuse_ap == "auto":
+            # an aperture followed on its own surface by a stop / Zernike / save could only ride
+            # on a transform-free pass: the stand-alone aperture kernel is cheaper there
             aps = [p["aperture"] for p in plans if p["aperture"] is not None]
-            fuse_ap = bool(aps) and all(_aperture_fits_line_records(h, o, dev.n, dev.precision) for h, o in aps)
+            fuse_ap = (bool(aps) and not own_breaker and
+                       all(_aperture_fits_line_records(h, o, dev.n, dev.precision) for h, o in aps))
         if fuse_ap:
             _queue_apertures(comp, plans)
         breaker = saved or any(p["stop"] or p["zernike"] is not None or
