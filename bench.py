@@ -183,7 +183,7 @@ def main():
                                    f"1um*(1+k/512), {nb} wavefronts/GPU/step, {ffts} 2-D FFTs per wavefront "
                                    f"({n_ptp} ptp, {n_stw} stw, {n_wts} wts)",
                        "grid": n, "batch_per_gpu": nb, "parallelism": f"wavefront-sharded x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "fused_pass_kernel (rows and columns)", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "frugal_pass_kernel (every FFT pass launch, rows and columns)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "launches": launches, "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": pass_bytes,

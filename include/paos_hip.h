@@ -106,6 +106,12 @@ int paos_norm2(paos_ctx* ctx, double* host_out);
  * get a ticket (up to 64 outstanding), fetch after the work was synchronised. */
 int paos_norm2_enqueue(paos_ctx* ctx, int* ticket);
 int paos_norm2_fetch(paos_ctx* ctx, int ticket, double* host_out);
+/* PSF metrics on the GPU for Monte-Carlo studies (the encircled-energy workflow of
+ * docs/source/user/montecarlo/index.rst:26-66; PSF = |u|^2, plot.py:125-130).  Per item:
+ * [sum I, sum I*col, sum I*row, max I, then nr values: sum of I over pixels whose centre lies
+ * within radii_px[k] of (cx_px, cy_px)], nr <= 16.  host_out: [batch][4 + nr].  Synchronises. */
+int paos_psf_metrics(paos_ctx* ctx, int nr, const double* radii_px, double cx_px, double cy_px,
+                     double* host_out);
 /* quadratic phase u *= exp(i sgn [2 pi] coef ((x sx)^2 + (y sy)^2)), x, y centred pixel
  * indices: the field part of WFO.lens (wfo.py:359-366) with mul2pi = 1, sgn = -1,
  * coef = 0.5 lens_phase / wl. */

@@ -57,6 +57,7 @@ SYMBOLS = {
     "paos_norm2": (ctypes.c_int, [_c_ctx, _dbl_p]),
     "paos_norm2_enqueue": (ctypes.c_int, [_c_ctx, ctypes.POINTER(ctypes.c_int)]),
     "paos_norm2_fetch": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p]),
+    "paos_psf_metrics": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p, ctypes.c_double, ctypes.c_double, _dbl_p]),
     "paos_phase": (ctypes.c_int, [_c_ctx, _dbl_p, ctypes.c_int]),
     "paos_ptp": (ctypes.c_int, [_c_ctx, _dbl_p]),
     "paos_stw": (ctypes.c_int, [_c_ctx, _dbl_p, ctypes.c_int]),
@@ -208,6 +209,21 @@ class DeviceFields:
         out = np.empty(self.batch, dtype=np.float64)
         self._check(self._lib.paos_norm2_fetch(self._ctx, int(ticket), _dptr(out)), "paos_norm2_fetch")
         return out
+
+    def psf_metrics(self, radii_px=(), centre=None):
+        """Per item: dict(power, centroid (col,row), peak, encircled power per radius) of |u|^2,
+        computed on the GPU.  ``centre`` defaults to the grid centre (n/2, n/2)."""
+        r = np.ascontiguousarray(radii_px, dtype=np.float64).reshape(-1)
+        cxp, cyp = (self.n / 2, self.n / 2) if centre is None else centre
+        out = np.empty((self.batch, 4 + r.size), dtype=np.float64)
+        self._check(self._lib.paos_psf_metrics(self._ctx, int(r.size), _dptr(r) if r.size else None,
+                                               float(cxp), float(cyp), _dptr(out)), "paos_psf_metrics")
+        res = []
+        for row in out:
+            p = row[0]
+            res.append({"power": p, "centroid": (row[1] / p, row[2] / p) if p > 0 else (np.nan, np.nan),
+                        "peak": row[3], "encircled": row[4:].copy()})
+        return res
 
     def phase(self, blocks, mul2pi):
         b = as_blocks(blocks, self.batch, PHASE_STRIDE)

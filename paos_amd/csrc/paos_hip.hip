@@ -64,6 +64,9 @@ struct paos_ctx {
   void* staging = nullptr;  // n*n*16 bytes, row-major
   cx<double>* tables = nullptr;  // kMaxTables x batch x 2n separable phase factors
   double* mask = nullptr;        // batch x item_stride aperture weights (allocated on first use)
+  double* metric_partial = nullptr;  // psf metrics scratch
+  double* metric_out = nullptr;
+  double* metric_host = nullptr;     // pinned
   MaskLine* mask_lines = nullptr;  // batch x n line records of the aperture riding on a frugal pass
   double* mask_vals = nullptr;     // batch x n x 2 kMaskW partial weights
   int* mask_overflow = nullptr;    // device counter: partial runs that did not fit (must stay 0)
@@ -524,6 +527,10 @@ int run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double*
         }
     }
     if (ta.count > 0) {
+      if (!c->tables) {  // opt-in feature: allocate on first use
+        HIPCHK(c, hipMalloc(&c->tables, (size_t)kMaxTables * c->batch * 2 * c->n * sizeof(cx<double>)));
+        ta.tables = c->tables;
+      }
       const dim3 grid((2 * c->n + 255) / 256, c->batch, ta.count);
       hipLaunchKernelGGL(phase_table_kernel, grid, dim3(256), 0, c->stream, ta);
       HIPCHK(c, hipGetLastError());
@@ -650,7 +657,6 @@ int paos_ctx_create(int device, int n, int batch, int precision, paos_ctx** out)
   if ((e = hipMemsetAsync(c->field, 0, (size_t)c->item_stride * batch * eb, c->stream)) != hipSuccess) return bail(e, "hipMemset(field)");
   if ((e = hipMalloc(&c->tw, (size_t)n * eb)) != hipSuccess) return bail(e, "hipMalloc(tw)");
   if ((e = hipMalloc(&c->staging, (size_t)n * n * 16)) != hipSuccess) return bail(e, "hipMalloc(staging)");
-  if ((e = hipMalloc(&c->tables, (size_t)kMaxTables * batch * 2 * n * sizeof(cx<double>))) != hipSuccess) return bail(e, "hipMalloc(tables)");
   c->nparts = 1024;
   if ((e = hipMalloc(&c->partial, (size_t)batch * c->nparts * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(partial)");
   if ((e = hipMalloc(&c->norm2, (size_t)batch * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(norm2)");
@@ -710,6 +716,9 @@ int paos_ctx_destroy(paos_ctx* c) {
   if (c->staging) (void)hipFree(c->staging);
   if (c->tables) (void)hipFree(c->tables);
   if (c->mask) (void)hipFree(c->mask);
+  if (c->metric_partial) (void)hipFree(c->metric_partial);
+  if (c->metric_out) (void)hipFree(c->metric_out);
+  if (c->metric_host) (void)hipHostFree(c->metric_host);
   if (c->mask_lines) (void)hipFree(c->mask_lines);
   if (c->mask_vals) (void)hipFree(c->mask_vals);
   if (c->mask_overflow) (void)hipFree(c->mask_overflow);
@@ -861,6 +870,30 @@ int paos_make_stop(paos_ctx* c, const double* enable) {
                        c->norm2, c->item_stride, den, 1);
   HIPCHK(c, hipGetLastError());
   return PAOS_OK;
+}
+
+int paos_psf_metrics(paos_ctx* c, int nr, const double* radii_px, double cx_px, double cy_px, double* host_out) {
+  if (!c || !host_out || nr < 0 || nr > kMaxRadii || (nr > 0 && !radii_px)) return fail(c, PAOS_EINVAL, "bad metrics request");
+  const int nvals = 4 + nr, nblocks = 512;
+  if (!c->metric_partial) {
+    HIPCHK(c, hipMalloc(&c->metric_partial, (size_t)c->batch * nblocks * (4 + kMaxRadii) * sizeof(double)));
+    HIPCHK(c, hipMalloc(&c->metric_out, (size_t)c->batch * (4 + kMaxRadii) * sizeof(double)));
+    HIPCHK(c, hipHostMalloc(&c->metric_host, (size_t)c->batch * (4 + kMaxRadii) * sizeof(double)));
+  }
+  MetricArgs a{};
+  a.field = c->field; a.partial = c->metric_partial; a.n = c->n; a.nr = nr; a.pitch = c->pitch;
+  a.item_stride = c->item_stride; a.cx = cx_px; a.cy = cy_px;
+  for (int k = 0; k < nr; ++k) a.r2[k] = radii_px[k] * radii_px[k];
+  const dim3 grid(nblocks, c->batch), block(kPwThreads);
+  if (c->precision == PAOS_F64) hipLaunchKernelGGL((psf_metrics_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream, a);
+  else hipLaunchKernelGGL((psf_metrics_kernel<float, BR, Lay<float>::BC>), grid, block, 0, c->stream, a);
+  HIPCHK(c, hipGetLastError());
+  hipLaunchKernelGGL(psf_metrics_final_kernel, dim3(c->batch), dim3(64), 0, c->stream, c->metric_partial, c->metric_out, nblocks, nvals);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(c->metric_host, c->metric_out, (size_t)c->batch * nvals * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::memcpy(host_out, c->metric_host, (size_t)c->batch * nvals * sizeof(double));
+  return check_mask_overflow(c);
 }
 
 int paos_norm2_enqueue(paos_ctx* c, int* ticket) {

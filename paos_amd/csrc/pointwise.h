@@ -155,6 +155,74 @@ __global__ void stop_scale_kernel(cx<T>* field, const double* norm2, unsigned it
     f[m] = {(T)__dmul_rn((double)f[m].x, s), (T)__dmul_rn((double)f[m].y, s)};
 }
 
+// ---- PSF metrics for Monte-Carlo studies ------------------------------------
+// One pass over |u|^2 per item: total power, first moments (centroid), peak, and the power
+// inside circles of given radii (pixel units) about a given centre -- the ingredients of the
+// encircled-energy radii the reference's Monte-Carlo workflow derives from each PSF
+// (docs/source/user/montecarlo/index.rst:26-66) -- so thousands of draws never leave the GPU.
+constexpr int kMaxRadii = 16;
+struct MetricArgs {
+  const void* field;
+  double* partial;       // [item][block][4 + nr]
+  int n, nr;
+  unsigned pitch, item_stride;
+  double cx, cy;         // circle centre in pixel coordinates (column, row)
+  double r2[kMaxRadii];  // squared radii
+};
+
+template <typename T, int BR, int BC>
+__global__ void psf_metrics_kernel(MetricArgs a) {
+  const int item = blockIdx.y;
+  __shared__ double sh[kPwThreads / 64];
+  const cx<T>* f = reinterpret_cast<const cx<T>*>(a.field) + (size_t)item * a.item_stride;
+  double acc[4 + kMaxRadii];
+#pragma unroll
+  for (int k = 0; k < 4 + kMaxRadii; ++k) acc[k] = 0.0;
+  const size_t total = a.item_stride;
+  size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
+    int r, c;
+    if (!layout_unmap<BR, BC>(m, a.n, a.pitch, r, c)) continue;
+    const double x = (double)f[m].x, y = (double)f[m].y;
+    const double I = x * x + y * y;
+    acc[0] += I;
+    acc[1] += I * (double)c;
+    acc[2] += I * (double)r;
+    acc[3] = fmax(acc[3], I);
+    const double dx = (double)c - a.cx, dy = (double)r - a.cy;
+    const double d2 = dx * dx + dy * dy;
+#pragma unroll
+    for (int k = 0; k < kMaxRadii; ++k)
+      if (k < a.nr && d2 <= a.r2[k]) acc[4 + k] += I;
+  }
+  double* out = a.partial + ((size_t)item * gridDim.x + blockIdx.x) * (4 + a.nr);
+  for (int k = 0; k < 4 + a.nr; ++k) {
+    double v = acc[k];
+    if (k == 3) {  // max-reduce
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
+      if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+      __syncthreads();
+      if (threadIdx.x == 0) { double s = 0.0; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) s = fmax(s, sh[w]); out[k] = s; }
+    } else {
+      const double s = block_sum(v, sh);
+      if (threadIdx.x == 0) out[k] = s;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void psf_metrics_final_kernel(const double* partial, double* out, int nblocks, int nvals) {
+  const int item = blockIdx.x, k = threadIdx.x;
+  if (k >= nvals) return;
+  double s = 0.0;
+  for (int b = 0; b < nblocks; ++b) {
+    const double v = partial[((size_t)item * nblocks + b) * nvals + k];
+    s = (k == 3) ? fmax(s, v) : s + v;
+  }
+  out[(size_t)item * nvals + k] = s;
+}
+
 // ---- apertures ------------------------------------------------------------------
 // per-item block: [enable, xc, yc, a|w, b|h, theta, obscuration, subpixels]
 enum : int { AP_ENABLE = 0, AP_XC, AP_YC, AP_A, AP_B, AP_THETA, AP_OBSC, AP_SUBPIX, AP_STRIDE, AP_SHAPE = 8 };

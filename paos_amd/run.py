@@ -284,7 +284,7 @@ def run(pupil_diameter, wavelength, gridsize, zoom, field, opt_chain, precision=
 
 
 def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, precision="fp64",
-              device=0, outputs=("psf",), dev=None, sync=True, stats=None):
+              device=0, outputs=("psf",), dev=None, sync=True, stats=None, metrics_radii_px=None):
     """Propagate ``B = len(opt_chains)`` wavefronts together on one GPU.
 
     ``wavelengths[i]`` / ``opt_chains[i]`` describe wavefront ``i`` (chains must
@@ -294,7 +294,10 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
     ``dev.norm2_fetch``).  ``outputs`` picks which N x N arrays are copied back to the
     host per saved surface and item ('psf' = |u|^2, plot.py:125-130); ``()`` keeps
     every array on the GPU and returns scalars and the power only -- the mode the
-    throughput benchmark uses.  ``dev`` may pass a pre-allocated
+    throughput benchmark uses.  ``metrics_radii_px`` (up to 16 radii, pixels) adds
+    ``'metrics'`` = power, centroid, peak and encircled power per radius of |u|^2 computed on
+    the GPU (about the grid centre) -- what a Monte-Carlo encircled-energy study needs, without
+    moving a PSF.  ``dev`` may pass a pre-allocated
     ``DeviceFields(gridsize, B)`` to reuse across calls.
     """
     nb = len(opt_chains)
@@ -329,6 +332,10 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
             rec["_plan"] = plan
             results[i][item["num"]] = rec
             pending.append((i, rec))
+        if metrics_radii_px is not None:
+            met = dev.psf_metrics(metrics_radii_px)
+            for i, rec in pending:
+                rec["metrics"] = met[i]
         tickets.append((dev.norm2_enqueue(), pending))
 
     try:

@@ -48,6 +48,19 @@ class ModelDevice:
     def norm2(self):
         return np.array([np.sum(np.abs(u) ** 2) for u in self.u])
 
+    def psf_metrics(self, radii_px=(), centre=None):
+        n = self.n
+        cxp, cyp = (n / 2, n / 2) if centre is None else centre
+        yy, xx = np.mgrid[0:n, 0:n]
+        d2 = (xx - cxp) ** 2 + (yy - cyp) ** 2
+        out = []
+        for u in self.u:
+            I = u.real**2 + u.imag**2
+            p = I.sum()
+            out.append({"power": p, "centroid": ((I * xx).sum() / p, (I * yy).sum() / p), "peak": I.max(),
+                        "encircled": np.array([I[d2 <= r * r].sum() for r in radii_px])})
+        return out
+
     def norm2_enqueue(self):
         self._tickets = getattr(self, "_tickets", [])
         self._tickets.append(self.norm2())

@@ -337,6 +337,27 @@ def test_aperture_fusion_variants_agree(monkeypatch):
                 assert rel_err(fused[k]["wfo"], base[k]["wfo"]) < 1e-13, (args[2], mode, k)
 
 
+def test_psf_metrics_on_device(WFO):
+    """Power, centroid, peak and encircled energy of |u|^2 against NumPy on the downloaded PSF."""
+    n = 512
+    w = WFO(1.0, 1.0e-6, n, 4)
+    w.aperture(0.0, 0.0, hx=0.5, hy=0.4, shape="elliptical")
+    w.make_stop()
+    w.lens(10.0)
+    w.propagate(10.0)
+    psf = w.intensity
+    radii = [2.0, 5.5, 20.0, 300.0]
+    m = w._dev.psf_metrics(radii)[0]
+    yy, xx = np.mgrid[0:n, 0:n]
+    assert abs(m["power"] - psf.sum()) < 1e-13 and abs(m["peak"] - psf.max()) < 1e-18
+    assert abs(m["centroid"][0] - (psf * xx).sum() / psf.sum()) < 1e-9
+    assert abs(m["centroid"][1] - (psf * yy).sum() / psf.sum()) < 1e-9
+    d2 = (xx - n / 2) ** 2 + (yy - n / 2) ** 2
+    for r, ee in zip(radii, m["encircled"]):
+        assert abs(ee - psf[d2 <= r * r].sum()) < 1e-13
+    assert m["encircled"][-1] > 0.999 * m["power"]
+
+
 def test_fp32_mode_tolerance():
     """c64 storage / FFT arithmetic with fp64 phase arguments: expected ~3e-6."""
     from paos_amd.chains import syn20_chain

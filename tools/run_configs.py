@@ -79,20 +79,27 @@ def main():
     pup, par, wls, fields, chains = parse_config_variant(os.path.join(LENS, "Ariel_FGS-FGS1.ini"), unignore=("Z1",))
     base, wl = chains[0], 1e-6 * wls[0]
     t0 = time.perf_counter()
-    powers = []
+    powers, ree90 = [], []
+    radii = np.geomspace(2.0, 256.0, 16)  # pixels; rEE90 interpolated from the on-device encircled energies
     dev = _lib.DeviceFields(2048, 32)
     for lo in range(0, 256, 32):
         mc = [inject_wfe(base, table[:, k]) for k in range(lo, lo + 32)]
-        res = run_batch(pup, [wl] * 32, 2048, par["zoom"], fields[0], mc, outputs=(), dev=dev, sync=True)
-        powers += [r[max(r)]["power"] for r in res]
+        res = run_batch(pup, [wl] * 32, 2048, par["zoom"], fields[0], mc, outputs=(), dev=dev, sync=True,
+                        metrics_radii_px=radii)
+        for r in res:
+            rec = r[max(r)]
+            powers.append(rec["power"])
+            ee = rec["metrics"]["encircled"] / rec["metrics"]["power"]
+            ree90.append(float(np.interp(0.9, ee, radii)) * rec["dx"])
     dt = time.perf_counter() - t0
     dev.close()
     mc0 = inject_wfe(base, table[:, 0])
     ref = oracle_run(pup, wl, 512, par["zoom"], fields[0], mc0, light=True)
     got = run(pup, wl, 512, par["zoom"], fields[0], mc0)
     k = max(ref)
-    print(f"4 Ariel_FGS-FGS1 2048^2 fp64 256 WFE draws: {dt:.2f} s = {256 / dt:.1f} wavefronts/s on 1 GPU; image-plane power "
-          f"{min(powers):.6f}..{max(powers):.6f}; draw 0 @512^2 PSF err vs oracle {rel(got[k]['amplitude'] ** 2, ref[k]['amplitude'] ** 2):.1e}")
+    print(f"4 Ariel_FGS-FGS1 2048^2 fp64 256 WFE draws: {dt:.2f} s = {256 / dt:.1f} wavefronts/s on 1 GPU incl. on-device "
+          f"PSF metrics; image-plane power {min(powers):.6f}..{max(powers):.6f}; rEE90 {1e6 * min(ree90):.2f}..{1e6 * max(ree90):.2f} um "
+          f"(median {1e6 * float(np.median(ree90)):.2f}); draw 0 @512^2 PSF err vs oracle {rel(got[k]['amplitude'] ** 2, ref[k]['amplitude'] ** 2):.1e}")
 
     # 5. Excite_TEL, wavelength sweep, 4096^2, fp32 vs fp64 (one GPU: 8 of the 512 wavelengths)
     sweep = np.linspace(1.0, 4.0, 512)[::64]
