@@ -246,9 +246,14 @@ struct TileMap {
   __device__ __forceinline__ int col(int kp, int s = 0) const { return AXIS == 0 ? t + kp * TL : col0 + line + s * PAR; }
 };
 
+// Exchange area of one line.  Lanes of a wave alternate between the lines of a tile, so two
+// lines whose areas start a multiple of 256 B apart hit the same banks on every read
+// (SQ_LDS_BANK_CONFLICT = half of the LDS cycles, profiles/r01_sq_counters_frugal.txt);
+// a 128-B skew puts the second line on the other half of the 64 read banks.
 template <typename T, int N, bool SPLIT>
 constexpr size_t line_lds_bytes() {
-  return (size_t)lds_line_slots<N>() * (SPLIT ? sizeof(T) : 2 * sizeof(T));
+  const size_t b = (size_t)lds_line_slots<N>() * (SPLIT ? sizeof(T) : 2 * sizeof(T));
+  return (b % 256 == 0) ? b + 128 : b;
 }
 
 template <typename T, int E, int FR, int FEAT, typename Map>

@@ -678,6 +678,7 @@ int paos_ctx_create(int device, int n, int batch, int precision, paos_ctx** out)
 }
 
 int paos_profile_begin(paos_ctx* c, int kernel_kind, int max_launches) {
+  if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c || max_launches < 0) return fail(c, PAOS_EINVAL, "bad profile request");
   HIPCHK(c, hipStreamSynchronize(c->stream));
   while (c->prof_events.size() < (size_t)2 * max_launches) {
@@ -691,6 +692,7 @@ int paos_profile_begin(paos_ctx* c, int kernel_kind, int max_launches) {
 }
 
 int paos_profile_end(paos_ctx* c, int* launches, double* total_ms) {
+  if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c || !launches || !total_ms) return fail(c, PAOS_EINVAL, "null argument");
   HIPCHK(c, hipStreamSynchronize(c->stream));
   double sum = 0.0;
@@ -745,12 +747,14 @@ static int check_mask_overflow(paos_ctx* c) {
 }
 
 int paos_sync(paos_ctx* c) {
+  if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c) return fail(c, PAOS_EINVAL, "null context");
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return check_mask_overflow(c);
 }
 
 int paos_fill(paos_ctx* c, double re, double im) {
+  if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c) return fail(c, PAOS_EINVAL, "null context");
   const size_t total = (size_t)c->item_stride * c->batch;
   // padding blocks are filled too; they are never read by any operator
@@ -765,6 +769,7 @@ int paos_fill(paos_ctx* c, double re, double im) {
 }
 
 int paos_import(paos_ctx* c, int item, const void* host) {
+  if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c || !host || item < 0 || item >= c->batch) return fail(c, PAOS_EINVAL, "bad item or null buffer");
   const size_t bytes = (size_t)c->n * c->n * 16;
   HIPCHK(c, hipMemcpyAsync(c->staging, host, bytes, hipMemcpyHostToDevice, c->stream));
@@ -782,6 +787,7 @@ int paos_import(paos_ctx* c, int item, const void* host) {
 }
 
 int paos_export(paos_ctx* c, int item, int what, void* host_out) {
+  if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c || !host_out || item < 0 || item >= c->batch || what < 0 || what > 3)
     return fail(c, PAOS_EINVAL, "bad item/what or null buffer");
   if (c->precision == PAOS_F64)
@@ -816,6 +822,7 @@ static int aperture_launch(paos_ctx* c, int shape, const double* dp, int nitems,
 }
 
 int paos_aperture(paos_ctx* c, int shape, const double* params) {
+  if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c || !params) return fail(c, PAOS_EINVAL, "null argument");
   if (shape != PAOS_SHAPE_ELLIPSE && shape != PAOS_SHAPE_RECT) return fail(c, PAOS_EINVAL, "unknown aperture shape");
   const double* dp = nullptr;
@@ -825,6 +832,7 @@ int paos_aperture(paos_ctx* c, int shape, const double* params) {
 }
 
 int paos_aperture_render(paos_ctx* c, int shape, const double* params1, double* host_mask) {
+  if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c || !params1 || !host_mask) return fail(c, PAOS_EINVAL, "null argument");
   if (shape != PAOS_SHAPE_ELLIPSE && shape != PAOS_SHAPE_RECT) return fail(c, PAOS_EINVAL, "unknown aperture shape");
   const double* dp = nullptr;
@@ -853,6 +861,7 @@ static int norm2_launch(paos_ctx* c, const double* den) {
 }
 
 int paos_make_stop(paos_ctx* c, const double* enable) {
+  if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c) return fail(c, PAOS_EINVAL, "null context");
   const double* den = nullptr;
   if (enable) {
@@ -873,6 +882,7 @@ int paos_make_stop(paos_ctx* c, const double* enable) {
 }
 
 int paos_psf_metrics(paos_ctx* c, int nr, const double* radii_px, double cx_px, double cy_px, double* host_out) {
+  if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c || !host_out || nr < 0 || nr > kMaxRadii || (nr > 0 && !radii_px)) return fail(c, PAOS_EINVAL, "bad metrics request");
   const int nvals = 4 + nr, nblocks = 512;
   if (!c->metric_partial) {
@@ -897,6 +907,7 @@ int paos_psf_metrics(paos_ctx* c, int nr, const double* radii_px, double cx_px, 
 }
 
 int paos_norm2_enqueue(paos_ctx* c, int* ticket) {
+  if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c || !ticket) return fail(c, PAOS_EINVAL, "null argument");
   int rc = norm2_launch(c, nullptr);
   if (rc) return rc;
@@ -909,6 +920,7 @@ int paos_norm2_enqueue(paos_ctx* c, int* ticket) {
 }
 
 int paos_norm2_fetch(paos_ctx* c, int ticket, double* host_out) {
+  if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c || !host_out || ticket < 0 || ticket >= kNormSlots) return fail(c, PAOS_EINVAL, "bad ticket");
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::memcpy(host_out, c->norm2_host + (size_t)ticket * c->batch, (size_t)c->batch * sizeof(double));
@@ -916,6 +928,7 @@ int paos_norm2_fetch(paos_ctx* c, int ticket, double* host_out) {
 }
 
 int paos_norm2(paos_ctx* c, double* host_out) {
+  if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c || !host_out) return fail(c, PAOS_EINVAL, "null argument");
   int rc = norm2_launch(c, nullptr);
   if (rc) return rc;
@@ -926,6 +939,7 @@ int paos_norm2(paos_ctx* c, double* host_out) {
 }
 
 int paos_phase(paos_ctx* c, const double* params, int mul2pi) {
+  if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c || !params) return fail(c, PAOS_EINVAL, "null argument");
   Program g(c->batch);
   const int par = g.add_block(params, 0, 0, 0, 0, true);
@@ -935,15 +949,26 @@ int paos_phase(paos_ctx* c, const double* params, int mul2pi) {
 }
 
 int paos_run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks, int n_blocks) {
+  if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   return run_passes(c, passes, n_passes, blocks, n_blocks);
 }
 
-int paos_ptp(paos_ctx* c, const double* params) { return fft_op(c, OP_PTP, params, 0); }
-int paos_stw(paos_ctx* c, const double* params, int inverse) { return fft_op(c, OP_STW, params, inverse); }
-int paos_wts(paos_ctx* c, const double* params, int inverse) { return fft_op(c, OP_WTS, params, inverse); }
+int paos_ptp(paos_ctx* c, const double* params) {
+  if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
+  return fft_op(c, OP_PTP, params, 0);
+}
+int paos_stw(paos_ctx* c, const double* params, int inverse) {
+  if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
+  return fft_op(c, OP_STW, params, inverse);
+}
+int paos_wts(paos_ctx* c, const double* params, int inverse) {
+  if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
+  return fft_op(c, OP_WTS, params, inverse);
+}
 
 int paos_zernike(paos_ctx* c, int nmax, int kdim, const double* table, const double* params,
                  int param_stride, double* host_wfe) {
+  if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c || !table || !params) return fail(c, PAOS_EINVAL, "null argument");
   if (nmax < 0 || kdim < nmax / 2 + 1 || param_stride < ZP_HEAD + 2 * (nmax + 1) * kdim)
     return fail(c, PAOS_EINVAL, "inconsistent Zernike table dimensions");

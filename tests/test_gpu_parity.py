@@ -303,10 +303,17 @@ def test_batch_with_divergent_propagator_regimes():
     field = {"us": 0.0, "ut": 0.0}
     wls = [1.0e-6, 1.0e-5]
     chains = [_two_regime_chain(), _two_regime_chain()]
-    got = run_batch(1.0, wls, 256, 4, field, chains, outputs=("wfo",))
+    # 1024: the frugal kernels (per-item data, disabled phases as coef = 0); 256: the generic ones
+    for n in (1024, 256):
+        _check_divergent(run_batch, oracle_run, _two_regime_chain, wls, field, n)
+
+
+def _check_divergent(run_batch, oracle_run, _two_regime_chain, wls, field, n):
+    chains = [_two_regime_chain(), _two_regime_chain()]
+    got = run_batch(1.0, wls, n, 4, field, chains, outputs=("wfo",))
     props = []
     for i in range(2):
-        ref = oracle_run(1.0, wls[i], 256, 4, field, chains[i], light=True)
+        ref = oracle_run(1.0, wls[i], n, 4, field, chains[i], light=True)
         props.append(ref[3]["propagator"])
         for k in ref:
             assert rel_err(got[i][k]["wfo"], ref[k]["wfo"]) < FIELD_TOL, (i, k)
