@@ -8,10 +8,10 @@ LIB = paos_amd/libpaoship.so
 
 all: $(LIB)
 
-$(LIB): $(CSRC)/paos_hip.hip $(CSRC)/fft_core.h $(CSRC)/fft_kernels.h $(CSRC)/pointwise.h include/paos_hip.h
+$(LIB): $(CSRC)/paos_hip.hip $(CSRC)/fft_core.h $(CSRC)/fft_kernels.h $(CSRC)/frugal_pass.h $(CSRC)/pointwise.h include/paos_hip.h
 	$(HIPCC) $(HIPFLAGS) -shared -I$(CSRC) $(CSRC)/paos_hip.hip -o $(LIB)
 
-build/fftbench: tools/fftbench.hip $(CSRC)/fft_core.h $(CSRC)/fft_kernels.h
+build/fftbench: tools/fftbench.hip $(CSRC)/fft_core.h $(CSRC)/fft_kernels.h $(CSRC)/frugal_pass.h
 	mkdir -p build
 	$(HIPCC) -O3 --offload-arch=$(ARCH) -ffp-contract=off -I$(CSRC) tools/fftbench.hip -o build/fftbench
 

@@ -105,6 +105,27 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
   }
 }
 
+// Column tiles move whole 128-byte lines that no other workgroup touches during the pass, so
+// they go around the caches (nontemporal: +7 % on the in-place copy yardstick,
+// profiles/r01_membench_rmw_patterns.txt).  Row tiles share each line with their XCD sibling and
+// need the L2 to merge the halves, so they use ordinary accesses.
+template <bool NT, typename T>
+__device__ __forceinline__ cx<T> stream_load(const cx<T>* p) {
+  typedef T vec2 __attribute__((ext_vector_type(2)));
+  if constexpr (NT) {
+    const vec2 t = __builtin_nontemporal_load(reinterpret_cast<const vec2*>(p));
+    return {t.x, t.y};
+  } else {
+    return *p;
+  }
+}
+template <bool NT, typename T>
+__device__ __forceinline__ void stream_store(cx<T>* p, cx<T> v) {
+  typedef T vec2 __attribute__((ext_vector_type(2)));
+  if constexpr (NT) __builtin_nontemporal_store(vec2{v.x, v.y}, reinterpret_cast<vec2*>(p));
+  else *p = v;
+}
+
 // direction as data: conj(FFT(conj x)) with the conjugations as multiplications by +-1
 template <typename T, int N, int E, bool SPLIT>
 __device__ __forceinline__ void frugal_fft(cx<T>* v, void* lds, int t, const cx<T>* tw, double inv) {
@@ -134,7 +155,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, 4)
 
   cx<T> v[E];
 #pragma unroll
-  for (int k = 0; k < E; ++k) v[k] = f[m.base + (unsigned)k * m.stride];
+  for (int k = 0; k < E; ++k) v[k] = stream_load<AXIS == 1>(&f[m.base + (unsigned)k * m.stride]);
   __builtin_amdgcn_sched_barrier(0);
 
   frugal_slot<T, N, E, KPRE>(v, it.pre, it.pre_ph, m);
@@ -148,7 +169,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, 4)
     }
   }
 #pragma unroll
-  for (int k = 0; k < E; ++k) f[m.base + (unsigned)k * m.stride] = v[k];
+  for (int k = 0; k < E; ++k) stream_store<AXIS == 1>(&f[m.base + (unsigned)k * m.stride], v[k]);
 }
 
 }  // namespace paos
