@@ -35,12 +35,18 @@ __device__ __forceinline__ cx<T> cconj(cx<T> a) { return {a.x, -a.y}; }
 // sin and cos of a double: three-term Cody-Waite reduction by pi/2 + the classic minimax
 // kernels on [-pi/4, pi/4].  With FMA the first reduction step a - n*pio2_1 is exact for any
 // n (the difference needs <= 34 bits), the later steps round at 1e-16 of |r| <= 1, and the
-// three-term pi/2 is good to 8.5e-32 * n, so the result is ~1 ulp for |a| up to 2^40; the
+// three-term pi/2 is good to 8.5e-32 * n, so the result is ~1 ulp for |a| up to 2^40
+// (the rounding trick below needs |a * 2/pi| < 2^51); the
 // library validates on the host that no phase argument exceeds kMaxPhaseArg (paos_hip.hip)
 // so the kernels carry no Payne-Hanek fallback.  ~45 instructions, branch-free.
 constexpr double kMaxPhaseArg = 1.0e12;
 __device__ __forceinline__ void sincos_fast(double a, double* sn, double* cs) {
-  const double n = rint(a * 0.63661977236758134308);  // 2/pi
+  // round(a * 2/pi) by the 1.5 * 2^52 trick: the integer lands in the low mantissa bits, so its
+  // two low bits (the quadrant) are read straight from the register, no conversion
+  const double kMagic = 6755399441055744.0;
+  const double nb = fma(a, 0.63661977236758134308, kMagic);  // 2/pi
+  const unsigned q = (unsigned)__double2loint(nb);
+  const double n = nb - kMagic;
   double r = fma(-n, 1.57079632673412561417e+00, a);
   r = fma(-n, 6.07710050630396597660e-11, r);
   r = fma(-n, 2.02226624879595063154e-21, r);
@@ -57,11 +63,13 @@ __device__ __forceinline__ void sincos_fast(double a, double* sn, double* cs) {
   pc = fma(z, pc, -1.38888888888741095749e-03);
   pc = fma(z, pc, 4.16666666666666019037e-02);
   const double c = fma(z * z, pc, fma(z, -0.5, 1.0));
-  const int q = (int)((long long)n & 3);  // n may exceed 2^31 near kMaxPhaseArg
-  const double s1 = (q & 1) ? c : s;
-  const double c1 = (q & 1) ? s : c;
-  *sn = (q & 2) ? -s1 : s1;
-  *cs = ((q + 1) & 2) ? -c1 : c1;
+  const bool odd = (q & 1u) != 0;
+  const double s1 = odd ? c : s;
+  const double c1 = odd ? s : c;
+  // signs: sin flips in quadrants 2, 3; cos in 1, 2 -- an XOR on the sign bit
+  const int sflip = (int)((q & 2u) << 30), cflip = (int)(((q + 1u) & 2u) << 30);
+  *sn = __hiloint2double(__double2hiint(s1) ^ sflip, __double2loint(s1));
+  *cs = __hiloint2double(__double2hiint(c1) ^ cflip, __double2loint(c1));
 }
 
 // cos(2 pi m / 32), m = 0..8 (first octant pair); everything else by symmetry.

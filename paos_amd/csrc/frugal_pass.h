@@ -96,8 +96,8 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
       double sn, cs;
       sincos_fast(q, &sn, &cs);
       sn *= ph[j].sgn;
-      vd = {__dsub_rn(__dmul_rn(vd.x, cs), __dmul_rn(vd.y, sn)),
-            __dadd_rn(__dmul_rn(vd.x, sn), __dmul_rn(vd.y, cs))};
+      // only the phase ARGUMENT is rounded like the reference's; the product itself may use FMA
+      vd = {fma(vd.x, cs, -(vd.y * sn)), fma(vd.x, sn, vd.y * cs)};
     }
     const double f = (sign_on && ((row + col) & 1)) ? -sc : sc;
     v[k] = {(T)(vd.x * f), (T)(vd.y * f)};
