@@ -108,7 +108,7 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
 // Column tiles move whole 128-byte lines that no other workgroup touches during the pass, so
 // they go around the caches (nontemporal: +7 % on the in-place copy yardstick,
 // profiles/r01_membench_rmw_patterns.txt).  Row tiles share each line with their XCD sibling and
-// need the L2 to merge the halves, so they use ordinary accesses.
+// need the L2 to merge the halves, so they use ordinary accesses (nontemporal rows: -1.5 %).
 template <bool NT, typename T>
 __device__ __forceinline__ cx<T> stream_load(const cx<T>* p) {
   typedef T vec2 __attribute__((ext_vector_type(2)));

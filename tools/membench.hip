@@ -12,7 +12,7 @@ typedef double v2d __attribute__((ext_vector_type(2)));
 // one 16-byte element per thread
 __global__ void rmw_simple(v2d* p, size_t n) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) { v2d v = p[i]; v.x = v.x * 1.0000001; p[i] = v; }
+  if (i < n) { v2d v = p[i]; v = v * 1.0000001; p[i] = v; }
 }
 
 // U elements per thread, each wave-instruction one contiguous KiB; the workgroup owns a
@@ -26,7 +26,7 @@ __global__ void rmw_chunk(v2d* p, v2d* q, size_t n, int lds_bytes) {
 #pragma unroll
   for (int k = 0; k < U; ++k) v[k] = NT ? __builtin_nontemporal_load(&p[base + (size_t)k * blockDim.x]) : p[base + (size_t)k * blockDim.x];
 #pragma unroll
-  for (int k = 0; k < U; ++k) v[k].x = v[k].x * 1.0000001;
+  for (int k = 0; k < U; ++k) v[k] = v[k] * 1.0000001;
   v2d* o = OUT ? q : p;
 #pragma unroll
   for (int k = 0; k < U; ++k) {
@@ -53,7 +53,7 @@ __global__ void rmw_halfblocks(v2d* p, size_t n_tiles) {
     v[k] = p[blockrow + (size_t)blk * 8 + ((tile % 2) * 2 + br) * 2 + bc];
   }
 #pragma unroll
-  for (int k = 0; k < 16; ++k) v[k].x = v[k].x * 1.0000001;
+  for (int k = 0; k < 16; ++k) v[k] = v[k] * 1.0000001;
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
     const int blk = q + k * 128;
@@ -82,12 +82,12 @@ __global__ void rmw_halfblocks2(v2d* p, double* sink) {
       else v[k] = v2d{(double)k, (double)tid};
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) v[k].x = v[k].x * 1.0000001;
+    for (int k = 0; k < 16; ++k) v[k] = v[k] * 1.0000001;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int blk = q + k * 128;
       if (MODE != 1) p[blockrow + (size_t)blk * 8 + (sub * 2 + br) * 2 + bc] = v[k];
-      else acc += v[k].x;
+      else acc += v[k].x + v[k].y;
     }
   }
   if (MODE == 1 && acc == 1.2345e-300) sink[0] = acc;
@@ -96,14 +96,14 @@ __global__ void rmw_halfblocks2(v2d* p, double* sink) {
 // 2x2 blocks (64 B).  AXIS 0: a row tile (2 rows) is one contiguous block row.  AXIS 1: a column
 // tile (2 columns) is one 64-byte block per block row, stride = block-row pitch; tiles c and
 // c + 1 share 128-byte lines and run as XCD siblings.
-template <int AXIS>
+template <int AXIS, int PAD>
 __global__ void rmw_blk2x2(v2d* p) {
   extern __shared__ unsigned char smem[];
-  const int item = blockIdx.y;
-  int tile = blockIdx.x;
+  const int item = blockIdx.y + blockIdx.x / 2048;
+  int tile = blockIdx.x % 2048;
   const int tid = threadIdx.x;
   const int bc = tid % 2, br = (tid / 2) % 2, q = tid / 4;
-  const size_t pitch = (size_t)(4096 / 2 + 6) * 4;  // elements per block row: 2048 blocks + pad, 4 each
+  const size_t pitch = (size_t)(4096 / 2 + PAD) * 4;  // elements per block row: 2048 blocks + pad, 4 each
   v2d* f = p + (size_t)item * 2048 * pitch;
   size_t idx[16];
   if (AXIS == 1) { const int grp = tile / 16, in = tile % 16; tile = (grp * 8 + in % 8) * 2 + in / 8; }
@@ -117,7 +117,7 @@ __global__ void rmw_blk2x2(v2d* p) {
 #pragma unroll
   for (int k = 0; k < 16; ++k) v[k] = f[idx[k]];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) v[k].x = v[k].x * 1.0000001;
+  for (int k = 0; k < 16; ++k) v[k] = v[k] * 1.0000001;
 #pragma unroll
   for (int k = 0; k < 16; ++k) f[idx[k]] = v[k];
 }
@@ -133,7 +133,7 @@ __global__ void rmw_cols4x2(v2d* p) {
 #pragma unroll
   for (int k = 0; k < 16; ++k) v[k] = f[(size_t)(q + k * 64) * pitch + (size_t)tile * 8 + br * 2 + bc];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) v[k].x = v[k].x * 1.0000001;
+  for (int k = 0; k < 16; ++k) v[k] = v[k] * 1.0000001;
 #pragma unroll
   for (int k = 0; k < 16; ++k) f[(size_t)(q + k * 64) * pitch + (size_t)tile * 8 + br * 2 + bc] = v[k];
 }
@@ -153,7 +153,7 @@ float timeit(F f, int reps) {
 
 int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 10;
-  const size_t n = (size_t)8 * 4096 * 4096 + (size_t)8 * 4096 * 64;  // elements (16 B), with pitch padding room
+  const size_t n = (size_t)8 * 4096 * (4096 + 256);  // elements (16 B); room for every padded pitch used below (<= 2048 + 64 blocks of 4, 1024 + ... of 8)
   const size_t n_use = (size_t)8 * 4096 * 4096;
   v2d *p, *q;
   CK(hipMalloc(&p, n * 16)); CK(hipMalloc(&q, n * 16));
@@ -199,8 +199,17 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 70 * 1024));
     report(name, timeit([&] { hipLaunchKernelGGL(kern, grid, dim3(512), 70 * 1024, 0, p); }, reps));
   };
-  run1("2x2 blocks: row tile (contiguous block row)", rmw_blk2x2<0>, dim3(2048, 8));
-  run1("2x2 blocks: column tile (64-B blocks, stride pitch, siblings)", rmw_blk2x2<1>, dim3(2048, 8));
+  run1("2x2 blocks: row tile (contiguous block row), pad 6", rmw_blk2x2<0, 6>, dim3(2048, 8));
+  run1("2x2 blocks: row tile (contiguous block row), pad 0", rmw_blk2x2<0, 0>, dim3(2048, 8));
+  run1("2x2 blocks: row tile (contiguous block row), pad 64 (4 KiB)", rmw_blk2x2<0, 64>, dim3(2048, 8));
+  run1("2x2 blocks: row tile, pad 0, 1-D grid", rmw_blk2x2<0, 0>, dim3(2048 * 8, 1));
+  run1("2x2 blocks: column tile (64-B blocks, stride pitch, siblings), pad 6", rmw_blk2x2<1, 6>, dim3(2048, 8));
+  run1("2x2 blocks: column tile, pad 0", rmw_blk2x2<1, 0>, dim3(2048, 8));
   run1("4x2 blocks: column tile (128-B lines, stride pitch)", rmw_cols4x2, dim3(2048, 8));
+  {
+    auto k = rmw_chunk<16, false, false>;
+    CK(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 70 * 1024));
+    report("again at the end: chunk U=16, 512 thr, 70 KiB LDS (2 WG/CU)", timeit([&] { hipLaunchKernelGGL(k, dim3(n_use / (512 * 16)), dim3(512), 70 * 1024, 0, p, q, n_use, 0); }, reps));
+  }
   return 0;
 }
