@@ -187,7 +187,11 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "launches": launches, "avg_launch_ms": avg_ms,
                          "algorithmic_bytes_per_launch": pass_bytes,
-                         "fused_passes_per_wavefront": stats.get("fused_passes")},
+                         "fused_passes_per_wavefront": stats.get("fused_passes"),
+                         "copy_yardstick": {"in_place_copy_GBps": 5522.0, "same_tile_shape_GBps": 5080.0,
+                                            "what": "tools/membench.hip: in-place read-modify-write of the same 4096^2 c128 x 8 "
+                                                    "batch without the FFT (contiguous tiles / the FFT passes' tile shapes)",
+                                            "source": "profiles/r01_membench_rmw_patterns.txt"} if (n == 4096 and esz == 16) else None},
             "chain_roofline": {"algorithmic_bytes_per_wavefront": chain_bytes,
                                "achieved_GBps_per_gpu": chain_bytes * (value / world) / 1e9,
                                "frac_of_hbm_peak": chain_bytes * (value / world) / 1e9 / HBM_PEAK_GBS},
