@@ -78,9 +78,13 @@ def run(pupil_diameter, wavelength, gridsize, zoom, field, opt_chain, trace=None
         if item["type"] == "Zernike":
             radius = item["Zradius"] if np.isfinite(item["Zradius"]) else wfo.wz
             note("zernikes", radius)
+            zmask = False
+            if item["Zorthonorm"]:  # run.py:133-141: the pupil of THIS surface's aperture
+                assert "aperture" in item, "Zorthonorm requires aperture"
+                zmask = ~rec["aperture"].to_mask(method="exact").to_image(wfo._wfo.shape).astype(bool)
             rec["wfe"] = wfo.zernikes(item["Zindex"], item["Z"], item["Zordering"],
                                       item["Znormalize"], radius, origin=item["Zorigin"],
-                                      orthonorm=item["Zorthonorm"], mask=False)
+                                      orthonorm=item["Zorthonorm"], mask=zmask)
         if item["type"] in ("Grid Sag", "PSD"):
             raise NotImplementedError(f"surface type {item['type']} is out of scope")
 

@@ -5,8 +5,9 @@ paos/classes/zernike.py: index conversion j -> (m, n) (zernike.py:131-176),
 (m, n) -> j (zernike.py:178-207), radial part through the Jacobi polynomial
 (zernike.py:209-247), normalisation (zernike.py:77-83), the rho > 1 mask
 (zernike.py:85-89) and the azimuthal part cos(m phi) / sin(|m| phi)
-(zernike.py:100-104).  Pinned by tests/golden/zernike_*.npz (reference import)
-and by the reference notebook KAT.
+(zernike.py:100-104), and the Gram-Schmidt orthonormal variant PolyOrthoNorm
+(zernike.py:293-402).  Pinned by tests/golden/zernike_*.npz, orthonorm_*.npz
+(reference import) and by the reference notebook KAT.
 """
 import numpy as np
 from scipy.special import eval_jacobi
@@ -109,3 +110,28 @@ def zernike_stack(count, rho, phi, ordering="ansi", normalize=False):
         [nrm[k] * rad[(n[k], abs(m[k]))] * az[m[k]] for k in range(count)],
         fill_value=0.0,
     )
+
+
+def covariance(stack):
+    """M[i, j] = masked mean of Z[i] * Z[j], entries below 1e-10 zeroed -- zernike.py:293-318."""
+    k = stack.shape[0]
+    cov = np.empty((k, k))
+    for i in range(k):
+        for j in range(i, k):
+            cov[i, j] = cov[j, i] = np.ma.mean(stack[i] * stack[j])
+    cov[np.abs(cov) < 1e-10] = 0.0
+    return cov
+
+
+def poly_orthonorm_stack(count, rho, phi, ordering="ansi", normalize=False, mask=False):
+    """Polynomials orthonormal over the unmasked pixels: U = M Z with M the inverse of the
+    Cholesky factor of the covariance -- PolyOrthoNorm.__init__, zernike.py:388-402.
+    Returns (U, M)."""
+    stack = zernike_stack(count, rho, phi, ordering=ordering, normalize=normalize)
+    cov = covariance(stack)
+    qt = np.linalg.cholesky(cov)
+    m = np.linalg.inv(qt)
+    m[np.where(np.abs(m) < 1.0e-10)] = 0.0
+    full_mask = stack.mask | mask
+    z1 = np.tensordot(m, stack.filled(fill_value=0), axes=1)
+    return np.ma.MaskedArray(data=z1, mask=full_mask, fill_value=0.0), m

@@ -70,6 +70,18 @@ def syn20_chain(coefficients=None, focal=10.0, gap=0.1, abcd_cls=ABCD):
     return chain
 
 
+def syn20_orthonorm_chain(coefficients=None, yrad=0.35, abcd_cls=ABCD):
+    """SYN20 whose Zernike surface carries an elliptical pupil (0.5 x ``yrad`` m) and expands the
+    WFE in polynomials orthonormalised over that pupil (``Zorthonorm``, run.py:133-141)."""
+    chain = syn20_chain(coefficients, abcd_cls=abcd_cls)
+    z1 = chain[2]
+    assert z1["type"] == "Zernike"
+    z1["Zorthonorm"] = True
+    z1["aperture"] = {"shape": "elliptical", "type": "aperture", "xrad": 0.5, "yrad": yrad,
+                      "xc": 0.0, "yc": 0.0}
+    return chain
+
+
 def syn20_wavelength(k, base=1.0e-6, steps=512):
     """Wavelength sweep of SURVEY.md 8d: lambda_k = 1 um * (1 + k/512)."""
     return base * (1.0 + k / float(steps))

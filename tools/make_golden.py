@@ -18,6 +18,8 @@ Vector families:
   scalars_<chain>.npz pilot-beam scalars after EVERY surface of a chain (N=64)
   run_<chain>.npz     end-to-end run(): complex field, amplitude, phase, wfe of the
                       saved surfaces (N=128 SYN20/Hubble, N=64 others)
+  orthonorm.npz       PolyOrthoNorm (covariance, M, polynomials) on an elliptical annulus,
+                      WFO.zernikes(orthonorm=True), and run() of SYN20 with Zorthonorm (8f-3)
   kat.npz             the reference's own recorded known answers
 """
 import copy
@@ -38,6 +40,7 @@ ref_import.install(aperture_np.EllipticalAperture, aperture_np.RectangularApertu
 
 from paos.classes.abcd import ABCD as RefABCD  # noqa: E402
 from paos.classes.wfo import WFO as RefWFO  # noqa: E402
+from paos.classes.zernike import PolyOrthoNorm as RefPolyOrthoNorm  # noqa: E402
 from paos.classes.zernike import Zernike as RefZernike  # noqa: E402
 from paos.core.parseConfig import parse_config as ref_parse  # noqa: E402
 from paos.core.run import run as ref_run  # noqa: E402
@@ -48,6 +51,7 @@ from paos_amd.chains import (  # noqa: E402
     read_wfe_table,
     syn20_chain,
     syn20_coefficients,
+    syn20_orthonorm_chain,
 )
 
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -271,6 +275,55 @@ def gen_chain_runs(specs):
              scal=np.array([ret[20]["dx"], ret[20]["dy"], ret[20]["fratio"]]))
 
 
+def gen_orthonorm():
+    """PolyOrthoNorm (zernike.py:320-402) and the Zorthonorm path of run() (run.py:133-141)."""
+    out = {}
+    n = 64
+    x = np.linspace(-1.0, 1.0, n)
+    xx, yy = np.meshgrid(x, x)
+    mask = (xx**2 + (yy / 0.6) ** 2 > 1.0) | (xx**2 + yy**2 < 0.2**2)  # elliptical annulus
+    phi = np.arctan2(yy, xx)
+    out["poly_mask"] = mask
+    out["poly_rho"] = np.sqrt(xx**2 + yy**2)
+    out["poly_phi"] = phi
+    for ordering in ("noll", "ansi"):
+        rho = np.ma.MaskedArray(data=np.sqrt(xx**2 + yy**2), mask=mask.copy(), fill_value=0.0)
+        plain = RefZernike(15, rho.copy(), phi, ordering=ordering, normalize=True)
+        out[f"poly_{ordering}_cov"] = plain.cov()
+        poly = RefPolyOrthoNorm(15, rho, phi, ordering=ordering, normalize=True)
+        out[f"poly_{ordering}_M"] = poly.M
+        out[f"poly_{ordering}_U"] = poly().filled(0.0)
+        out[f"poly_{ordering}_Umask"] = np.ma.getmaskarray(poly())
+        coeff = np.linspace(-1.0, 1.0, 15)
+        out[f"poly_{ordering}_toZernike"] = poly.toZernike(coeff)
+
+    # WFO.zernikes with orthonorm=True and an explicit mask, seeded field
+    w = RefWFO(1.0, 1.2e-6, n, 2)
+    w._wfo = seeded_field(n, 77)
+    xs = (np.arange(n) - n // 2) * w.dx
+    gx, gy = np.meshgrid(xs, xs)
+    zmask = (gx / 0.45) ** 2 + (gy / 0.3) ** 2 > 1.0
+    coeff = 1.0e-9 * np.array([0.0, 30.0, -20.0, 50.0, 10.0, -15.0, 25.0, 5.0, -8.0, 12.0])
+    out["wfo_in"] = w.wfo.copy()
+    out["wfo_zmask"] = zmask
+    out["wfo_coeff"] = coeff
+    wfe = w.zernikes(np.arange(10), coeff, "noll", True, 0.5, origin="x", orthonorm=True, mask=zmask)
+    out["wfo_wfe"] = wfe.filled(0.0)
+    out["wfo_wfe_mask"] = np.ma.getmaskarray(wfe)
+    out["wfo_out"] = w.wfo
+
+    # run(): SYN20 with an elliptical pupil on the Zernike surface and Zorthonorm
+    for size in (64, 128):
+        chain = syn20_orthonorm_chain(abcd_cls=RefABCD)
+        chain[2]["save"] = True
+        ret = ref_run(1.0, 1.0e-6, size, 4, {"us": 0.0, "ut": 0.0}, chain)
+        out[f"run{size}_S02_wfe"] = ret[2]["wfe"].filled(0.0)
+        out[f"run{size}_S02_wfe_mask"] = np.ma.getmaskarray(ret[2]["wfe"])
+        out[f"run{size}_S02_wfo"] = ret[2]["wfo"]
+        out[f"run{size}_S20_wfo"] = ret[20]["wfo"]
+    save("orthonorm.npz", **out)
+
+
 def gen_kat():
     w = RefWFO(1.0, 3e-6, 256, 4)
     w.lens(10.0)
@@ -297,6 +350,7 @@ def main():
     specs = chain_specs()
     gen_chain_scalars(specs)
     gen_chain_runs(specs)
+    gen_orthonorm()
     gen_kat()
 
 
