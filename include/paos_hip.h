@@ -142,6 +142,28 @@ int paos_run_passes(paos_ctx* ctx, const paos_pass* passes, int n_passes, const 
 int paos_zernike(paos_ctx* ctx, int nmax, int kdim, const double* table, const double* params,
                  int param_stride, double* host_wfe);
 
+
+/* ---- PolyOrthoNorm / Zorthonorm ------------------------------------------------ */
+/* The pupil the polynomials are orthonormalised on -- run.py:133-141: the pixels where the exact
+ * mask of this surface's aperture object is non-zero (whatever its obscuration flag).  One weight
+ * map per batch item stays in HBM until the next call.  params as for paos_aperture. */
+int paos_pupil_aperture(paos_ctx* ctx, int shape, const double* params);
+/* the same from a host array (row-major doubles, 0 = masked): the `mask` argument of
+ * WFO.zernikes, wfo.py:583,623-627.  Synchronises. */
+int paos_pupil_upload(paos_ctx* ctx, int item, const double* host_weights);
+/* Zernike.cov (zernike.py:293-318) without its final division: per item, the sums over the
+ * unmasked pixels (rho <= 1, and pupil weight != 0 when use_pupil) of Z_i Z_j for the first K
+ * polynomials, i <= j enumerated row by row, followed by the pixel count:
+ * host_out[batch][K (K + 1) / 2 + 1].  poly[K][4] = {|m|, k = (n - |m|) / 2, is_sin, factor}
+ * with factor = (-1)^k norm; table / params as for paos_zernike (the coefficient planes of
+ * params are not read).  K <= 64.  Synchronises. */
+int paos_zernike_gram(paos_ctx* ctx, int nmax, int kdim, const double* table, const double* params,
+                      int param_stride, int K, const double* poly, int use_pupil, double* host_out);
+/* paos_zernike restricted to the pupil: pixels outside it keep their value and read NaN in
+ * host_wfe (the mask of PolyOrthoNorm's polynomials, zernike.py:396-400). */
+int paos_zernike_pupil(paos_ctx* ctx, int nmax, int kdim, const double* table, const double* params,
+                       int param_stride, double* host_wfe);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,11 @@ SYMBOLS = {
     "paos_wts": (ctypes.c_int, [_c_ctx, _dbl_p, ctypes.c_int]),
     "paos_run_passes": (ctypes.c_int, [_c_ctx, ctypes.POINTER(Pass), ctypes.c_int, _dbl_p, ctypes.c_int]),
     "paos_zernike": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, _dbl_p, _dbl_p, ctypes.c_int, _dbl_p]),
+    "paos_pupil_aperture": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p]),
+    "paos_pupil_upload": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p]),
+    "paos_zernike_gram": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, _dbl_p, _dbl_p, ctypes.c_int,
+                                         ctypes.c_int, _dbl_p, ctypes.c_int, _dbl_p]),
+    "paos_zernike_pupil": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, _dbl_p, _dbl_p, ctypes.c_int, _dbl_p]),
 }
 
 _lib = None
@@ -261,13 +266,45 @@ class DeviceFields:
         self._check(self._lib.paos_run_passes(self._ctx, arr, len(passes), _dptr(b), b.shape[0]),
                     "paos_run_passes")
 
-    def zernike(self, nmax, kdim, table, blocks, want_wfe=False):
+    def zernike(self, nmax, kdim, table, blocks, want_wfe=False, pupil=False):
+        """``pupil=True``: only pixels inside the pupil set by pupil_aperture / pupil_upload."""
         t = np.ascontiguousarray(table, dtype=np.float64).reshape(-1)
         b = np.ascontiguousarray(blocks, dtype=np.float64)
         if b.ndim != 2 or b.shape[0] != self.batch:
             raise ValueError("zernike blocks must be [batch][stride]")
         out = np.empty((self.n, self.n), dtype=np.float64) if want_wfe else None
-        self._check(self._lib.paos_zernike(self._ctx, int(nmax), int(kdim), _dptr(t), _dptr(b),
-                                           int(b.shape[1]), _dptr(out) if want_wfe else None),
-                    "paos_zernike")
+        fn = self._lib.paos_zernike_pupil if pupil else self._lib.paos_zernike
+        self._check(fn(self._ctx, int(nmax), int(kdim), _dptr(t), _dptr(b), int(b.shape[1]),
+                       _dptr(out) if want_wfe else None),
+                    "paos_zernike_pupil" if pupil else "paos_zernike")
         return out
+
+    def pupil_aperture(self, shape, blocks):
+        """Pupil = pixels where the exact mask of the aperture object is non-zero (run.py:136-141)."""
+        b = np.ascontiguousarray(blocks, dtype=np.float64)
+        if b.shape != (self.batch, APERTURE_STRIDE):
+            raise ValueError("aperture blocks must be [batch][8]")
+        self._check(self._lib.paos_pupil_aperture(self._ctx, int(shape), _dptr(b)), "paos_pupil_aperture")
+
+    def pupil_upload(self, item, weights):
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        if w.shape != (self.n, self.n):
+            raise ValueError("pupil weights must be [n][n]")
+        self._check(self._lib.paos_pupil_upload(self._ctx, int(item), _dptr(w)), "paos_pupil_upload")
+
+    def zernike_gram(self, nmax, kdim, table, blocks, poly, pupil=True):
+        """(sums[batch][K(K+1)/2], count[batch]): sums of Z_i Z_j (i <= j, row by row) over the
+        unmasked pixels and their number -- the raw material of Zernike.cov (zernike.py:293-318)."""
+        t = np.ascontiguousarray(table, dtype=np.float64).reshape(-1)
+        b = np.ascontiguousarray(blocks, dtype=np.float64)
+        q = np.ascontiguousarray(poly, dtype=np.float64)
+        if b.ndim != 2 or b.shape[0] != self.batch:
+            raise ValueError("zernike blocks must be [batch][stride]")
+        if q.ndim != 2 or q.shape[1] != 4:
+            raise ValueError("poly must be [K][4]")
+        k = q.shape[0]
+        out = np.empty((self.batch, k * (k + 1) // 2 + 1), dtype=np.float64)
+        self._check(self._lib.paos_zernike_gram(self._ctx, int(nmax), int(kdim), _dptr(t), _dptr(b),
+                                                int(b.shape[1]), int(k), _dptr(q), 1 if pupil else 0, _dptr(out)),
+                    "paos_zernike_gram")
+        return out[:, :-1], out[:, -1]

@@ -966,12 +966,12 @@ int paos_wts(paos_ctx* c, const double* params, int inverse) {
   return fft_op(c, OP_WTS, params, inverse);
 }
 
-int paos_zernike(paos_ctx* c, int nmax, int kdim, const double* table, const double* params,
-                 int param_stride, double* host_wfe) {
-  if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
+static int zernike_apply(paos_ctx* c, int nmax, int kdim, const double* table, const double* params,
+                         int param_stride, double* host_wfe, bool use_pupil) {
   if (!c || !table || !params) return fail(c, PAOS_EINVAL, "null argument");
   if (nmax < 0 || kdim < nmax / 2 + 1 || param_stride < ZP_HEAD + 2 * (nmax + 1) * kdim)
     return fail(c, PAOS_EINVAL, "inconsistent Zernike table dimensions");
+  if (use_pupil && !c->mask) return fail(c, PAOS_EINVAL, "no pupil defined (paos_pupil_aperture / paos_pupil_upload)");
   const double *dt = nullptr, *dp = nullptr;
   int rc = arena_push(c, table, (size_t)(nmax + 1) * kdim * 3, &dt);
   if (rc) return rc;
@@ -979,17 +979,128 @@ int paos_zernike(paos_ctx* c, int nmax, int kdim, const double* table, const dou
   if (rc) return rc;
   const dim3 grid(pw_blocks(c), c->batch), block(kPwThreads);
   double* wfe = host_wfe ? (double*)c->staging : nullptr;
+  const double* pupil = use_pupil ? c->mask : nullptr;
   if (c->precision == PAOS_F64)
     hipLaunchKernelGGL((zernike_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream, (cx<double>*)c->field,
-                       dt, dp, param_stride, c->n, c->pitch, c->item_stride, nmax, kdim, wfe);
+                       dt, dp, param_stride, c->n, c->pitch, c->item_stride, nmax, kdim, wfe, pupil);
   else
     hipLaunchKernelGGL((zernike_kernel<float, BR, Lay<float>::BC>), grid, block, 0, c->stream, (cx<float>*)c->field, dt,
-                       dp, param_stride, c->n, c->pitch, c->item_stride, nmax, kdim, wfe);
+                       dp, param_stride, c->n, c->pitch, c->item_stride, nmax, kdim, wfe, pupil);
   HIPCHK(c, hipGetLastError());
   if (host_wfe) {
     HIPCHK(c, hipMemcpyAsync(host_wfe, c->staging, (size_t)c->n * c->n * 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
   }
+  return PAOS_OK;
+}
+
+int paos_zernike(paos_ctx* c, int nmax, int kdim, const double* table, const double* params,
+                 int param_stride, double* host_wfe) {
+  if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
+  return zernike_apply(c, nmax, kdim, table, params, param_stride, host_wfe, false);
+}
+
+int paos_zernike_pupil(paos_ctx* c, int nmax, int kdim, const double* table, const double* params,
+                       int param_stride, double* host_wfe) {
+  if (c) (void)hipSetDevice(c->device);
+  return zernike_apply(c, nmax, kdim, table, params, param_stride, host_wfe, true);
+}
+
+static int ensure_pupil(paos_ctx* c) {
+  if (!c->mask) HIPCHK(c, hipMalloc(&c->mask, (size_t)c->batch * c->item_stride * sizeof(double)));
+  return PAOS_OK;
+}
+
+int paos_pupil_aperture(paos_ctx* c, int shape, const double* params) {
+  if (c) (void)hipSetDevice(c->device);
+  if (!c || !params) return fail(c, PAOS_EINVAL, "null argument");
+  if (shape != PAOS_SHAPE_ELLIPSE && shape != PAOS_SHAPE_RECT) return fail(c, PAOS_EINVAL, "unknown aperture shape");
+  int rc = ensure_pupil(c);
+  if (rc) return rc;
+  const double* dp = nullptr;
+  rc = arena_push(c, params, (size_t)c->batch * AP_STRIDE, &dp);
+  if (rc) return rc;
+  const dim3 grid(pw_blocks(c), c->batch), block(kPwThreads);
+  // the mask values of the aperture OBJECT, whatever its obscuration flag says (run.py:136-141)
+  if (shape == PAOS_SHAPE_ELLIPSE)
+    hipLaunchKernelGGL((aperture_kernel<double, BR, Lay<double>::BC, 0>), grid, block, 0, c->stream, (cx<double>*)nullptr,
+                       dp, (const double*)nullptr, AP_STRIDE, c->n, c->pitch, c->item_stride, c->mask, 2);
+  else
+    hipLaunchKernelGGL((aperture_kernel<double, BR, Lay<double>::BC, 1>), grid, block, 0, c->stream, (cx<double>*)nullptr,
+                       dp, (const double*)nullptr, AP_STRIDE, c->n, c->pitch, c->item_stride, c->mask, 2);
+  HIPCHK(c, hipGetLastError());
+  return PAOS_OK;
+}
+
+int paos_pupil_upload(paos_ctx* c, int item, const double* host_weights) {
+  if (c) (void)hipSetDevice(c->device);
+  if (!c || !host_weights) return fail(c, PAOS_EINVAL, "null argument");
+  if (item < 0 || item >= c->batch) return fail(c, PAOS_EINVAL, "item out of range");
+  int rc = ensure_pupil(c);
+  if (rc) return rc;
+  HIPCHK(c, hipMemcpyAsync(c->staging, host_weights, (size_t)c->n * c->n * 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL((import_weights_kernel<BR, Lay<double>::BC>), dim3(pw_blocks(c)), dim3(kPwThreads), 0, c->stream,
+                     (const double*)c->staging, c->mask + (size_t)item * c->item_stride, c->n, c->pitch, c->item_stride);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // host_weights is borrowed
+  return PAOS_OK;
+}
+
+int paos_zernike_gram(paos_ctx* c, int nmax, int kdim, const double* table, const double* params,
+                      int param_stride, int K, const double* poly, int use_pupil, double* host_out) {
+  if (c) (void)hipSetDevice(c->device);
+  if (!c || !table || !params || !poly || !host_out) return fail(c, PAOS_EINVAL, "null argument");
+  if (nmax < 0 || kdim < nmax / 2 + 1 || param_stride < ZP_HEAD)
+    return fail(c, PAOS_EINVAL, "inconsistent Zernike table dimensions");
+  if (K < 1 || K > kGramMaxK) return fail(c, PAOS_EUNSUPPORTED, "1 <= K <= 64 polynomials");
+  if (use_pupil && !c->mask) return fail(c, PAOS_EINVAL, "no pupil defined (paos_pupil_aperture / paos_pupil_upload)");
+  // poly[j] = {|m|, k, is_sin, factor}  ->  slot table + factors
+  const size_t ncoef = (size_t)(nmax + 1) * kdim;
+  std::vector<double> slots(2 * ncoef, -1.0), fac(K);
+  for (int j = 0; j < K; ++j) {
+    const int am = (int)poly[4 * j], k = (int)poly[4 * j + 1], is_sin = poly[4 * j + 2] != 0.0;
+    if (am < 0 || am > nmax || k < 0 || k >= kdim || am + 2 * k > nmax)
+      return fail(c, PAOS_EINVAL, "polynomial outside the recurrence table");
+    double& slot = slots[2 * ((size_t)am * kdim + k) + (is_sin ? 1 : 0)];
+    if (slot >= 0.0) return fail(c, PAOS_EINVAL, "polynomial listed twice");
+    slot = (double)j;
+    fac[j] = poly[4 * j + 3];
+  }
+  const double *dt = nullptr, *dp = nullptr, *dslots = nullptr, *dfac = nullptr;
+  int rc;
+  if ((rc = arena_push(c, table, ncoef * 3, &dt))) return rc;
+  if ((rc = arena_push(c, params, (size_t)c->batch * param_stride, &dp))) return rc;
+  if ((rc = arena_push(c, slots.data(), slots.size(), &dslots))) return rc;
+  if ((rc = arena_push(c, fac.data(), fac.size(), &dfac))) return rc;
+  const int nvals = K * (K + 1) / 2 + 1;
+  const size_t chunks = ((size_t)c->item_stride + kGramPix - 1) / kGramPix;
+  const int nblocks = (int)(chunks < 512 ? chunks : 512);
+  double *partial = nullptr, *sums = nullptr;
+  HIPCHK(c, hipMalloc(&partial, (size_t)c->batch * nblocks * nvals * sizeof(double)));
+  if (hipMalloc(&sums, (size_t)c->batch * nvals * sizeof(double)) != hipSuccess) {
+    (void)hipFree(partial);
+    return fail(c, PAOS_EHIP, "hipMalloc(gram sums)");
+  }
+  const size_t lds = (size_t)K * kGramRow * sizeof(double);
+  auto kern = zernike_gram_kernel<BR, Lay<double>::BC>;
+  hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(kern, dim3(nblocks, c->batch), dim3(kGramThreads), lds, c->stream, dt, dp, param_stride, c->n,
+                       c->pitch, c->item_stride, nmax, kdim, K, dslots, dfac,
+                       use_pupil ? (const double*)c->mask : (const double*)nullptr, partial);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(zernike_gram_final_kernel, dim3((nvals + 255) / 256, c->batch), dim3(256), 0, c->stream,
+                       (const double*)partial, sums, nblocks, nvals);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(host_out, sums, (size_t)c->batch * nvals * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+  (void)hipFree(partial);
+  (void)hipFree(sums);
+  if (e != hipSuccess) return fail(c, PAOS_EHIP, std::string("zernike gram: ") + hipGetErrorString(e));
   return PAOS_OK;
 }
 

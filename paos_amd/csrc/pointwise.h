@@ -347,7 +347,7 @@ __global__ void aperture_kernel(cx<T>* field, const double* params, const double
   // 8-double blocks of paos_aperture, in the next block set for a pass-program operator
   const double* p2 = params2 ? params2 + (size_t)item * param_stride : p + AP_THETA;
   if (p[AP_ENABLE] == 0.0) return;
-  if (weights_out && SHAPE != (int)p2[3]) return;
+  if (weights_out == 1 && SHAPE != (int)p2[3]) return;  // 2: paos_pupil_aperture, shape chosen by the host
   const double xc = p[AP_XC], yc = p[AP_YC], a = p[AP_A], b = p[AP_B], theta = p2[0];
   const bool obsc = p2[1] != 0.0;
   const int subpix = (int)p2[2];
@@ -505,7 +505,7 @@ enum : int { ZP_ENABLE = 0, ZP_DX, ZP_DY, ZP_RADIUS, ZP_ORIGIN_Y, ZP_COS_OFF, ZP
 template <typename T, int BR, int BC>
 __global__ void zernike_kernel(cx<T>* field, const double* table, const double* params,
                                int param_stride, int n, unsigned pitch, unsigned item_stride,
-                               int nmax, int kdim, double* wfe_out) {
+                               int nmax, int kdim, double* wfe_out, const double* pupil) {
   const int item = blockIdx.y;
   const double* p = params + (size_t)item * param_stride;
   if (p[ZP_ENABLE] == 0.0) return;
@@ -523,7 +523,8 @@ __global__ void zernike_kernel(cx<T>* field, const double* table, const double* 
     const double x = (double)(c - n / 2) * dx, y = (double)(r - n / 2) * dy;
     const double rr = sqrt(__dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y)));
     const double rho = rr / radius;
-    const bool masked = rho > 1.0;
+    // outside the unit disk, or outside the pupil the polynomials were orthonormalised on
+    const bool masked = rho > 1.0 || (pupil && pupil[(size_t)item * item_stride + m] == 0.0);
     double wfe = 0.0;
     if (!masked) {
       double c1 = 1.0, s1 = 0.0;
@@ -560,6 +561,145 @@ __global__ void zernike_kernel(cx<T>* field, const double* table, const double* 
               (T)__dadd_rn(__dmul_rn(v.x, sn), __dmul_rn(v.y, cs))};
     }
     if (wfe_out && item == 0) wfe_out[(size_t)r * n + c] = masked ? __longlong_as_double(0x7ff8000000000000LL) : wfe;
+  }
+}
+
+// ---- PolyOrthoNorm: Gram sums of the Zernike polynomials over the pupil -----------------------
+// zernike.py:293-318 (cov) needs mean(Z_i Z_j) over the unmasked pixels for the first K
+// polynomials.  Per 128-pixel chunk, 128 threads evaluate the K values of their pixel into LDS
+// (one Jacobi recurrence + one rotation per pixel, like zernike_kernel), then the 256 threads of
+// the workgroup each own up to kGramAcc (i, j) pairs and add the chunk's products.  Fixed chunk ->
+// workgroup mapping and a second, ordered stage over workgroups: bit-reproducible sums.
+constexpr int kGramMaxK = 64, kGramPix = 128, kGramThreads = 256, kGramRow = kGramPix + 1;
+constexpr int kGramAcc = (kGramMaxK * (kGramMaxK + 1) / 2 + kGramThreads - 1) / kGramThreads;
+
+// slots[(am * kdim + k) * 2 + {0: cos, 1: sin}] = polynomial index j or -1; fac[j] = its
+// normalisation with the (-1)^k of the Jacobi form folded in (doubles: they ride the arena).
+template <int BR, int BC>
+__global__ void __launch_bounds__(kGramThreads)
+    zernike_gram_kernel(const double* table, const double* params, int param_stride, int n, unsigned pitch,
+                        unsigned item_stride, int nmax, int kdim, int K, const double* slots,
+                        const double* fac, const double* pupil, double* partial) {
+  extern __shared__ double zbuf[];  // [K][kGramRow]
+  const int item = blockIdx.y, tid = threadIdx.x;
+  const double* p = params + (size_t)item * param_stride;
+  const int npairs = K * (K + 1) / 2;
+  double* out = partial + ((size_t)item * gridDim.x + blockIdx.x) * (npairs + 1);
+  if (p[ZP_ENABLE] == 0.0) {
+    for (int q = tid; q <= npairs; q += kGramThreads) out[q] = 0.0;
+    return;
+  }
+  const double dx = p[ZP_DX], dy = p[ZP_DY], radius = p[ZP_RADIUS];
+  const bool origin_y = p[ZP_ORIGIN_Y] != 0.0;
+  const double co = p[ZP_COS_OFF], so = p[ZP_SIN_OFF];
+  int pi[kGramAcc], pj[kGramAcc];
+  double acc[kGramAcc];
+#pragma unroll
+  for (int a = 0; a < kGramAcc; ++a) {
+    acc[a] = 0.0;
+    // pair q = (i, j), i <= j, enumerated row by row: q = i K - i (i - 1) / 2 + (j - i)
+    int q = tid + a * kGramThreads, i = 0;
+    if (q < npairs) {
+      while (q >= K - i) { q -= K - i; ++i; }
+      pi[a] = i; pj[a] = i + q;
+    } else {
+      pi[a] = pj[a] = -1;
+    }
+  }
+  double count = 0.0;
+  const size_t total = item_stride;
+  for (size_t chunk = blockIdx.x; chunk * kGramPix < total; chunk += gridDim.x) {
+    int valid = 0;
+    if (tid < kGramPix) {
+      const size_t m = chunk * kGramPix + tid;
+      int r = 0, c = 0;
+      double rr = 0.0, rho = 2.0, x = 0.0, y = 0.0;
+      if (m < total && layout_unmap<BR, BC>(m, n, pitch, r, c)) {
+        x = (double)(c - n / 2) * dx;
+        y = (double)(r - n / 2) * dy;
+        rr = sqrt(__dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y)));
+        rho = rr / radius;
+        valid = rho <= 1.0 && (!pupil || pupil[(size_t)item * item_stride + m] != 0.0);
+      }
+      if (valid) {
+        double c1 = 1.0, s1 = 0.0;
+        if (rr > 0.0) {
+          c1 = (origin_y ? y : x) / rr;
+          s1 = (origin_y ? x : y) / rr;
+        }
+        const double cr = c1 * co - s1 * so, sr = s1 * co + c1 * so;
+        const double xj = 1.0 - 2.0 * rho * rho;
+        double rho_pow = 1.0, cm = 1.0, sm = 0.0;
+        for (int am = 0; am <= nmax; ++am) {
+          const int kmax = (nmax - am) / 2;
+          double pkm1 = 0.0, pk = 1.0;
+          for (int k = 0; k <= kmax; ++k) {
+            if (k > 0) {
+              const double* abc = table + ((size_t)am * kdim + k) * 3;
+              const double pn = (abc[0] * xj + abc[1]) * pk - abc[2] * pkm1;
+              pkm1 = pk;
+              pk = pn;
+            }
+            const size_t ci = (size_t)am * kdim + k;
+            const int jc = (int)slots[2 * ci], js = (int)slots[2 * ci + 1];
+            const double base = rho_pow * pk;
+            if (jc >= 0) zbuf[jc * kGramRow + tid] = fac[jc] * base * cm;
+            if (js >= 0) zbuf[js * kGramRow + tid] = fac[js] * base * sm;
+          }
+          rho_pow *= rho;
+          const double cn = cm * cr - sm * sr;
+          sm = sm * cr + cm * sr;
+          cm = cn;
+        }
+        count += 1.0;
+      } else {
+        for (int j = 0; j < K; ++j) zbuf[j * kGramRow + tid] = 0.0;
+      }
+    }
+    if (!__syncthreads_or(valid)) continue;  // (also publishes zbuf)
+#pragma unroll
+    for (int a = 0; a < kGramAcc; ++a) {
+      if (pi[a] < 0) continue;
+      const double* zi = zbuf + pi[a] * kGramRow;
+      const double* zj = zbuf + pj[a] * kGramRow;
+      double sum = 0.0;
+      for (int px = 0; px < kGramPix; ++px) sum += zi[px] * zj[px];
+      acc[a] += sum;
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < kGramAcc; ++a)
+    if (pi[a] >= 0) out[tid + a * kGramThreads] = acc[a];
+  // pixel count of this workgroup: ordered sum over the 128 counting threads
+  __syncthreads();
+  if (tid < kGramPix) zbuf[tid] = count;
+  __syncthreads();
+  if (tid == 0) {
+    double t = 0.0;
+    for (int k = 0; k < kGramPix; ++k) t += zbuf[k];
+    out[npairs] = t;
+  }
+}
+
+// out[item][q] = sum over workgroups, in order
+__global__ void zernike_gram_final_kernel(const double* partial, double* out, int nblocks, int nvals) {
+  const int item = blockIdx.y;
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= nvals) return;
+  double t = 0.0;
+  for (int b = 0; b < nblocks; ++b) t += partial[((size_t)item * nblocks + b) * nvals + q];
+  out[(size_t)item * nvals + q] = t;
+}
+
+// row-major host weights (staging) -> one item of the pupil weight map, in the field's layout
+template <int BR, int BC>
+__global__ void import_weights_kernel(const double* src, double* dst, int n, unsigned pitch, unsigned item_stride) {
+  const size_t total = item_stride;
+  size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
+    int r, c;
+    dst[m] = layout_unmap<BR, BC>(m, n, pitch, r, c) ? src[(size_t)r * n + c] : 0.0;
   }
 }
 

@@ -235,3 +235,31 @@ def zernike_block(m, n, norm, coeffs, dx, dy, radius, wl, origin="x", offset_deg
     off = np.deg2rad(offset_deg)
     head = [1.0, dx, dy, radius, 1.0 if origin == "y" else 0.0, np.cos(off), np.sin(off), 1.0 / wl]
     return np.concatenate([head, cosp.ravel(), sinp.ravel()]), nmax, kdim
+
+
+def gram_polynomials(m, n, norm):
+    """[K][4] descriptors of paos_zernike_gram: |m|, k = (n - |m|)/2, is_sin, (-1)^k norm
+    (the radial part is (-1)^k rho^|m| P_k, zernike.py:245-247; m < 0 takes sin, :100-104)."""
+    rows = []
+    for mk, nk, nrm in zip(np.asarray(m, dtype=int), np.asarray(n, dtype=int), norm):
+        k = (nk - abs(mk)) // 2
+        rows.append([abs(mk), k, 1.0 if mk < 0 else 0.0, (-1.0) ** k * nrm])
+    return np.array(rows, dtype=np.float64)
+
+
+def orthonorm_matrix(sums, count, k):
+    """M of PolyOrthoNorm: covariance = masked mean of Z_i Z_j with |.| < 1e-10 zeroed
+    (zernike.py:311-316), M = inv(cholesky(cov)) with |.| < 1e-10 zeroed (zernike.py:392-395).
+    ``sums`` lists i <= j row by row (paos_zernike_gram).  numpy raises LinAlgError exactly where
+    the reference does (polynomials not independent over the pupil)."""
+    if count <= 0:
+        raise ValueError("the pupil of the orthonormal polynomials is empty")
+    cov = np.empty((k, k), dtype=np.float64)
+    iu = np.triu_indices(k)
+    cov[iu] = np.asarray(sums, dtype=np.float64) / float(count)
+    cov.T[iu] = cov[iu]
+    cov[np.abs(cov) < 1e-10] = 0.0
+    qt = np.linalg.cholesky(cov)
+    m = np.linalg.inv(qt)
+    m[np.abs(m) < 1.0e-10] = 0.0
+    return m

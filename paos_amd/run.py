@@ -25,7 +25,8 @@ from .abcd import ABCD
 from .aperture import EllipticalAperture, bbox_misses_grid, make_aperture
 from .coordinate_break import coordinate_break
 from .passes import PassCompiler
-from .planner import PilotBeam, jacobi_recurrence, zernike_block
+from .planner import (PilotBeam, gram_polynomials, jacobi_recurrence, orthonorm_matrix,
+                      zernike_block)
 from .zernike import Zernike, norm_factors
 
 # Apertures ride on FFT passes as PW_MASK operators when the library can hold them as per-line
@@ -97,8 +98,15 @@ def _plan_surface(st, item):
 
     if item["type"] == "Zernike":
         radius = item["Zradius"] if math.isfinite(item["Zradius"]) else beam.wz
-        if item["Zorthonorm"]:
-            raise NotImplementedError("Zorthonorm=True (PolyOrthoNorm) is not accelerated yet")
+        pupil = None
+        if item["Zorthonorm"]:  # run.py:133-141: orthonormal over THIS surface's aperture object
+            assert "aperture" in item, "Zorthonorm requires aperture"
+            if plan["aperture"] is None:
+                raise KeyError("aperture")  # the reference finds no _retval_["aperture"]
+            pupil = plan["aperture"][0]
+            if not isinstance(pupil, EllipticalAperture):
+                raise NotImplementedError("Zorthonorm over a rectangular aperture needs photutils' exact "
+                                          "rectangle overlap, which is not restated")
         index = np.asarray(item["Zindex"])
         assert not np.any(np.diff(index) - 1), "Zernike sequence should be continuous"
         ordering = item["Zordering"]
@@ -107,7 +115,7 @@ def _plan_surface(st, item):
         m, n = Zernike.j2mn(len(index), ordering)
         plan["zernike"] = dict(m=m, n=n, norm=norm_factors(m, n, item["Znormalize"]),
                                Z=np.asarray(item["Z"], dtype=np.float64), dx=beam.dx, dy=beam.dy,
-                               radius=radius, wl=beam.wl, origin=item["Zorigin"])
+                               radius=radius, wl=beam.wl, origin=item["Zorigin"], pupil=pupil)
     if item["type"] in ("Grid Sag", "PSD"):
         raise NotImplementedError(f"surface type {item['type']} is outside the accelerated path")
 
@@ -162,12 +170,41 @@ def _launch_zernike(dev, plans, want_wfe=False):
     nmax = max(int(z["n"].max()) for z in zs if z is not None)
     kdim = nmax // 2 + 1
     stride = _lib.ZERNIKE_HEAD + 2 * (nmax + 1) * kdim
-    blocks = np.zeros((len(plans), stride), dtype=np.float64)
+    table = jacobi_recurrence(nmax)
+    ortho = [z is not None and z["pupil"] is not None for z in zs]
+
+    def build(coeffs):
+        blocks = np.zeros((len(plans), stride), dtype=np.float64)
+        for i, z in enumerate(zs):
+            if z is not None:
+                blocks[i], _, _ = zernike_block(z["m"], z["n"], z["norm"], coeffs[i], z["dx"], z["dy"],
+                                                z["radius"], z["wl"], origin=z["origin"], nmax=nmax)
+        return blocks
+
+    coeffs = [z["Z"] if z is not None else None for z in zs]
+    if not any(ortho):
+        return dev.zernike(nmax, kdim, table, build(coeffs), want_wfe=want_wfe)
+
+    # PolyOrthoNorm (zernike.py:320-402): U = M Z, so sum_k c_k U_k = sum_n (M^T c)_n Z_n -- the
+    # ordinary expansion with transformed coefficients, restricted to the pupil.
+    live = [z for z in zs if z is not None]
+    if not all(ortho[i] for i, z in enumerate(zs) if z is not None):
+        raise NotImplementedError("a batch must use Zorthonorm on all of its items or on none")
+    if any(not (np.array_equal(z["m"], live[0]["m"]) and np.array_equal(z["n"], live[0]["n"])
+                and np.array_equal(z["norm"], live[0]["norm"])) for z in live):
+        raise NotImplementedError("batched Zorthonorm surfaces must share index range, ordering and normalisation")
+    ap = np.zeros((len(plans), _lib.APERTURE_STRIDE), dtype=np.float64)
     for i, z in enumerate(zs):
         if z is not None:
-            blocks[i], _, _ = zernike_block(z["m"], z["n"], z["norm"], z["Z"], z["dx"], z["dy"],
-                                            z["radius"], z["wl"], origin=z["origin"], nmax=nmax)
-    return dev.zernike(nmax, kdim, jacobi_recurrence(nmax), blocks, want_wfe=want_wfe)
+            ap[i] = z["pupil"].block(obscuration=False)
+    dev.pupil_aperture(_lib.SHAPE_ELLIPSE, ap)
+    k = len(live[0]["m"])
+    sums, counts = dev.zernike_gram(nmax, kdim, table, build(coeffs), gram_polynomials(live[0]["m"], live[0]["n"],
+                                                                                      live[0]["norm"]), pupil=True)
+    for i, z in enumerate(zs):
+        if z is not None:
+            coeffs[i] = orthonorm_matrix(sums[i], counts[i], k).T @ np.asarray(z["Z"], dtype=np.float64)
+    return dev.zernike(nmax, kdim, table, build(coeffs), want_wfe=want_wfe, pupil=True)
 
 
 def _queue_apertures(comp, plans):

@@ -10,7 +10,7 @@ import numpy as np
 
 from . import _lib
 from .aperture import bbox_misses_grid, make_aperture, EllipticalAperture
-from .planner import PilotBeam, jacobi_recurrence, zernike_block
+from .planner import PilotBeam, gram_polynomials, jacobi_recurrence, orthonorm_matrix, zernike_block
 from .zernike import Zernike, norm_factors
 
 
@@ -133,20 +133,36 @@ class WFO:
 
     def zernikes(self, index, Z, ordering, normalize, radius, offset=0.0, origin="x",
                  orthonorm=False, mask=False):
-        """wfo.py:574-654.  Returns the masked wfe map like the reference."""
+        """wfo.py:574-654.  Returns the masked wfe map like the reference.  ``mask`` (True =
+        outside the pupil) restricts the map, and with ``orthonorm`` the polynomials are the
+        Gram-Schmidt combinations orthonormal over the unmasked pixels (PolyOrthoNorm,
+        zernike.py:320-402)."""
         index = np.asarray(index)
         assert not np.any(np.diff(index) - 1), "Zernike sequence should be continuous"
-        if orthonorm:
-            raise NotImplementedError("PolyOrthoNorm (Zorthonorm=True) is not accelerated yet")
-        if mask is not False and np.any(mask):
-            raise NotImplementedError("an explicit pupil mask is only used with orthonorm=True")
         if ordering not in ("ansi", "noll", "fringe", "standard"):
             raise AssertionError("Unrecognised ordering scheme.")
         m, n = Zernike.j2mn(len(index), ordering)
+        norm = norm_factors(m, n, normalize)
         b = self._beam
-        block, nmax, kdim = zernike_block(m, n, norm_factors(m, n, normalize), np.asarray(Z, float),
-                                          b.dx, b.dy, radius, b.wl, origin=origin, offset_deg=offset)
-        wfe = self._dev.zernike(nmax, kdim, jacobi_recurrence(nmax), [block], want_wfe=True)
+        coeff = np.asarray(Z, float)
+        pupil = mask is not False and mask is not None
+        if pupil:
+            mask = np.asarray(mask, dtype=bool)
+            if mask.shape != (b.n, b.n):
+                raise ValueError("mask must have the shape of the field")
+            self._dev.pupil_upload(0, (~mask).astype(np.float64))
+
+        def block_for(c):
+            return zernike_block(m, n, norm, c, b.dx, b.dy, radius, b.wl, origin=origin, offset_deg=offset)
+
+        block, nmax, kdim = block_for(coeff)
+        table = jacobi_recurrence(nmax)
+        if orthonorm:
+            sums, counts = self._dev.zernike_gram(nmax, kdim, table, [block], gram_polynomials(m, n, norm),
+                                                  pupil=pupil)
+            coeff = orthonorm_matrix(sums[0], counts[0], len(m)).T @ coeff
+            block, _, _ = block_for(coeff)
+        wfe = self._dev.zernike(nmax, kdim, table, [block], want_wfe=True, pupil=pupil)
         outside = np.isnan(wfe)
         return np.ma.MaskedArray(data=np.where(outside, 0.0, wfe), mask=outside, fill_value=0.0)
 

@@ -87,45 +87,102 @@ class ModelDevice:
                 mask = aperture_np.rectangle_mask((self.n, self.n), xc, yc, a, bb, theta)
             self.u[i] *= (1 - mask) if obsc else mask
 
-    def zernike(self, nmax, kdim, table, blocks, want_wfe=False):
+    def _zernike_terms(self, nmax, kdim, table, b):
+        """Yield (am, k, rho_pow * P_k, cos(am phi), sin(am phi)) maps and rho, like the kernels."""
+        n = self.n
+        _, dx, dy, radius, origin_y, co, so, _ = b[:8]
+        x = (np.arange(n) - n // 2) * dx
+        y = (np.arange(n) - n // 2) * dy
+        xx, yy = np.meshgrid(x, y)
+        rr = np.sqrt(xx**2 + yy**2)
+        rho = rr / radius
+        with np.errstate(invalid="ignore", divide="ignore"):
+            c1 = np.where(rr > 0, (yy if origin_y else xx) / rr, 1.0)
+            s1 = np.where(rr > 0, (xx if origin_y else yy) / rr, 0.0)
+        cr, sr = c1 * co - s1 * so, s1 * co + c1 * so
+        xj = 1.0 - 2.0 * rho * rho
+        terms = []
+        rho_pow, cm, sm = np.ones_like(rho), np.ones_like(rho), np.zeros_like(rho)
+        for am in range(nmax + 1):
+            pkm1, pk = np.zeros_like(rho), np.ones_like(rho)
+            for k in range((nmax - am) // 2 + 1):
+                if k > 0:
+                    a_, b_, c_ = table[am, k]
+                    pkm1, pk = pk, (a_ * xj + b_) * pk - c_ * pkm1
+                terms.append((am, k, rho_pow * pk, cm, sm))
+            rho_pow = rho_pow * rho
+            cm, sm = cm * cr - sm * sr, sm * cr + cm * sr
+        return rho, terms
+
+    def zernike(self, nmax, kdim, table, blocks, want_wfe=False, pupil=False):
         """Mirror of csrc/pointwise.h zernike_kernel (same recurrences, NumPy)."""
         self.log.append(("zernike", nmax))
         table = np.asarray(table).reshape(nmax + 1, kdim, 3)
-        n = self.n
         wfe0 = None
         for i, b in enumerate(np.asarray(blocks)):
             if not b[0]:
                 continue
-            _, dx, dy, radius, origin_y, co, so, inv_wl = b[:8]
+            inv_wl = b[7]
             cc = b[8:8 + (nmax + 1) * kdim].reshape(nmax + 1, kdim)
             ss = b[8 + (nmax + 1) * kdim:8 + 2 * (nmax + 1) * kdim].reshape(nmax + 1, kdim)
-            x = (np.arange(n) - n // 2) * dx
-            y = (np.arange(n) - n // 2) * dy
-            xx, yy = np.meshgrid(x, y)
-            rr = np.sqrt(xx**2 + yy**2)
-            rho = rr / radius
-            with np.errstate(invalid="ignore", divide="ignore"):
-                c1 = np.where(rr > 0, (yy if origin_y else xx) / rr, 1.0)
-                s1 = np.where(rr > 0, (xx if origin_y else yy) / rr, 0.0)
-            cr, sr = c1 * co - s1 * so, s1 * co + c1 * so
-            xj = 1.0 - 2.0 * rho * rho
+            rho, terms = self._zernike_terms(nmax, kdim, table, b)
             wfe = np.zeros_like(rho)
-            rho_pow, cm, sm = np.ones_like(rho), np.ones_like(rho), np.zeros_like(rho)
-            for am in range(nmax + 1):
-                pkm1, pk = np.zeros_like(rho), np.ones_like(rho)
-                for k in range((nmax - am) // 2 + 1):
-                    if k > 0:
-                        a_, b_, c_ = table[am, k]
-                        pkm1, pk = pk, (a_ * xj + b_) * pk - c_ * pkm1
-                    wfe += (rho_pow * pk) * (cc[am, k] * cm + ss[am, k] * sm)
-                rho_pow = rho_pow * rho
-                cm, sm = cm * cr - sm * sr, sm * cr + cm * sr
+            for am, k, base, cm, sm in terms:
+                wfe += base * (cc[am, k] * cm + ss[am, k] * sm)
             masked = rho > 1.0
+            if pupil:
+                masked = masked | (self.pupil[i] == 0.0)
             wfe = np.where(masked, 0.0, wfe)
             self.u[i] = self.u[i] * np.exp(1j * ((6.283185307179586 * wfe) * inv_wl))
             if i == 0:
                 wfe0 = np.where(masked, np.nan, wfe)
         return wfe0 if want_wfe else None
+
+    def pupil_aperture(self, shape, blocks):
+        """Weights of the aperture OBJECT (obscuration flag ignored), csrc: paos_pupil_aperture."""
+        self.log.append(("pupil_aperture", shape))
+        if not hasattr(self, "pupil"):
+            self.pupil = np.ones((self.batch, self.n, self.n))
+        for i, b in enumerate(np.asarray(blocks)):
+            if not b[0]:
+                continue
+            _, xc, yc, a, bb, theta, _obsc, _sub = b
+            if shape != _lib.SHAPE_ELLIPSE:
+                raise NotImplementedError
+            m = aperture_np.ellipse_mask((self.n, self.n), xc, yc, a, bb, theta)
+            self.pupil[i] = np.zeros((self.n, self.n)) if m is None else m
+
+    def pupil_upload(self, item, weights):
+        self.log.append(("pupil_upload", item))
+        if not hasattr(self, "pupil"):
+            self.pupil = np.ones((self.batch, self.n, self.n))
+        self.pupil[item] = np.asarray(weights, dtype=np.float64)
+
+    def zernike_gram(self, nmax, kdim, table, blocks, poly, pupil=True):
+        """Mirror of zernike_gram_kernel: sums of Z_i Z_j over the unmasked pixels + their count."""
+        self.log.append(("zernike_gram", len(poly)))
+        table = np.asarray(table).reshape(nmax + 1, kdim, 3)
+        poly = np.asarray(poly)
+        k = len(poly)
+        sums = np.zeros((self.batch, k * (k + 1) // 2))
+        counts = np.zeros(self.batch)
+        iu = np.triu_indices(k)
+        for i, b in enumerate(np.asarray(blocks)):
+            if not b[0]:
+                continue
+            rho, terms = self._zernike_terms(nmax, kdim, table, b)
+            lookup = {(am, kk): (base, cm, sm) for am, kk, base, cm, sm in terms}
+            valid = rho <= 1.0
+            if pupil:
+                valid = valid & (self.pupil[i] != 0.0)
+            z = []
+            for am, kk, is_sin, fac in poly:
+                base, cm, sm = lookup[(int(am), int(kk))]
+                z.append(np.where(valid, fac * base * (sm if is_sin else cm), 0.0))
+            z = np.array(z).reshape(k, -1)
+            sums[i] = (z @ z.T)[iu]
+            counts[i] = valid.sum()
+        return sums, counts
 
     # ---- pass programs -----------------------------------------------------------------
     def _apply(self, u, op, p):

@@ -415,3 +415,128 @@ def test_full_size_4096_vs_oracle_single_ptp(WFO):
     r._wfo = u0.copy()
     r.ptp(2.5)
     assert rel_err(w.wfo, r._wfo) < FIELD_TOL
+
+
+@pytest.mark.gpu
+def test_wfo_zernikes_orthonorm_vs_reference_vectors(WFO):
+    """WFO.zernikes(orthonorm=True, mask=...) -- wfo.py:574-654 with PolyOrthoNorm
+    (zernike.py:320-402): Gram sums on the GPU, Cholesky / inverse on the host."""
+    g = load_golden("orthonorm.npz")
+    w = WFO(1.0, 1.2e-6, 64, 2)
+    w._wfo = g["wfo_in"]
+    wfe = w.zernikes(np.arange(10), g["wfo_coeff"], "noll", True, 0.5, origin="x", orthonorm=True,
+                     mask=g["wfo_zmask"])
+    assert np.array_equal(np.ma.getmaskarray(wfe), g["wfo_wfe_mask"])
+    assert rel_err(wfe.filled(0.0), g["wfo_wfe"]) < 1e-11
+    assert rel_err(w.wfo, g["wfo_out"]) < FIELD_TOL
+    # a plain expansion restricted by a mask (no orthonormalisation)
+    from oracle.pop_numpy import RefWFO
+
+    ref = RefWFO(1.0, 1.2e-6, 64, 2)
+    ref._wfo = g["wfo_in"].copy()
+    want = ref.zernikes(np.arange(10), g["wfo_coeff"], "noll", True, 0.5, mask=g["wfo_zmask"].copy())
+    w2 = WFO(1.0, 1.2e-6, 64, 2)
+    w2._wfo = g["wfo_in"]
+    got = w2.zernikes(np.arange(10), g["wfo_coeff"], "noll", True, 0.5, mask=g["wfo_zmask"])
+    assert np.array_equal(np.ma.getmaskarray(got), np.ma.getmaskarray(want))
+    assert rel_err(w2.wfo, ref._wfo) < FIELD_TOL
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [64, 128, 512])
+def test_run_zorthonorm(n):
+    """run() with Zorthonorm=True on an elliptical pupil (run.py:133-141): against the
+    reference's vectors at 64 / 128, against the oracle at 512."""
+    from paos_amd.chains import syn20_orthonorm_chain
+    from paos_amd.run import run
+
+    chain = syn20_orthonorm_chain()
+    chain[2]["save"] = True
+    ret = run(1.0, 1.0e-6, n, 4, {"us": 0.0, "ut": 0.0}, chain)
+    if n <= 128:
+        g = load_golden("orthonorm.npz")
+        want_wfe, want_mask = g[f"run{n}_S02_wfe"], g[f"run{n}_S02_wfe_mask"]
+        want2, want20 = g[f"run{n}_S02_wfo"], g[f"run{n}_S20_wfo"]
+    else:
+        from oracle.run_np import run as oracle_run
+
+        ref = oracle_run(1.0, 1.0e-6, n, 4, {"us": 0.0, "ut": 0.0}, chain)
+        want_wfe, want_mask = ref[2]["wfe"].filled(0.0), np.ma.getmaskarray(ref[2]["wfe"])
+        want2, want20 = ref[2]["wfo"], ref[20]["wfo"]
+    assert np.array_equal(np.ma.getmaskarray(ret[2]["wfe"]), want_mask)
+    assert rel_err(ret[2]["wfe"].filled(0.0), want_wfe) < 1e-11
+    assert rel_err(ret[2]["wfo"], want2) < FIELD_TOL
+    assert rel_err(ret[20]["wfo"], want20) < FIELD_TOL
+    psf, ref_psf = np.abs(ret[20]["wfo"]) ** 2, np.abs(want20) ** 2
+    assert rel_err(psf, ref_psf) < 1e-10
+
+
+@pytest.mark.gpu
+def test_zorthonorm_batch_and_errors():
+    from paos_amd.chains import syn20_orthonorm_chain, syn20_chain
+    from paos_amd.run import run, run_batch
+
+    wls = [1.0e-6, 1.3e-6]
+    chain = syn20_orthonorm_chain()
+    field = {"us": 0.0, "ut": 0.0}
+    batch = run_batch(1.0, wls, 128, 4, field, [chain, chain], outputs=("wfo",))
+    for wl, got in zip(wls, batch):
+        one = run(1.0, wl, 128, 4, field, chain)
+        assert rel_err(got[20]["wfo"], one[20]["wfo"]) < 1e-13
+    with pytest.raises(NotImplementedError):
+        run_batch(1.0, wls, 128, 4, field, [chain, syn20_chain()])
+    bad = syn20_orthonorm_chain()
+    bad[2]["aperture"]["shape"] = "rectangular"
+    with pytest.raises(NotImplementedError):
+        run(1.0, 1.0e-6, 64, 4, field, bad)
+    bad = syn20_orthonorm_chain()
+    del bad[2]["aperture"]
+    with pytest.raises(AssertionError):
+        run(1.0, 1.0e-6, 64, 4, field, bad)
+
+
+@pytest.mark.gpu
+def test_zernike_gram_full_size_properties():
+    """4096^2: the Gram sums obey what the polynomials guarantee -- piston^2 sums to the pixel
+    count, the count is the number of pupil pixels, products of opposite parity cancel on a centred
+    elliptical pupil, and the orthonormalised set has unit covariance."""
+    import time
+
+    from paos_amd import _lib
+    from paos_amd.aperture import make_aperture
+    from paos_amd.planner import (gram_polynomials, jacobi_recurrence, orthonorm_matrix,
+                                  zernike_block)
+    from paos_amd.zernike import Zernike, norm_factors
+
+    n, k = 4096, 36
+    dx = 1.0 / 1024
+    dev = _lib.DeviceFields(n, 1)
+    try:
+        m, nn = Zernike.j2mn(k, "noll")
+        norm = norm_factors(m, nn, True)
+        block, nmax, kdim = zernike_block(m, nn, norm, np.zeros(k), dx, dx, 0.5, 1.0e-6)
+        ap = make_aperture(n, dx, dx, 0.0, 0.0, hx=0.5, hy=0.3, shape="elliptical")
+        dev.pupil_aperture(_lib.SHAPE_ELLIPSE, [ap.block()])
+        poly = gram_polynomials(m, nn, norm)
+        dev.zernike_gram(nmax, kdim, jacobi_recurrence(nmax), [block], poly)  # warm-up
+        t0 = time.perf_counter()
+        sums, counts = dev.zernike_gram(nmax, kdim, jacobi_recurrence(nmax), [block], poly)
+        dt = time.perf_counter() - t0
+        print(f"zernike_gram 4096^2 K=36: {dt * 1e3:.2f} ms")
+        mask = dev.aperture_mask(_lib.SHAPE_ELLIPSE, ap.block())
+        ax = (np.arange(n) - n // 2) * dx
+        rho = np.sqrt(ax[None, :] ** 2 + ax[:, None] ** 2) / 0.5
+        assert counts[0] == np.count_nonzero((mask != 0) & (rho <= 1.0))
+        iu = np.triu_indices(k)
+        cov = np.zeros((k, k))
+        cov[iu] = sums[0] / counts[0]
+        assert sums[0][0] == counts[0]  # piston: Z_0 = 1 everywhere
+        # x -> -x flips cos(m phi) terms of odd m and sin(m phi) terms of even m
+        odd_x = np.where(m >= 0, np.abs(m) % 2 == 1, np.abs(m) % 2 == 0)
+        cross = odd_x[:, None] != odd_x[None, :]
+        assert np.max(np.abs(cov[np.triu(cross)])) < 1e-12
+        mm = orthonorm_matrix(sums[0], counts[0], k)
+        full = cov + np.triu(cov, 1).T
+        assert np.allclose(mm @ full @ mm.T, np.eye(k), atol=1e-9)
+    finally:
+        dev.close()

@@ -229,3 +229,39 @@ def test_run_passes_rejects_oversized_slots():
     assert all(len(p.get(s, ())) <= _lib.MAX_PW for p in passes for s in ("pre", "mid", "post"))
     assert sum(1 for p in passes if p["axis"] == -1) >= 1
     assert blocks.shape[1:] == (1, 5)
+
+
+def test_zorthonorm_host_logic_reproduces_reference():
+    """Zorthonorm (run.py:133-141, PolyOrthoNorm zernike.py:320-402) through the product's host
+    logic -- Gram sums -> covariance -> M = inv(chol) -> transformed coefficients -> ordinary
+    expansion inside the pupil -- equals the reference's run() output."""
+    from paos_amd.chains import syn20_orthonorm_chain
+
+    g = load_golden("orthonorm.npz")
+    for n in (64, 128):
+        chain = syn20_orthonorm_chain()
+        chain[2]["save"] = True
+        saved, dev, _ = _model_run(dict(pup=1.0, wl=1.0e-6, zoom=4, field=FIELD, chain=chain), n)
+        wfe = saved[0][2]["wfe"]
+        assert np.array_equal(np.isnan(wfe), g[f"run{n}_S02_wfe_mask"])
+        assert rel_err(np.nan_to_num(wfe), g[f"run{n}_S02_wfe"]) < 1e-12
+        assert rel_err(saved[0][2]["wfo"], g[f"run{n}_S02_wfo"]) < 1e-12
+        assert rel_err(saved[0][20]["wfo"], g[f"run{n}_S20_wfo"]) < 1e-12
+        assert ("pupil_aperture", _lib.SHAPE_ELLIPSE) in dev.log and ("zernike_gram", 36) in dev.log
+
+
+def test_orthonorm_matrix_matches_reference():
+    from paos_amd.planner import gram_polynomials, orthonorm_matrix
+    from paos_amd.zernike import Zernike, norm_factors
+
+    g = load_golden("orthonorm.npz")
+    for ordering in ("noll", "ansi"):
+        m, nn = Zernike.j2mn(15, ordering)
+        norm = norm_factors(m, nn, True)
+        # covariance -> M from the reference's own covariance (its masked means times the pixel count)
+        cov = g[f"poly_{ordering}_cov"]
+        iu = np.triu_indices(15)
+        count = float((~g["poly_mask"] & (g["poly_rho"] <= 1.0)).sum())
+        M = orthonorm_matrix(cov[iu] * count, count, 15)
+        assert np.allclose(M, g[f"poly_{ordering}_M"], rtol=1e-9, atol=1e-12)
+        assert gram_polynomials(m, nn, norm).shape == (15, 4)
