@@ -540,3 +540,31 @@ def test_zernike_gram_full_size_properties():
         assert np.allclose(mm @ full @ mm.T, np.eye(k), atol=1e-9)
     finally:
         dev.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["Ariel_AIRS-CH1", "Ariel_FGS-FGS2", "Ariel_FGS-NIRSpec", "Ariel_FGS-VISPhot",
+                                  "lens_file_TA_Ground", "lens_file_TA_OGSE_Ground", "lens_file_template",
+                                  "periscope"])
+def test_remaining_lens_files_vs_reference_vectors(name):
+    """Every other runnable shipped lens file, first and last wavelength, against the reference's
+    own output at 64^2 and against the oracle at 256^2 (PSF to the north-star tolerance)."""
+    from oracle.run_np import run as oracle_run
+    from paos_amd.parse_config import parse_config
+    from paos_amd.run import run
+
+    g = load_golden("run_more_chains.npz")
+    pup, par, wls, fields, chains = parse_config(os.path.join(DATA, "lens", name + ".ini"))
+    for tag, iw in (("first", 0), ("last", len(wls) - 1)):
+        key = f"{name}_{tag}"
+        ret = run(pup, 1.0e-6 * wls[iw], 64, par["zoom"], fields[0], chains[iw])
+        nums = sorted(ret.keys())
+        assert np.array_equal(nums, g[key + "_nums"])
+        table = np.array([[ret[k][f] for f in ("wl", "dx", "dy", "wz", "distancetofocus", "fratio")] for k in nums])
+        assert np.array_equal(table, g[key + "_table"]), key
+        assert [ret[k]["propagator"] for k in nums] == list(g[key + "_propagator"])
+        assert rel_err(ret[nums[-1]]["wfo"], g[key + "_wfo"]) < FIELD_TOL, key
+    ret = run(pup, 1.0e-6 * wls[0], 256, par["zoom"], fields[0], chains[0])
+    ref = oracle_run(pup, 1.0e-6 * wls[0], 256, par["zoom"], fields[0], chains[0])
+    last = sorted(ret.keys())[-1]
+    assert rel_err(np.abs(ret[last]["wfo"]) ** 2, np.abs(ref[last]["wfo"]) ** 2) < 1e-10

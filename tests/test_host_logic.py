@@ -265,3 +265,22 @@ def test_orthonorm_matrix_matches_reference():
         M = orthonorm_matrix(cov[iu] * count, count, 15)
         assert np.allclose(M, g[f"poly_{ordering}_M"], rtol=1e-9, atol=1e-12)
         assert gram_polynomials(m, nn, norm).shape == (15, 4)
+
+
+@pytest.mark.parametrize("name", ["Ariel_AIRS-CH1", "Ariel_FGS-FGS2", "Ariel_FGS-NIRSpec", "Ariel_FGS-VISPhot",
+                                  "lens_file_TA_Ground", "lens_file_TA_OGSE_Ground", "lens_file_template",
+                                  "periscope"])
+def test_remaining_lens_files_through_the_pass_compiler(name):
+    g = load_golden("run_more_chains.npz")
+    pup, par, wls, fields, chains = parse_config(os.path.join(DATA, "lens", name + ".ini"))
+    for tag, iw in (("first", 0), ("last", len(wls) - 1)):
+        key = f"{name}_{tag}"
+        spec = dict(pup=pup, wl=1.0e-6 * wls[iw], zoom=par["zoom"], field=fields[0], chain=chains[iw])
+        saved, _, _ = _model_run(spec, 64)
+        nums = sorted(saved[0].keys())
+        assert np.array_equal(nums, g[key + "_nums"])
+        table = np.array([[saved[0][k][f] for f in ("wl", "dx", "dy", "wz", "distancetofocus", "fratio")]
+                          for k in nums])
+        assert np.array_equal(table, g[key + "_table"]), key
+        assert [saved[0][k]["propagator"] for k in nums] == list(g[key + "_propagator"])
+        assert rel_err(saved[0][nums[-1]]["wfo"], g[key + "_wfo"]) < 1e-12, key

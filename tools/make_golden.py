@@ -18,6 +18,8 @@ Vector families:
   scalars_<chain>.npz pilot-beam scalars after EVERY surface of a chain (N=64)
   run_<chain>.npz     end-to-end run(): complex field, amplitude, phase, wfe of the
                       saved surfaces (N=128 SYN20/Hubble, N=64 others)
+  run_more_chains.npz the other eight runnable shipped lens files, first and last wavelength:
+                      scalars + propagators of the saved surfaces, field of the last one (N=64)
   orthonorm.npz       PolyOrthoNorm (covariance, M, polynomials) on an elliptical annulus,
                       WFO.zernikes(orthonorm=True), and run() of SYN20 with Zorthonorm (8f-3)
   kat.npz             the reference's own recorded known answers
@@ -275,6 +277,27 @@ def gen_chain_runs(specs):
              scal=np.array([ret[20]["dx"], ret[20]["dy"], ret[20]["fratio"]]))
 
 
+MORE_CHAINS = ("Ariel_AIRS-CH1", "Ariel_FGS-FGS2", "Ariel_FGS-NIRSpec", "Ariel_FGS-VISPhot",
+               "lens_file_TA_Ground", "lens_file_TA_OGSE_Ground", "lens_file_template", "periscope")
+
+
+def gen_more_chains():
+    out = {}
+    for name in MORE_CHAINS:
+        pup, par, wls, fields, chains = ref_parse(os.path.join(LENS, name + ".ini"))
+        for tag, iw in (("first", 0), ("last", len(wls) - 1)):
+            ret = ref_run(pup, 1.0e-6 * wls[iw], 64, par["zoom"], fields[0], chains[iw])
+            nums = np.array(sorted(ret.keys()))
+            key = f"{name}_{tag}"
+            out[key + "_wl_um"] = np.float64(wls[iw])
+            out[key + "_nums"] = nums
+            out[key + "_table"] = np.array([[ret[k]["wl"], ret[k]["dx"], ret[k]["dy"], ret[k]["wz"],
+                                             ret[k]["distancetofocus"], ret[k]["fratio"]] for k in nums])
+            out[key + "_propagator"] = np.array([ret[k]["propagator"] for k in nums])
+            out[key + "_wfo"] = ret[nums[-1]]["wfo"]
+    save("run_more_chains.npz", **out)
+
+
 def gen_orthonorm():
     """PolyOrthoNorm (zernike.py:320-402) and the Zorthonorm path of run() (run.py:133-141)."""
     out = {}
@@ -350,6 +373,7 @@ def main():
     specs = chain_specs()
     gen_chain_scalars(specs)
     gen_chain_runs(specs)
+    gen_more_chains()
     gen_orthonorm()
     gen_kat()
 
