@@ -568,3 +568,23 @@ def test_remaining_lens_files_vs_reference_vectors(name):
     ref = oracle_run(pup, 1.0e-6 * wls[0], 256, par["zoom"], fields[0], chains[0])
     last = sorted(ret.keys())[-1]
     assert rel_err(np.abs(ret[last]["wfo"]) ** 2, np.abs(ref[last]["wfo"]) ** 2) < 1e-10
+
+
+@pytest.mark.gpu
+def test_self_regression_like_the_reference_test():
+    """tests/regressionTest.py:35-90 runs the Hubble_simple pipeline twice and demands bit-equal
+    datasets.  Same here: two runs, every array of every saved surface bitwise identical."""
+    from paos_amd.parse_config import parse_config
+    from paos_amd.run import run
+
+    pup, par, wls, fields, chains = parse_config(os.path.join(DATA, "lens", "Hubble_simple.ini"))
+    first = run(pup, 1.0e-6 * wls[0], par["grid_size"], par["zoom"], fields[0], chains[0])
+    second = run(pup, 1.0e-6 * wls[0], par["grid_size"], par["zoom"], fields[0], chains[0])
+    assert sorted(first) == sorted(second)
+    for k in first:
+        for name, val in first[k].items():
+            other = second[k][name]
+            if isinstance(val, np.ndarray):
+                assert np.array_equal(np.ma.getdata(val), np.ma.getdata(other)), (k, name)
+            elif isinstance(val, (float, int, str)):
+                assert val == other, (k, name)
