@@ -64,6 +64,7 @@ SYMBOLS = {
     "paos_wts": (ctypes.c_int, [_c_ctx, _dbl_p, ctypes.c_int]),
     "paos_run_passes": (ctypes.c_int, [_c_ctx, ctypes.POINTER(Pass), ctypes.c_int, _dbl_p, ctypes.c_int]),
     "paos_zernike": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, _dbl_p, _dbl_p, ctypes.c_int, _dbl_p]),
+    "paos_start": (ctypes.c_int, [_c_ctx, ctypes.c_double, ctypes.c_double, ctypes.c_int, _dbl_p, _dbl_p]),
     "paos_pupil_aperture": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p]),
     "paos_pupil_upload": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p]),
     "paos_zernike_gram": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, _dbl_p, _dbl_p, ctypes.c_int,
@@ -278,6 +279,18 @@ class DeviceFields:
                        _dptr(out) if want_wfe else None),
                     "paos_zernike_pupil" if pupil else "paos_zernike")
         return out
+
+    def start(self, value, shape, blocks, stop=None):
+        """fill(value) + aperture(shape, blocks) + make_stop(stop) in one write of the field."""
+        b = np.ascontiguousarray(blocks, dtype=np.float64)
+        if b.shape != (self.batch, APERTURE_STRIDE):
+            raise ValueError("aperture blocks must be [batch][8]")
+        st = None if stop is None else np.ascontiguousarray(stop, dtype=np.float64)
+        if st is not None and st.shape != (self.batch,):
+            raise ValueError("stop flags must be [batch]")
+        v = complex(value)
+        self._check(self._lib.paos_start(self._ctx, v.real, v.imag, int(shape), _dptr(b),
+                                         _dptr(st) if st is not None else None), "paos_start")
 
     def pupil_aperture(self, shape, blocks):
         """Pupil = pixels where the exact mask of the aperture object is non-zero (run.py:136-141)."""

@@ -768,6 +768,41 @@ int paos_fill(paos_ctx* c, double re, double im) {
   return PAOS_OK;
 }
 
+int paos_start(paos_ctx* c, double re, double im, int shape, const double* aperture, const double* stop) {
+  if (c) (void)hipSetDevice(c->device);
+  if (!c || !aperture) return fail(c, PAOS_EINVAL, "null argument");
+  if (shape != PAOS_SHAPE_ELLIPSE && shape != PAOS_SHAPE_RECT) return fail(c, PAOS_EINVAL, "unknown aperture shape");
+  std::vector<double> flags(c->batch, 0.0);
+  bool any_stop = false;
+  if (stop)
+    for (int i = 0; i < c->batch; ++i) { flags[i] = stop[i] != 0.0 ? 1.0 : 0.0; any_stop |= flags[i] != 0.0; }
+  const double *dp = nullptr, *ds = nullptr;
+  int rc;
+  if ((rc = arena_push(c, aperture, (size_t)c->batch * AP_STRIDE, &dp))) return rc;
+  if ((rc = arena_push(c, flags.data(), flags.size(), &ds))) return rc;
+  const dim3 block(kPwThreads);
+#define START_LAUNCH(T, S)                                                                              \
+  do {                                                                                                  \
+    if (any_stop) {                                                                                     \
+      hipLaunchKernelGGL((start_power_kernel<T, BR, Lay<T>::BC, S>), dim3(c->nparts, c->batch), block, 0, \
+                         c->stream, dp, c->n, c->pitch, c->item_stride, re, im, c->partial, ds);        \
+      hipLaunchKernelGGL(norm2_final_kernel, dim3(c->batch), block, 0, c->stream, c->partial, c->norm2,   \
+                         c->nparts, ds, 1);                                                             \
+    }                                                                                                   \
+    hipLaunchKernelGGL((start_write_kernel<T, BR, Lay<T>::BC, S>), dim3(pw_blocks(c), c->batch), block, 0, \
+                       c->stream, (cx<T>*)c->field, dp, c->n, c->pitch, c->item_stride, re, im,          \
+                       (const double*)c->norm2, ds);                                                    \
+  } while (0)
+  if (c->precision == PAOS_F64) {
+    if (shape == PAOS_SHAPE_ELLIPSE) START_LAUNCH(double, 0); else START_LAUNCH(double, 1);
+  } else {
+    if (shape == PAOS_SHAPE_ELLIPSE) START_LAUNCH(float, 0); else START_LAUNCH(float, 1);
+  }
+#undef START_LAUNCH
+  HIPCHK(c, hipGetLastError());
+  return PAOS_OK;
+}
+
 int paos_import(paos_ctx* c, int item, const void* host) {
   if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c || !host || item < 0 || item >= c->batch) return fail(c, PAOS_EINVAL, "bad item or null buffer");

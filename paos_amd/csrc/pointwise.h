@@ -337,6 +337,57 @@ __device__ __forceinline__ ApertureBox make_box(double xc, double yc, double xe,
 // apply -- row-major mask of item 0 (weights_out == 0, for the aperture object's to_image) or,
 // with weights_out != 0, the multiplicative weight (mask, or 1 - mask for an obscuration) of
 // EVERY item in the field's own layout, for a PWK_MASK operator riding on an FFT pass.
+// Per-item aperture geometry and the per-pixel weight, shared by every kernel that evaluates a mask.
+template <int SHAPE>
+struct ApertureEval {
+  double xc, yc, a, b, theta, ct, st, hw, hh, full_disk;
+  bool obsc;
+  int subpix;
+  ApertureBox box;
+
+  // p = [enable, xc, yc, a|w, b|h, ...]; p2 = [theta, obscuration, subpixels, shape]
+  __device__ __forceinline__ void init(const double* p, const double* p2) {
+    xc = p[AP_XC]; yc = p[AP_YC]; a = p[AP_A]; b = p[AP_B]; theta = p2[0];
+    obsc = p2[1] != 0.0;
+    subpix = (int)p2[2];
+    ct = cos(theta); st = sin(theta);
+    double xe, ye;
+    hw = hh = full_disk = 0.0;
+    if (SHAPE == 0) {
+      xe = sqrt(__dadd_rn(__dmul_rn(__dmul_rn(a, ct), __dmul_rn(a, ct)),
+                          __dmul_rn(__dmul_rn(b, st), __dmul_rn(b, st))));
+      ye = sqrt(__dadd_rn(__dmul_rn(__dmul_rn(a, st), __dmul_rn(a, st)),
+                          __dmul_rn(__dmul_rn(b, ct), __dmul_rn(b, ct))));
+      full_disk = fmin(__dmul_rn(__dmul_rn(3.141592653589793, a), b), 1.0);
+    } else {
+      hw = a / 2.0;
+      hh = b / 2.0;
+      xe = fmax(fabs(__dsub_rn(__dmul_rn(hw, ct), __dmul_rn(hh, st))),
+                fabs(__dadd_rn(__dmul_rn(hw, ct), __dmul_rn(hh, st))));
+      ye = fmax(fabs(__dadd_rn(__dmul_rn(hw, st), __dmul_rn(hh, ct))),
+                fabs(__dsub_rn(__dmul_rn(hw, st), __dmul_rn(hh, ct))));
+    }
+    box = make_box(xc, yc, xe, ye);
+  }
+  // the photutils mask value of pixel (r, c)
+  __device__ __forceinline__ double mask(int r, int c) const {
+    if (!(c >= box.ixmin && c < box.ixmax && r >= box.iymin && r < box.iymax)) return 0.0;
+    if (SHAPE == 0) return ellipse_pixel(c, r, xc, yc, a, b, ct, st, full_disk);
+    if (theta == 0.0) {
+      const int cxn = subpixel_count_1d(c, xc, hw, subpix);
+      const int cyn = subpixel_count_1d(r, yc, hh, subpix);
+      return (double)(cxn * cyn) / (double)(subpix * subpix);
+    }
+    return rect_pixel(c, r, xc, yc, hw, hh, ct, st, subpix);
+  }
+  // the multiplicative weight: mask, or 1 - mask for an obscuration (wfo.py:273-276)
+  __device__ __forceinline__ double weight(double m) const { return obsc ? __dsub_rn(1.0, m) : m; }
+};
+
+// SHAPE 0: exact ellipse, 1: sub-pixel rectangle.  ``mask_out`` non-null: render instead of
+// apply -- row-major mask of item 0 (weights_out == 0, for the aperture object's to_image) or,
+// with weights_out != 0, the multiplicative weight (mask, or 1 - mask for an obscuration) of
+// EVERY item in the field's own layout, for a PWK_MASK operator riding on an FFT pass.
 template <typename T, int BR, int BC, int SHAPE>
 __global__ void aperture_kernel(cx<T>* field, const double* params, const double* params2,
                                 int param_stride, int n, unsigned pitch, unsigned item_stride,
@@ -348,45 +399,16 @@ __global__ void aperture_kernel(cx<T>* field, const double* params, const double
   const double* p2 = params2 ? params2 + (size_t)item * param_stride : p + AP_THETA;
   if (p[AP_ENABLE] == 0.0) return;
   if (weights_out == 1 && SHAPE != (int)p2[3]) return;  // 2: paos_pupil_aperture, shape chosen by the host
-  const double xc = p[AP_XC], yc = p[AP_YC], a = p[AP_A], b = p[AP_B], theta = p2[0];
-  const bool obsc = p2[1] != 0.0;
-  const int subpix = (int)p2[2];
-  const double ct = cos(theta), st = sin(theta);
-  double xe, ye, hw = 0.0, hh = 0.0, full_disk = 0.0;
-  if (SHAPE == 0) {
-    xe = sqrt(__dadd_rn(__dmul_rn(__dmul_rn(a, ct), __dmul_rn(a, ct)),
-                        __dmul_rn(__dmul_rn(b, st), __dmul_rn(b, st))));
-    ye = sqrt(__dadd_rn(__dmul_rn(__dmul_rn(a, st), __dmul_rn(a, st)),
-                        __dmul_rn(__dmul_rn(b, ct), __dmul_rn(b, ct))));
-    full_disk = fmin(__dmul_rn(__dmul_rn(3.141592653589793, a), b), 1.0);
-  } else {
-    hw = a / 2.0;
-    hh = b / 2.0;
-    xe = fmax(fabs(__dsub_rn(__dmul_rn(hw, ct), __dmul_rn(hh, st))),
-              fabs(__dadd_rn(__dmul_rn(hw, ct), __dmul_rn(hh, st))));
-    ye = fmax(fabs(__dadd_rn(__dmul_rn(hw, st), __dmul_rn(hh, ct))),
-              fabs(__dsub_rn(__dmul_rn(hw, st), __dmul_rn(hh, ct))));
-  }
-  const ApertureBox box = make_box(xc, yc, xe, ye);
+  ApertureEval<SHAPE> ap;
+  ap.init(p, p2);
   cx<T>* f = field ? field + (size_t)item * item_stride : nullptr;
   const size_t total = item_stride;
   size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
     int r, c;
     if (!layout_unmap<BR, BC>(m, n, pitch, r, c)) continue;
-    double mask = 0.0;
-    if (c >= box.ixmin && c < box.ixmax && r >= box.iymin && r < box.iymax) {
-      if (SHAPE == 0) {
-        mask = ellipse_pixel(c, r, xc, yc, a, b, ct, st, full_disk);
-      } else if (theta == 0.0) {
-        const int cxn = subpixel_count_1d(c, xc, hw, subpix);
-        const int cyn = subpixel_count_1d(r, yc, hh, subpix);
-        mask = (double)(cxn * cyn) / (double)(subpix * subpix);
-      } else {
-        mask = rect_pixel(c, r, xc, yc, hw, hh, ct, st, subpix);
-      }
-    }
-    const double w = obsc ? __dsub_rn(1.0, mask) : mask;
+    const double mask = ap.mask(r, c);
+    const double w = ap.weight(mask);
     if (mask_out) {
       if (weights_out) mask_out[(size_t)item * item_stride + m] = w;
       else if (item == 0) mask_out[(size_t)r * n + c] = mask;
@@ -403,6 +425,67 @@ __global__ void aperture_kernel(cx<T>* field, const double* params, const double
       v.y = (T)__dmul_rn((double)v.y, w);
       f[m] = v;
     }
+  }
+}
+
+// ---- the first surface in one go: ones -> aperture -> [make_stop] ------------------------------
+// wfo.py:118 (u = 1), :273-276 (u *= w), :200-201 (u /= sqrt(sum |u|^2)) on a field that is still
+// the constant `value`.  Stage 1 sums |value w|^2 from the weights alone (no HBM traffic), stage 2
+// (norm2_final_kernel) orders the partial sums, stage 3 writes value * w [* 1/sqrt(norm)] once:
+// 16 B/px instead of fill 16 + aperture ~8 + norm 16 + scale 32.
+template <typename T, int BR, int BC, int SHAPE>
+__global__ void start_power_kernel(const double* params, int n, unsigned pitch, unsigned item_stride,
+                                   double vre, double vim, double* partial, const double* stop) {
+  const int item = blockIdx.y;
+  if (stop[item] == 0.0) return;
+  __shared__ double sh[kPwThreads / 64];
+  const double* p = params + (size_t)item * AP_STRIDE;
+  ApertureEval<SHAPE> ap;
+  ap.init(p, p + AP_THETA);
+  const bool on = p[AP_ENABLE] != 0.0;
+  const double v0re = (double)(T)vre, v0im = (double)(T)vim;  // what fill stores
+  const size_t total = item_stride;
+  double acc = 0.0;
+  size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
+    int r, c;
+    if (!layout_unmap<BR, BC>(m, n, pitch, r, c)) continue;
+    const double w = on ? ap.weight(ap.mask(r, c)) : 1.0;
+    // the value aperture_kernel leaves in the field, read back the way norm2_partial_kernel does
+    const double x = w == 1.0 ? v0re : (w == 0.0 ? 0.0 : (double)(T)__dmul_rn(v0re, w));
+    const double y = w == 1.0 ? v0im : (w == 0.0 ? 0.0 : (double)(T)__dmul_rn(v0im, w));
+    acc += __dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y));
+  }
+  const double s = block_sum(acc, sh);
+  if (threadIdx.x == 0) partial[(size_t)item * gridDim.x + blockIdx.x] = s;
+}
+
+template <typename T, int BR, int BC, int SHAPE>
+__global__ void start_write_kernel(cx<T>* field, const double* params, int n, unsigned pitch,
+                                   unsigned item_stride, double vre, double vim, const double* norm2,
+                                   const double* stop) {
+  const int item = blockIdx.y;
+  const double* p = params + (size_t)item * AP_STRIDE;
+  ApertureEval<SHAPE> ap;
+  ap.init(p, p + AP_THETA);
+  const bool on = p[AP_ENABLE] != 0.0;
+  const bool scaled = stop[item] != 0.0;
+  const double s = scaled ? 1.0 / sqrt(norm2[item]) : 1.0;
+  const double v0re = (double)(T)vre, v0im = (double)(T)vim;
+  cx<T>* f = field + (size_t)item * item_stride;
+  const size_t total = item_stride;
+  size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
+    int r, c;
+    double x = 0.0, y = 0.0;
+    if (layout_unmap<BR, BC>(m, n, pitch, r, c)) {
+      const double w = on ? ap.weight(ap.mask(r, c)) : 1.0;
+      // the same roundings as fill -> aperture_kernel -> stop_scale_kernel, via the field's type
+      x = w == 1.0 ? v0re : (w == 0.0 ? 0.0 : (double)(T)__dmul_rn(v0re, w));
+      y = w == 1.0 ? v0im : (w == 0.0 ? 0.0 : (double)(T)__dmul_rn(v0im, w));
+      if (scaled) { x = __dmul_rn(x, s); y = __dmul_rn(y, s); }
+    }
+    f[m] = {(T)x, (T)y};
   }
 }
 

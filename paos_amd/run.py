@@ -240,8 +240,24 @@ def _queue_steps(comp, plans):
             comp.wts(rows, inverse)
 
 
-def _walk(dev, states, chains, on_saved, stats=None):
-    """Drive all items through their chains in lock-step, one surface at a time."""
+def _start_field(dev, plans, value):
+    """The wavefront is still the constant ``value`` (wfo.py:118).  When every item opens with a
+    stand-alone aperture of one shape, ones -> aperture -> [make_stop] is a single write of the
+    field (paos_start); otherwise fill and let the surface run as usual.  Returns True when the
+    first surface's aperture and stop are done."""
+    aps = [p["aperture"] for p in plans]
+    if any(a is None for a in aps) or len({isinstance(a[0], EllipticalAperture) for a in aps}) != 1:
+        dev.fill(value)
+        return False
+    code = _lib.SHAPE_ELLIPSE if isinstance(aps[0][0], EllipticalAperture) else _lib.SHAPE_RECT
+    dev.start(value, code, [a[0].block(obscuration=a[1]) for a in aps],
+              [1.0 if p["stop"] else 0.0 for p in plans])
+    return True
+
+
+def _walk(dev, states, chains, on_saved, stats=None, fresh=None):
+    """Drive all items through their chains in lock-step, one surface at a time.  ``fresh``: the
+    constant the field is meant to hold but has not been filled with yet (see _start_field)."""
     keys = [list(c.keys()) for c in chains]
     if any(k != keys[0] for k in keys[1:]):
         raise ValueError("batched chains must list the same surfaces (same keys, same order)")
@@ -251,6 +267,15 @@ def _walk(dev, states, chains, on_saved, stats=None):
         items = [c[key] for c in chains]
         plans = [_plan_surface(st, it) for st, it in zip(states, items)]
         saved = any(it["save"] for it in items)
+        if fresh is not None:
+            value, fresh = fresh, None
+            if _start_field(dev, plans, value):
+                want_wfe = len(plans) == 1 and bool(items[0]["save"])
+                wfe = _launch_zernike(dev, plans, want_wfe=want_wfe)
+                if saved:
+                    on_saved(key, items, plans, wfe)
+                _queue_steps(comp, plans)
+                continue
         fuse_ap = FUSE_APERTURES
         own_breaker = saved or any(p["stop"] or p["zernike"] is not None for p in plans)
         if fuse_ap == "auto":
@@ -274,6 +299,8 @@ def _walk(dev, states, chains, on_saved, stats=None):
         if saved:
             on_saved(key, items, plans, wfe)
         _queue_steps(comp, plans)
+    if fresh is not None:  # an empty chain still yields the initial wavefront
+        dev.fill(fresh)
     npass += comp.flush(dev)
     if stats is not None:
         stats["fused_passes"] = npass
@@ -287,7 +314,6 @@ def run(pupil_diameter, wavelength, gridsize, zoom, field, opt_chain, precision=
     retval = {}
     state = _Item(pupil_diameter, wavelength, gridsize, zoom, field)
     dev = _lib.DeviceFields(int(gridsize), 1, precision, device)
-    dev.fill(1.0 + 0.0j)
 
     def on_saved(key, items, plans, wfe):
         item, plan = items[0], plans[0]
@@ -309,7 +335,7 @@ def run(pupil_diameter, wavelength, gridsize, zoom, field, opt_chain, precision=
         retval[item["num"]] = rec
 
     try:
-        _walk(dev, [state], [opt_chain], on_saved)
+        _walk(dev, [state], [opt_chain], on_saved, fresh=1.0 + 0.0j)
         dev.sync()
     finally:
         dev.close()
@@ -349,7 +375,6 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
         dev = _lib.DeviceFields(int(gridsize), nb, precision, device)
     elif dev.batch != nb or dev.n != int(gridsize):
         raise ValueError("supplied DeviceFields does not match the batch")
-    dev.fill(1.0 + 0.0j)
     results = [dict() for _ in range(nb)]
     what = {"psf": _lib.WHAT_INTENSITY, "wfo": _lib.WHAT_FIELD, "amplitude": _lib.WHAT_AMPLITUDE,
             "phase": _lib.WHAT_PHASE}
@@ -376,7 +401,7 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
         tickets.append((dev.norm2_enqueue(), pending))
 
     try:
-        _walk(dev, states, list(opt_chains), on_saved, stats=stats)
+        _walk(dev, states, list(opt_chains), on_saved, stats=stats, fresh=1.0 + 0.0j)
         if sync or own:
             for ticket, pending in tickets:
                 power = dev.norm2_fetch(ticket)

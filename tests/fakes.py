@@ -75,6 +75,16 @@ class ModelDevice:
             if enable is None or enable[i]:
                 self.u[i] /= np.sqrt(np.sum(np.abs(self.u[i]) ** 2))
 
+    def start(self, value, shape, blocks, stop=None):
+        """paos_start: fill -> aperture -> make_stop on the flagged items."""
+        self.log.append(("start", shape))
+        self.u[:] = value
+        n0 = len(self.log)
+        self.aperture(shape, blocks)
+        if stop is not None and any(stop):
+            self.make_stop(stop)
+        del self.log[n0:]
+
     def aperture(self, shape, blocks):
         self.log.append(("aperture", shape))
         for i, b in enumerate(blocks):

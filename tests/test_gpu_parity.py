@@ -588,3 +588,39 @@ def test_self_regression_like_the_reference_test():
                 assert np.array_equal(np.ma.getdata(val), np.ma.getdata(other)), (k, name)
             elif isinstance(val, (float, int, str)):
                 assert val == other, (k, name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("precision", ["fp64", "fp32"])
+def test_start_equals_fill_aperture_stop(precision):
+    """paos_start (ones -> aperture -> make_stop in one write) leaves bit for bit the field of
+    paos_fill + paos_aperture + paos_make_stop, per item flags included."""
+    from paos_amd import _lib
+    from paos_amd.aperture import make_aperture
+
+    n, nb = 256, 4
+    dx = 1.0 / 64
+    cases = [
+        (_lib.SHAPE_ELLIPSE, [make_aperture(n, dx, dx, 0.01 * i, -0.02 * i, hx=0.5 + 0.01 * i, hy=0.4, shape="elliptical")
+                              for i in range(nb)], [False, True, False, True]),
+        (_lib.SHAPE_RECT, [make_aperture(n, dx, dx, 0.0, 0.03 * i, hx=0.3, hy=0.2 + 0.01 * i, shape="rectangular")
+                           for i in range(nb)], [False, False, True, False]),
+    ]
+    a = _lib.DeviceFields(n, nb, precision)
+    b = _lib.DeviceFields(n, nb, precision)
+    try:
+        for code, handles, obsc in cases:
+            for stop in ([1.0, 0.0, 1.0, 1.0], None):
+                blocks = [h.block(obscuration=o) for h, o in zip(handles, obsc)]
+                blocks[3][0] = 0.0  # item 3: no aperture at all
+                value = 0.75 - 0.5j
+                a.fill(value)
+                a.aperture(code, blocks)
+                if stop is not None:
+                    a.make_stop(stop)
+                b.start(value, code, blocks, stop)
+                for i in range(nb):
+                    assert np.array_equal(a.download(i), b.download(i)), (code, stop, i)
+    finally:
+        a.close()
+        b.close()

@@ -77,7 +77,6 @@ def _model_run(spec, n, chains=None, wls=None):
     chains = chains or [spec["chain"]]
     wls = wls or [spec["wl"]]
     dev = ModelDevice(n, len(chains))
-    dev.fill(1.0)
     states = [_Item(spec["pup"], wl, n, spec["zoom"], spec["field"]) for wl in wls]
     saved = {}
 
@@ -87,7 +86,7 @@ def _model_run(spec, n, chains=None, wls=None):
                 saved.setdefault(i, {})[it["num"]] = dict(pl["scalars"], wfo=dev.download(i), wfe=wfe)
 
     stats = {}
-    _walk(dev, states, chains, on_saved, stats=stats)
+    _walk(dev, states, chains, on_saved, stats=stats, fresh=1.0 + 0.0j)
     return saved, dev, stats
 
 
@@ -135,7 +134,9 @@ def test_syn20_pass_budget():
         prun.FUSE_APERTURES = "auto"
     assert stats["fused_passes"] == dev.pass_count == 49
     kinds = [name for name, _ in dev.log]
-    assert kinds.count("aperture") == 7 and kinds.count("make_stop") == 1 and kinds.count("zernike") == 1
+    # the first surface (ones -> aperture -> stop) is one "start" launch
+    assert kinds.count("start") == 1 and kinds.count("aperture") == 6 and kinds.count("make_stop") == 0
+    assert kinds.count("zernike") == 1 and kinds.count("fill") == 0
     assert -1 not in [d for name, d in dev.log if name == "pass"]  # every lens rides on a transform
     prun.FUSE_APERTURES = True
     try:
@@ -143,7 +144,7 @@ def test_syn20_pass_budget():
     finally:
         prun.FUSE_APERTURES = "auto"
     kinds = [name for name, _ in dev.log]
-    assert kinds.count("aperture") == 0 and stats["fused_passes"] == 45
+    assert kinds.count("aperture") == 0 and kinds.count("start") == 1 and stats["fused_passes"] == 44
     gr = load_golden("run_SYN20.npz")
     saved, _, _ = _model_run(_spec("SYN20"), 128)
     prun.FUSE_APERTURES = True
