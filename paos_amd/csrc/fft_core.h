@@ -225,6 +225,8 @@ __device__ __forceinline__ void apply_twiddle_chain(cx<T>* v, cx<T> w1) {
 #define PAOS_DIAG 0
 #endif
 #define PAOS_SYNC() do { if (!(PAOS_DIAG & 1)) __syncthreads(); } while (0)
+// inside fft_stages; bit 2 (timing only): only the first exchange keeps its barriers
+#define PAOS_SYNC_X() do { if (!((PAOS_DIAG & 4) && NS > 1)) PAOS_SYNC(); } while (0)
 
 // All stages of one line.  ``lds`` is this line's exchange area: cx<T> slots
 // when !SPLIT, T slots (real and imaginary parts exchanged one after the other,
@@ -281,12 +283,12 @@ __device__ __forceinline__ void fft_stages(cx<T>* v, void* lds, int t,
       for (int s = 0; s < TPT; ++s)
 #pragma unroll
         for (int r = 0; r < R; ++r) if (!(PAOS_DIAG & 2)) l[wb[s] + lds_pad(r * NS)] = v[s * R + r];
-      PAOS_SYNC();
+      PAOS_SYNC_X();
 #pragma unroll
       for (int s = 0; s < TPT2; ++s)
 #pragma unroll
         for (int r = 0; r < R2; ++r) if (!(PAOS_DIAG & 2)) v[s * R2 + r] = l[ridx(s, r)];
-      if constexpr (!SN::LAST) PAOS_SYNC();
+      if constexpr (!SN::LAST) PAOS_SYNC_X();
     } else {
       T* l = reinterpret_cast<T*>(lds);
 #pragma unroll
@@ -296,7 +298,7 @@ __device__ __forceinline__ void fft_stages(cx<T>* v, void* lds, int t,
 #pragma unroll
           for (int r = 0; r < R; ++r)
             if (!(PAOS_DIAG & 2)) l[wb[s] + lds_pad(r * NS)] = part ? v[s * R + r].y : v[s * R + r].x;
-        PAOS_SYNC();
+        PAOS_SYNC_X();
 #pragma unroll
         for (int s = 0; s < TPT2; ++s)
 #pragma unroll
@@ -306,7 +308,7 @@ __device__ __forceinline__ void fft_stages(cx<T>* v, void* lds, int t,
               if (part) v[s * R2 + r].y = val; else v[s * R2 + r].x = val;
             }
           }
-        if (part == 0 || !SN::LAST) PAOS_SYNC();
+        if (part == 0 || !SN::LAST) PAOS_SYNC_X();
       }
     }
     PAOS_FENCE();
