@@ -15,7 +15,9 @@ launch carries a per-item parameter block with an enable flag, so items whose
 planners disagree (a ptp skipped for one wavelength, II vs OI) still share
 launches.
 """
+import atexit
 import math
+import threading
 from copy import deepcopy
 
 import numpy as np
@@ -306,6 +308,40 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None):
         stats["fused_passes"] = npass
 
 
+# One idle single-wavefront context per (grid, precision, device) is kept between run() calls:
+# creating and destroying one (HBM, pinned staging, twiddles) costs ~7 ms, several times the
+# propagation of a small grid.  A context is either in the pool or in use by exactly one call, so
+# concurrent run() calls from several threads each get their own.
+_IDLE_CONTEXTS = {}
+_IDLE_LOCK = threading.Lock()
+
+
+def _borrow_context(n, precision, device):
+    with _IDLE_LOCK:
+        dev = _IDLE_CONTEXTS.pop((n, precision, device), None)
+    return dev if dev is not None else _lib.DeviceFields(n, 1, precision, device)
+
+
+def _return_context(dev, n, precision, device):
+    with _IDLE_LOCK:
+        if (n, precision, device) not in _IDLE_CONTEXTS:
+            _IDLE_CONTEXTS[(n, precision, device)] = dev
+            return
+    dev.close()
+
+
+def release_contexts():
+    """Free the idle contexts kept by run() (also done at interpreter exit)."""
+    with _IDLE_LOCK:
+        devs = list(_IDLE_CONTEXTS.values())
+        _IDLE_CONTEXTS.clear()
+    for dev in devs:
+        dev.close()
+
+
+atexit.register(release_contexts)
+
+
 def run(pupil_diameter, wavelength, gridsize, zoom, field, opt_chain, precision="fp64", device=0):
     """Drop-in for ``paos.core.run.run``: same arguments, same returned dict
     ``{num: {aperture, [wfe], amplitude, wz, distancetofocus, fratio, phase, dx, dy, wfo,
@@ -313,7 +349,7 @@ def run(pupil_diameter, wavelength, gridsize, zoom, field, opt_chain, precision=
     assert isinstance(opt_chain, dict), "opt_chain must be a dict"
     retval = {}
     state = _Item(pupil_diameter, wavelength, gridsize, zoom, field)
-    dev = _lib.DeviceFields(int(gridsize), 1, precision, device)
+    dev = _borrow_context(int(gridsize), precision, device)
 
     def on_saved(key, items, plans, wfe):
         item, plan = items[0], plans[0]
@@ -337,8 +373,10 @@ def run(pupil_diameter, wavelength, gridsize, zoom, field, opt_chain, precision=
     try:
         _walk(dev, [state], [opt_chain], on_saved, fresh=1.0 + 0.0j)
         dev.sync()
-    finally:
-        dev.close()
+    except BaseException:
+        dev.close()  # whatever state it is in, it does not go back to the pool
+        raise
+    _return_context(dev, int(gridsize), precision, device)
     for rec in retval.values():
         plan = rec.pop("_plan")
         rec["ABCDt"] = deepcopy(plan["ABCDt"])
