@@ -95,6 +95,13 @@ int paos_import(paos_ctx* ctx, int item, const void* host_c128);
  * definition of paos/core/plot.py:125-130.  Synchronises. */
 int paos_export(paos_ctx* ctx, int item, int what, void* host_out);
 
+/* Page-locked host memory for results (no reference counterpart).  paos_export into pageable
+ * memory is bounded by first-touch page faults and on-the-fly pinning (~3 GB/s); into a buffer from
+ * paos_host_alloc it is one DMA.  paos_export_pinned requires such a buffer. */
+int paos_host_alloc(unsigned long long bytes, void** out);
+int paos_host_free(void* p);
+int paos_export_pinned(paos_ctx* ctx, int item, int what, void* pinned_out);
+
 /* ---- operators ------------------------------------------------------------------------ */
 /* WFO.aperture (wfo.py:203-278): multiply by the exact ellipse mask
  * (EllipticalAperture.to_mask("exact")) or the 32x32 sub-pixel rectangle mask

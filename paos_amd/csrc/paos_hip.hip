@@ -860,8 +860,7 @@ int paos_import(paos_ctx* c, int item, const void* host) {
   return PAOS_OK;
 }
 
-int paos_export(paos_ctx* c, int item, int what, void* host_out) {
-  if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
+static int export_impl(paos_ctx* c, int item, int what, void* host_out, bool pinned) {
   if (!c || !host_out || item < 0 || item >= c->batch || what < 0 || what > 3)
     return fail(c, PAOS_EINVAL, "bad item/what or null buffer");
   if (c->precision == PAOS_F64)
@@ -874,9 +873,42 @@ int paos_export(paos_ctx* c, int item, int what, void* host_out) {
                        c->n, c->pitch, what);
   HIPCHK(c, hipGetLastError());
   const size_t bytes = (size_t)c->n * c->n * (what == PAOS_WHAT_FIELD ? 16 : 8);
-  int rc = copy_to_host(c, host_out, c->staging, bytes);
-  if (rc) return rc;
+  if (pinned) {  // one DMA into page-locked memory
+    HIPCHK(c, hipMemcpyAsync(host_out, c->staging, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  } else {
+    int rc = copy_to_host(c, host_out, c->staging, bytes);
+    if (rc) return rc;
+  }
   return check_mask_overflow(c);
+}
+
+int paos_export(paos_ctx* c, int item, int what, void* host_out) {
+  if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
+  return export_impl(c, item, what, host_out, false);
+}
+
+int paos_export_pinned(paos_ctx* c, int item, int what, void* pinned_out) {
+  if (c) (void)hipSetDevice(c->device);
+  return export_impl(c, item, what, pinned_out, true);
+}
+
+int paos_host_alloc(unsigned long long bytes, void** out) {
+  if (!out || bytes == 0) return fail(nullptr, PAOS_EINVAL, "null argument");
+  *out = nullptr;
+  const hipError_t e = hipHostMalloc(out, (size_t)bytes);
+  if (e != hipSuccess) {
+    *out = nullptr;
+    return fail(nullptr, PAOS_EHIP, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+  }
+  return PAOS_OK;
+}
+
+int paos_host_free(void* p) {
+  if (!p) return PAOS_OK;
+  const hipError_t e = hipHostFree(p);
+  if (e != hipSuccess) return fail(nullptr, PAOS_EHIP, std::string("hipHostFree: ") + hipGetErrorString(e));
+  return PAOS_OK;
 }
 
 static int aperture_launch(paos_ctx* c, int shape, const double* dp, int nitems, double* mask_out) {

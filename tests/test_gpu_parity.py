@@ -624,3 +624,37 @@ def test_start_equals_fill_aperture_stop(precision):
     finally:
         a.close()
         b.close()
+
+
+@pytest.mark.gpu
+def test_large_downloads_use_page_locked_arrays_and_recycle_them():
+    """Arrays above 4 MiB come back in page-locked memory that returns to a pool when the array
+    dies; the values are those of the ordinary path."""
+    import gc
+
+    from paos_amd import _lib
+
+    n = 1024
+    dev = _lib.DeviceFields(n, 1)
+    try:
+        rng = np.random.default_rng(5)
+        u = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+        dev.upload(0, u)
+        a = dev.download(0)
+        assert np.array_equal(a, u) and a.flags.writeable
+        amp = dev.download(0, _lib.WHAT_AMPLITUDE)
+        assert rel_err(amp, np.abs(u)) < 1e-15
+        live = _lib._pin_live
+        assert live >= a.nbytes + amp.nbytes
+        view = a[10:20]
+        del a
+        gc.collect()
+        assert _lib._pin_live == live  # a view keeps the buffer
+        assert np.array_equal(view, u[10:20])
+        del view, amp
+        gc.collect()
+        assert _lib._pin_live == live - u.nbytes - u.nbytes // 2
+        b = dev.download(0)  # recycled buffer
+        assert np.array_equal(b, u)
+    finally:
+        dev.close()
