@@ -54,6 +54,8 @@ struct FrugalItem {
   FrugalPhase mid_ph[kFrugalMaxMid];
 };
 
+constexpr int kTwiddleLds = 256;  // table entries the stage twiddles can address: k N / (NS R) < N / R <= 256
+
 struct FrugalArgs {
   void* field;
   const void* tw;
@@ -151,7 +153,13 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, 4)
   const TileMap<N, E, LINES, TILES, AXIS, BR, BC> m(blockIdx.x, threadIdx.x, a.pitch);
   cx<T>* f = reinterpret_cast<cx<T>*>(a.field) + (size_t)item * a.item_stride;
   void* lds = smem + (size_t)m.lds_line * line_lds_bytes<T, N, SPLIT>();
-  const cx<T>* tw = reinterpret_cast<const cx<T>*>(a.tw);
+  // The stage twiddles (indices < 256 of the table for every supported N) sit in LDS behind the
+  // exchange areas: the load that follows each exchange barrier is then a ~100-cycle ds_read
+  // instead of a dependent global load.  Published by the first exchange's barriers.
+  cx<T>* tw_lds = reinterpret_cast<cx<T>*>(smem + (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT>());
+  for (int i = threadIdx.x; i < kTwiddleLds; i += TILES * LINES * N / E)
+    tw_lds[i] = reinterpret_cast<const cx<T>*>(a.tw)[i];
+  const cx<T>* tw = tw_lds;
 
   cx<T> v[E];
 #pragma unroll

@@ -351,7 +351,7 @@ int frugal_launch(paos_ctx* c, const FrugalArgs& a) {
   constexpr int TILES = AXIS == 0 ? C::ROW_TILES : C::COL_TILES;
   constexpr bool SPLIT = true;  // several workgroups share the 160 KiB of LDS
   const dim3 grid(N / LINES / TILES, c->batch), block(TILES * LINES * N / C::E);
-  const size_t lds = (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT>();
+  const size_t lds = (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT>() + kTwiddleLds * sizeof(cx<T>);
   auto kern = frugal_pass_kernel<T, N, C::E, LINES, TILES, AXIS, BR, C::BC, SPLIT, KPRE, KMID, NFFT>;
   static thread_local bool configured = false;
   if (!configured) {

@@ -174,7 +174,7 @@ void bench_frugal(const char* name, int batch, int reps, int pad_blocks) {
   FrugalArgs a{d, dtw, ditems, pitch, item_stride};
   const dim3 grid(N / LINES, batch), block(LINES * N / E);
   constexpr bool SPLIT = true;
-  const size_t lds = LINES * line_lds_bytes<T, N, SPLIT>();
+  const size_t lds = LINES * line_lds_bytes<T, N, SPLIT>() + kTwiddleLds * sizeof(cx<T>);
   auto kf = frugal_pass_kernel<T, N, E, LINES, 1, AXIS, BR, BC, SPLIT, KPRE, KMID, NFFT>;
   CK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   Timer tm;
