@@ -404,6 +404,8 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
     nb = len(opt_chains)
     if len(wavelengths) != nb:
         raise ValueError("one wavelength per chain is required")
+    if nb == 0:
+        return []
     unknown = set(outputs) - {"psf", "wfo", "amplitude", "phase"}
     if unknown:
         raise ValueError(f"unknown outputs {sorted(unknown)}")

@@ -658,3 +658,30 @@ def test_large_downloads_use_page_locked_arrays_and_recycle_them():
         assert np.array_equal(b, u)
     finally:
         dev.close()
+
+
+@pytest.mark.gpu
+def test_edge_cases_empty_and_rejected_inputs():
+    """Empty inputs and the argument checks of WFO.__init__ (wfo.py:100-103)."""
+    from paos_amd import _lib
+    from paos_amd.chains import syn20_chain
+    from paos_amd.run import run, run_batch
+
+    field = {"us": 0.0, "ut": 0.0}
+    assert run(1.0, 1.0e-6, 64, 4, field, {}) == {}
+    assert run_batch(1.0, [], 64, 4, field, []) == []
+    unsaved = syn20_chain()
+    for item in unsaved.values():
+        item["save"] = False
+    assert run(1.0, 1.0e-6, 64, 4, field, unsaved) == {}
+    for bad in (dict(gridsize=100), dict(zoom=0), dict(pupil_diameter=-1.0), dict(wavelength=0.0)):
+        kw = dict(pupil_diameter=1.0, wavelength=1.0e-6, gridsize=64, zoom=4)
+        kw.update(bad)
+        with pytest.raises(AssertionError):
+            run(kw["pupil_diameter"], kw["wavelength"], kw["gridsize"], kw["zoom"], field, syn20_chain())
+    with pytest.raises(_lib.PaosHipError):  # beyond what the kernels are instantiated for
+        run(1.0, 1.0e-6, 8192, 4, field, syn20_chain())
+    with pytest.raises(ValueError):
+        run_batch(1.0, [1.0e-6], 64, 4, field, [syn20_chain(), syn20_chain()])
+    with pytest.raises(AssertionError):
+        run(1.0, 1.0e-6, 64, 4, field, [])
