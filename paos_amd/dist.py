@@ -74,3 +74,62 @@ def syn20_work(total, mode="wavelengths", wfe_table=None):
         return {"wavelengths": [1.0e-6] * total,
                 "coefficients": [np.append(np.zeros(3), table[:, k] * 1.0e-9) for k in range(total)]}
     raise ValueError(mode)
+
+
+def run_sharded(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, batch=8,
+                precision="fp64", device=None, outputs=(), metrics_radii_px=None, gather=True,
+                make_device=None):
+    """The reference's fan-out over wavelengths / Monte-Carlo draws (pipeline.py:139-150,
+    joblib workers on one host) on N GPUs: call from every rank of an initialised process group
+    (or from a single process).  Rank 0 supplies ``wavelengths`` and ``opt_chains`` (other ranks
+    may pass None); they travel in ONE broadcast.  Every rank then propagates its contiguous
+    shard in batches of ``batch`` wavefronts with ``run_batch`` -- no further communication --
+    and returns ``[(global index, result dict), ...]`` for its shard; with ``gather`` the
+    per-wavefront results (scalars, power, metrics, and whatever ``outputs`` asks for) are
+    collected so that every rank returns the full, index-ordered list.
+
+    ``device``: GPU ordinal of this rank (default LOCAL_RANK, else 0).  ``make_device(n, nb)``
+    lets the CPU tests substitute a model of the device."""
+    import os
+
+    from . import _lib
+    from .run import run_batch
+
+    try:
+        import torch.distributed as dist
+        live = dist.is_available() and dist.is_initialized()
+    except ImportError:  # single process without torch
+        dist, live = None, False
+    rank = dist.get_rank() if live else 0
+    world = dist.get_world_size() if live else 1
+    work = {"wavelengths": list(wavelengths), "chains": list(opt_chains)} if rank == 0 else None
+    work = broadcast_blob(work, src=0)
+    total = len(work["chains"])
+    if len(work["wavelengths"]) != total:
+        raise ValueError("one wavelength per chain is required")
+    lo, hi = shard_bounds(total, rank, world)
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    mine = []
+    dev, dev_nb = None, 0
+    try:
+        for start in range(lo, hi, int(batch)):
+            stop = min(start + int(batch), hi)
+            nb = stop - start
+            if dev is None or nb != dev_nb:  # one context per batch size (the tail may be shorter)
+                if dev is not None:
+                    dev.close()
+                dev = (make_device or (lambda n, b: _lib.DeviceFields(n, b, precision, device)))(int(gridsize), nb)
+                dev_nb = nb
+            res = run_batch(pupil_diameter, work["wavelengths"][start:stop], gridsize, zoom, field,
+                            work["chains"][start:stop], precision=precision, outputs=outputs, dev=dev,
+                            metrics_radii_px=metrics_radii_px)
+            mine.extend(zip(range(start, stop), res))
+    finally:
+        if dev is not None:
+            dev.close()
+    if not (gather and live and world > 1):
+        return mine
+    parts = [None] * world
+    dist.all_gather_object(parts, mine)
+    return sorted((pair for part in parts for pair in part), key=lambda p: p[0])

@@ -138,3 +138,58 @@ def test_two_rank_gloo_sharding():
     for idx in (0, 4):
         ref = oracle_run(1.0, syn20_wavelength(idx), 64, 4, {"us": 0.0, "ut": 0.0}, syn20_chain(), light=True)
         assert abs(power[(idx, 20)] - np.sum(ref[20]["amplitude"] ** 2)) < 1e-12
+
+
+def _sharded_worker(rank, world, port, out):
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    try:
+        import sys
+
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from fakes import ModelDevice
+        from paos_amd.chains import syn20_chain, syn20_wavelength
+        from paos_amd.dist import run_sharded
+
+        total = 5
+        wls = [syn20_wavelength(k * 50) for k in range(total)] if rank == 0 else None
+        chains = [syn20_chain() for _ in range(total)] if rank == 0 else None
+        res = run_sharded(1.0, wls, 64, 4, {"us": 0.0, "ut": 0.0}, chains, batch=2, outputs=("psf",),
+                          make_device=lambda n, nb: ModelDevice(n, nb))
+        out.put((rank, [(i, float(r[20]["power"]), float(r[20]["psf"].sum()), r[20]["dx"]) for i, r in res]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_run_sharded_two_ranks_gloo():
+    """run_sharded: rank 0 alone holds the work, both ranks return the full ordered result list,
+    and it equals the single-process run."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from oracle.run_np import run as oracle_run
+    from paos_amd.chains import syn20_chain, syn20_wavelength
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(out.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert results[0] == results[1]
+    assert [i for i, *_ in results[0]] == [0, 1, 2, 3, 4]
+    for i, power, psf_sum, dx in (results[0][0], results[0][4]):
+        ref = oracle_run(1.0, syn20_wavelength(i * 50), 64, 4, {"us": 0.0, "ut": 0.0}, syn20_chain(), light=True)
+        assert abs(power - np.sum(ref[20]["amplitude"] ** 2)) < 1e-12
+        assert abs(psf_sum - np.sum(ref[20]["amplitude"] ** 2)) < 1e-12
+        assert dx == ref[20]["dx"]

@@ -685,3 +685,20 @@ def test_edge_cases_empty_and_rejected_inputs():
         run_batch(1.0, [1.0e-6], 64, 4, field, [syn20_chain(), syn20_chain()])
     with pytest.raises(AssertionError):
         run(1.0, 1.0e-6, 64, 4, field, [])
+
+
+@pytest.mark.gpu
+def test_run_sharded_single_process_matches_run_batch():
+    """run_sharded without a process group: batches of 2 (with a shorter tail) == one run_batch."""
+    from paos_amd.chains import syn20_chain, syn20_wavelength
+    from paos_amd.dist import run_sharded
+    from paos_amd.run import run_batch
+
+    field = {"us": 0.0, "ut": 0.0}
+    wls = [syn20_wavelength(60 * k) for k in range(5)]
+    chains = [syn20_chain() for _ in wls]
+    whole = run_batch(1.0, wls, 128, 4, field, chains, outputs=("psf",))
+    parts = run_sharded(1.0, wls, 128, 4, field, chains, batch=2, outputs=("psf",))
+    assert [i for i, _ in parts] == [0, 1, 2, 3, 4]
+    for (i, got), want in zip(parts, whole):
+        assert np.array_equal(got[20]["psf"], want[20]["psf"]) and got[20]["power"] == want[20]["power"]
