@@ -16,7 +16,7 @@ from .coordinate_break import coordinate_break
 from .parse_config import parse_config
 from .zernike import Zernike
 
-__all__ = ["ABCD", "WFO", "Zernike", "coordinate_break", "parse_config", "run", "run_batch"]
+__all__ = ["ABCD", "WFO", "Zernike", "coordinate_break", "parse_config", "run", "run_batch", "run_sharded"]
 __version__ = "0.1.0"
 
 
@@ -31,4 +31,8 @@ def __getattr__(name):
         from . import run as _run
 
         return getattr(_run, name)
+    if name == "run_sharded":
+        from .dist import run_sharded
+
+        return run_sharded
     raise AttributeError(name)
