@@ -285,3 +285,16 @@ def test_remaining_lens_files_through_the_pass_compiler(name):
         assert np.array_equal(table, g[key + "_table"]), key
         assert [saved[0][k]["propagator"] for k in nums] == list(g[key + "_propagator"])
         assert rel_err(saved[0][nums[-1]]["wfo"], g[key + "_wfo"]) < 1e-12, key
+
+
+def test_package_exports_resolve_lazily():
+    import importlib
+
+    import paos_amd
+
+    for name in paos_amd.__all__:
+        assert getattr(paos_amd, name) is not None, name
+    assert callable(paos_amd.run_batch) and callable(paos_amd.run_sharded)
+    assert callable(importlib.import_module("paos_amd.run").run)
+    with pytest.raises(AttributeError):
+        paos_amd.no_such_thing
