@@ -52,7 +52,6 @@ from paos_amd.chains import (  # noqa: E402
     inject_wfe,
     read_wfe_table,
     syn20_chain,
-    syn20_coefficients,
     syn20_orthonorm_chain,
 )
 
