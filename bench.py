@@ -114,7 +114,7 @@ def main():
 
     def step():
         return run_batch(1.0, wavelengths, n, 4, field, chains, precision=args.precision,
-                         outputs=(), dev=dev, sync=False, stats=stats)
+                         outputs=(), dev=dev, sync=False, stats=stats, keep_psf=True)
 
     def barrier():
         dev.sync()
@@ -181,7 +181,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"SYN20 20-surface chain, {n}x{n} {args.precision}, wavelength sweep "
                                    f"1um*(1+k/512), {nb} wavefronts/GPU/step, {ffts} 2-D FFTs per wavefront "
-                                   f"({n_ptp} ptp, {n_stw} stw, {n_wts} wts)",
+                                   f"({n_ptp} ptp, {n_stw} stw, {n_wts} wts); the final |u|^2 of every wavefront is written "
+                                   f"to HBM (8 B/px) and stays there, powers of the saved surfaces are reduced on the GPU",
                        "grid": n, "batch_per_gpu": nb, "parallelism": f"wavefront-sharded x{world}"},
             "roofline": {"bound": "hbm", "kernel": "frugal_pass_kernel (every FFT pass launch, rows and columns)", "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -95,6 +95,11 @@ int paos_import(paos_ctx* ctx, int item, const void* host_c128);
  * definition of paos/core/plot.py:125-130.  Synchronises. */
 int paos_export(paos_ctx* ctx, int item, int what, void* host_out);
 
+/* PSF = |u|^2 (plot.py:125-130) of EVERY batch item written to a device buffer and kept there
+ * (row-major doubles): the final intensity write of a propagation whose results are consumed on
+ * the GPU or fetched later.  paos_psf_fetch copies one item's PSF to the host (synchronises). */
+int paos_psf_keep(paos_ctx* ctx);
+int paos_psf_fetch(paos_ctx* ctx, int item, double* host_out);
 /* Page-locked host memory for results (no reference counterpart).  paos_export into pageable
  * memory is bounded by first-touch page faults and on-the-fly pinning (~3 GB/s); into a buffer from
  * paos_host_alloc it is one DMA.  paos_export_pinned requires such a buffer. */

@@ -66,6 +66,8 @@ SYMBOLS = {
     "paos_wts": (ctypes.c_int, [_c_ctx, _dbl_p, ctypes.c_int]),
     "paos_run_passes": (ctypes.c_int, [_c_ctx, ctypes.POINTER(Pass), ctypes.c_int, _dbl_p, ctypes.c_int]),
     "paos_zernike": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, _dbl_p, _dbl_p, ctypes.c_int, _dbl_p]),
+    "paos_psf_keep": (ctypes.c_int, [_c_ctx]),
+    "paos_psf_fetch": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p]),
     "paos_host_alloc": (ctypes.c_int, [ctypes.c_ulonglong, ctypes.POINTER(ctypes.c_void_p)]),
     "paos_host_free": (ctypes.c_int, [ctypes.c_void_p]),
     "paos_export_pinned": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
@@ -266,6 +268,15 @@ class DeviceFields:
         out = np.empty((self.n, self.n), dtype=dtype)
         self._check(self._lib.paos_export(self._ctx, int(item), int(what),
                                           out.ctypes.data_as(ctypes.c_void_p)), "paos_export")
+        return out
+
+    def psf_keep(self):
+        """|u|^2 of every item into the context's device-resident PSF buffer (no host copy)."""
+        self._check(self._lib.paos_psf_keep(self._ctx), "paos_psf_keep")
+
+    def psf_fetch(self, item=0):
+        out = np.empty((self.n, self.n), dtype=np.float64)
+        self._check(self._lib.paos_psf_fetch(self._ctx, int(item), _dptr(out)), "paos_psf_fetch")
         return out
 
     # -- operators ------------------------------------------------------------------

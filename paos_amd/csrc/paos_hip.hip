@@ -59,6 +59,7 @@ struct paos_ctx {
   int device = 0, n = 0, batch = 0, precision = 0;
   unsigned pitch = 0, item_stride = 0;
   hipStream_t stream = nullptr;
+  double* psf = nullptr;  // batch x n x n intensities kept on the device (paos_psf_keep)
   void* bounce[2] = {nullptr, nullptr};  // pinned host buffers for device -> pageable host copies
   hipEvent_t bounce_ev[2] = {nullptr, nullptr};
   void* field = nullptr;
@@ -762,6 +763,7 @@ int paos_ctx_destroy(paos_ctx* c) {
   if (c->partial) (void)hipFree(c->partial);
   if (c->norm2) (void)hipFree(c->norm2);
   if (c->norm2_host) (void)hipHostFree(c->norm2_host);
+  if (c->psf) (void)hipFree(c->psf);
   for (int i = 0; i < 2; ++i) {
     if (c->bounce[i]) (void)hipHostFree(c->bounce[i]);
     if (c->bounce_ev[i]) (void)hipEventDestroy(c->bounce_ev[i]);
@@ -891,6 +893,28 @@ int paos_export(paos_ctx* c, int item, int what, void* host_out) {
 int paos_export_pinned(paos_ctx* c, int item, int what, void* pinned_out) {
   if (c) (void)hipSetDevice(c->device);
   return export_impl(c, item, what, pinned_out, true);
+}
+
+int paos_psf_keep(paos_ctx* c) {
+  if (c) (void)hipSetDevice(c->device);
+  if (!c) return fail(c, PAOS_EINVAL, "null context");
+  if (!c->psf) HIPCHK(c, hipMalloc(&c->psf, (size_t)c->batch * c->n * c->n * sizeof(double)));
+  const dim3 grid(pw_blocks(c), c->batch), block(kPwThreads);
+  if (c->precision == PAOS_F64)
+    hipLaunchKernelGGL((intensity_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream,
+                       (const cx<double>*)c->field, c->psf, c->n, c->pitch, c->item_stride);
+  else
+    hipLaunchKernelGGL((intensity_kernel<float, BR, Lay<float>::BC>), grid, block, 0, c->stream,
+                       (const cx<float>*)c->field, c->psf, c->n, c->pitch, c->item_stride);
+  HIPCHK(c, hipGetLastError());
+  return PAOS_OK;
+}
+
+int paos_psf_fetch(paos_ctx* c, int item, double* host_out) {
+  if (c) (void)hipSetDevice(c->device);
+  if (!c || !host_out || item < 0 || item >= c->batch) return fail(c, PAOS_EINVAL, "bad item or null buffer");
+  if (!c->psf) return fail(c, PAOS_EINVAL, "no PSF kept (paos_psf_keep)");
+  return copy_to_host(c, host_out, c->psf + (size_t)item * c->n * c->n, (size_t)c->n * c->n * sizeof(double));
 }
 
 int paos_host_alloc(unsigned long long bytes, void** out) {

@@ -70,6 +70,23 @@ __global__ void export_kernel(const cx<T>* f, double* out, int n, unsigned pitch
   }
 }
 
+// |u|^2 of every batch item, row-major doubles, into a device buffer: the PSF of plot.py:125-130
+// kept in HBM (24 B/px: 16 read + 8 written)
+template <typename T, int BR, int BC>
+__global__ void intensity_kernel(const cx<T>* field, double* out, int n, unsigned pitch, unsigned item_stride) {
+  const int item = blockIdx.y;
+  const cx<T>* f = field + (size_t)item * item_stride;
+  double* o = out + (size_t)item * n * n;
+  const size_t total = item_stride;
+  size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
+    int r, c;
+    if (!layout_unmap<BR, BC>(m, n, pitch, r, c)) continue;
+    const double x = (double)f[m].x, y = (double)f[m].y;
+    o[(size_t)r * n + c] = __dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y));
+  }
+}
+
 // ---- stand-alone pointwise pass (op list without a transform) --------------------
 // Used when a lens (wfo.py:359-366) is not adjacent to an FFT pass it could ride on.
 template <typename T, int BR, int BC>

@@ -385,7 +385,8 @@ def run(pupil_diameter, wavelength, gridsize, zoom, field, opt_chain, precision=
 
 
 def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, precision="fp64",
-              device=0, outputs=("psf",), dev=None, sync=True, stats=None, metrics_radii_px=None):
+              device=0, outputs=("psf",), dev=None, sync=True, stats=None, metrics_radii_px=None,
+              keep_psf=False):
     """Propagate ``B = len(opt_chains)`` wavefronts together on one GPU.
 
     ``wavelengths[i]`` / ``opt_chains[i]`` describe wavefront ``i`` (chains must
@@ -398,7 +399,9 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
     throughput benchmark uses.  ``metrics_radii_px`` (up to 16 radii, pixels) adds
     ``'metrics'`` = power, centroid, peak and encircled power per radius of |u|^2 computed on
     the GPU (about the grid centre) -- what a Monte-Carlo encircled-energy study needs, without
-    moving a PSF.  ``dev`` may pass a pre-allocated
+    moving a PSF.  ``keep_psf`` writes |u|^2 of every item at the LAST surface of the chain (when it
+    is saved) into the context's device-resident PSF buffer (``dev.psf_fetch(i)`` reads one back):
+    the final intensity write of a run whose PSFs stay in HBM.  ``dev`` may pass a pre-allocated
     ``DeviceFields(gridsize, B)`` to reuse across calls.
     """
     nb = len(opt_chains)
@@ -419,6 +422,7 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
     what = {"psf": _lib.WHAT_INTENSITY, "wfo": _lib.WHAT_FIELD, "amplitude": _lib.WHAT_AMPLITUDE,
             "phase": _lib.WHAT_PHASE}
 
+    last_key = list(opt_chains[0].keys())[-1] if len(opt_chains[0]) else None
     tickets = []  # (ticket, [(item index, record)]): powers are fetched after the walk, so the
     # host keeps planning while the GPU works (no mid-chain synchronisation)
 
@@ -438,6 +442,8 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
             met = dev.psf_metrics(metrics_radii_px)
             for i, rec in pending:
                 rec["metrics"] = met[i]
+        if keep_psf and key == last_key:
+            dev.psf_keep()
         tickets.append((dev.norm2_enqueue(), pending))
 
     try:

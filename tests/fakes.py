@@ -75,6 +75,13 @@ class ModelDevice:
             if enable is None or enable[i]:
                 self.u[i] /= np.sqrt(np.sum(np.abs(self.u[i]) ** 2))
 
+    def psf_keep(self):
+        self.log.append(("psf_keep", None))
+        self.psf = np.abs(self.u) ** 2
+
+    def psf_fetch(self, item=0):
+        return self.psf[item].copy()
+
     def start(self, value, shape, blocks, stop=None):
         """paos_start: fill -> aperture -> make_stop on the flagged items."""
         self.log.append(("start", shape))

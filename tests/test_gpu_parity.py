@@ -703,3 +703,24 @@ def test_run_sharded_single_process_matches_run_batch():
     assert [i for i, _ in parts] == [0, 1, 2, 3, 4]
     for (i, got), want in zip(parts, whole):
         assert np.array_equal(got[20]["psf"], want[20]["psf"]) and got[20]["power"] == want[20]["power"]
+
+
+@pytest.mark.gpu
+def test_keep_psf_on_device_matches_download():
+    """run_batch(keep_psf=True): the PSFs of the last surface stay in HBM and read back equal to
+    the ordinary intensity download."""
+    from paos_amd import _lib
+    from paos_amd.chains import syn20_chain, syn20_wavelength
+    from paos_amd.run import run_batch
+
+    field = {"us": 0.0, "ut": 0.0}
+    wls = [syn20_wavelength(100 * k) for k in range(3)]
+    chains = [syn20_chain() for _ in wls]
+    dev = _lib.DeviceFields(256, 3)
+    try:
+        res = run_batch(1.0, wls, 256, 4, field, chains, outputs=("psf",), dev=dev, keep_psf=True)
+        for i in range(3):
+            assert np.array_equal(dev.psf_fetch(i), res[i][20]["psf"])
+            assert abs(res[i][20]["psf"].sum() - res[i][20]["power"]) < 1e-12
+    finally:
+        dev.close()
