@@ -386,7 +386,7 @@ def run(pupil_diameter, wavelength, gridsize, zoom, field, opt_chain, precision=
 
 def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, precision="fp64",
               device=0, outputs=("psf",), dev=None, sync=True, stats=None, metrics_radii_px=None,
-              keep_psf=False):
+              keep_psf=False, power=True):
     """Propagate ``B = len(opt_chains)`` wavefronts together on one GPU.
 
     ``wavelengths[i]`` / ``opt_chains[i]`` describe wavefront ``i`` (chains must
@@ -401,7 +401,9 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
     the GPU (about the grid centre) -- what a Monte-Carlo encircled-energy study needs, without
     moving a PSF.  ``keep_psf`` writes |u|^2 of every item at the LAST surface of the chain (when it
     is saved) into the context's device-resident PSF buffer (``dev.psf_fetch(i)`` reads one back):
-    the final intensity write of a run whose PSFs stay in HBM.  ``dev`` may pass a pre-allocated
+    the final intensity write of a run whose PSFs stay in HBM.  ``power=False`` skips the sum |u|^2
+    reduction per saved surface (the reference does not return it; chains that save a dozen
+    surfaces spend 7 % of their time there).  ``dev`` may pass a pre-allocated
     ``DeviceFields(gridsize, B)`` to reuse across calls.
     """
     nb = len(opt_chains)
@@ -444,7 +446,8 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
                 rec["metrics"] = met[i]
         if keep_psf and key == last_key:
             dev.psf_keep()
-        tickets.append((dev.norm2_enqueue(), pending))
+        if power:
+            tickets.append((dev.norm2_enqueue(), pending))
 
     try:
         _walk(dev, states, list(opt_chains), on_saved, stats=stats, fresh=1.0 + 0.0j)

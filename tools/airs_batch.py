@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """BASELINE.json configs[2]: Ariel_AIRS-CH0.ini, 64-wavelength batch, 2048^2 fp64 on one MI355X,
-results kept in HBM (powers reduced on the GPU).  Meant to run under rocprofv3 --kernel-trace
+results kept in HBM (final PSFs written on the device; `POWER=1` also reduces sum |u|^2 at each of
+the 12 saved surfaces).  Meant to run under rocprofv3 --kernel-trace
 (tools/profile_round.sh style); prints wavefronts/s and the mean time of a pass launch."""
 import os
 import sys
@@ -25,7 +26,7 @@ stats = {}
 
 def step():
     return run_batch(pup, w, n, par["zoom"], fields[0], chains, outputs=(), dev=dev, sync=False, stats=stats,
-                     keep_psf=True)
+                     keep_psf=True, power=os.environ.get("POWER") == "1")
 
 
 step()
