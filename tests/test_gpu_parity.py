@@ -724,3 +724,27 @@ def test_keep_psf_on_device_matches_download():
             assert abs(res[i][20]["psf"].sum() - res[i][20]["power"]) < 1e-12
     finally:
         dev.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["Hubble_simple", "Ariel_AIRS-CH0", "SYN20"])
+def test_off_axis_field_point_vs_reference_vectors(name):
+    """Off-axis field point (decentred apertures, run.py:96-121) against the reference's output."""
+    from paos_amd.chains import syn20_chain
+    from paos_amd.parse_config import parse_config
+    from paos_amd.run import run
+
+    g = load_golden("run_offaxis.npz")
+    field = {"us": float(g["us"]), "ut": float(g["ut"])}
+    if name == "SYN20":
+        pup, wl, zoom, chain = 1.0, 1.0e-6, 4, syn20_chain()
+    else:
+        pup, par, wls, _, chains = parse_config(os.path.join(DATA, "lens", name + ".ini"))
+        wl, zoom, chain = 1.0e-6 * wls[0], par["zoom"], chains[0]
+    ret = run(pup, wl, 64, zoom, field, chain)
+    nums = sorted(ret.keys())
+    assert np.array_equal(nums, g[name + "_nums"])
+    table = np.array([[ret[k][f] for f in ("wl", "dx", "dy", "wz", "distancetofocus", "fratio")] for k in nums])
+    assert np.array_equal(table, g[name + "_table"])
+    assert rel_err(ret[nums[0]]["wfo"], g[name + "_first_wfo"]) < FIELD_TOL
+    assert rel_err(ret[nums[-1]]["wfo"], g[name + "_wfo"]) < FIELD_TOL

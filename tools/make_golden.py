@@ -20,6 +20,8 @@ Vector families:
                       saved surfaces (N=128 SYN20/Hubble, N=64 others)
   run_more_chains.npz the other eight runnable shipped lens files, first and last wavelength:
                       scalars + propagators of the saved surfaces, field of the last one (N=64)
+  run_offaxis.npz     Hubble_simple, Ariel_AIRS-CH0 and SYN20 for an off-axis field point (the ray
+                      vectors move the apertures, run.py:96-121): scalars + last field (N=64)
   orthonorm.npz       PolyOrthoNorm (covariance, M, polynomials) on an elliptical annulus,
                       WFO.zernikes(orthonorm=True), and run() of SYN20 with Zorthonorm (8f-3)
   kat.npz             the reference's own recorded known answers
@@ -297,6 +299,23 @@ def gen_more_chains():
     save("run_more_chains.npz", **out)
 
 
+OFFAXIS = {"us": 5.0e-5, "ut": -2.0e-5}
+
+
+def gen_offaxis(specs):
+    out = {"us": np.float64(OFFAXIS["us"]), "ut": np.float64(OFFAXIS["ut"])}
+    for name in ("Hubble_simple", "Ariel_AIRS-CH0", "SYN20"):
+        s = specs[name]
+        ret = ref_run(s["pup"], s["wl"], 64, s["zoom"], dict(OFFAXIS), s["chain"])
+        nums = np.array(sorted(ret.keys()))
+        out[name + "_nums"] = nums
+        out[name + "_table"] = np.array([[ret[k]["wl"], ret[k]["dx"], ret[k]["dy"], ret[k]["wz"],
+                                          ret[k]["distancetofocus"], ret[k]["fratio"]] for k in nums])
+        out[name + "_wfo"] = ret[nums[-1]]["wfo"]
+        out[name + "_first_wfo"] = ret[nums[0]]["wfo"]
+    save("run_offaxis.npz", **out)
+
+
 def gen_orthonorm():
     """PolyOrthoNorm (zernike.py:320-402) and the Zorthonorm path of run() (run.py:133-141)."""
     out = {}
@@ -373,6 +392,7 @@ def main():
     gen_chain_scalars(specs)
     gen_chain_runs(specs)
     gen_more_chains()
+    gen_offaxis(specs)
     gen_orthonorm()
     gen_kat()
 
