@@ -141,6 +141,17 @@ class PassCompiler:
         self.open = None
         self._open_pass(axis, inv, [(_lib.PW_SCALE, 0, scl)])
 
+    def open_takes_mask(self):
+        """True when a pass is still open whose operator slot after its transform can take an
+        aperture (none there yet, room left): an aperture queued now rides on that pass even if the
+        program is flushed right afterwards."""
+        o = self.open
+        if o is None or self.tail:
+            return False
+        if any(op[0] == _lib.PW_MASK for op in o["mid"]):
+            return False
+        return len(o["mid"]) + 1 <= _lib.MAX_PW
+
     # ---- execution -----------------------------------------------------------------------
     def pending(self):
         return bool(self.passes or self.tail or self.open)

@@ -283,8 +283,10 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None):
         if fuse_ap == "auto":
             # an aperture followed on its own surface by a stop / Zernike / save could only ride
             # on a transform-free pass: the stand-alone aperture kernel is cheaper there
+            # -- unless the previous propagation left a pass open: then the aperture becomes the
+            # last operator of that pass (applied while the tile is stored) at no extra traffic
             aps = [p["aperture"] for p in plans if p["aperture"] is not None]
-            fuse_ap = (bool(aps) and not own_breaker and
+            fuse_ap = (bool(aps) and (not own_breaker or comp.open_takes_mask()) and
                        all(_aperture_fits_line_records(h, o, dev.n, dev.precision) for h, o in aps))
         if fuse_ap:
             _queue_apertures(comp, plans)
