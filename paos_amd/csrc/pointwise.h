@@ -515,8 +515,10 @@ __global__ void start_write_kernel(cx<T>* field, const double* params, int n, un
 //   rectangle: mask = (cx(col)/S)(cy(row)/S) is separable, so along a row the record holds
 //              cx(col)/S and lm = cy(row)/S (and vice versa); obscurations of rectangles are not
 //              separable as 1 - mask and stay on the stand-alone kernel.
+constexpr int kMaskWaves = 4;  // waves (= lines) per workgroup of mask_lines_kernel
+
 template <int SHAPE>
-__global__ void mask_lines_kernel(const double* params, const double* params2, int param_stride, int n,
+__global__ void __launch_bounds__(kMaskWaves * 64) mask_lines_kernel(const double* params, const double* params2, int param_stride, int n,
                                   int axis, MaskLine* lines, double* vals, int* overflow) {
   const int item = blockIdx.y;
   const int line = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -552,7 +554,13 @@ __global__ void mask_lines_kernel(const double* params, const double* params2, i
   const bool line_in_box = axis == 0 ? (line >= box.iymin && line < box.iymax) : (line >= box.ixmin && line < box.ixmax);
   const int scan_lo = line_in_box ? max(0, (axis == 0 ? box.ixmin : box.iymin)) & ~63 : 0;
   const int scan_hi = line_in_box ? min(n, axis == 0 ? box.ixmax : box.iymax) : 0;
-  // pass 1: extents
+  // pass 1: extents.  Chunks of 64 pixels that hold partially covered pixels keep their weights in
+  // a small per-wave LDS cache, so that pass 2 does not evaluate the exact overlap a second time.
+  constexpr int kCache = 6;                           // chunks per line (two edge zones, a few chunks each)
+  __shared__ double cache_w[kMaskWaves][kCache][64];
+  __shared__ int cache_base[kMaskWaves][kCache];
+  const int wave = threadIdx.x >> 6;
+  int ncache = 0;
   for (int base = scan_lo; base < scan_hi; base += 64) {
     const int pos = base + lane;
     const int c = axis == 0 ? pos : line, r = axis == 0 ? line : pos;
@@ -572,24 +580,42 @@ __global__ void mask_lines_kernel(const double* params, const double* params2, i
       if (p1 < 0) p1 = base + (int)__ffsll((long long)is_in) - 1;
       p2i = base + 64 - (int)__clzll((long long)is_in);
     }
+    if ((not_out & ~is_in) != 0 && ncache < kCache) {  // wave-uniform: some pixel is neither out nor in
+      cache_w[wave][ncache][lane] = w;
+      if (lane == 0) cache_base[wave][ncache] = base;
+      ++ncache;
+    }
   }
+  // the cache is written and read by this wave only: order the LDS traffic, no workgroup barrier
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   if (p3 <= p0) { p0 = p1 = p2i = p3 = 0; }           // the line never leaves w_out
   else if (p1 < 0) { p1 = p2i = p3; }                  // no interior: one partial run [p0, p3)
   if (p1 - p0 > kMaskW || p3 - p2i > kMaskW) {
     if (lane == 0) atomicAdd(overflow, 1);
     p0 = p1 = p2i = p3 = 0;
   }
-  // pass 2: partial values
+  // pass 2: partial values, from the cache where the chunk was kept
   for (int side = 0; side < 2; ++side) {
     const int lo = side == 0 ? p0 : p2i, hi = side == 0 ? p1 : p3;
     for (int pos = lo + lane; pos < hi; pos += 64) {
-      const int c = axis == 0 ? pos : line, r = axis == 0 ? line : pos;
-      double mask = 0.0;
-      if (c >= box.ixmin && c < box.ixmax && r >= box.iymin && r < box.iymax) {
-        if (SHAPE == 0) mask = ellipse_pixel(c, r, xc, yc, a, b, 1.0, 0.0, full_disk);
-        else mask = (double)(axis == 0 ? subpixel_count_1d(c, xc, hw, subpix) : subpixel_count_1d(r, yc, hh, subpix)) / (double)subpix;
+      int slot = -1;
+      for (int k = 0; k < ncache; ++k)
+        if (cache_base[wave][k] == (pos & ~63)) slot = k;
+      double w;
+      if (slot >= 0) {
+        w = cache_w[wave][slot][pos & 63];
+      } else {
+        const int c = axis == 0 ? pos : line, r = axis == 0 ? line : pos;
+        double mask = 0.0;
+        if (c >= box.ixmin && c < box.ixmax && r >= box.iymin && r < box.iymax) {
+          if (SHAPE == 0) mask = ellipse_pixel(c, r, xc, yc, a, b, 1.0, 0.0, full_disk);
+          else mask = (double)(axis == 0 ? subpixel_count_1d(c, xc, hw, subpix) : subpixel_count_1d(r, yc, hh, subpix)) / (double)subpix;
+        }
+        w = (SHAPE == 0 && obsc) ? __dsub_rn(1.0, mask) : mask;
       }
-      vout[side * kMaskW + pos - lo] = (SHAPE == 0 && obsc) ? __dsub_rn(1.0, mask) : mask;
+      vout[side * kMaskW + pos - lo] = w;
     }
   }
   if (lane == 0) *out = {p0, p1, p2i, p3, lm, 0.0};
