@@ -95,6 +95,17 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
       const double x = (double)gx * ph[j].sx, y = (double)gy * ph[j].sy;
       const double s = __dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y));
       const double q = __dmul_rn(ph[j].m2, __dmul_rn(ph[j].coef, s));
+      if constexpr (sizeof(T) == 4) {
+        // fp32 mode: the argument is still formed in fp64 like the reference's, reduced to a
+        // fraction of a turn in fp64, and only then handed to the hardware sin / cos (inputs in
+        // revolutions, ~1e-7 absolute) -- the field itself carries no more than that
+        const double turns = q * 0.15915494309189535;  // 1 / (2 pi)
+        const float frac = (float)(turns - rint(turns));
+        const float snf = __builtin_amdgcn_sinf(frac) * (float)ph[j].sgn, csf = __builtin_amdgcn_cosf(frac);
+        const float xr = (float)vd.x, xi = (float)vd.y;
+        vd = {(double)fmaf(xr, csf, -(xi * snf)), (double)fmaf(xr, snf, xi * csf)};
+        continue;
+      }
       double sn, cs;
       sincos_fast(q, &sn, &cs);
       sn *= ph[j].sgn;
