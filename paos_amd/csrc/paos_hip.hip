@@ -350,7 +350,9 @@ int frugal_launch(paos_ctx* c, const FrugalArgs& a) {
   using C = FftCfg<T, N>;
   constexpr int LINES = AXIS == 0 ? C::ROW_LINES : C::COL_LINES;
   constexpr int TILES = AXIS == 0 ? C::ROW_TILES : C::COL_TILES;
-  constexpr bool SPLIT = true;  // several workgroups share the 160 KiB of LDS
+  // several workgroups share the 160 KiB of LDS: c128 exchanges re and im in turn; a c64 line
+  // fits whole (the same 35 KiB) and so needs half the barriers
+  constexpr bool SPLIT = sizeof(T) == 8;
   const dim3 grid(N / LINES / TILES, c->batch), block(TILES * LINES * N / C::E);
   const size_t lds = (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT>() + kTwiddleLds * sizeof(cx<T>);
   auto kern = frugal_pass_kernel<T, N, C::E, LINES, TILES, AXIS, BR, C::BC, SPLIT, KPRE, KMID, NFFT>;
