@@ -154,7 +154,7 @@ struct TableArgs {
   TableJob jobs[kMaxTables];
 };
 
-__global__ void phase_table_kernel(TableArgs a) {
+static __global__ void phase_table_kernel(TableArgs a) {  // static: the header is compiled into several translation units
   const int item = blockIdx.y, tb = blockIdx.z;
   const TableJob job = a.jobs[tb];
   const double* p = a.blocks + ((size_t)job.block * a.batch + item) * FP_STRIDE;

@@ -3,6 +3,12 @@
 // Host side of the library: context / buffer management, the per-call parameter
 // arena (pinned ring -> device), launch geometry per grid size, error mapping.
 // No PyTorch, no hipFFT, no CPU fallback: every operator is a kernel launch.
+// Built either as one translation unit (PAOS_PART undefined) or as six in parallel:
+// -DPAOS_PART=0 (everything but the frugal pass-kernel families) and -DPAOS_PART=1..5 (one family
+// each), linked together -- see Makefile / __graft_entry__.build().
+#ifndef PAOS_PART
+#define PAOS_PART -1
+#endif
 #include "../../include/paos_hip.h"
 
 #include <hip/hip_runtime.h>
@@ -17,7 +23,9 @@
 #include <vector>
 
 #include "frugal_pass.h"
+#if PAOS_PART <= 0
 #include "pointwise.h"
+#endif
 
 using namespace paos;
 
@@ -154,11 +162,13 @@ int copy_to_host(paos_ctx* c, void* host, const void* dev, size_t bytes) {
   return PAOS_OK;
 }
 
+#if PAOS_PART <= 0
 int pw_blocks(const paos_ctx* c) {
   const size_t total = (size_t)c->item_stride;
   size_t b = (total + kPwThreads - 1) / kPwThreads;
   return (int)(b < 2048 ? b : 2048);
 }
+#endif
 
 // ---- FFT launch geometry per grid size ----------------------------------------------
 // Row pass: LINES = BR rows per tile; column pass: LINES = BC columns per tile.
@@ -400,6 +410,46 @@ int frugal_axis(paos_ctx* c, const FrugalArgs& a, int axis, int kpre, int kmid, 
   return axis == 0 ? frugal_kpre<T, N, 0>(c, a, kpre, kmid, nfft) : frugal_kpre<T, N, 1>(c, a, kpre, kmid, nfft);
 }
 
+}  // namespace
+
+// The 48 pass-kernel shapes of one (type, N) family behind one ordinary function, so that the
+// library can be compiled as six translation units in parallel (PAOS_PART, see the top of the
+// file): -1 = everything here, 0 = all but these families, 1..5 = one family each.
+#define PAOS_HIDDEN __attribute__((visibility("hidden")))
+PAOS_HIDDEN int paos_frugal_d1024(paos_ctx* c, const FrugalArgs& a, int axis, int kpre, int kmid, int nfft);
+PAOS_HIDDEN int paos_frugal_d2048(paos_ctx* c, const FrugalArgs& a, int axis, int kpre, int kmid, int nfft);
+PAOS_HIDDEN int paos_frugal_d4096(paos_ctx* c, const FrugalArgs& a, int axis, int kpre, int kmid, int nfft);
+PAOS_HIDDEN int paos_frugal_f2048(paos_ctx* c, const FrugalArgs& a, int axis, int kpre, int kmid, int nfft);
+PAOS_HIDDEN int paos_frugal_f4096(paos_ctx* c, const FrugalArgs& a, int axis, int kpre, int kmid, int nfft);
+#if PAOS_PART < 0 || PAOS_PART == 1
+int paos_frugal_d1024(paos_ctx* c, const FrugalArgs& a, int axis, int kpre, int kmid, int nfft) {
+  return frugal_axis<double, 1024>(c, a, axis, kpre, kmid, nfft);
+}
+#endif
+#if PAOS_PART < 0 || PAOS_PART == 2
+int paos_frugal_d2048(paos_ctx* c, const FrugalArgs& a, int axis, int kpre, int kmid, int nfft) {
+  return frugal_axis<double, 2048>(c, a, axis, kpre, kmid, nfft);
+}
+#endif
+#if PAOS_PART < 0 || PAOS_PART == 3
+int paos_frugal_d4096(paos_ctx* c, const FrugalArgs& a, int axis, int kpre, int kmid, int nfft) {
+  return frugal_axis<double, 4096>(c, a, axis, kpre, kmid, nfft);
+}
+#endif
+#if PAOS_PART < 0 || PAOS_PART == 4
+int paos_frugal_f2048(paos_ctx* c, const FrugalArgs& a, int axis, int kpre, int kmid, int nfft) {
+  return frugal_axis<float, 2048>(c, a, axis, kpre, kmid, nfft);
+}
+#endif
+#if PAOS_PART < 0 || PAOS_PART == 5
+int paos_frugal_f4096(paos_ctx* c, const FrugalArgs& a, int axis, int kpre, int kmid, int nfft) {
+  return frugal_axis<float, 4096>(c, a, axis, kpre, kmid, nfft);
+}
+#endif
+
+#if PAOS_PART <= 0  // ---- everything below belongs to the main translation unit ----------------
+namespace {
+
 // returns PAOS_OK and sets *done when the pass ran on the frugal path
 int try_frugal(paos_ctx* c, const paos_pass& p, const double* host_blocks, const double* dblocks, bool* done) {
   *done = false;
@@ -432,14 +482,14 @@ int try_frugal(paos_ctx* c, const paos_pass& p, const double* host_blocks, const
   FrugalArgs a{c->field, c->tw, reinterpret_cast<const FrugalItem*>(ditems), c->pitch, c->item_stride};
   if (c->precision == PAOS_F64) {
     switch (c->n) {
-      case 1024: rc = frugal_axis<double, 1024>(c, a, p.axis, kpre, kmid, nfft); break;
-      case 2048: rc = frugal_axis<double, 2048>(c, a, p.axis, kpre, kmid, nfft); break;
-      default: rc = frugal_axis<double, 4096>(c, a, p.axis, kpre, kmid, nfft); break;
+      case 1024: rc = paos_frugal_d1024(c, a, p.axis, kpre, kmid, nfft); break;
+      case 2048: rc = paos_frugal_d2048(c, a, p.axis, kpre, kmid, nfft); break;
+      default: rc = paos_frugal_d4096(c, a, p.axis, kpre, kmid, nfft); break;
     }
   } else {
     switch (c->n) {
-      case 2048: rc = frugal_axis<float, 2048>(c, a, p.axis, kpre, kmid, nfft); break;
-      default: rc = frugal_axis<float, 4096>(c, a, p.axis, kpre, kmid, nfft); break;
+      case 2048: rc = paos_frugal_f2048(c, a, p.axis, kpre, kmid, nfft); break;
+      default: rc = paos_frugal_f4096(c, a, p.axis, kpre, kmid, nfft); break;
     }
   }
   if (rc == PAOS_OK) *done = true;
@@ -1232,3 +1282,5 @@ int paos_zernike_gram(paos_ctx* c, int nmax, int kdim, const double* table, cons
 }
 
 }  // extern "C"
+
+#endif  // PAOS_PART <= 0

@@ -147,7 +147,7 @@ __global__ void norm2_partial_kernel(const cx<T>* field, double* partial, int n,
   if (threadIdx.x == 0) partial[(size_t)item * gridDim.x + blockIdx.x] = s;
 }
 
-__global__ void norm2_final_kernel(const double* partial, double* norm2, int nparts,
+static __global__ void norm2_final_kernel(const double* partial, double* norm2, int nparts,
                                    const double* enable, int enable_stride) {
   const int item = blockIdx.x;
   if (enable && enable[(size_t)item * enable_stride] == 0.0) return;
@@ -188,7 +188,7 @@ struct MetricArgs {
 };
 
 template <typename T, int BR, int BC>
-__global__ void psf_metrics_kernel(MetricArgs a) {
+static __global__ void psf_metrics_kernel(MetricArgs a) {
   const int item = blockIdx.y;
   __shared__ double sh[kPwThreads / 64];
   const cx<T>* f = reinterpret_cast<const cx<T>*>(a.field) + (size_t)item * a.item_stride;
@@ -229,7 +229,7 @@ __global__ void psf_metrics_kernel(MetricArgs a) {
   }
 }
 
-__global__ void psf_metrics_final_kernel(const double* partial, double* out, int nblocks, int nvals) {
+static __global__ void psf_metrics_final_kernel(const double* partial, double* out, int nblocks, int nvals) {
   const int item = blockIdx.x, k = threadIdx.x;
   if (k >= nvals) return;
   double s = 0.0;
@@ -809,7 +809,7 @@ __global__ void __launch_bounds__(kGramThreads)
 }
 
 // out[item][q] = sum over workgroups, in order
-__global__ void zernike_gram_final_kernel(const double* partial, double* out, int nblocks, int nvals) {
+static __global__ void zernike_gram_final_kernel(const double* partial, double* out, int nblocks, int nvals) {
   const int item = blockIdx.y;
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nvals) return;
