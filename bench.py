@@ -64,6 +64,41 @@ def cpu_baseline(gridsize):
     }
 
 
+def _oracle_seconds(task):
+    """Worker of the parallel CPU baseline: one wavefront of the sweep, returns its wall time."""
+    k, n_s = task
+    from oracle.run_np import run as oracle_run
+    from paos_amd.chains import syn20_chain, syn20_wavelength
+
+    t0 = time.perf_counter()
+    oracle_run(1.0, syn20_wavelength(k), n_s, 4, {"us": 0.0, "ut": 0.0}, syn20_chain(), light=True)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline_parallel(gridsize, workers=8):
+    """The reference's own way to use a CPU (pipeline.py:140: joblib over wavelengths): ``workers``
+    processes, one wavelength of the sweep each, 2048^2, scaled like cpu_baseline.  Must run BEFORE
+    this process touches the GPU (the workers are forked)."""
+    import multiprocessing as mp
+
+    n_s = min(gridsize, 2048)
+    workers = max(1, min(workers, os.cpu_count() or 1))
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(workers) as pool:
+        each = pool.map(_oracle_seconds, [(64 * k, n_s) for k in range(workers)])
+    wall = time.perf_counter() - t0
+    scale = (gridsize / n_s) ** 2
+    return {
+        "value": workers / (wall * scale),
+        "unit": "wavefronts/s",
+        "cores": workers,
+        "kind": "port",
+        "sample": f"{workers} worker processes (the reference fans out over wavelengths with joblib, "
+                  f"pipeline.py:140), one SYN20 wavefront each at {n_s}x{n_s}: {wall:.1f} s wall "
+                  f"({min(each):.1f}-{max(each):.1f} s per worker); scaled by {scale:g}x pixels",
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,6 +117,11 @@ def main():
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         args.gpus = world
+
+    # forked CPU workers: before anything initialises the GPU in this process
+    cpu_parallel = None
+    if world == 1 and not args.no_cpu_baseline:
+        cpu_parallel = cpu_baseline_parallel(args.grid)
 
     dist = None
     if world > 1 or os.environ.get("PAOS_BENCH_FORCE_DIST") == "1":  # the flag exercises the
@@ -206,6 +246,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n)
+            out["cpu_baseline_parallel"] = cpu_parallel
         print(json.dumps(out), flush=True)
     dev.close()
     if dist is not None:
