@@ -330,10 +330,9 @@ __device__ __forceinline__ void unpermute_slots(cx<T>* v) {
 
 // --------------------------------------------------------------------------
 // HBM layout of a field.  Blocks of BR rows x BC columns are contiguous, blocks
-// are ordered row-major.  BR = 1 is plain row-major.  With c128 and
-// BR x BC = 2 x 4 a block is exactly one 128-byte line in either direction, so
-// the row pass (2 rows per workgroup) and the column pass (4 columns per
-// workgroup) both move whole lines.
+// are ordered row-major.  BR = 1 is plain row-major.  The library uses BR x BC = 4 x 2: with
+// c128 a block is exactly one 128-byte line, which the column pass (2 columns per workgroup)
+// moves whole and the row pass moves whole (4 rows per workgroup) or in halves (2 rows, N >= 2048).
 // ``pitch`` = elements from one block-row to the next: n * BR when dense; the
 // context pads it by a few blocks so that the column pass (stride = pitch) does
 // not march through HBM channels with a power-of-two stride.

@@ -30,11 +30,11 @@
 using namespace paos;
 
 // ---- build-time layout choice -------------------------------------------------------
-// A field is stored as 128-byte blocks of 4 rows x (2 complex128 | 4 complex64) columns,
-// blocks row-major, so one cache line is a unit of work for the row pass (4 rows per
-// workgroup) and for the column pass (2|4 columns per workgroup) alike (DESIGN.md
+// A field is stored as blocks of 4 rows x 2 columns (128 B of complex128, 64 B of complex64),
+// blocks row-major, so whole or half cache lines are the unit of work for the row pass (2 or 4
+// rows per workgroup) and for the column pass (2 columns per workgroup) alike (DESIGN.md
 // section 2).  PAD_BLOCKS extra blocks per block row de-tune the power-of-two stride of
-// the column pass (measured: 3.5 -> 4.8 TB/s at 4096^2, profiles/r01_fftbench.txt).
+// the column pass (measured: 3.5 -> 4.8 TB/s at 4096^2, profiles/r01_fftbench_v2_pitchpad.txt).
 #ifndef PAOS_BR
 #define PAOS_BR 4
 #endif
