@@ -42,7 +42,7 @@ using namespace paos;
 #define PAOS_PAD_BLOCKS 3
 #endif
 static constexpr int BR = PAOS_BR;
-static constexpr int kNormSlots = 64;  // outstanding paos_norm2_enqueue results
+[[maybe_unused]] static constexpr int kNormSlots = 64;  // outstanding paos_norm2_enqueue results
 template <typename T>
 struct Lay {
   // 2 columns for both types: a block is 128 B of complex128 or 64 B of complex64.  (4 columns
