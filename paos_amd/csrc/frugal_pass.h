@@ -158,7 +158,10 @@ template <typename T, int N, int E, int LINES, int TILES, int AXIS, int BR, int 
 __global__ void __launch_bounds__(TILES* LINES* N / E, 4)
     frugal_pass_kernel(FrugalArgs a) {
   const int item = blockIdx.y;
-  const FrugalItem& it = a.items[item];
+  // constant address space: the per-item records are invariant during the kernel, so the scalar
+  // loads of their fields may be kept or merged across the workgroup barriers instead of re-issued
+  typedef const __attribute__((address_space(4))) FrugalItem* ConstItemPtr;
+  const FrugalItem& it = *(const FrugalItem*)((ConstItemPtr)a.items + item);
   if (it.active == 0.0) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const TileMap<N, E, LINES, TILES, AXIS, BR, BC> m(blockIdx.x, threadIdx.x, a.pitch);
