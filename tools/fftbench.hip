@@ -141,9 +141,9 @@ void bench_variant(const char* name, int batch, int reps, int pad_blocks = 0) {
   CK(hipFree(dtw));
 }
 
-template <typename T, int N, int AXIS, int KPRE, int KMID, int NFFT>
+template <typename T, int N, int AXIS, int KPRE, int KMID, int NFFT, int LINES = 2>
 void bench_frugal(const char* name, int batch, int reps, int pad_blocks) {
-  constexpr int E = 16, LINES = 2, BR = 4, BC = 2;
+  constexpr int E = 16, BR = 4, BC = 2;
   const unsigned pitch = (unsigned)N * BR + (unsigned)pad_blocks * BR * BC;
   const unsigned item_stride = pitch * (N / BR);
   cx<T>* d;
@@ -211,6 +211,8 @@ int main(int argc, char** argv) {
   bench_frugal<double, 4096, 1, 0, 0, 1>("frugal cols single", b4, reps, pad);
   bench_frugal<double, 4096, 0, 0, 1, 2>("frugal rows double 1 phase", b4, reps, pad);
   bench_frugal<double, 4096, 1, 0, 1, 2>("frugal cols double 1 phase", b4, reps, pad);
+  bench_frugal<double, 4096, 0, 0, 0, 1, 4>("frugal rows single, 4-row tiles (1024 thr)", b4, reps, pad);
+  bench_frugal<double, 4096, 0, 0, 1, 2, 4>("frugal rows double 1 phase, 4-row tiles", b4, reps, pad);
   bench_frugal<double, 4096, 0, 1, 2, 2>("frugal rows double 1+2 phases", b4, reps, pad);
   bench_frugal<double, 4096, 0, 2, 3, 2>("frugal rows double 2+3 phases", b4, reps, pad);
   return 0;
