@@ -130,8 +130,14 @@ def main():
         import torch
         import torch.distributed as dist
 
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("PAOS_BENCH_REHEARSAL") == "1":
+            # several ranks sharing ONE GPU over gloo: rehearses the N > 1 control flow (broadcast,
+            # shards, barrier, MAX reduction) on a single-GPU box; the numbers mean nothing
+            local_rank = 0
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from paos_amd import _lib
     from paos_amd.chains import syn20_chain
@@ -160,9 +166,10 @@ def main():
         dev.sync()
         if dist is not None:
             dist.barrier()
-            import torch
+            if dist.get_backend() == "nccl":
+                import torch
 
-            torch.cuda.synchronize()
+                torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
