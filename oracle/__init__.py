@@ -13,7 +13,7 @@ product path fails loudly if the HIP library is missing.
 Pinning (see tests/test_oracle_golden.py and DESIGN.md section 3):
   * everything except aperture-mask VALUES is pinned to golden vectors generated
     by importing the reference itself in the build container
-    (tools/make_golden.py -> tests/golden/*.npz) plus the reference's own
+    (tests/golden_tools/make_golden.py -> tests/golden/*.npz) plus the reference's own
     notebook known-answers (SURVEY.md section 9.9);
   * aperture-mask values come from photutils 1.11.0 (poetry.lock:2360), which is
     absent from /root/reference and from this image: that boundary is

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Generate golden vectors by running the PAOS reference itself (build container only).
 
-    python tools/make_golden.py            # writes tests/golden/*.npz
+    python tests/golden_tests/golden_tools/make_golden.py   # writes tests/golden/*.npz
 
 The reference tree (/root/reference, read-only) is imported UNMODIFIED through
-tools/ref_import.py (stub modules only for absent third-party packages).  The
+tests/golden_tests/golden_tools/ref_import.py (stub modules only for absent third-party packages).  The
 only non-reference arithmetic in these vectors is the aperture-mask VALUES,
 which come from oracle/aperture_np.py through the photutils stub classes
 (photutils is absent; SURVEY.md 8c, "parity unpinned" at that boundary).
@@ -33,7 +33,7 @@ import sys
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-ROOT = os.path.dirname(HERE)
+ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 sys.path.insert(0, ROOT)
 

@@ -1,6 +1,6 @@
 """Import the PAOS reference (read-only, /root/reference) in THIS container only.
 
-Used exclusively by tools/make_golden.py to generate golden fixtures; never
+Used exclusively by tests/golden_tools/make_golden.py to generate golden fixtures; never
 shipped to the GPU box (the reference does not travel).  Recipe from SURVEY.md
 section 8c: a fake ``paos`` package whose __path__ points at the reference tree
 (bypassing paos/__init__.py, which needs loguru + package metadata), a no-op

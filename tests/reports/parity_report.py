@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Print the measured GPU-vs-oracle errors (fields, PSF) for DESIGN.md / profiles.
 
-    python tools/parity_report.py [--sizes 256 512 1024] > profiles/rNN_parity.txt
+    python tests/reports/parity_report.py [--sizes 256 512 1024] > profiles/rNN_parity.txt
 """
 import argparse
 import os
@@ -10,7 +10,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 from oracle.run_np import run as oracle_run  # noqa: E402

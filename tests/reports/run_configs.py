@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Run the five BASELINE.json configurations on one MI355X and print what was measured.
 
-    python tools/run_configs.py > profiles/rNN_baseline_configs.txt
+    python tests/reports/run_configs.py > profiles/rNN_baseline_configs.txt
 
 Multi-GPU configs (4, 5) are run here as their single-GPU shard (the driver's scaling run
 covers N > 1); parity is checked against the NumPy oracle on one item per config at a size
@@ -13,7 +13,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 from oracle.run_np import run as oracle_run  # noqa: E402
@@ -45,7 +45,7 @@ def timed_batch(pup, wls, n, zoom, field, chains, precision="fp64", reps=3, outp
 
 
 def main():
-    print("# BASELINE.json configs on 1 x MI355X (see tools/run_configs.py)")
+    print("# BASELINE.json configs on 1 x MI355X (see tests/reports/run_configs.py)")
 
     # 1. Hubble_simple, 1 wavelength, 512^2: the reference's own CPU-runnable case
     pup, par, wls, fields, chains = parse_config(os.path.join(LENS, "Hubble_simple.ini"))
