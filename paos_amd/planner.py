@@ -213,6 +213,25 @@ def jacobi_recurrence(nmax):
     return tab
 
 
+_BLOCK_TEMPLATES = {}
+
+
+def _block_template(m, n, norm, nmax):
+    """Where each polynomial's coefficient lands in the [|m|][k] planes, and its (-1)^k * norm
+    prefactor -- the same for every wavefront of a batch, so computed once per (m, n, norm, nmax)."""
+    key = (m.tobytes(), n.tobytes(), np.asarray(norm, dtype=np.float64).tobytes(), int(nmax))
+    hit = _BLOCK_TEMPLATES.get(key)
+    if hit is None:
+        kdim = nmax // 2 + 1
+        k = (n - np.abs(m)) // 2
+        pref = np.array([(-1.0) ** int(kk) * float(nrm) for kk, nrm in zip(k, norm)], dtype=np.float64)
+        flat = np.abs(m) * kdim + k
+        if len(_BLOCK_TEMPLATES) > 256:
+            _BLOCK_TEMPLATES.clear()
+        hit = _BLOCK_TEMPLATES[key] = (pref, flat[m >= 0], m >= 0, flat[m < 0], m < 0, kdim)
+    return hit
+
+
 def zernike_block(m, n, norm, coeffs, dx, dy, radius, wl, origin="x", offset_deg=0.0, nmax=None):
     """Per-item parameter block of paos_zernike: header + cos / sin coefficient
     planes indexed [|m|][k], k = (n - |m|)/2, with (-1)^k * norm * Z folded in."""
@@ -220,21 +239,17 @@ def zernike_block(m, n, norm, coeffs, dx, dy, radius, wl, origin="x", offset_deg
     n = np.asarray(n, dtype=int)
     if nmax is None:
         nmax = int(n.max())
-    kdim = nmax // 2 + 1
-    cosp = np.zeros((nmax + 1, kdim), dtype=np.float64)
-    sinp = np.zeros((nmax + 1, kdim), dtype=np.float64)
-    for mk, nk, nrm, ck in zip(m, n, norm, coeffs):
-        k = (nk - abs(mk)) // 2
-        val = (-1.0) ** k * nrm * ck
-        if mk >= 0:
-            cosp[abs(mk), k] += val
-        else:
-            sinp[abs(mk), k] += val
+    pref, at_cos, is_cos, at_sin, is_sin, kdim = _block_template(m, n, norm, nmax)
+    vals = pref * np.asarray(coeffs, dtype=np.float64)  # ((-1)^k * norm) * Z, term by term
+    cosp = np.zeros((nmax + 1) * kdim, dtype=np.float64)
+    sinp = np.zeros((nmax + 1) * kdim, dtype=np.float64)
+    np.add.at(cosp, at_cos, vals[is_cos])  # += like the loop form (repeated indices accumulate)
+    np.add.at(sinp, at_sin, vals[is_sin])
     if origin not in ("x", "y"):
         raise ValueError(f"Origin {origin} not recognised. Origin shall be either x or y")
     off = np.deg2rad(offset_deg)
     head = [1.0, dx, dy, radius, 1.0 if origin == "y" else 0.0, np.cos(off), np.sin(off), 1.0 / wl]
-    return np.concatenate([head, cosp.ravel(), sinp.ravel()]), nmax, kdim
+    return np.concatenate([head, cosp, sinp]), nmax, kdim
 
 
 def gram_polynomials(m, n, norm):

@@ -29,7 +29,7 @@ from .coordinate_break import coordinate_break
 from .passes import PassCompiler
 from .planner import (PilotBeam, gram_polynomials, jacobi_recurrence, orthonorm_matrix,
                       zernike_block)
-from .zernike import Zernike, norm_factors
+from .zernike import zernike_tables
 
 # Apertures ride on FFT passes as PW_MASK operators when the library can hold them as per-line
 # records (csrc/frugal_pass.h: MaskLine; complex128, N >= 1024, untilted ellipse whose partial
@@ -114,19 +114,20 @@ def _plan_surface(st, item):
         ordering = item["Zordering"]
         if ordering not in ("ansi", "noll", "fringe", "standard"):
             raise AssertionError("Unrecognised ordering scheme.")
-        m, n = Zernike.j2mn(len(index), ordering)
-        plan["zernike"] = dict(m=m, n=n, norm=norm_factors(m, n, item["Znormalize"]),
+        m, n, norm = zernike_tables(len(index), ordering, bool(item["Znormalize"]))
+        plan["zernike"] = dict(m=m, n=n, norm=norm,
                                Z=np.asarray(item["Z"], dtype=np.float64), dx=beam.dx, dy=beam.dy,
                                radius=radius, wl=beam.wl, origin=item["Zorigin"], pupil=pupil)
     if item["type"] in ("Grid Sag", "PSD"):
         raise NotImplementedError(f"surface type {item['type']} is outside the accelerated path")
 
     # push_results scalars (run.py:12-27) are those BEFORE magnification / lens / propagate
-    plan["scalars"] = {
-        "wz": beam.wz, "distancetofocus": beam.distancetofocus, "fratio": beam.fratio,
-        "dx": beam.dx, "dy": beam.dy, "wl": beam.wl, "extent": beam.extent,
-        "propagator": beam.propagator,
-    }
+    if item["save"]:
+        plan["scalars"] = {
+            "wz": beam.wz, "distancetofocus": beam.distancetofocus, "fratio": beam.fratio,
+            "dx": beam.dx, "dy": beam.dy, "wl": beam.wl, "extent": beam.extent,
+            "propagator": beam.propagator,
+        }
 
     Ms = item["ABCDs"].M
     Mt = item["ABCDt"].M

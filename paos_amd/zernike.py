@@ -10,6 +10,8 @@ pinned for the first 400 indices of every ordering (tests/golden/zernike_index.n
 """
 import math
 
+import functools
+
 import numpy as np
 
 ORDERINGS = ("ansi", "noll", "fringe", "standard")
@@ -53,12 +55,8 @@ class Zernike:
 
     @staticmethod
     def j2mn(N, ordering):
-        if ordering not in _TABLE:
-            raise NameError("Ordering not supported.")
-        pairs = [_TABLE[ordering](j) for j in range(int(N))]
-        m = np.array([p[0] for p in pairs], dtype=int)
-        n = np.array([p[1] for p in pairs], dtype=int)
-        return m, n
+        m, n = _j2mn_cached(int(N), ordering)
+        return m.copy(), n.copy()
 
     @staticmethod
     def mn2j(m, n, ordering):
@@ -79,6 +77,29 @@ class Zernike:
             bump = np.where(low, m <= 0, m >= 0).astype(np.int64)
             return (n * (n + 1) // 2 + am + bump).astype(np.int64)
         raise NameError("Ordering not supported.")
+
+
+@functools.lru_cache(maxsize=64)
+def _j2mn_cached(count, ordering):
+    """Index tables are pure functions of (count, ordering); the planner asks for them once per
+    wavefront and Zernike surface.  The cached arrays are read-only."""
+    if ordering not in _TABLE:
+        raise NameError("Ordering not supported.")
+    pairs = [_TABLE[ordering](j) for j in range(count)]
+    m = np.array([p[0] for p in pairs], dtype=int)
+    n = np.array([p[1] for p in pairs], dtype=int)
+    m.setflags(write=False)
+    n.setflags(write=False)
+    return m, n
+
+
+@functools.lru_cache(maxsize=64)
+def zernike_tables(count, ordering, normalize):
+    """(m, n, norm) of the first ``count`` polynomials, read-only and shared between calls."""
+    m, n = _j2mn_cached(int(count), ordering)
+    norm = norm_factors(m, n, normalize)
+    norm.setflags(write=False)
+    return m, n, norm
 
 
 def norm_factors(m, n, normalize):
