@@ -38,6 +38,7 @@ enum { PAOS_PW_SIGN = 1, PAOS_PW_QPHASE_CENTRED = 2, PAOS_PW_QPHASE_NATURAL = 3,
        PAOS_PW_MASK = 5 };
 enum { PAOS_PWF_MUL2PI = 1 };
 enum { PAOS_MAX_PW = 6 };
+enum { PAOS_NORM_SLOTS = 64 };  /* outstanding paos_norm2_enqueue tickets */
 enum { PAOS_WHAT_FIELD = 0, PAOS_WHAT_AMPLITUDE = 1, PAOS_WHAT_PHASE = 2, PAOS_WHAT_INTENSITY = 3 };
 
 /* parameter-block layouts (doubles per batch item) */
@@ -121,7 +122,9 @@ int paos_make_stop(paos_ctx* ctx, const double* enable);
 /* sum |u|^2 per item to the host (np.sum(np.abs(u)**2), wfo.py:200).  Synchronises. */
 int paos_norm2(paos_ctx* ctx, double* host_out);
 /* The same without stalling the host: enqueue the reduction and its copy to pinned memory,
- * get a ticket (up to 64 outstanding), fetch after the work was synchronised. */
+ * get a ticket, fetch later (the fetch synchronises).  At most PAOS_NORM_SLOTS tickets may be
+ * outstanding: one more paos_norm2_enqueue fails with PAOS_EINVAL until a ticket is fetched, and
+ * a ticket can be fetched once. */
 int paos_norm2_enqueue(paos_ctx* ctx, int* ticket);
 int paos_norm2_fetch(paos_ctx* ctx, int ticket, double* host_out);
 /* PSF metrics on the GPU for Monte-Carlo studies (the encircled-energy workflow of
@@ -134,6 +137,11 @@ int paos_psf_metrics(paos_ctx* ctx, int nr, const double* radii_px, double cx_px
  * indices: the field part of WFO.lens (wfo.py:359-366) with mul2pi = 1, sgn = -1,
  * coef = 0.5 lens_phase / wl. */
 int paos_phase(paos_ctx* ctx, const double* params, int mul2pi);
+/* Tabulated phase screen, the field part of WFO.grid_sag (wfo.py:869-871) and WFO.psd
+ * (wfo.py:945-949): u[item] *= exp(2 pi i wfe / wl) with wfe a host map in metres (row-major
+ * n x n doubles, finite: masked pixels filled with 0 as the reference does).  The resampling of a
+ * sag map and the random draw of a PSD screen stay on the host (paos_amd/wfo.py).  Synchronises. */
+int paos_phase_map(paos_ctx* ctx, int item, const double* host_wfe, double wl);
 /* WFO.ptp (wfo.py:462-472): ifft2(exp(-i coef (fx^2+fy^2)) fft2(u)), ortho norms, shifts
  * cancelled; sx, sy = 1/(n dx), 1/(n dy) (np.fft.fftfreq spacing), coef = pi wl dz. */
 int paos_ptp(paos_ctx* ctx, const double* params);

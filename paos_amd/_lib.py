@@ -21,6 +21,7 @@ KERNEL_PASS_ROWS, KERNEL_PASS_COLS, KERNEL_PASS_ANY = 0, 1, 2
 PW_SIGN, PW_QPHASE_CENTRED, PW_QPHASE_NATURAL, PW_SCALE, PW_MASK = 1, 2, 3, 4, 5
 PWF_MUL2PI = 1
 MAX_PW = 6
+NORM_SLOTS = 64  # PAOS_NORM_SLOTS: tickets of paos_norm2_enqueue that may be outstanding
 
 
 class PwOp(ctypes.Structure):
@@ -61,6 +62,7 @@ SYMBOLS = {
     "paos_norm2_fetch": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p]),
     "paos_psf_metrics": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p, ctypes.c_double, ctypes.c_double, _dbl_p]),
     "paos_phase": (ctypes.c_int, [_c_ctx, _dbl_p, ctypes.c_int]),
+    "paos_phase_map": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p, ctypes.c_double]),
     "paos_ptp": (ctypes.c_int, [_c_ctx, _dbl_p]),
     "paos_stw": (ctypes.c_int, [_c_ctx, _dbl_p, ctypes.c_int]),
     "paos_wts": (ctypes.c_int, [_c_ctx, _dbl_p, ctypes.c_int]),
@@ -331,6 +333,13 @@ class DeviceFields:
     def phase(self, blocks, mul2pi):
         b = as_blocks(blocks, self.batch, PHASE_STRIDE)
         self._check(self._lib.paos_phase(self._ctx, _dptr(b), int(bool(mul2pi))), "paos_phase")
+
+    def phase_map(self, item, wfe, wl):
+        """u[item] *= exp(2 pi i wfe / wl) for a host map (metres) -- wfo.py:869-871, 945-949."""
+        w = np.ascontiguousarray(wfe, dtype=np.float64)
+        if w.shape != (self.n, self.n):
+            raise ValueError(f"phase map must have shape {(self.n, self.n)}")
+        self._check(self._lib.paos_phase_map(self._ctx, int(item), _dptr(w), float(wl)), "paos_phase_map")
 
     def ptp(self, blocks):
         b = as_blocks(blocks, self.batch, PHASE_STRIDE)

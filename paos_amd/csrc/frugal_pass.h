@@ -56,12 +56,33 @@ struct FrugalItem {
 
 constexpr int kTwiddleLds = 256;  // table entries the stage twiddles can address: k N / (NS R) < N / R <= 256
 
+// PAOS_STAMPS (tools/fftbench.hip timeline builds only): wave 0 of every workgroup records
+// s_memtime at the phase boundaries plus where it ran (HW_ID, XCC_ID) into FrugalArgs::stamps.
+#ifndef PAOS_STAMPS
+#define PAOS_STAMPS 0
+#endif
+constexpr int kStampSlots = 12;
+
 struct FrugalArgs {
   void* field;
   const void* tw;
   const FrugalItem* items;  // [batch]
   unsigned pitch, item_stride;
+#if PAOS_STAMPS
+  unsigned long long* stamps;  // [gridDim.y][gridDim.x][kStampSlots]
+#endif
 };
+#if PAOS_STAMPS
+#define PAOS_STAMP(i)                                                                              \
+  do {                                                                                             \
+    if (threadIdx.x == 0)                                                                          \
+      a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kStampSlots + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#define PAOS_STAMP_WAIT_VM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#else
+#define PAOS_STAMP(i) do { } while (0)
+#define PAOS_STAMP_WAIT_VM() do { } while (0)
+#endif
 
 template <typename T, int N, int E, int K, typename Map>
 __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, const FrugalPhase* ph,
@@ -174,24 +195,45 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, 4)
   for (int i = threadIdx.x; i < kTwiddleLds; i += TILES * LINES * N / E)
     tw_lds[i] = reinterpret_cast<const cx<T>*>(a.tw)[i];
   const cx<T>* tw = tw_lds;
+#if PAOS_STAMPS
+  if (threadIdx.x == 0) {
+    unsigned long long* st = a.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kStampSlots;
+    st[8] = __builtin_amdgcn_s_memrealtime();
+    st[9] = ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | 4);
+  }
+#endif
+  PAOS_STAMP(0);
 
   cx<T> v[E];
 #pragma unroll
   for (int k = 0; k < E; ++k) v[k] = stream_load<AXIS == 1>(&f[m.base + (unsigned)k * m.stride]);
   __builtin_amdgcn_sched_barrier(0);
+  PAOS_STAMP_WAIT_VM();
+  PAOS_STAMP(1);
 
   frugal_slot<T, N, E, KPRE>(v, it.pre, it.pre_ph, m);
+  PAOS_STAMP(2);
   const bool ran1 = it.fft1_on != 0.0;
   if (ran1) frugal_fft<T, N, E, SPLIT>(v, lds, m.t, tw, it.fft1_inv);
+  PAOS_STAMP(3);
   frugal_slot<T, N, E, KMID>(v, it.mid, it.mid_ph, m);
+  PAOS_STAMP(4);
   if constexpr (NFFT == 2) {
     if (it.fft2_on != 0.0) {
       if (ran1) __syncthreads();
       frugal_fft<T, N, E, SPLIT>(v, lds, m.t, tw, it.fft2_inv);
     }
   }
+  PAOS_STAMP(5);
 #pragma unroll
   for (int k = 0; k < E; ++k) stream_store<AXIS == 1>(&f[m.base + (unsigned)k * m.stride], v[k]);
+  PAOS_STAMP(6);
+  PAOS_STAMP_WAIT_VM();
+  PAOS_STAMP(7);
+#if PAOS_STAMPS
+  if (threadIdx.x == 0)
+    a.stamps[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kStampSlots + 10] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 }  // namespace paos

@@ -18,8 +18,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <set>
 #include <string>
-#include <unordered_set>
+#include <utility>
 #include <vector>
 
 #include "frugal_pass.h"
@@ -42,7 +44,7 @@ using namespace paos;
 #define PAOS_PAD_BLOCKS 3
 #endif
 static constexpr int BR = PAOS_BR;
-[[maybe_unused]] static constexpr int kNormSlots = 64;  // outstanding paos_norm2_enqueue results
+[[maybe_unused]] static constexpr int kNormSlots = PAOS_NORM_SLOTS;  // outstanding paos_norm2_enqueue results
 template <typename T>
 struct Lay {
   // 2 columns for both types: a block is 128 B of complex128 or 64 B of complex64.  (4 columns
@@ -85,6 +87,7 @@ struct paos_ctx {
   double* norm2 = nullptr;
   double* norm2_host = nullptr;  // pinned, kNormSlots x batch
   int norm_slot = 0;
+  bool norm_busy[64] = {};       // ticket handed out and not fetched yet (kNormSlots entries)
   int nparts = 0;
   Arena arena;
   std::string err;
@@ -112,6 +115,35 @@ int fail(paos_ctx* c, int code, const std::string& msg) {
   } while (0)
 
 size_t elem_bytes(const paos_ctx* c) { return c->precision == PAOS_F64 ? 16 : 8; }
+
+// Make room for `total` doubles of pushes that must ALL stay live until the work enqueued with
+// them has run (a pass program: its block table plus one record set per pass).  A ring wrap in the
+// middle of such a sequence would overwrite parameters that later launches still read, so the
+// wrap (one stream synchronisation) or a growth of the arena happens here, before the first push.
+int arena_reserve(paos_ctx* c, size_t total) {
+  Arena& a = c->arena;
+  total += 64;  // rounding of the individual pushes
+  if (total > a.cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    size_t cap = a.cap;
+    while (cap < total) cap *= 2;
+    double *h = nullptr, *d = nullptr;
+    HIPCHK(c, hipHostMalloc(&h, cap * sizeof(double)));
+    if (hipMalloc(&d, cap * sizeof(double)) != hipSuccess) {
+      (void)hipHostFree(h);
+      return fail(c, PAOS_EHIP, "hipMalloc(arena growth)");
+    }
+    (void)hipHostFree(a.host);
+    (void)hipFree(a.dev);
+    a.host = h; a.dev = d; a.cap = cap; a.head = 0;
+    return PAOS_OK;
+  }
+  if (a.head + total > a.cap) {
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    a.head = 0;
+  }
+  return PAOS_OK;
+}
 
 // copy `count` doubles into the arena; returns the device pointer through *dev
 int arena_push(paos_ctx* c, const double* src, size_t count, const double** dev) {
@@ -195,14 +227,24 @@ struct FftCfg {
   static constexpr int MINW = 1;
 };
 
+int opt_in_lds(paos_ctx* c, const void* kern, size_t lds) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> configured;
+  std::lock_guard<std::mutex> lock(mu);
+  const std::pair<int, const void*> key(c->device, kern);
+  if (configured.count(key)) return PAOS_OK;
+  HIPCHK(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  configured.insert(key);
+  return PAOS_OK;
+}
+
 template <typename Kern>
 int launch_pass(paos_ctx* c, Kern kern, dim3 grid, dim3 block, size_t lds, const PassArgs& a, int kind) {
-  // kernels that need more than the default 64 KiB of dynamic LDS opt in once
-  static thread_local std::unordered_set<const void*> configured;
-  if (lds > 48 * 1024 && !configured.count((const void*)kern)) {
-    HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds));
-    configured.insert((const void*)kern);
+  // kernels that need more than the default 64 KiB of dynamic LDS opt in once PER DEVICE (the
+  // attribute belongs to the device's copy of the function; one process may drive several GPUs)
+  if (lds > 48 * 1024) {
+    int rc = opt_in_lds(c, (const void*)kern, lds);
+    if (rc) return rc;
   }
   const bool timed = (c->prof_kind == kind || c->prof_kind == PAOS_KERNEL_PASS_ANY) &&
                      (c->prof_used + 2 <= c->prof_events.size());
@@ -366,10 +408,9 @@ int frugal_launch(paos_ctx* c, const FrugalArgs& a) {
   const dim3 grid(N / LINES / TILES, c->batch), block(TILES * LINES * N / C::E);
   const size_t lds = (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT>() + kTwiddleLds * sizeof(cx<T>);
   auto kern = frugal_pass_kernel<T, N, C::E, LINES, TILES, AXIS, BR, C::BC, SPLIT, KPRE, KMID, NFFT>;
-  static thread_local bool configured = false;
-  if (!configured) {
-    HIPCHK(c, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    configured = true;
+  {
+    int rc = opt_in_lds(c, (const void*)kern, lds);
+    if (rc) return rc;
   }
   const int kind = AXIS == 0 ? PAOS_KERNEL_PASS_ROWS : PAOS_KERNEL_PASS_COLS;
   const bool timed = (c->prof_kind == kind || c->prof_kind == PAOS_KERNEL_PASS_ANY) &&
@@ -580,7 +621,12 @@ int run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double*
       }
   }
   const double* dblocks = nullptr;
-  int rc = arena_push(c, blocks, (size_t)n_blocks * c->batch * FP_STRIDE, &dblocks);
+  // everything this program pushes stays live until its last pass has run: the block table and,
+  // per pass, one FrugalItem record per batch item (each push is rounded up to 16 doubles)
+  const size_t per_pass = ((size_t)c->batch * sizeof(FrugalItem) / sizeof(double) + 15) & ~size_t(15);
+  int rc = arena_reserve(c, (size_t)n_blocks * c->batch * FP_STRIDE + 16 + (size_t)n_passes * per_pass);
+  if (rc) return rc;
+  rc = arena_push(c, blocks, (size_t)n_blocks * c->batch * FP_STRIDE, &dblocks);
   if (rc) return rc;
   // Walk the program in chunks whose phase operators fit the table store: fill the tables of
   // a chunk with one small launch, then run its passes.
@@ -1089,9 +1135,12 @@ int paos_psf_metrics(paos_ctx* c, int nr, const double* radii_px, double cx_px, 
 int paos_norm2_enqueue(paos_ctx* c, int* ticket) {
   if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c || !ticket) return fail(c, PAOS_EINVAL, "null argument");
+  const int slot = c->norm_slot;
+  if (c->norm_busy[slot])  // the ring is full: the oldest ticket has not been fetched
+    return fail(c, PAOS_EINVAL, "64 power reductions outstanding: fetch earlier tickets (paos_norm2_fetch) first");
   int rc = norm2_launch(c, nullptr);
   if (rc) return rc;
-  const int slot = c->norm_slot;
+  c->norm_busy[slot] = true;
   c->norm_slot = (slot + 1) % kNormSlots;
   HIPCHK(c, hipMemcpyAsync(c->norm2_host + (size_t)slot * c->batch, c->norm2, (size_t)c->batch * sizeof(double),
                            hipMemcpyDeviceToHost, c->stream));
@@ -1102,7 +1151,9 @@ int paos_norm2_enqueue(paos_ctx* c, int* ticket) {
 int paos_norm2_fetch(paos_ctx* c, int ticket, double* host_out) {
   if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c || !host_out || ticket < 0 || ticket >= kNormSlots) return fail(c, PAOS_EINVAL, "bad ticket");
+  if (!c->norm_busy[ticket]) return fail(c, PAOS_EINVAL, "ticket is not outstanding (already fetched, or never issued)");
   HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->norm_busy[ticket] = false;
   std::memcpy(host_out, c->norm2_host + (size_t)ticket * c->batch, (size_t)c->batch * sizeof(double));
   return check_mask_overflow(c);
 }
@@ -1126,6 +1177,25 @@ int paos_phase(paos_ctx* c, const double* params, int mul2pi) {
   paos_pass& p = g.add_pass(-1, -1, -1);
   push(p.pre, p.n_pre, PAOS_PW_QPHASE_CENTRED, par, mul2pi ? PAOS_PWF_MUL2PI : 0);
   return run_passes(c, g.passes.data(), 1, g.blocks.data(), 1);
+}
+
+int paos_phase_map(paos_ctx* c, int item, const double* host_wfe, double wl) {
+  if (c) (void)hipSetDevice(c->device);
+  if (!c || !host_wfe || item < 0 || item >= c->batch) return fail(c, PAOS_EINVAL, "bad item or null buffer");
+  if (!(wl > 0.0) || !std::isfinite(wl)) return fail(c, PAOS_EINVAL, "wavelength must be positive and finite");
+  const size_t count = (size_t)c->n * c->n;
+  for (size_t i = 0; i < count; ++i)  // the device sincos handles any finite argument; reject the rest here
+    if (!std::isfinite(host_wfe[i])) return fail(c, PAOS_EINVAL, "the phase map holds a non-finite value (fill masked pixels with 0)");
+  HIPCHK(c, hipMemcpyAsync(c->staging, host_wfe, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (c->precision == PAOS_F64)
+    hipLaunchKernelGGL((phase_map_kernel<double, BR, Lay<double>::BC>), dim3(pw_blocks(c)), dim3(kPwThreads), 0, c->stream,
+                       (cx<double>*)c->field + (size_t)item * c->item_stride, (const double*)c->staging, c->n, c->pitch, wl);
+  else
+    hipLaunchKernelGGL((phase_map_kernel<float, BR, Lay<float>::BC>), dim3(pw_blocks(c)), dim3(kPwThreads), 0, c->stream,
+                       (cx<float>*)c->field + (size_t)item * c->item_stride, (const double*)c->staging, c->n, c->pitch, wl);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // the host buffer is only borrowed
+  return PAOS_OK;
 }
 
 int paos_run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks, int n_blocks) {

@@ -87,6 +87,26 @@ __global__ void intensity_kernel(const cx<T>* field, double* out, int n, unsigne
   }
 }
 
+// ---- tabulated phase screen: the field part shared by WFO.grid_sag and WFO.psd ---------------
+// u *= exp(2 pi i wfe / wl) (wfo.py:869-871, 945-949) for a host-supplied map (row-major doubles in
+// the staging buffer).  NumPy forms the argument as fl(fl(2 pi w) / wl) and multiplies the complex
+// numbers without FMA contraction; both are kept.
+template <typename T, int BR, int BC>
+__global__ void phase_map_kernel(cx<T>* f, const double* staged, int n, unsigned pitch, double wl) {
+  const size_t total = (size_t)pitch * (n / BR);
+  size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
+    int r, c;
+    if (!layout_unmap<BR, BC>(m, n, pitch, r, c)) continue;
+    const double w = staged[(size_t)r * n + c];
+    const double arg = __ddiv_rn(__dmul_rn(6.283185307179586, w), wl);
+    double sn, cs;
+    sincos(arg, &sn, &cs);
+    const double x = (double)f[m].x, y = (double)f[m].y;
+    f[m] = {(T)__dsub_rn(__dmul_rn(x, cs), __dmul_rn(y, sn)), (T)__dadd_rn(__dmul_rn(x, sn), __dmul_rn(y, cs))};
+  }
+}
+
 // ---- stand-alone pointwise pass (op list without a transform) --------------------
 // Used when a lens (wfo.py:359-366) is not adjacent to an FFT pass it could ride on.
 template <typename T, int BR, int BC>

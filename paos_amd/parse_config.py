@@ -18,8 +18,8 @@ on purpose:
 * an ``ABCD`` surface right-multiplies the user matrix onto a thickness matrix
   (:349-354).
 
-``Grid Sag`` and ``PSD`` surfaces are out of scope and
-raise ``NotImplementedError`` here.
+``Grid Sag`` and ``PSD`` surfaces are parsed like the reference does (:218-284); the unit of a PSD
+surface is kept as its name instead of an astropy object.
 """
 import configparser
 import os
@@ -95,8 +95,32 @@ def _surface(el, item, n1, glass):
         item["ABCDt"], item["ABCDs"] = _plain_surface(0.0, 0.0, n1, n1)
         return n1
 
-    if kind in ("Grid Sag", "PSD"):
-        raise NotImplementedError(f"surface type {kind!r} is outside the accelerated path")
+    if kind == "Grid Sag":  # parseConfig.py:218-258
+        wave = 1.0e-6 * _num(el.get("Par1", ""))
+        for key, par in (("nx", "Par2"), ("ny", "Par3"), ("delx", "Par4"), ("dely", "Par5"), ("xdec", "Par6"),
+                         ("ydec", "Par7")):
+            item[key] = _num(el.get(par, ""))
+        path = el.get("Par8", "")
+        if not os.path.exists(path):
+            raise ValueError(f"Grid sag file does not exist: {path}")
+        with open(path, "rb") as fh:
+            grid_sag = np.load(fh, allow_pickle=True).item()
+        assert "data" in grid_sag.keys(), "The .npy file must contain a dictionary with a 'data' key"
+        for key in ("nx", "ny", "delx", "dely", "xdec", "ydec"):
+            if key in grid_sag.keys():
+                item[key] = grid_sag[key]
+        item["grid_sag"] = grid_sag["data"] * wave
+        item["ABCDt"], item["ABCDs"] = _plain_surface(0.0, 0.0, n1, n1)
+        return n1
+
+    if kind == "PSD":  # parseConfig.py:274-284; ``units`` stays the unit NAME (astropy is not needed:
+        # psd.py:160 only asks it for the factor to metres, paos_amd/phase_maps.py)
+        for key, par in (("A", "Par1"), ("B", "Par2"), ("C", "Par3"), ("fknee", "Par4"), ("fmin", "Par5"),
+                         ("fmax", "Par6"), ("SR", "Par7")):
+            item[key] = _num(el.get(par, ""))
+        item["units"] = el.get("Par8", "")
+        item["ABCDt"], item["ABCDs"] = _plain_surface(0.0, 0.0, n1, n1)
+        return n1
 
     if kind == "Coordinate Break":
         for key, par in (("xdec", "Par1"), ("ydec", "Par2"), ("xrot", "Par3"), ("yrot", "Par4")):

@@ -27,6 +27,7 @@ from .abcd import ABCD
 from .aperture import EllipticalAperture, bbox_misses_grid, make_aperture
 from .coordinate_break import coordinate_break
 from .passes import PassCompiler
+from .phase_maps import grid_sag_map, psd_map
 from .planner import (PilotBeam, gram_polynomials, jacobi_recurrence, orthonorm_matrix,
                       zernike_block)
 from .zernike import zernike_tables
@@ -72,7 +73,7 @@ def _plan_surface(st, item):
     """Host half of one loop iteration of run.py:77-224 for one wavefront.  Returns the
     device work as a dict of slots and advances the host state."""
     beam = st.beam
-    plan = {"aperture": None, "stop": False, "zernike": None, "lens": None, "steps": []}
+    plan = {"aperture": None, "stop": False, "zernike": None, "lens": None, "steps": [], "phase_map": None}
 
     if item["type"] == "Coordinate Break":
         st.vt, st.vs = coordinate_break(st.vt, st.vs, item["xdec"], item["ydec"], item["xrot"],
@@ -118,8 +119,12 @@ def _plan_surface(st, item):
         plan["zernike"] = dict(m=m, n=n, norm=norm,
                                Z=np.asarray(item["Z"], dtype=np.float64), dx=beam.dx, dy=beam.dy,
                                radius=radius, wl=beam.wl, origin=item["Zorigin"], pupil=pupil)
-    if item["type"] in ("Grid Sag", "PSD"):
-        raise NotImplementedError(f"surface type {item['type']} is outside the accelerated path")
+    if item["type"] == "Grid Sag":  # run.py:154-164
+        plan["phase_map"] = (grid_sag_map(item["grid_sag"], item["nx"], item["ny"], item["delx"], item["dely"],
+                                          item["xdec"], item["ydec"], (beam.n, beam.n), beam.dx, beam.dy), beam.wl)
+    if item["type"] == "PSD":  # run.py:166-177
+        plan["phase_map"] = (psd_map((beam.n, beam.n), beam.dx, beam.dy, item["A"], item["B"], item["C"],
+                                     item["fknee"], item["fmin"], item["fmax"], item["SR"], item["units"]), beam.wl)
 
     # push_results scalars (run.py:12-27) are those BEFORE magnification / lens / propagate
     if item["save"]:
@@ -210,6 +215,19 @@ def _launch_zernike(dev, plans, want_wfe=False):
     return dev.zernike(nmax, kdim, table, build(coeffs), want_wfe=want_wfe, pupil=True)
 
 
+def _launch_phase_maps(dev, plans, wfe):
+    """Grid Sag / PSD surfaces (run.py:154-177): each item's host-built WFE map multiplies its field
+    (paos_phase_map).  Returns what the surface's ``wfe`` entry holds for a single wavefront: the map
+    of the LAST of Zernike / Grid Sag / PSD (each assignment at run.py:143,156,168 overwrites)."""
+    for i, p in enumerate(plans):
+        if p["phase_map"] is not None:
+            m, wl = p["phase_map"]
+            dev.phase_map(i, np.ma.filled(m, 0.0), wl)
+            if len(plans) == 1:
+                wfe = m
+    return wfe
+
+
 def _queue_apertures(comp, plans):
     """Apertures as pass operators (their weight maps are rendered right before the pass
     they ride on, csrc/paos_hip.hip: launch_one_pass)."""
@@ -275,12 +293,14 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None):
             if _start_field(dev, plans, value):
                 want_wfe = len(plans) == 1 and bool(items[0]["save"])
                 wfe = _launch_zernike(dev, plans, want_wfe=want_wfe)
+                wfe = _launch_phase_maps(dev, plans, wfe)
                 if saved:
                     on_saved(key, items, plans, wfe)
                 _queue_steps(comp, plans)
                 continue
         fuse_ap = FUSE_APERTURES
-        own_breaker = saved or any(p["stop"] or p["zernike"] is not None for p in plans)
+        own_breaker = saved or any(p["stop"] or p["zernike"] is not None or p["phase_map"] is not None
+                                   for p in plans)
         if fuse_ap == "auto":
             # an aperture followed on its own surface by a stop / Zernike / save could only ride
             # on a transform-free pass: the stand-alone aperture kernel is cheaper there
@@ -291,7 +311,7 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None):
                        all(_aperture_fits_line_records(h, o, dev.n, dev.precision) for h, o in aps))
         if fuse_ap:
             _queue_apertures(comp, plans)
-        breaker = saved or any(p["stop"] or p["zernike"] is not None or
+        breaker = saved or any(p["stop"] or p["zernike"] is not None or p["phase_map"] is not None or
                                (p["aperture"] is not None and not fuse_ap) for p in plans)
         if breaker:
             npass += comp.flush(dev)  # the field must be current before a non-fusable operator
@@ -301,6 +321,7 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None):
             dev.make_stop([1.0 if p["stop"] else 0.0 for p in plans])
         want_wfe = len(plans) == 1 and bool(items[0]["save"])
         wfe = _launch_zernike(dev, plans, want_wfe=want_wfe)
+        wfe = _launch_phase_maps(dev, plans, wfe)
         if saved:
             on_saved(key, items, plans, wfe)
         _queue_steps(comp, plans)
@@ -357,7 +378,9 @@ def run(pupil_diameter, wavelength, gridsize, zoom, field, opt_chain, precision=
     def on_saved(key, items, plans, wfe):
         item, plan = items[0], plans[0]
         rec = {"aperture": plan["aperture"][0] if plan["aperture"] else None}
-        if wfe is not None:
+        if isinstance(wfe, np.ma.MaskedArray):  # Grid Sag / PSD: the host-built map itself
+            rec["wfe"] = wfe
+        elif wfe is not None:
             outside = np.isnan(wfe)
             rec["wfe"] = np.ma.MaskedArray(data=np.where(outside, 0.0, wfe), mask=outside,
                                            fill_value=0.0)
@@ -429,7 +452,16 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
 
     last_key = list(opt_chains[0].keys())[-1] if len(opt_chains[0]) else None
     tickets = []  # (ticket, [(item index, record)]): powers are fetched after the walk, so the
-    # host keeps planning while the GPU works (no mid-chain synchronisation)
+    # host keeps planning while the GPU works (no mid-chain synchronisation) -- except when a chain
+    # saves more surfaces than the library has ticket slots: then the oldest are fetched early
+    drained = [0]
+
+    def drain():
+        for ticket, pending in tickets[drained[0]:]:
+            values = dev.norm2_fetch(ticket)
+            for i, rec in pending:
+                rec["power"] = float(values[i])
+        drained[0] = len(tickets)
 
     def on_saved(key, items, plans, wfe):
         pending = []
@@ -450,17 +482,16 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
         if keep_psf and key == last_key:
             dev.psf_keep()
         if power:
+            if len(tickets) - drained[0] >= _lib.NORM_SLOTS - 1:
+                drain()  # the ticket ring of the library is about to fill: fetch what is pending
             tickets.append((dev.norm2_enqueue(), pending))
 
     try:
         _walk(dev, states, list(opt_chains), on_saved, stats=stats, fresh=1.0 + 0.0j)
         if sync or own:
-            for ticket, pending in tickets:
-                power = dev.norm2_fetch(ticket)
-                for i, rec in pending:
-                    rec["power"] = float(power[i])
-        else:  # caller synchronises later: hand out the tickets
-            for ticket, pending in tickets:
+            drain()
+        else:  # caller synchronises later: hand out the tickets still outstanding
+            for ticket, pending in tickets[drained[0]:]:
                 for i, rec in pending:
                     rec["power_ticket"] = ticket
     finally:

@@ -4,12 +4,15 @@ Same constructor, read-only properties and methods as ``paos.classes.wfo.WFO``
 (reference paos/classes/wfo.py:12-654).  The N x N complex field lives in HBM
 (``_lib.DeviceFields``); every method below runs the scalar pilot-beam part on
 the host (``planner.PilotBeam``) and the field part as HIP kernels.  ``grid_sag``
-and ``psd`` (wfo.py:656-949) are outside the accelerated path and raise.
+and ``psd`` (wfo.py:656-949) build their WFE map on the host (``phase_maps``: the reference's own
+NumPy / SciPy steps; the scikit-image resampling of a sag at another pixel scale is not restated and
+raises) and apply it with the ``paos_phase_map`` kernel.
 """
 import numpy as np
 
 from . import _lib
 from .aperture import bbox_misses_grid, make_aperture, EllipticalAperture
+from .phase_maps import grid_sag_map, psd_map
 from .planner import PilotBeam, gram_polynomials, jacobi_recurrence, orthonorm_matrix, zernike_block
 from .zernike import Zernike, norm_factors
 
@@ -166,8 +169,19 @@ class WFO:
         outside = np.isnan(wfe)
         return np.ma.MaskedArray(data=np.where(outside, 0.0, wfe), mask=outside, fill_value=0.0)
 
-    def grid_sag(self, *args, **kwargs):
-        raise NotImplementedError("grid_sag is outside the accelerated path (SURVEY.md section 2)")
+    def grid_sag(self, sag, nx, ny, delx, dely, xdec=0.0, ydec=0.0):
+        """wfo.py:656-871: add a user-specified sag (metres) to the wavefront; returns the masked
+        WFE map.  Maps must come at the wavefront's pixel scale (see ``phase_maps``)."""
+        b = self._beam
+        wfe = grid_sag_map(sag, nx, ny, delx, dely, xdec, ydec, (b.n, b.n), b.dx, b.dy)
+        self._dev.phase_map(0, wfe.filled(0), b.wl)
+        return wfe
 
-    def psd(self, *args, **kwargs):
-        raise NotImplementedError("psd is outside the accelerated path (SURVEY.md section 2)")
+    def psd(self, A=10.0, B=0.0, C=0.0, fknee=1.0, fmin=None, fmax=None, SR=0.0, units="m"):
+        """wfo.py:873-949: add a WFE screen drawn from a power spectral density plus surface
+        roughness; returns the WFE map.  The draw uses NumPy's legacy global generator like the
+        reference (``np.random.seed`` makes it reproducible)."""
+        b = self._beam
+        wfe = psd_map((b.n, b.n), b.dx, b.dy, A, B, C, fknee, fmin, fmax, SR, units)
+        self._dev.phase_map(0, np.ma.filled(wfe, 0.0), b.wl)
+        return wfe

@@ -1,0 +1,145 @@
+"""Host-side parity added in round 2 (no GPU): the lens-file parser against per-surface pins taken from
+the reference's own parse_config, the glass catalogue against Material.nmat, and the host
+half of the Grid Sag / PSD phase screens against maps produced by the reference's WFO.grid_sag / WFO.psd
+(fixtures: tests/golden/r2_*.npz, made by tests/golden_tools/make_golden_r2.py)."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LENS = os.path.join(ROOT, "data", "lens")
+
+PARSED = ("Ariel_AIRS-CH0", "Ariel_AIRS-CH1", "Ariel_FGS-FGS1", "Ariel_FGS-FGS2", "Ariel_FGS-NIRSpec",
+          "Ariel_FGS-VISPhot", "Excite_TEL", "Hubble_simple", "lens_file_TA_Ground", "lens_file_TA_Ground_PSD",
+          "lens_file_TA_OGSE_Ground", "lens_file_template", "periscope")
+
+
+@pytest.mark.parametrize("name", PARSED)
+def test_parser_matches_reference_surface_by_surface(name):
+    """ABCD matrices, n1n2, power, M, thickness, cout of EVERY surface, first and last wavelength --
+    bit for bit what parseConfig.py:141-399 builds."""
+    from paos_amd.parse_config import parse_config
+
+    g = load_golden("r2_parser_pins.npz")
+    pup, par, wls, fields, chains = parse_config(os.path.join(LENS, name + ".ini"))
+    assert pup == g[f"{name}_pup"]
+    assert np.array_equal(np.array(wls, dtype=np.float64), g[f"{name}_wls"])
+    assert np.array_equal(np.array([[f["us"], f["ut"]] for f in fields]), g[f"{name}_fields"])
+    assert [par["grid_size"], par["zoom"]] == list(g[f"{name}_grid_zoom"])
+    for tag, iw in (("first", 0), ("last", len(wls) - 1)):
+        chain, key = chains[iw], f"{name}_{tag}"
+        nums = sorted(chain)
+        assert nums == list(g[key + "_nums"])
+        assert [chain[k]["type"] for k in nums] == list(g[key + "_types"])
+        flags = np.array([[bool(chain[k]["is_stop"]), bool(chain[k]["save"]), "aperture" in chain[k]] for k in nums])
+        assert np.array_equal(flags, g[key + "_flags"])
+        assert np.array_equal(np.array([chain[k]["ABCDt"]() for k in nums]), g[key + "_ABCDt"]), (name, tag)
+        assert np.array_equal(np.array([chain[k]["ABCDs"]() for k in nums]), g[key + "_ABCDs"]), (name, tag)
+        props = np.array([[getattr(chain[k][m], a) for m in ("ABCDt", "ABCDs")
+                           for a in ("n1n2", "power", "M", "thickness", "cout")] for k in nums], dtype=np.float64)
+        assert np.array_equal(props, g[key + "_props"], equal_nan=True), (name, tag)
+        aps = np.array([[chain[k]["aperture"][a] for a in ("xrad", "yrad", "xc", "yc")] if "aperture" in chain[k]
+                        else [np.nan] * 4 for k in nums], dtype=np.float64)
+        assert np.array_equal(aps, g[key + "_apertures"], equal_nan=True), (name, tag)
+
+
+def test_psd_surface_parameters_and_unparsable_files():
+    from paos_amd.parse_config import parse_config
+
+    g = load_golden("r2_parser_pins.npz")
+    _, _, _, _, chains = parse_config(os.path.join(LENS, "lens_file_TA_Ground_PSD.ini"))
+    psd = [it for it in chains[0].values() if it["type"] == "PSD"]
+    assert len(psd) == 1
+    got = np.array([psd[0][k] for k in ("A", "B", "C", "fknee", "fmin", "fmax", "SR")], dtype=np.float64)
+    assert np.array_equal(got, g["psd_params"], equal_nan=True)
+    assert psd[0]["units"] == str(g["psd_units"])
+    # the two shipped files the reference itself cannot parse fail the same way here
+    with pytest.raises(KeyError):
+        parse_config(os.path.join(LENS, "template.ini"))  # no 'version' (parseConfig.py:77)
+    with pytest.raises(ValueError, match="Grid sag file does not exist"):
+        parse_config(os.path.join(LENS, "test_Grid_Sag.ini"))  # ./sag.npy is not shipped
+
+
+def test_grid_sag_surface_parses_with_a_sag_file(tmp_path):
+    """test_Grid_Sag.ini with the sag file it names present (parseConfig.py:218-258)."""
+    import configparser
+
+    from paos_amd.parse_config import parse_config
+
+    sag = {"data": np.arange(12.0).reshape(3, 4), "nx": 4, "ny": 3, "delx": 1e-3}
+    np.save(tmp_path / "sag.npy", sag, allow_pickle=True)
+    cfg = configparser.ConfigParser()
+    cfg.read(os.path.join(LENS, "test_Grid_Sag.ini"))
+    hit = [s for s in cfg.sections() if s.startswith("lens_") and cfg[s].get("SurfaceType") == "Grid Sag"]
+    assert hit
+    for s in hit:
+        cfg[s]["Par8"] = str(tmp_path / "sag.npy")
+    with open(tmp_path / "gs.ini", "w") as fh:
+        cfg.write(fh)
+    _, _, wls, _, chains = parse_config(str(tmp_path / "gs.ini"))
+    item = [it for it in chains[0].values() if it["type"] == "Grid Sag"][0]
+    wave = 1.0e-6 * float(cfg[hit[0]]["Par1"])
+    assert np.array_equal(item["grid_sag"], sag["data"] * wave)
+    assert item["nx"] == 4 and item["ny"] == 3 and item["delx"] == 1e-3
+    assert np.array_equal(item["ABCDt"](), np.eye(2))
+
+
+def test_material_matches_reference():
+    from paos_amd.material import Material
+
+    g = load_golden("r2_material.npz")
+    for i, (wl, t, p) in enumerate(g["cases"]):
+        mat = Material(wl, Tambient=t, Pambient=p)
+        for j, name in enumerate(g["glasses"]):
+            assert np.array_equal(np.array(mat.nmat(str(name))), g["nmat"][i, j]), (wl, name)
+    assert np.array_equal(Material(g["nair_wl"], Tambient=-50.0, Pambient=0.8).nair(-50.0, 0.8), g["nair"])
+
+
+def _beam(anam):
+    from paos_amd.planner import PilotBeam
+
+    b = PilotBeam(1.0, 2.0e-6, 64, 4)
+    if anam:
+        b.magnification(1.25, 0.8)
+    return b
+
+
+def test_grid_sag_maps_match_reference():
+    from paos_amd.phase_maps import grid_sag_map
+
+    g = load_golden("r2_phase_maps.npz")
+    for tag, anam, kw in (("same", False, {}), ("same_anam", True, {}), ("pad", False, {}), ("crop", False, {}),
+                          ("shift", False, dict(xdec=1.5, ydec=-0.25))):
+        b = _beam(anam)
+        sag = g[f"gs_{tag}_sag"]
+        got = grid_sag_map(sag.copy(), sag.shape[1], sag.shape[0], b.dx, b.dy, kw.get("xdec", 0.0), kw.get("ydec", 0.0),
+                           (64, 64), b.dx, b.dy)
+        assert np.array_equal(np.ma.getmaskarray(got), g[f"gs_{tag}_mask"]), tag
+        assert np.array_equal(got.filled(0.0), g[f"gs_{tag}_wfe"]), tag
+    b = _beam(False)
+    with pytest.raises(NotImplementedError, match="rescale"):
+        grid_sag_map(np.ones((64, 64)), 64, 64, 2 * b.dx, 2 * b.dy, 0.0, 0.0, (64, 64), b.dx, b.dy)
+    with pytest.raises(NotImplementedError):
+        grid_sag_map(np.ones((64, 63)), 63, 64, b.dx, b.dy, 0.0, 0.0, (64, 64), b.dx, b.dy)
+    with pytest.raises(AssertionError):
+        grid_sag_map(np.ones((64, 64)), 32, 64, b.dx, b.dy, 0.0, 0.0, (64, 64), b.dx, b.dy)
+
+
+def test_psd_maps_match_reference():
+    from paos_amd.phase_maps import psd_map
+
+    g = load_golden("r2_phase_maps.npz")
+    cases = {"powerlaw": dict(A=7.0, B=0.0, C=1.5, fknee=1.0, fmin=None, fmax=None, SR=0.0, units="nm"),
+             "knee_sr": dict(A=12.0, B=1.0, C=2.2, fknee=3.0, fmin=0.5, fmax=6.0, SR=2.0, units="nm")}
+    for tag, kw in cases.items():
+        for anam in (False, True):
+            b = _beam(anam)
+            np.random.seed(1234)
+            got = psd_map((64, 64), b.dx, b.dy, **kw)
+            assert np.array_equal(np.ma.filled(got, 0.0), g[f"psd_{tag}{'_anam' if anam else ''}_wfe"]), (tag, anam)
+    b = _beam(False)
+    with pytest.raises(AssertionError, match="fmax"):
+        psd_map((64, 64), b.dx, b.dy, fmax=1e9)
