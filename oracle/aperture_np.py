@@ -31,7 +31,7 @@ p -> p+d the part inside the circle contributes 1/2 cross and the parts
 outside contribute 1/2 of their signed subtended angle.  All cross products are
 taken against the SHORT edge vector d so the result is conditioned like
 photutils' own triangle formula (relative error ~ 1e-16 * a).
-The HIP kernel paos_amd/csrc/aperture.hip performs the same operations in the
+The HIP kernels (paos_amd/csrc/pointwise.h: ellipse_pixel / rect_pixel / ApertureEval) perform the same operations in the
 same order, so the {0, partial, 1} classification is bit-identical by
 construction.
 """
@@ -224,8 +224,13 @@ class RectangularAperture:
         self.w, self.h, self.theta = float(w), float(h), float(theta)
 
     def to_mask(self, method="subpixel", subpixels=SUBPIX_DEFAULT):
+        if method == "exact":
+            # photutils has no exact rectangle overlap: Aperture._translate_mask_mode turns
+            # ("exact", rectangle) into ("subpixel", subpixels=32) -- the request run.py:137 makes for
+            # a Zorthonorm surface with a rectangular aperture (restated from memory, unpinned)
+            method, subpixels = "subpixel", 32
         if method != "subpixel":
-            raise NotImplementedError("oracle restates method='subpixel' only")
+            raise NotImplementedError("oracle restates method='subpixel' (and 'exact' -> subpixel 32) only")
         xc, yc = self.positions
         return _MaskImage(
             lambda shape: rectangle_mask(

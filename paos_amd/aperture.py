@@ -60,8 +60,10 @@ class RectangularAperture:
                 1.0 if obscuration else 0.0, float(subpixels)]
 
     def to_mask(self, method="subpixel", subpixels=32):
+        if method == "exact":  # photutils serves "exact" rectangles with the 32 x 32 sub-pixel rule
+            method, subpixels = "subpixel", 32
         if method != "subpixel":
-            raise NotImplementedError("only method='subpixel' is used by PAOS for rectangles")
+            raise NotImplementedError("only method='subpixel' (or 'exact' = subpixel 32) is used by PAOS for rectangles")
         return _MaskImage(_lib.SHAPE_RECT, self.block(subpixels=subpixels))
 
     def __repr__(self):

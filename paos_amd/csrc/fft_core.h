@@ -235,9 +235,16 @@ __device__ __forceinline__ void apply_twiddle_chain(cx<T>* v, cx<T> w1) {
 // which keeps a 4096-point c128 pass at ~118 VGPRs -- four waves per SIMD, i.e. two 512-thread
 // workgroups per CU whose load / compute / store phases overlap (profiles/r01_vgpr_experiments.txt).
 #define PAOS_FENCE() do { if constexpr (FR != 0) __builtin_amdgcn_sched_barrier(0); } while (0)
+#ifndef PAOS_TABLE_TWIDDLES
+#define PAOS_TABLE_TWIDDLES 1
+#endif
+// ``circle`` (frugal complex128 kernels, else nullptr): exp(+2 pi i m / 256), m < 256, in LDS.  The
+// stage whose twiddles are 256th roots of unity (NS * R == 256: w^r = exp(-2 pi i k r / 256) with
+// k r < 256) reads its 15 powers from it instead of multiplying them up -- 15 ds_read_b128 for
+// 14 complex products.
 template <typename T, int N, int E, int DIR, bool SPLIT, int NS = 1, int FR = 0>
 __device__ __forceinline__ void fft_stages(cx<T>* v, void* lds, int t,
-                                           const cx<T>* __restrict__ tw) {
+                                           const cx<T>* __restrict__ tw, const cx<double>* circle = nullptr) {
   using S = StageInfo<N, E, NS>;
   constexpr int TL = N / E;
   constexpr int R = S::R;
@@ -248,10 +255,24 @@ __device__ __forceinline__ void fft_stages(cx<T>* v, void* lds, int t,
     if constexpr (NS > 1) {
       const int j = t + s * TL;
       const int k = j & (NS - 1);
-      cx<T> w1 = tw[k * (N / (NS * R))];
-      if constexpr (DIR < 0) w1.y = -w1.y;
-      if constexpr (FR != 0) apply_twiddle_chain<R>(v + s * R, w1);
-      else apply_twiddle_powers<R>(v + s * R, w1);
+      if constexpr (FR != 0 && PAOS_TABLE_TWIDDLES && sizeof(T) == 8 && NS * R == 256) {
+        // two reads in flight ahead of the product that consumes them; the fences keep the scheduler
+        // from hoisting all fifteen (60 VGPRs) above the first product
+        cx<double> wa = circle[k], wb = circle[2 * k];
+#pragma unroll
+        for (int r = 1; r < R; ++r) {
+          const cx<double> w = wa;
+          wa = wb;
+          if (r + 2 < R) wb = circle[k * (r + 2)];
+          v[s * R + r] = cmul(v[s * R + r], cx<T>{(T)w.x, (T)(DIR > 0 ? -w.y : w.y)});
+          PAOS_FENCE();
+        }
+      } else {
+        cx<T> w1 = tw[k * (N / (NS * R))];
+        if constexpr (DIR < 0) w1.y = -w1.y;
+        if constexpr (FR != 0) apply_twiddle_chain<R>(v + s * R, w1);
+        else apply_twiddle_powers<R>(v + s * R, w1);
+      }
       PAOS_FENCE();
     }
     dft<R, DIR>(v + s * R);
@@ -312,7 +333,7 @@ __device__ __forceinline__ void fft_stages(cx<T>* v, void* lds, int t,
       }
     }
     PAOS_FENCE();
-    fft_stages<T, N, E, DIR, SPLIT, NS * R, FR>(v, lds, t, tw);
+    fft_stages<T, N, E, DIR, SPLIT, NS * R, FR>(v, lds, t, tw, circle);
   }
 }
 

@@ -84,18 +84,45 @@ struct FrugalArgs {
 #define PAOS_STAMP_WAIT_VM() do { } while (0)
 #endif
 
+// sin and cos of a phase argument from a 256-entry table of the unit circle in LDS plus two
+// short Taylor kernels:  a = n (2 pi / 256) + r, |r| <= pi / 256,  exp(i a) = C[n mod 256] (cos r + i sin r).
+// Two-term Cody-Waite reduction with FMA (the host bounds |a| < 1e12, so n < 2^46 and n * lo(pi/128)
+// is known to 1e-20), Taylor remainders r^7/5040 < 1e-17 and r^8/40320 < 2e-20: ~1.5e-16 absolute,
+// like sincos_fast, in 17 fp64 instructions and one ds_read_b128 instead of ~40 -- the phase factors
+// were 40 % of the vector instructions of a two-transform pass, and these passes run at the rate
+// the fp64 pipe (and the power cap that throttles it) allows (profiles/r02_timeline_*.txt).
+constexpr int kCircleLds = 256;
+__device__ __forceinline__ void sincos_tab(double a, const cx<double>* circle, double* sn, double* cs) {
+  const double kMagic = 6755399441055744.0;  // 1.5 * 2^52: the integer lands in the low mantissa bits
+  const double nb = fma(a, 40.743665431525205956834243423363677, kMagic);  // 128 / pi
+  const unsigned j = (unsigned)__double2loint(nb) & (unsigned)(kCircleLds - 1);
+  const double n = nb - kMagic;
+  double r = fma(-n, 2.45436926061702596754894014318e-02, a);   // hi(pi / 128)
+  r = fma(-n, 9.56755311833869697380e-19, r);                   // lo(pi / 128)
+  const cx<double> c = circle[j];
+  const double z = r * r;
+  const double ps = fma(z, 8.33333333333333333333e-03, -1.66666666666666666667e-01);
+  const double s1 = fma(r * z, ps, r);
+  double pc = fma(z, -1.38888888888888888889e-03, 4.16666666666666666667e-02);
+  pc = fma(z, pc, -0.5);
+  const double c1 = fma(z, pc, 1.0);
+  *cs = fma(c.x, c1, -(c.y * s1));
+  *sn = fma(c.y, c1, c.x * s1);
+}
+
 template <typename T, int N, int E, int K, typename Map>
 __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, const FrugalPhase* ph,
-                                            const Map& m) {
+                                            const Map& m, const cx<double>* circle, bool conj_out) {
+  constexpr int TL = N / E;
+  static_assert(TL % 2 == 0, "the checkerboard sign is constant along a thread's elements");
   const double sc = sl.scale;
-  const bool sign_on = sl.sign_on != 0.0;
+  const int line = Map::kAxis == 0 ? m.row(0) : m.col(0);  // this thread's row (column): constant
   if (sl.mask_on != 0.0) {  // wave-uniform: an aperture rides on this slot
-    const int line = Map::kAxis == 0 ? m.row(0) : m.col(0);  // constant per thread
     const MaskLine ml = sl.lines[line];
     const double* vals = sl.vals + (size_t)line * (2 * kMaskW);
 #pragma unroll
     for (int k = 0; k < E; ++k) {
-      const int pos = Map::kAxis == 0 ? m.col(k) : m.row(k);
+      const int pos = m.t + k * TL;
       double w = (pos >= ml.p1 && pos < ml.p2) ? sl.w_in : sl.w_out;
       if (pos >= ml.p0 && pos < ml.p1) w = vals[pos - ml.p0];
       if (pos >= ml.p2 && pos < ml.p3) w = vals[kMaskW + pos - ml.p2];
@@ -104,17 +131,34 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
     }
     __builtin_amdgcn_sched_barrier(0);
   }
+  // (-1)^(row+col): the position along the line advances by TL (even) from element to element
+  const double f = (sl.sign_on != 0.0 && ((line + m.t) & 1)) ? -sc : sc;
+  const double fy = conj_out ? -f : f;  // the conjugation in front of an inverse transform rides on the scale
+  // Per phase, what does not depend on the element: the squared coordinate ACROSS the line and
+  // the scale ALONG it.  Coordinates are exact integers times the sampling step, formed like the
+  // reference's (g * dx, one rounding); centred index g = i - N/2, natural order g = i or i - N.
+  constexpr int KK = K > 0 ? K : 1;
+  double across2[KK], step[KK];
+  const double td = (double)m.t;
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const bool nat = ph[j].natural != 0.0;
+    const int ga = nat ? ((line < N / 2) ? line : line - N) : line - N / 2;
+    const double a = (double)ga * (Map::kAxis == 0 ? ph[j].sy : ph[j].sx);
+    across2[j] = __dmul_rn(a, a);
+    step[j] = Map::kAxis == 0 ? ph[j].sx : ph[j].sy;
+  }
 #pragma unroll
   for (int k = 0; k < E; ++k) {
-    const int row = m.row(k), col = m.col(k);
     cx<double> vd = {(double)v[k].x, (double)v[k].y};
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      const bool nat = ph[j].natural != 0.0;
-      const int gx = nat ? ((col < N / 2) ? col : col - N) : col - N / 2;
-      const int gy = nat ? ((row < N / 2) ? row : row - N) : row - N / 2;
-      const double x = (double)gx * ph[j].sx, y = (double)gy * ph[j].sy;
-      const double s = __dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y));
+      // element k sits at position t + k TL < N/2 exactly when k < E/2 (t < TL): the index offset
+      // is a compile-time constant per k, picked by the wave-uniform order flag
+      const double off = (ph[j].natural != 0.0) ? (double)(k * TL - (k >= E / 2 ? N : 0)) : (double)(k * TL - N / 2);
+      const double x = __dmul_rn(td + off, step[j]);
+      // x^2 + y^2 in the reference's order (addition commutes, so which of the two is "x" is moot)
+      const double s = __dadd_rn(__dmul_rn(x, x), across2[j]);
       const double q = __dmul_rn(ph[j].m2, __dmul_rn(ph[j].coef, s));
       if constexpr (sizeof(T) == 4) {
         // fp32 mode: the argument is still formed in fp64 like the reference's, reduced to a
@@ -128,13 +172,12 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
         continue;
       }
       double sn, cs;
-      sincos_fast(q, &sn, &cs);
+      sincos_tab(q, circle, &sn, &cs);
       sn *= ph[j].sgn;
       // only the phase ARGUMENT is rounded like the reference's; the product itself may use FMA
       vd = {fma(vd.x, cs, -(vd.y * sn)), fma(vd.x, sn, vd.y * cs)};
     }
-    const double f = (sign_on && ((row + col) & 1)) ? -sc : sc;
-    v[k] = {(T)(vd.x * f), (T)(vd.y * f)};
+    v[k] = {(T)(vd.x * f), (T)(vd.y * fy)};
     if ((k + 1) % PAOS_FENCE_EVERY == 0) __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -160,23 +203,52 @@ __device__ __forceinline__ void stream_store(cx<T>* p, cx<T> v) {
   else *p = v;
 }
 
-// direction as data: conj(FFT(conj x)) with the conjugations as multiplications by +-1
+// Direction as data: IFFT(x) = conj(FFT(conj x)).  A scalar branch between a forward and an inverse
+// instantiation would spare the conjugations but costs ~60 spilled VGPRs at the join (measured), so
+// the direction stays data and the conjugations are made cheap instead: the one in FRONT of the
+// transform is folded into the slot that precedes it (frugal_slot multiplies the imaginary part by
+// -f instead of f), the one BEHIND it is an XOR on the sign bit (half the issue cost of an fp64 multiply).
+template <typename T>
+__device__ __forceinline__ T flip_sign(T x, unsigned mask_hi) {
+  if constexpr (sizeof(T) == 8)
+    return __hiloint2double(__double2hiint(x) ^ (int)mask_hi, __double2loint(x));
+  else
+    return __uint_as_float(__float_as_uint(x) ^ mask_hi);
+}
 template <typename T, int N, int E, bool SPLIT>
-__device__ __forceinline__ void frugal_fft(cx<T>* v, void* lds, int t, const cx<T>* tw, double inv) {
-  const T s = inv != 0.0 ? (T)-1 : (T)1;
-#pragma unroll
-  for (int k = 0; k < E; ++k) v[k].y *= s;
-  __builtin_amdgcn_sched_barrier(0);
-  fft_stages<T, N, E, +1, SPLIT, 1, 1>(v, lds, t, tw);
+__device__ __forceinline__ void frugal_fft(cx<T>* v, void* lds, int t, const cx<T>* tw, const cx<double>* circle,
+                                           double inv) {
+  fft_stages<T, N, E, +1, SPLIT, 1, 1>(v, lds, t, tw, circle);
   unpermute_slots<N, E>(v);
+  const unsigned mask = inv != 0.0 ? 0x80000000u : 0u;
 #pragma unroll
-  for (int k = 0; k < E; ++k) v[k].y *= s;
+  for (int k = 0; k < E; ++k) v[k].y = flip_sign(v[k].y, mask);
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// dynamic LDS of one workgroup: exchange areas | stage twiddles | (c128 with phases) circle table
+template <typename T, int N, int LINES, int TILES, bool SPLIT, int KPRE, int KMID>
+constexpr size_t frugal_lds_bytes() {
+  return (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT>() + kTwiddleLds * sizeof(cx<T>) +
+         (sizeof(T) == 8 ? kCircleLds * sizeof(cx<double>) : 0);
+}
+
+// Waves per SIMD the kernel is compiled for.  N = 4096: 512-thread workgroups, two per CU (their
+// tiles fill the register file) = 4 waves per SIMD = 128 VGPRs.  Smaller N: 256-thread workgroups
+// whose number per CU is bounded by LDS -- three of ~43 KiB -- so the compiler may as well have the 168
+// VGPRs three waves per SIMD leave it (at 128 these shapes spilled 50-180 B per lane).
+#ifndef PAOS_NT_FULL_LINES
+#define PAOS_NT_FULL_LINES 1
+#endif
+#ifndef PAOS_MINW_SMALL
+#define PAOS_MINW_SMALL 3
+#endif
+template <int N, int THREADS>
+constexpr int frugal_min_waves() { return THREADS >= 512 ? 4 : PAOS_MINW_SMALL; }
+
 template <typename T, int N, int E, int LINES, int TILES, int AXIS, int BR, int BC, bool SPLIT,
           int KPRE, int KMID, int NFFT>
-__global__ void __launch_bounds__(TILES* LINES* N / E, 4)
+__global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<N, TILES * LINES * N / E>()))
     frugal_pass_kernel(FrugalArgs a) {
   const int item = blockIdx.y;
   // constant address space: the per-item records are invariant during the kernel, so the scalar
@@ -195,6 +267,17 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, 4)
   for (int i = threadIdx.x; i < kTwiddleLds; i += TILES * LINES * N / E)
     tw_lds[i] = reinterpret_cast<const cx<T>*>(a.tw)[i];
   const cx<T>* tw = tw_lds;
+  // the unit circle in 256 steps for the phase factors (sincos_tab) and the twiddles of the second
+  // stage: conj of every (N/256)-th entry of the twiddle table.  Published by the first exchange's barriers.
+  const cx<double>* circle = nullptr;
+  if constexpr (sizeof(T) == 8) {
+    cx<double>* cl = reinterpret_cast<cx<double>*>(tw_lds + kTwiddleLds);
+    for (int i = threadIdx.x; i < kCircleLds; i += TILES * LINES * N / E) {
+      const cx<T> w = reinterpret_cast<const cx<T>*>(a.tw)[i * (N / kCircleLds)];
+      cl[i] = {(double)w.x, -(double)w.y};
+    }
+    circle = cl;
+  }
 #if PAOS_STAMPS
   if (threadIdx.x == 0) {
     unsigned long long* st = a.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kStampSlots;
@@ -204,29 +287,33 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, 4)
 #endif
   PAOS_STAMP(0);
 
+  // tiles that own whole 128-byte lines (column tiles; row tiles that span a full block row) stream
+  // around the caches; row tiles that share lines with a sibling need the L2 to merge the halves
+  constexpr bool NT = PAOS_NT_FULL_LINES ? (AXIS == 1 || LINES == BR) : (AXIS == 1);
   cx<T> v[E];
 #pragma unroll
-  for (int k = 0; k < E; ++k) v[k] = stream_load<AXIS == 1>(&f[m.base + (unsigned)k * m.stride]);
+  for (int k = 0; k < E; ++k) v[k] = stream_load<NT>(&f[m.base + (unsigned)k * m.stride]);
   __builtin_amdgcn_sched_barrier(0);
   PAOS_STAMP_WAIT_VM();
   PAOS_STAMP(1);
 
-  frugal_slot<T, N, E, KPRE>(v, it.pre, it.pre_ph, m);
-  PAOS_STAMP(2);
   const bool ran1 = it.fft1_on != 0.0;
-  if (ran1) frugal_fft<T, N, E, SPLIT>(v, lds, m.t, tw, it.fft1_inv);
+  const bool ran2 = NFFT == 2 && it.fft2_on != 0.0;
+  frugal_slot<T, N, E, KPRE>(v, it.pre, it.pre_ph, m, circle, ran1 && it.fft1_inv != 0.0);
+  PAOS_STAMP(2);
+  if (ran1) frugal_fft<T, N, E, SPLIT>(v, lds, m.t, tw, circle, it.fft1_inv);
   PAOS_STAMP(3);
-  frugal_slot<T, N, E, KMID>(v, it.mid, it.mid_ph, m);
+  frugal_slot<T, N, E, KMID>(v, it.mid, it.mid_ph, m, circle, ran2 && it.fft2_inv != 0.0);
   PAOS_STAMP(4);
   if constexpr (NFFT == 2) {
-    if (it.fft2_on != 0.0) {
+    if (ran2) {
       if (ran1) __syncthreads();
-      frugal_fft<T, N, E, SPLIT>(v, lds, m.t, tw, it.fft2_inv);
+      frugal_fft<T, N, E, SPLIT>(v, lds, m.t, tw, circle, it.fft2_inv);
     }
   }
   PAOS_STAMP(5);
 #pragma unroll
-  for (int k = 0; k < E; ++k) stream_store<AXIS == 1>(&f[m.base + (unsigned)k * m.stride], v[k]);
+  for (int k = 0; k < E; ++k) stream_store<NT>(&f[m.base + (unsigned)k * m.stride], v[k]);
   PAOS_STAMP(6);
   PAOS_STAMP_WAIT_VM();
   PAOS_STAMP(7);

@@ -406,7 +406,7 @@ int frugal_launch(paos_ctx* c, const FrugalArgs& a) {
   // fits whole (the same 35 KiB) and so needs half the barriers
   constexpr bool SPLIT = sizeof(T) == 8;
   const dim3 grid(N / LINES / TILES, c->batch), block(TILES * LINES * N / C::E);
-  const size_t lds = (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT>() + kTwiddleLds * sizeof(cx<T>);
+  const size_t lds = frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID>();
   auto kern = frugal_pass_kernel<T, N, C::E, LINES, TILES, AXIS, BR, C::BC, SPLIT, KPRE, KMID, NFFT>;
   {
     int rc = opt_in_lds(c, (const void*)kern, lds);

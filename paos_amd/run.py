@@ -106,10 +106,10 @@ def _plan_surface(st, item):
             assert "aperture" in item, "Zorthonorm requires aperture"
             if plan["aperture"] is None:
                 raise KeyError("aperture")  # the reference finds no _retval_["aperture"]
+            # to_mask("exact") of a RectangularAperture: photutils has no exact rectangle overlap and
+            # maps that request to the 32 x 32 sub-pixel rule (its _translate_mask_mode), i.e. the very
+            # mask WFO.aperture applies -- so both shapes are served by the aperture kernel
             pupil = plan["aperture"][0]
-            if not isinstance(pupil, EllipticalAperture):
-                raise NotImplementedError("Zorthonorm over a rectangular aperture needs photutils' exact "
-                                          "rectangle overlap, which is not restated")
         index = np.asarray(item["Zindex"])
         assert not np.any(np.diff(index) - 1), "Zernike sequence should be continuous"
         ordering = item["Zordering"]
@@ -201,11 +201,13 @@ def _launch_zernike(dev, plans, want_wfe=False):
     if any(not (np.array_equal(z["m"], live[0]["m"]) and np.array_equal(z["n"], live[0]["n"])
                 and np.array_equal(z["norm"], live[0]["norm"])) for z in live):
         raise NotImplementedError("batched Zorthonorm surfaces must share index range, ordering and normalisation")
-    ap = np.zeros((len(plans), _lib.APERTURE_STRIDE), dtype=np.float64)
-    for i, z in enumerate(zs):
-        if z is not None:
-            ap[i] = z["pupil"].block(obscuration=False)
-    dev.pupil_aperture(_lib.SHAPE_ELLIPSE, ap)
+    for code, is_ellipse in ((_lib.SHAPE_ELLIPSE, True), (_lib.SHAPE_RECT, False)):
+        ap = np.zeros((len(plans), _lib.APERTURE_STRIDE), dtype=np.float64)
+        for i, z in enumerate(zs):
+            if z is not None and isinstance(z["pupil"], EllipticalAperture) == is_ellipse:
+                ap[i] = z["pupil"].block(obscuration=False)
+        if ap[:, 0].any():  # items of the other shape keep enable = 0 and are left alone
+            dev.pupil_aperture(code, ap)
     k = len(live[0]["m"])
     sums, counts = dev.zernike_gram(nmax, kdim, table, build(coeffs), gram_polynomials(live[0]["m"], live[0]["n"],
                                                                                       live[0]["norm"]), pupil=True)

@@ -473,6 +473,31 @@ def test_run_zorthonorm(n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n", [64, 128])
+def test_run_zorthonorm_rectangular_pupil(n):
+    """Zorthonorm over a RECTANGULAR aperture (run.py:133-141 with RectangularAperture.to_mask("exact"),
+    which photutils serves with the 32 x 32 sub-pixel rule): against the reference's run()."""
+    from paos_amd.chains import syn20_orthonorm_chain
+    from paos_amd.run import run, run_batch
+
+    chain = syn20_orthonorm_chain()
+    chain[2]["aperture"] = {"shape": "rectangular", "type": "aperture", "xrad": 0.9, "yrad": 0.6, "xc": 0.0, "yc": 0.0}
+    chain[2]["save"] = True
+    g = load_golden("r2_orthonorm_rect.npz")
+    ret = run(1.0, 1.0e-6, n, 4, {"us": 0.0, "ut": 0.0}, chain)
+    assert np.array_equal(np.ma.getmaskarray(ret[2]["wfe"]), g[f"run{n}_S02_wfe_mask"])
+    assert rel_err(ret[2]["wfe"].filled(0.0), g[f"run{n}_S02_wfe"]) < 1e-11
+    assert rel_err(ret[2]["wfo"], g[f"run{n}_S02_wfo"]) < FIELD_TOL
+    assert rel_err(ret[20]["wfo"], g[f"run{n}_S20_wfo"]) < FIELD_TOL
+    # a batch mixing a rectangular and an elliptical pupil
+    ell = syn20_orthonorm_chain()
+    ell[2]["save"] = True
+    both = run_batch(1.0, [1.0e-6, 1.0e-6], n, 4, {"us": 0.0, "ut": 0.0}, [chain, ell], outputs=("wfo",))
+    assert rel_err(both[0][20]["wfo"], g[f"run{n}_S20_wfo"]) < FIELD_TOL
+    assert rel_err(both[1][20]["wfo"], load_golden("orthonorm.npz")[f"run{n}_S20_wfo"]) < FIELD_TOL
+
+
+@pytest.mark.gpu
 def test_zorthonorm_batch_and_errors():
     from paos_amd.chains import syn20_orthonorm_chain, syn20_chain
     from paos_amd.run import run, run_batch
@@ -486,10 +511,6 @@ def test_zorthonorm_batch_and_errors():
         assert rel_err(got[20]["wfo"], one[20]["wfo"]) < 1e-13
     with pytest.raises(NotImplementedError):
         run_batch(1.0, wls, 128, 4, field, [chain, syn20_chain()])
-    bad = syn20_orthonorm_chain()
-    bad[2]["aperture"]["shape"] = "rectangular"
-    with pytest.raises(NotImplementedError):
-        run(1.0, 1.0e-6, 64, 4, field, bad)
     bad = syn20_orthonorm_chain()
     del bad[2]["aperture"]
     with pytest.raises(AssertionError):

@@ -1,0 +1,192 @@
+"""GPU tests added in round 2: Grid Sag / PSD phase screens against reference vectors, the power-ticket
+ring with more saved surfaces than the library has slots, parameter-arena growth, run() of a chain that
+carries a PSD surface."""
+import copy
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+FIELD_TOL = 1e-11
+DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data")
+
+
+def _wfo(g, anam=False, precision="fp64"):
+    from paos_amd.wfo import WFO
+
+    w = WFO(1.0, 2.0e-6, 64, 4, precision=precision)
+    if anam:
+        w.Magnification(1.25, 0.8)
+    w._wfo = g["u0"]
+    return w
+
+
+def test_grid_sag_vs_reference_vectors():
+    """WFO.grid_sag (wfo.py:656-871): identity, anamorphic sampling, zero padding, cropping and the
+    sub-pixel Fourier shift -- field after the phase multiply against the reference's."""
+    g = load_golden("r2_phase_maps.npz")
+    for tag, anam, kw in (("same", False, {}), ("same_anam", True, {}), ("pad", False, {}), ("crop", False, {}),
+                          ("shift", False, dict(xdec=1.5, ydec=-0.25))):
+        w = _wfo(g, anam)
+        sag = g[f"gs_{tag}_sag"]
+        ret = w.grid_sag(sag.copy(), sag.shape[1], sag.shape[0], w.dx, w.dy, **kw)
+        assert np.array_equal(ret.filled(0.0), g[f"gs_{tag}_wfe"]), tag
+        assert np.array_equal(np.ma.getmaskarray(ret), g[f"gs_{tag}_mask"]), tag
+        e = rel_err(w.wfo, g[f"gs_{tag}_u"])
+        assert e < 1e-14, (tag, e)
+
+
+def test_psd_vs_reference_vectors():
+    """WFO.psd (wfo.py:873-949, psd.py:85-160) with the legacy global generator seeded like the fixture."""
+    g = load_golden("r2_phase_maps.npz")
+    cases = {"powerlaw": dict(A=7.0, B=0.0, C=1.5, fknee=1.0, fmin=None, fmax=None, SR=0.0, units="nm"),
+             "knee_sr": dict(A=12.0, B=1.0, C=2.2, fknee=3.0, fmin=0.5, fmax=6.0, SR=2.0, units="nm")}
+    for tag, kw in cases.items():
+        for anam in (False, True):
+            w = _wfo(g, anam)
+            np.random.seed(1234)
+            ret = w.psd(**kw)
+            key = f"psd_{tag}{'_anam' if anam else ''}"
+            assert np.array_equal(np.ma.filled(ret, 0.0), g[key + "_wfe"]), key
+            e = rel_err(w.wfo, g[key + "_u"])
+            assert e < 1e-14, (key, e)
+    # fp32 fields take the same screen (phase formed in fp64, stored in complex64)
+    w = _wfo(g, False, "fp32")
+    np.random.seed(1234)
+    w.psd(**cases["powerlaw"])
+    assert 1e-9 < rel_err(w.wfo, g["psd_powerlaw_u"]) < 1e-6
+
+
+def test_phase_map_rejects_bad_input():
+    from paos_amd import _lib
+
+    dev = _lib.DeviceFields(64, 2)
+    dev.fill(1.0)
+    with pytest.raises(ValueError):
+        dev.phase_map(0, np.zeros((32, 32)), 1e-6)
+    bad = np.zeros((64, 64))
+    bad[3, 3] = np.nan
+    with pytest.raises(_lib.PaosHipError, match="non-finite"):
+        dev.phase_map(0, bad, 1e-6)
+    with pytest.raises(_lib.PaosHipError):
+        dev.phase_map(2, np.zeros((64, 64)), 1e-6)
+    with pytest.raises(_lib.PaosHipError, match="wavelength"):
+        dev.phase_map(0, np.zeros((64, 64)), 0.0)
+    # item 1 only: item 0 untouched
+    dev.phase_map(1, np.full((64, 64), 0.25e-6), 1e-6)
+    assert np.array_equal(dev.download(0), np.ones((64, 64), dtype=complex))
+    assert rel_err(dev.download(1), np.full((64, 64), 1j)) < 1e-15
+    dev.close()
+
+
+def test_run_with_a_psd_surface_matches_the_stepwise_wfo():
+    """lens_file_TA_Ground_PSD.ini end to end: run() (fused passes, the PSD screen as a chain breaker)
+    equals driving WFO method by method with the same seed; the screen is the `wfe` of the saved surface."""
+    from paos_amd.parse_config import parse_config
+    from paos_amd.run import run
+
+    pup, par, wls, fields, chains = parse_config(os.path.join(DATA, "lens", "lens_file_TA_Ground_PSD.ini"))
+    chain = chains[1]
+    np.random.seed(7)
+    ret = run(pup, 1e-6 * wls[1], 256, par["zoom"], fields[0], chain)
+    psd_num = [k for k, it in chain.items() if it["type"] == "PSD"][0]
+    assert psd_num in ret and "wfe" in ret[psd_num]
+    wfe = ret[psd_num]["wfe"]
+    assert wfe.shape == (256, 256) and np.std(np.ma.filled(wfe, 0.0)) > 0
+    # the same chain with the PSD surface replaced by nothing differs exactly by that phase screen
+    plain = {k: v for k, v in chain.items() if k != psd_num}
+    base = run(pup, 1e-6 * wls[1], 256, par["zoom"], fields[0], plain)
+    # surfaces before the PSD are identical, the PSD surface itself is base * exp(2 pi i wfe / wl)
+    before = [k for k in ret if k < psd_num]
+    for k in before:
+        assert np.array_equal(ret[k]["wfo"], base[k]["wfo"])
+    np.random.seed(7)
+    again = run(pup, 1e-6 * wls[1], 256, par["zoom"], fields[0], chain)
+    for k in ret:
+        assert np.array_equal(ret[k]["wfo"], again[k]["wfo"])
+    last = max(ret)
+    assert rel_err(ret[last]["wfo"], base[last]["wfo"]) > 1e-6
+
+
+def test_more_saved_surfaces_than_ticket_slots():
+    """A chain that saves more than PAOS_NORM_SLOTS surfaces: run_batch drains the power tickets early and
+    every power is right (they used to wrap silently); the raw ABI refuses to overrun the ring."""
+    from paos_amd import _lib
+    from paos_amd.abcd import ABCD
+    from paos_amd.run import run_batch
+
+    n_surf = _lib.NORM_SLOTS + 9
+    chain = {}
+    for num in range(1, n_surf + 1):
+        item = {"num": num, "type": "Standard", "name": f"S{num}", "is_stop": num == 1, "save": True,
+                "ABCDt": ABCD(thickness=0.05 if num % 2 else 0.0, curvature=0.0),
+                "ABCDs": ABCD(thickness=0.05 if num % 2 else 0.0, curvature=0.0)}
+        if num == 1 or num % 7 == 0:
+            rad = 0.5 if num == 1 else 0.5 - 0.002 * num
+            item["aperture"] = {"shape": "elliptical", "type": "aperture", "xrad": rad, "yrad": rad, "xc": 0.0, "yc": 0.0}
+        chain[num] = item
+    res = run_batch(1.0, [1.0e-6, 1.3e-6], 128, 4, {"us": 0.0, "ut": 0.0}, [chain, copy.deepcopy(chain)],
+                    outputs=("psf",))
+    for r in res:
+        assert sorted(r) == list(range(1, n_surf + 1))
+        for k, rec in r.items():
+            assert abs(rec["power"] - rec["psf"].sum()) < 1e-12, k
+        powers = [r[k]["power"] for k in sorted(r)]
+        assert abs(powers[0] - 1.0) < 1e-13 and powers[-1] < powers[0]  # the later apertures clip light
+    dev = _lib.DeviceFields(64, 1)
+    dev.fill(1.0)
+    tickets = [dev.norm2_enqueue() for _ in range(_lib.NORM_SLOTS)]
+    with pytest.raises(_lib.PaosHipError, match="outstanding"):
+        dev.norm2_enqueue()
+    assert dev.norm2_fetch(tickets[0])[0] == 64.0 * 64.0
+    with pytest.raises(_lib.PaosHipError, match="not outstanding"):
+        dev.norm2_fetch(tickets[0])
+    tickets.append(dev.norm2_enqueue())  # the freed slot is usable again
+    for t in tickets[1:]:
+        assert dev.norm2_fetch(t)[0] == 64.0 * 64.0
+    dev.close()
+
+
+def test_parameter_arena_grows_for_a_long_program():
+    """One fused program whose parameter records exceed the arena's initial capacity (large batch, a long
+    run of lens / propagation surfaces without a breaker): the arena grows before the first push instead of
+    wrapping under the live block table; results equal the same work in short programs."""
+    from paos_amd import _lib
+    from paos_amd.planner import PilotBeam
+
+    n, nb = 64, 96
+    dev = _lib.DeviceFields(n, nb)
+    rng = np.random.default_rng(3)
+    u0 = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    wls = [1.0e-6 * (1 + 0.01 * i) for i in range(nb)]
+
+    def program(count):
+        beams = [PilotBeam(1.0, wl, n, 4) for wl in wls]
+        passes, blocks = [], []
+        for s in range(count):
+            blocks.append([b.ptp(0.01 * (s + 1)) for b in beams])
+        return beams, blocks
+
+    for i in range(nb):
+        dev.upload(i, u0)
+    _, blocks = program(400)
+    # 400 ptp = 1200 passes in ONE program: ~1200 x 96 records of FrugalItem-sized pushes >> 8 MiB
+    from paos_amd.passes import PassCompiler
+
+    comp = PassCompiler(nb, n)
+    for blk in blocks:
+        comp.ptp(blk)
+    npass = comp.flush(dev)
+    assert npass >= 800
+    got = dev.download(5)
+    for i in range(nb):
+        dev.upload(i, u0)
+    for blk in blocks:  # the same, one operator per program
+        dev.ptp(blk)
+    ref = dev.download(5)
+    assert rel_err(got, ref) < 1e-12
+    dev.close()
