@@ -12,14 +12,19 @@ all: $(LIB)
 # part 0 = everything but the frugal pass-kernel families, parts 1..5 = one (type, N) family each.
 DEPS = $(CSRC)/paos_hip.hip $(CSRC)/fft_core.h $(CSRC)/fft_kernels.h $(CSRC)/frugal_pass.h $(CSRC)/pointwise.h include/paos_hip.h
 PARTS = 0 1 2 3 4 5
-OBJS = $(foreach k,$(PARTS),build/obj/part$(k).o)
+OBJS = $(foreach k,$(PARTS),build/obj/part$(k).o) build/obj/comm.o
+
+# the multi-GPU fan-out (include/paos_comm.h): host code only, RCCL is dlopen'ed at run time
+build/obj/comm.o: $(CSRC)/paos_comm.cpp include/paos_comm.h include/paos_hip.h
+	mkdir -p build/obj
+	$(HIPCC) -O2 -fPIC -std=c++17 -Wall -c $(CSRC)/paos_comm.cpp -o $@
 
 build/obj/part%.o: $(DEPS)
 	mkdir -p build/obj
 	$(HIPCC) $(HIPFLAGS) -DPAOS_PART=$* -I$(CSRC) -c $(CSRC)/paos_hip.hip -o $@
 
 $(LIB): $(OBJS)
-	$(HIPCC) -shared -fPIC $(OBJS) -o $(LIB)
+	$(HIPCC) -shared -fPIC $(OBJS) -ldl -o $(LIB)
 
 build/fftbench: tools/fftbench.hip $(CSRC)/fft_core.h $(CSRC)/fft_kernels.h $(CSRC)/frugal_pass.h
 	mkdir -p build

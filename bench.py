@@ -5,13 +5,24 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" propagates one batch of ``--batch`` wavefronts (wavelength sweep
-lambda_k = 1 um (1 + k/512)) per GPU through all 20 surfaces on the HIP path; fields
-are created and stay in HBM.  With N GPUs every rank gets its own contiguous block of
-the sweep (weak scaling) after ONE broadcast of the work description from rank 0.
-Rank 0 prints one JSON line (contract in the task statement) with two extra objects:
-``roofline`` (dominant kernel: the fused FFT pass, every launch HIP-event timed inside the
-timed region) and ``cpu_baseline`` (the NumPy oracle on a bounded sample, rank 0, N=1 only).
+A "step" propagates one batch of ``--batch`` wavefronts (wavelength sweep lambda_k = 1 um (1 + k/512)) per GPU
+through all 20 surfaces on the HIP path; fields are created and stay in HBM.  With N GPUs every rank gets its own
+contiguous block of the sweep (weak scaling) after ONE broadcast of the packed work description from rank 0
+(paos_comm_bcast_blob: RCCL over xGMI, driven from libpaoship.so -- torch is only the launcher, it is never
+imported here).  Rank 0 prints one JSON line (contract in the task statement) with these extra objects:
+
+  roofline           the dominant kernel (the fused FFT pass): every pass launch of the timed region is
+                     bracketed by HIP events on the context's stream; `achieved` = 32 B/px x N^2 x batch (one read
+                     and one write of every element) / mean duration of the launches that process every tile
+                     (launches that skip dead tiles behind an aperture move fewer bytes and are listed apart under
+                     `pruned`); `copy_yardstick` is measured in this run (paos_copy_yardstick); `traffic` is null
+                     here -- PMC counters cannot be read from inside the process; profiles/r02_pmc_* holds them.
+  chain_vs_survey_model / ptp_step   the whole chain and one ptp priced with SURVEY 8d's UNFUSED byte model (2 passes
+                     per 2-D FFT) next to the bytes the fused passes really move (`frac_bytes_moved`).
+  extra              the same chain at 2048^2 and 1024^2 (the north star's sweep), value + roofline each.
+  cpu_baseline       the NumPy oracle ("port") on the host: one wavefront of the workload at the benchmark grid
+                     on one core, and `cpu_baseline_parallel`: min(batch, cores, memory) worker processes over
+                     wavelengths at the benchmark grid -- the reference's own joblib scheme (pipeline.py:140).
 """
 import argparse
 import json
@@ -24,6 +35,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+ON_AXIS = {"us": 0.0, "ut": 0.0}
 
 
 def chain_fft_counts(wavelength, gridsize):
@@ -31,7 +43,7 @@ def chain_fft_counts(wavelength, gridsize):
     from paos_amd.chains import syn20_chain
     from paos_amd.run import _Item, _plan_surface
 
-    st = _Item(1.0, wavelength, gridsize, 4, {"us": 0.0, "ut": 0.0})
+    st = _Item(1.0, wavelength, gridsize, 4, ON_AXIS)
     counts = {"ptp": 0, "stw": 0, "wts": 0}
     for item in syn20_chain().values():
         for step in _plan_surface(st, item)["steps"]:
@@ -39,63 +51,125 @@ def chain_fft_counts(wavelength, gridsize):
     return counts["ptp"], counts["stw"], counts["wts"]
 
 
-def cpu_baseline(gridsize):
-    """NumPy oracle ("port") on the host, 1 core: the full SYN20 chain for two wavelengths of the
-    sweep at 2048^2 (saved surfaces only, like the reference's run()), scaled by the pixel ratio
-    to the benchmark grid (flatters the CPU: its cost per pixel grows with the grid).  ~10-30 s."""
-    from oracle.run_np import run as oracle_run
-    from paos_amd.chains import syn20_chain, syn20_wavelength
-
-    n_s = min(gridsize, 2048)
-    sample = [syn20_wavelength(0), syn20_wavelength(256)]
-    t0 = time.perf_counter()
-    for wl in sample:
-        oracle_run(1.0, wl, n_s, 4, {"us": 0.0, "ut": 0.0}, syn20_chain(), light=True)
-    dt = (time.perf_counter() - t0) / len(sample)
-    scale = (gridsize / n_s) ** 2
-    return {
-        "value": 1.0 / (dt * scale),
-        "unit": "wavefronts/s",
-        "cores": 1,
-        "kind": "port",
-        "sample": f"full SYN20 chain, {len(sample)} wavelengths of the sweep, {n_s}x{n_s} complex128, "
-                  f"oracle/run_np.py (NumPy pocketfft, single thread): {dt:.1f} s per wavefront; scaled by "
-                  f"{scale:g}x pixels to {gridsize}x{gridsize}; host has {os.cpu_count()} logical CPUs",
-    }
-
-
 def _oracle_seconds(task):
-    """Worker of the parallel CPU baseline: one wavefront of the sweep, returns its wall time."""
-    k, n_s = task
+    """One SYN20 wavefront of the sweep through the NumPy oracle; returns its wall time."""
+    k, n = task
     from oracle.run_np import run as oracle_run
     from paos_amd.chains import syn20_chain, syn20_wavelength
 
     t0 = time.perf_counter()
-    oracle_run(1.0, syn20_wavelength(k), n_s, 4, {"us": 0.0, "ut": 0.0}, syn20_chain(), light=True)
+    oracle_run(1.0, syn20_wavelength(k), n, 4, ON_AXIS, syn20_chain(), light=True)
     return time.perf_counter() - t0
 
 
-def cpu_baseline_parallel(gridsize, workers=8):
-    """The reference's own way to use a CPU (pipeline.py:140: joblib over wavelengths): ``workers``
-    processes, one wavelength of the sweep each, 2048^2, scaled like cpu_baseline.  Must run BEFORE
+def cpu_baseline(gridsize):
+    """The oracle on ONE core: one wavefront of the workload at the benchmark grid (saved surfaces only, like the
+    reference's run()).  ~50 s at 4096^2 on the GPU box's host."""
+    dt = _oracle_seconds((0, gridsize))
+    return {
+        "value": 1.0 / dt,
+        "unit": "wavefronts/s",
+        "cores": 1,
+        "kind": "port",
+        "sample": f"full SYN20 chain, 1 wavelength of the sweep at the benchmark grid {gridsize}x{gridsize} complex128, "
+                  f"oracle/run_np.py (NumPy pocketfft, single thread): {dt:.1f} s per wavefront; host has "
+                  f"{os.cpu_count()} logical CPUs",
+    }
+
+
+def cpu_baseline_parallel(gridsize, batch):
+    """The reference's own way to use a CPU (pipeline.py:140: joblib over wavelengths): n_jobs = min(batch, cores)
+    worker processes, one wavelength of the sweep each, at the benchmark grid; n_jobs is also capped by memory (the
+    oracle peaks at ~17 GB per 4096^2 wavefront: the reference's Zernike evaluation holds 36 maps).  Must run BEFORE
     this process touches the GPU (the workers are forked)."""
     import multiprocessing as mp
 
-    n_s = min(gridsize, 2048)
-    workers = max(1, min(workers, os.cpu_count() or 1))
+    cores = os.cpu_count() or 1
+    per_worker_gb = 17.0 * (gridsize / 4096.0) ** 2 + 0.5
+    try:
+        import psutil
+
+        avail_gb = psutil.virtual_memory().available / 1e9
+    except Exception:  # noqa: BLE001
+        avail_gb = 64.0
+    by_memory = max(1, int(0.6 * avail_gb / per_worker_gb))
+    workers = max(1, min(batch, cores, by_memory))
     t0 = time.perf_counter()
     with mp.get_context("fork").Pool(workers) as pool:
-        each = pool.map(_oracle_seconds, [(64 * k, n_s) for k in range(workers)])
+        each = pool.map(_oracle_seconds, [(64 * k, gridsize) for k in range(workers)])
     wall = time.perf_counter() - t0
-    scale = (gridsize / n_s) ** 2
     return {
-        "value": workers / (wall * scale),
+        "value": workers / wall,
         "unit": "wavefronts/s",
         "cores": workers,
         "kind": "port",
-        "sample": f"{workers} worker processes (the reference fans out over wavelengths with joblib, "
-                  f"pipeline.py:140), one SYN20 wavefront each at {n_s}x{n_s}: {wall:.1f} s wall "
-                  f"({min(each):.1f}-{max(each):.1f} s per worker); scaled by {scale:g}x pixels",
+        "sample": f"{workers} worker processes = min(batch {batch}, {cores} logical CPUs, memory: {avail_gb:.0f} GB free at "
+                  f"~{per_worker_gb:.0f} GB per worker) over wavelengths (pipeline.py:140), one SYN20 wavefront each at "
+                  f"{gridsize}x{gridsize}: {wall:.1f} s wall ({min(each):.1f}-{max(each):.1f} s per worker)",
+    }
+
+
+def measure(dev, n, nb, precision, wavelengths, chains, steps, warmup, comm=None):
+    """Timed region of the contract: W untimed steps, then exactly K steps between barriers; every pass launch
+    is event-timed.  Returns a dict of raw numbers."""
+    from paos_amd import _lib
+    from paos_amd.run import run_batch
+
+    stats = {}
+
+    def step():
+        return run_batch(1.0, wavelengths, n, 4, ON_AXIS, chains, precision=precision, outputs=(), dev=dev,
+                         sync=False, stats=stats, keep_psf=True)
+
+    def barrier():
+        dev.sync()
+        if comm is not None:
+            comm.barrier()
+
+    def release(results):  # power tickets of a step nobody will read (no synchronisation)
+        if results is not None:
+            for t in {rec["power_ticket"] for r in results for rec in r.values() if "power_ticket" in rec}:
+                dev.norm2_release(t)
+
+    res = None
+    for _ in range(warmup):
+        release(res)
+        res = step()
+    barrier()
+    dev.profile_begin(_lib.KERNEL_PASS_ANY, max_launches=64 * 1024)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        release(res)
+        res = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    launches, kern_ms, pruned, pruned_ms = dev.profile_end_split()
+    if comm is not None:
+        elapsed = comm.max(elapsed)
+    return {"elapsed": elapsed, "launches": launches, "kern_ms": kern_ms, "pruned": pruned, "pruned_ms": pruned_ms,
+            "fused_passes": stats.get("fused_passes"), "res": res}
+
+
+def roofline_block(m, n, nb, esz, dev, kernel_name):
+    pass_bytes = 2 * esz * n * n * nb  # one pass over the batch: every element read + written once
+    full = m["launches"] - m["pruned"]
+    full_ms = (m["kern_ms"] - m["pruned_ms"]) / max(full, 1)
+    achieved = pass_bytes / (full_ms * 1e-3) / 1e9 if full else 0.0
+    y_ms, y_bytes = dev.copy_yardstick(10)
+    return {
+        "bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+        "traffic_note": "PMC counters are not readable in-process; per-kernel FETCH_SIZE / WRITE_SIZE of this command "
+                        "under rocprofv3: profiles/r02_pmc_hbm_traffic_bench.txt",
+        "launches": full, "avg_launch_ms": full_ms, "algorithmic_bytes_per_launch": pass_bytes,
+        "pruned": {"launches": m["pruned"], "avg_launch_ms": m["pruned_ms"] / max(m["pruned"], 1),
+                   "what": "pass launches behind an aperture that skip the tiles / loads of rows or columns the aperture "
+                           "has zeroed (they move fewer bytes and are kept out of `achieved`)"},
+        "all_pass_launches_avg_ms": m["kern_ms"] / max(m["launches"], 1),
+        "fused_passes_per_wavefront": m["fused_passes"],
+        "copy_yardstick": {"ms_per_launch": y_ms, "GBps": y_bytes / (y_ms * 1e-3) / 1e9,
+                           "what": "measured in this run (paos_copy_yardstick): in-place copy of the same batch buffer, "
+                                   "16 B per lane, unit stride, no transform"},
     }
 
 
@@ -105,10 +179,13 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid", type=int, default=4096)
-    ap.add_argument("--batch", type=int, default=8, help="wavefronts per GPU per step")
+    ap.add_argument("--batch", type=int, default=0, help="wavefronts per GPU per step (default: 8 at 4096^2, 2 GiB of fields)")
     ap.add_argument("--precision", default="fp64", choices=["fp64", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the 2048^2 / 1024^2 entries")
     args = ap.parse_args()
+    if args.batch <= 0:
+        args.batch = max(8, 8 * (4096 // args.grid) ** 2)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -121,72 +198,42 @@ def main():
     # forked CPU workers: before anything initialises the GPU in this process
     cpu_parallel = None
     if world == 1 and not args.no_cpu_baseline:
-        cpu_parallel = cpu_baseline_parallel(args.grid)
+        cpu_parallel = cpu_baseline_parallel(args.grid, args.batch)
 
-    dist = None
-    if world > 1 or os.environ.get("PAOS_BENCH_FORCE_DIST") == "1":  # the flag exercises the
-        # process-group path with a single rank (what a 1-GPU box can test)
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        import torch
-        import torch.distributed as dist
-
-        if os.environ.get("PAOS_BENCH_REHEARSAL") == "1":
-            # several ranks sharing ONE GPU over gloo: rehearses the N > 1 control flow (broadcast,
-            # shards, barrier, MAX reduction) on a single-GPU box; the numbers mean nothing
-            local_rank = 0
-            dist.init_process_group(backend="gloo")
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     from paos_amd import _lib
     from paos_amd.chains import syn20_chain
-    from paos_amd.dist import broadcast_blob, max_over_ranks, shard_bounds, syn20_work
-    from paos_amd.run import run_batch
+    from paos_amd.dist import broadcast_work, shard_bounds, syn20_work
+
+    comm = None
+    if world > 1 or os.environ.get("PAOS_BENCH_FORCE_COMM") == "1":
+        from paos_amd.comm import Comm
+
+        if os.environ.get("PAOS_BENCH_REHEARSAL") == "1":
+            # several ranks sharing ONE GPU over the TCP transport: rehearses the N > 1 control flow (broadcast,
+            # shards, barrier, MAX reduction) on a single-GPU box; the numbers mean nothing
+            local_rank = 0
+            comm = Comm.from_env(transport="socket")
+        else:
+            comm = Comm.from_env(transport="rccl")  # one process per GPU, RCCL over xGMI
 
     n, nb = args.grid, args.batch
     total = nb * world
-    # rank 0 describes the whole job; one broadcast (RCCL over xGMI when N > 1)
     work = syn20_work(total, "wavelengths") if rank == 0 else None
-    work = broadcast_blob(work, src=0)
+    work = broadcast_work(work, comm)  # the ONE broadcast
     lo, hi = shard_bounds(total, rank, world)
     wavelengths = work["wavelengths"][lo:hi]
     chains = [syn20_chain(coefficients=c) for c in work["coefficients"][lo:hi]]
-    field = {"us": 0.0, "ut": 0.0}
 
     dev = _lib.DeviceFields(n, nb, args.precision, device=local_rank)
+    m = measure(dev, n, nb, args.precision, wavelengths, chains, args.steps, args.warmup, comm)
+    esz = 16 if args.precision == "fp64" else 8
+    frugal = n >= (1024 if args.precision == "fp64" else 2048)
+    kernel_name = ("frugal_pass_kernel" if frugal else "fused_pass_kernel") + " (every FFT pass launch, rows and columns)"
 
-    stats = {}
-
-    def step():
-        return run_batch(1.0, wavelengths, n, 4, field, chains, precision=args.precision,
-                         outputs=(), dev=dev, sync=False, stats=stats, keep_psf=True)
-
-    def barrier():
-        dev.sync()
-        if dist is not None:
-            dist.barrier()
-            if dist.get_backend() == "nccl":
-                import torch
-
-                torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    dev.profile_begin(_lib.KERNEL_PASS_ANY, max_launches=64 * 1024)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        res = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    launches, kern_ms = dev.profile_end()
-    elapsed = max_over_ranks(elapsed)
-
-    # The north star's headline step: one ptp (fft2 -> H -> ifft2, wfo.py:462-472) on the
-    # whole batch, timed alone with the pass timer (3 launches: rows | cols x2 fused | rows).
-    ptp_ms = None
     if rank == 0:
+        # The north star's headline step: one ptp (fft2 -> H -> ifft2, wfo.py:462-472) on the whole batch, timed
+        # alone with the pass timer (3 launches: rows | cols x2 fused | rows).
         from paos_amd.planner import PilotBeam
 
         blk = [PilotBeam(1.0, wl, n, 4).ptp(2.5) for wl in wavelengths]
@@ -195,69 +242,76 @@ def main():
         dev.profile_begin(_lib.KERNEL_PASS_ANY, max_launches=64)
         for _ in range(5):
             dev.ptp(blk)
-        nl, tot = dev.profile_end()
+        _, tot = dev.profile_end()
         ptp_ms = tot / 5.0
 
-    if rank == 0:
-        esz = 16 if args.precision == "fp64" else 8
-        value = total * args.steps / elapsed
+        value = total * args.steps / m["elapsed"]
         n_ptp, n_stw, n_wts = chain_fft_counts(wavelengths[0], n)
         ffts = 2 * n_ptp + n_stw + n_wts
-        # 2 passes x (read + write) per 2-D FFT + one 8 B/px intensity write
-        chain_bytes = (ffts * 4 * esz + 8) * n * n
-        pass_bytes = 2 * esz * n * n * nb  # one pass over the batch: every element read + written once
-        avg_ms = kern_ms / max(launches, 1)
-        achieved = pass_bytes / (avg_ms * 1e-3) / 1e9 if launches else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath) and n == 4096 and args.precision == "fp64":
-            with open(tpath) as fh:
-                traffic = json.load(fh).get("fused_pass_bytes_per_launch")
+        survey_bytes = (ffts * 4 * esz + 8) * n * n  # 2 passes x (read + write) per 2-D FFT + the 8 B/px PSF write
+        moved_bytes = (m["fused_passes"] * 2 * esz + 85) * n * n  # fused passes + start / Zernike / reductions / PSF
+        per_gpu = value / world
+        dtype = "c128 (f64)" if args.precision == "fp64" else "c64 (f32, f64 phase arguments)"
         out = {
-            "metric": "wavefronts/sec (4096^2 c128, 20-surface chain) + achieved HBM GB/s",
+            "metric": f"wavefronts/sec ({n}^2 {'c128' if esz == 16 else 'c64'}, 20-surface chain) + achieved HBM GB/s",
             "value": value,
             "unit": "wavefronts/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": 1e3 * m["elapsed"] / args.steps,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "c128 (f64)" if args.precision == "fp64" else "c64 (f32, f64 phases)",
+            "dtype": dtype,
             "data": "synthetic",
-            "config": {"workload": f"SYN20 20-surface chain, {n}x{n} {args.precision}, wavelength sweep "
-                                   f"1um*(1+k/512), {nb} wavefronts/GPU/step, {ffts} 2-D FFTs per wavefront "
-                                   f"({n_ptp} ptp, {n_stw} stw, {n_wts} wts); the final |u|^2 of every wavefront is written "
-                                   f"to HBM (8 B/px) and stays there, powers of the saved surfaces are reduced on the GPU",
-                       "grid": n, "batch_per_gpu": nb, "parallelism": f"wavefront-sharded x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "frugal_pass_kernel (every FFT pass launch, rows and columns)", "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "launches": launches, "avg_launch_ms": avg_ms,
-                         "algorithmic_bytes_per_launch": pass_bytes,
-                         "fused_passes_per_wavefront": stats.get("fused_passes"),
-                         "copy_yardstick": {"in_place_copy_GBps": 5522.0, "same_tile_shape_GBps": 5080.0,
-                                            "what": "tools/membench.hip: in-place read-modify-write of the same 4096^2 c128 x 8 "
-                                                    "batch without the FFT (contiguous tiles / the FFT passes' tile shapes)",
-                                            "source": "profiles/r01_membench_rmw_patterns.txt"} if (n == 4096 and esz == 16) else None},
-            "chain_roofline": {"algorithmic_bytes_per_wavefront": chain_bytes,
-                               "achieved_GBps_per_gpu": chain_bytes * (value / world) / 1e9,
-                               "frac_of_hbm_peak": chain_bytes * (value / world) / 1e9 / HBM_PEAK_GBS},
+            "config": {"workload": f"SYN20 20-surface chain, {n}x{n} {args.precision}, wavelength sweep 1um*(1+k/512), "
+                                   f"{nb} wavefronts/GPU/step, {ffts} 2-D FFTs per wavefront ({n_ptp} ptp, {n_stw} stw, "
+                                   f"{n_wts} wts); the final |u|^2 of every wavefront is written to HBM (8 B/px) and stays "
+                                   f"there, powers of the saved surfaces are reduced on the GPU",
+                       "grid": n, "batch_per_gpu": nb, "parallelism": f"wavefront-sharded x{world}",
+                       "transport": comm.transport if comm is not None else "none (single process)"},
+            "roofline": roofline_block(m, n, nb, esz, dev, kernel_name),
+            "chain_vs_survey_model": {
+                "survey_model_bytes_per_wavefront": survey_bytes,
+                "frac_of_hbm_peak_vs_survey_model": survey_bytes * per_gpu / 1e9 / HBM_PEAK_GBS,
+                "bytes_moved_per_wavefront": moved_bytes,
+                "frac_bytes_moved": moved_bytes * per_gpu / 1e9 / HBM_PEAK_GBS,
+                "note": "SURVEY 8d prices the chain UNFUSED (two HBM passes per 2-D FFT); the fused path moves fewer "
+                        "bytes, so the first figure is a speed-up in model units, not a roofline fraction"},
             "ptp_step": {"what": "one ptp over the batch: 2 2-D FFTs + H, 3 fused passes",
                          "ms_per_wavefront": ptp_ms / nb,
-                         "algorithmic_GBps": 8 * esz * n * n * nb / (ptp_ms * 1e-3) / 1e9,
-                         "frac_of_hbm_peak": 8 * esz * n * n * nb / (ptp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "frac_of_hbm_peak_vs_survey_model": 8 * esz * n * n * nb / (ptp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "frac_bytes_moved": 6 * esz * n * n * nb / (ptp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "note": "SURVEY 8d prices a ptp at 128 B/px (4 passes); the fused path moves 96 B/px"},
-            "power_check": float(dev.norm2_fetch(res[0][20]["power_ticket"])[0]),
+            "power_check": float(dev.norm2_fetch(m["res"][0][20]["power_ticket"])[0]),
             "build": dev.build_info(),
         }
+        dev.close()
+        if world == 1 and not args.no_extras and n == 4096:
+            extra = {}
+            for n2, nb2 in ((2048, 16), (1024, 64)):
+                w2 = syn20_work(nb2, "wavelengths")
+                ch2 = [syn20_chain(coefficients=c) for c in w2["coefficients"]]
+                dev2 = _lib.DeviceFields(n2, nb2, args.precision)
+                m2 = measure(dev2, n2, nb2, args.precision, w2["wavelengths"], ch2, max(args.steps, 5), max(args.warmup, 2))
+                fr2 = n2 >= (1024 if args.precision == "fp64" else 2048)
+                extra[f"{n2}^2"] = {
+                    "value": nb2 * max(args.steps, 5) / m2["elapsed"], "unit": "wavefronts/s", "batch": nb2,
+                    "ms_per_step": 1e3 * m2["elapsed"] / max(args.steps, 5),
+                    "roofline": roofline_block(m2, n2, nb2, esz, dev2,
+                                               ("frugal_pass_kernel" if fr2 else "fused_pass_kernel") + " (every FFT pass launch)")}
+                dev2.close()
+            out["extra"] = extra
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n)
             out["cpu_baseline_parallel"] = cpu_parallel
         print(json.dumps(out), flush=True)
-    dev.close()
-    if dist is not None:
-        dist.destroy_process_group()
+    else:
+        dev.close()
+    if comm is not None:
+        comm.barrier()
+        comm.close()
 
 
 if __name__ == "__main__":

@@ -79,6 +79,9 @@ void* paos_stream(paos_ctx* ctx);
  * the launch count and the summed durations.  Used by bench.py for the roofline figure. */
 int paos_profile_begin(paos_ctx* ctx, int kernel_kind, int max_launches);
 int paos_profile_end(paos_ctx* ctx, int* launches, double* total_ms);
+/* the same, also telling apart the launches that skipped dead tiles or loads (pruned passes move fewer
+ * bytes, so a bandwidth figure must be taken over the others) */
+int paos_profile_end_split(paos_ctx* ctx, int* launches, double* total_ms, int* pruned_launches, double* pruned_ms);
 
 /* ---- field I/O ---------------------------------------------------------------------- */
 /* u[:] = re + i im for every batch item -- np.ones(..., complex128), wfo.py:118 */
@@ -127,6 +130,8 @@ int paos_norm2(paos_ctx* ctx, double* host_out);
  * a ticket can be fetched once. */
 int paos_norm2_enqueue(paos_ctx* ctx, int* ticket);
 int paos_norm2_fetch(paos_ctx* ctx, int ticket, double* host_out);
+/* give a ticket back without reading it (no synchronisation) */
+int paos_norm2_release(paos_ctx* ctx, int ticket);
 /* PSF metrics on the GPU for Monte-Carlo studies (the encircled-energy workflow of
  * docs/source/user/montecarlo/index.rst:26-66; PSF = |u|^2, plot.py:125-130).  Per item:
  * [sum I, sum I*col, sum I*row, max I, then nr values: sum of I over pixels whose centre lies
@@ -160,6 +165,19 @@ int paos_wts(paos_ctx* ctx, const double* params, int inverse);
  * paos_wts / paos_phase above are one-operator programs of the same machinery. */
 int paos_run_passes(paos_ctx* ctx, const paos_pass* passes, int n_passes, const double* blocks,
                     int n_blocks);
+/* The same with a promise about the field on entry: for item i, the rows outside
+ * [live_rows[2 i], live_rows[2 i + 1]) are exactly zero in memory (what WFO.aperture, wfo.py:273-276,
+ * leaves outside the bounding box of a clear aperture).  Transforms of zero rows are zero rows, so the
+ * first passes skip them -- the results are the same, only the traffic is not.  (Inside a program the
+ * library tracks by itself which rows / columns the apertures riding on its passes have zeroed.) */
+/* Measurement aid: an in-place copy of the whole batch (every element read and written back unchanged,
+ * 16 B per lane, unit stride), `reps` launches timed with HIP events on the context's stream: the
+ * yardstick bench.py prints next to the pass kernels' rate.  The field is left as it was. */
+int paos_copy_yardstick(paos_ctx* ctx, int reps, double* ms_per_launch, double* bytes_per_launch);
+/* Measurement / test aid: on = 0 makes every pass process every tile (no dead-line pruning). */
+int paos_ctx_set_pruning(paos_ctx* ctx, int on);
+int paos_run_passes_live(paos_ctx* ctx, const paos_pass* passes, int n_passes, const double* blocks,
+                         int n_blocks, const double* live_rows);
 /* WFO.zernikes (wfo.py:620-652) with Zernike polynomials (zernike.py:85-109,245-247):
  * u *= exp(2 pi i wfe / wl) inside rho <= 1.  `table` holds the Jacobi recurrence
  * constants [(nmax+1)][kdim][3]; `params` the per-item blocks (PAOS_ZERNIKE_HEAD +

@@ -51,6 +51,7 @@ SYMBOLS = {
     "paos_stream": (ctypes.c_void_p, [_c_ctx]),
     "paos_profile_begin": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int]),
     "paos_profile_end": (ctypes.c_int, [_c_ctx, ctypes.POINTER(ctypes.c_int), _dbl_p]),
+    "paos_profile_end_split": (ctypes.c_int, [_c_ctx, ctypes.POINTER(ctypes.c_int), _dbl_p, ctypes.POINTER(ctypes.c_int), _dbl_p]),
     "paos_fill": (ctypes.c_int, [_c_ctx, ctypes.c_double, ctypes.c_double]),
     "paos_import": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_void_p]),
     "paos_export": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
@@ -60,6 +61,7 @@ SYMBOLS = {
     "paos_norm2": (ctypes.c_int, [_c_ctx, _dbl_p]),
     "paos_norm2_enqueue": (ctypes.c_int, [_c_ctx, ctypes.POINTER(ctypes.c_int)]),
     "paos_norm2_fetch": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p]),
+    "paos_norm2_release": (ctypes.c_int, [_c_ctx, ctypes.c_int]),
     "paos_psf_metrics": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p, ctypes.c_double, ctypes.c_double, _dbl_p]),
     "paos_phase": (ctypes.c_int, [_c_ctx, _dbl_p, ctypes.c_int]),
     "paos_phase_map": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p, ctypes.c_double]),
@@ -67,6 +69,9 @@ SYMBOLS = {
     "paos_stw": (ctypes.c_int, [_c_ctx, _dbl_p, ctypes.c_int]),
     "paos_wts": (ctypes.c_int, [_c_ctx, _dbl_p, ctypes.c_int]),
     "paos_run_passes": (ctypes.c_int, [_c_ctx, ctypes.POINTER(Pass), ctypes.c_int, _dbl_p, ctypes.c_int]),
+    "paos_copy_yardstick": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p, _dbl_p]),
+    "paos_ctx_set_pruning": (ctypes.c_int, [_c_ctx, ctypes.c_int]),
+    "paos_run_passes_live": (ctypes.c_int, [_c_ctx, ctypes.POINTER(Pass), ctypes.c_int, _dbl_p, ctypes.c_int, _dbl_p]),
     "paos_zernike": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, _dbl_p, _dbl_p, ctypes.c_int, _dbl_p]),
     "paos_psf_keep": (ctypes.c_int, [_c_ctx]),
     "paos_psf_fetch": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p]),
@@ -248,6 +253,13 @@ class DeviceFields:
                     "paos_profile_end")
         return n.value, ms.value
 
+    def profile_end_split(self):
+        """(launches, total ms, pruned launches, their ms): pruned = skipped dead tiles / loads."""
+        n, ms, pn, pms = ctypes.c_int(0), ctypes.c_double(0.0), ctypes.c_int(0), ctypes.c_double(0.0)
+        self._check(self._lib.paos_profile_end_split(self._ctx, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(pn),
+                                                     ctypes.byref(pms)), "paos_profile_end_split")
+        return n.value, ms.value, pn.value, pms.value
+
     # -- field I/O ----------------------------------------------------------------
     def fill(self, value=1.0 + 0.0j):
         value = complex(value)
@@ -315,6 +327,9 @@ class DeviceFields:
         self._check(self._lib.paos_norm2_fetch(self._ctx, int(ticket), _dptr(out)), "paos_norm2_fetch")
         return out
 
+    def norm2_release(self, ticket):
+        self._check(self._lib.paos_norm2_release(self._ctx, int(ticket)), "paos_norm2_release")
+
     def psf_metrics(self, radii_px=(), centre=None):
         """Per item: dict(power, centroid (col,row), peak, encircled power per radius) of |u|^2,
         computed on the GPU.  ``centre`` defaults to the grid centre (n/2, n/2)."""
@@ -353,9 +368,21 @@ class DeviceFields:
         b = as_blocks(blocks, self.batch, PHASE_STRIDE)
         self._check(self._lib.paos_wts(self._ctx, _dptr(b), int(bool(inverse))), "paos_wts")
 
-    def run_passes(self, passes, blocks):
+    def copy_yardstick(self, reps=10):
+        """(ms per launch, bytes per launch) of an in-place copy of the whole batch (measurement aid)."""
+        ms, nbytes = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        self._check(self._lib.paos_copy_yardstick(self._ctx, int(reps), ctypes.byref(ms), ctypes.byref(nbytes)),
+                    "paos_copy_yardstick")
+        return ms.value, nbytes.value
+
+    def set_pruning(self, on):
+        """Dead-line pruning of the pass programs on (default) / off -- results are identical."""
+        self._check(self._lib.paos_ctx_set_pruning(self._ctx, 1 if on else 0), "paos_ctx_set_pruning")
+
+    def run_passes(self, passes, blocks, live_rows=None):
         """passes: list of dicts {axis, fft1, fft2, pre, mid, post} with operator tuples
-        (kind, flags, block); blocks: array [n_blocks][batch][PHASE_STRIDE]."""
+        (kind, flags, block); blocks: array [n_blocks][batch][PHASE_STRIDE].  ``live_rows``
+        ([batch][2], optional): rows outside [lo, hi) of item i are exactly zero in memory."""
         b = np.ascontiguousarray(blocks, dtype=np.float64)
         if b.ndim != 3 or b.shape[1:] != (self.batch, PHASE_STRIDE):
             raise ValueError("blocks must be [n_blocks][batch][5]")
@@ -370,6 +397,13 @@ class DeviceFields:
                 lst = getattr(dst, name)
                 for i, (kind, flags, block) in enumerate(ops):
                     lst[i].kind, lst[i].flags, lst[i].block = kind, flags, block
+        if live_rows is not None:
+            lr = np.ascontiguousarray(live_rows, dtype=np.float64)
+            if lr.shape != (self.batch, 2):
+                raise ValueError("live_rows must be [batch][2]")
+            self._check(self._lib.paos_run_passes_live(self._ctx, arr, len(passes), _dptr(b), b.shape[0], _dptr(lr)),
+                        "paos_run_passes_live")
+            return
         self._check(self._lib.paos_run_passes(self._ctx, arr, len(passes), _dptr(b), b.shape[0]),
                     "paos_run_passes")
 

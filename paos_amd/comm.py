@@ -1,0 +1,135 @@
+"""ctypes face of include/paos_comm.h: the process group of the wavefront fan-out (one process per GPU).
+
+``Comm.from_env()`` joins the job a launcher started (``python -m torch.distributed.run`` exports RANK,
+WORLD_SIZE, LOCAL_RANK, MASTER_PORT, TORCHELASTIC_RUN_ID; any launcher that sets RANK / WORLD_SIZE and a
+job key works) WITHOUT importing torch: RCCL is driven from libpaoship.so directly.  Transports: "rccl"
+(device buffers over xGMI) and "socket" (TCP through rank 0; what the CPU tests use).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import _lib
+
+SOCKET, RCCL = 0, 1
+_c_comm = ctypes.c_void_p
+_dbl_p = ctypes.POINTER(ctypes.c_double)
+
+SYMBOLS = {
+    "paos_comm_init_rank": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p,
+                                           ctypes.c_char_p, ctypes.c_double, ctypes.POINTER(_c_comm)]),
+    "paos_comm_destroy": (ctypes.c_int, [_c_comm]),
+    "paos_comm_rank": (ctypes.c_int, [_c_comm]),
+    "paos_comm_size": (ctypes.c_int, [_c_comm]),
+    "paos_comm_transport": (ctypes.c_int, [_c_comm]),
+    "paos_comm_last_error": (ctypes.c_char_p, []),
+    "paos_comm_bcast_size": (ctypes.c_int, [_c_comm, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
+    "paos_comm_bcast_blob": (ctypes.c_int, [_c_comm, ctypes.c_void_p, ctypes.c_ulonglong, ctypes.c_int]),
+    "paos_comm_allgather_scalars": (ctypes.c_int, [_c_comm, _dbl_p, ctypes.c_int, _dbl_p]),
+    "paos_comm_allgatherv_scalars": (ctypes.c_int, [_c_comm, _dbl_p, ctypes.c_int, _dbl_p, ctypes.c_ulonglong,
+                                                    ctypes.POINTER(ctypes.c_int)]),
+    "paos_comm_max": (ctypes.c_int, [_c_comm, _dbl_p]),
+    "paos_comm_barrier": (ctypes.c_int, [_c_comm]),
+}
+
+_bound = None
+
+
+def _load():
+    global _bound
+    if _bound is None:
+        lib = _lib.load()
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _bound = lib
+    return _bound
+
+
+class CommError(RuntimeError):
+    pass
+
+
+class Comm:
+    def __init__(self, nranks=1, rank=0, device=0, transport="socket", key=None, rendezvous_dir=None, timeout=120.0):
+        self._lib = _load()
+        code = {"socket": SOCKET, "rccl": RCCL}[transport]
+        self._h = _c_comm()
+        rc = self._lib.paos_comm_init_rank(int(nranks), int(rank), int(device), code,
+                                           key.encode() if key else None,
+                                           rendezvous_dir.encode() if rendezvous_dir else None, float(timeout),
+                                           ctypes.byref(self._h))
+        if rc != 0:
+            self._h = _c_comm()
+            raise CommError(f"paos_comm_init_rank failed ({rc}): {self._lib.paos_comm_last_error().decode()}")
+        self.rank, self.size, self.transport, self.device = int(rank), int(nranks), transport, int(device)
+
+    @classmethod
+    def from_env(cls, transport=None, timeout=300.0):
+        """Join the job described by the launcher's environment.  ``transport`` defaults to "rccl" when
+        PAOS_COMM_TRANSPORT is unset (one GPU per rank: LOCAL_RANK) -- set it to "socket" for ranks
+        that share a GPU or have none."""
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        transport = transport or os.environ.get("PAOS_COMM_TRANSPORT", "rccl")
+        key = os.environ.get("PAOS_COMM_KEY") or "_".join(
+            [os.environ.get("TORCHELASTIC_RUN_ID", "job"), os.environ.get("MASTER_PORT", "0"),
+             os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")])
+        return cls(world, rank, local, transport, key=key, timeout=timeout)
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise CommError(f"{what} failed ({rc}): {self._lib.paos_comm_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.paos_comm_destroy(self._h)
+            self._h = _c_comm()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def bcast_blob(self, blob, root=0):
+        """``blob`` (bytes) from ``root`` to every rank; the others pass None."""
+        size = ctypes.c_ulonglong(len(blob) if self.rank == root else 0)
+        self._check(self._lib.paos_comm_bcast_size(self._h, ctypes.byref(size), int(root)), "paos_comm_bcast_size")
+        buf = (ctypes.c_char * max(1, size.value))()
+        if self.rank == root:
+            ctypes.memmove(buf, blob, size.value)
+        self._check(self._lib.paos_comm_bcast_blob(self._h, buf, size.value, int(root)), "paos_comm_bcast_blob")
+        return bytes(buf[:size.value])
+
+    def allgather_scalars(self, values):
+        """Every rank contributes a 1-D float64 array (lengths may differ); returns the list of all of
+        them, indexed by rank."""
+        v = np.ascontiguousarray(values, dtype=np.float64).reshape(-1)
+        counts = (ctypes.c_int * self.size)()
+        # sizes first (so the receive buffer can be allocated), then the ragged gather
+        mine = np.array([float(v.size)])
+        sizes = np.empty(self.size)
+        self._check(self._lib.paos_comm_allgather_scalars(self._h, mine.ctypes.data_as(_dbl_p), 1,
+                                                          sizes.ctypes.data_as(_dbl_p)), "paos_comm_allgather_scalars")
+        total = int(sizes.sum())
+        out = np.empty(max(total, 1))
+        self._check(self._lib.paos_comm_allgatherv_scalars(self._h, v.ctypes.data_as(_dbl_p) if v.size else None,
+                                                           int(v.size), out.ctypes.data_as(_dbl_p), total, counts),
+                    "paos_comm_allgatherv_scalars")
+        parts, o = [], 0
+        for r in range(self.size):
+            parts.append(out[o:o + counts[r]].copy())
+            o += counts[r]
+        return parts
+
+    def max(self, value):
+        x = ctypes.c_double(float(value))
+        self._check(self._lib.paos_comm_max(self._h, ctypes.byref(x)), "paos_comm_max")
+        return x.value
+
+    def barrier(self):
+        self._check(self._lib.paos_comm_barrier(self._h), "paos_comm_barrier")

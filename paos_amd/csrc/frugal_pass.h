@@ -48,6 +48,15 @@ static_assert(sizeof(FrugalSlot) == 7 * sizeof(double), "record of 8-byte fields
 struct FrugalItem {
   double active;  // 0: the item takes no part in this pass (no load, no store)
   double fft1_on, fft1_inv, fft2_on, fft2_inv;
+  // Pruning (zero lines of a field stay zero under every operator of a pass, and a transform of a
+  // zero line is a zero line): the host tracks which rows / columns an aperture has just zeroed.
+  //   lines outside [line_lo, line_hi) come out zero: tiles made of such lines only are not
+  //     processed -- written with zeros when line_fill != 0, otherwise left alone because the next
+  //     pass (along the other axis) will not read them;
+  //   positions along a line outside [pos_lo, pos_hi) are known to be zero (and may hold stale
+  //     data): they are not loaded.
+  // Full ranges [0, N) switch all of it off.  Bounds are multiples of the block height.
+  double line_lo, line_hi, line_fill, pos_lo, pos_hi;
   FrugalSlot pre;
   FrugalPhase pre_ph[kFrugalMaxPre];
   FrugalSlot mid;
@@ -259,6 +268,17 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<N, TILE
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const TileMap<N, E, LINES, TILES, AXIS, BR, BC> m(blockIdx.x, threadIdx.x, a.pitch);
   cx<T>* f = reinterpret_cast<cx<T>*>(a.field) + (size_t)item * a.item_stride;
+  constexpr bool NT = PAOS_NT_FULL_LINES ? (AXIS == 1 || LINES == BR) : (AXIS == 1);
+  if constexpr (TILES == 1) {  // a tile of dead lines: nothing to transform
+    const int l0 = AXIS == 0 ? m.row0 : m.col0;
+    if (l0 + LINES <= (int)it.line_lo || l0 >= (int)it.line_hi) {
+      if (it.line_fill != 0.0) {
+#pragma unroll
+        for (int k = 0; k < E; ++k) stream_store<NT>(&f[m.base + (unsigned)k * m.stride], cx<T>{(T)0, (T)0});
+      }
+      return;
+    }
+  }
   void* lds = smem + (size_t)m.lds_line * line_lds_bytes<T, N, SPLIT>();
   // The stage twiddles (indices < 256 of the table for every supported N) sit in LDS behind the
   // exchange areas: the load that follows each exchange barrier is then a ~100-cycle ds_read
@@ -288,11 +308,20 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<N, TILE
   PAOS_STAMP(0);
 
   // tiles that own whole 128-byte lines (column tiles; row tiles that span a full block row) stream
-  // around the caches; row tiles that share lines with a sibling need the L2 to merge the halves
-  constexpr bool NT = PAOS_NT_FULL_LINES ? (AXIS == 1 || LINES == BR) : (AXIS == 1);
+  // around the caches (NT); row tiles that share lines with a sibling need the L2 to merge the halves
   cx<T> v[E];
+  const int plo = (int)it.pos_lo, phi = (int)it.pos_hi;
+  if (plo <= 0 && phi >= N) {  // wave-uniform: the whole line is live
 #pragma unroll
-  for (int k = 0; k < E; ++k) v[k] = stream_load<NT>(&f[m.base + (unsigned)k * m.stride]);
+    for (int k = 0; k < E; ++k) v[k] = stream_load<NT>(&f[m.base + (unsigned)k * m.stride]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+      const int pos = m.t + k * (N / E);
+      v[k] = cx<T>{(T)0, (T)0};
+      if (pos >= plo && pos < phi) v[k] = stream_load<NT>(&f[m.base + (unsigned)k * m.stride]);
+    }
+  }
   __builtin_amdgcn_sched_barrier(0);
   PAOS_STAMP_WAIT_VM();
   PAOS_STAMP(1);

@@ -86,6 +86,7 @@ struct paos_ctx {
   double* partial = nullptr;
   double* norm2 = nullptr;
   double* norm2_host = nullptr;  // pinned, kNormSlots x batch
+  bool prune = true;  // skip tiles / loads of lines an aperture has zeroed (paos_ctx_set_pruning)
   int norm_slot = 0;
   bool norm_busy[64] = {};       // ticket handed out and not fetched yet (kNormSlots entries)
   int nparts = 0;
@@ -94,6 +95,8 @@ struct paos_ctx {
   // optional per-kernel-class timing with HIP events on the context's stream
   int prof_kind = -1;
   std::vector<hipEvent_t> prof_events;  // start/stop pairs
+  std::vector<int> prof_tags;           // per pair: 1 = the launch skipped dead tiles / loads (pruned)
+  int prof_next_tag = 0;
   size_t prof_used = 0;
 };
 
@@ -253,6 +256,7 @@ int launch_pass(paos_ctx* c, Kern kern, dim3 grid, dim3 block, size_t lds, const
   HIPCHK(c, hipGetLastError());
   if (timed) {
     HIPCHK(c, hipEventRecord(c->prof_events[c->prof_used + 1], c->stream));
+    c->prof_tags.push_back(0);
     c->prof_used += 2;
   }
   return PAOS_OK;
@@ -393,8 +397,90 @@ bool lower_frugal(const paos_ctx* c, const paos_pass& p, const double* blocks /*
       }
     }
     fi.active = active ? 1.0 : 0.0;
+    fi.line_lo = 0.0; fi.line_hi = (double)c->n; fi.line_fill = 0.0; fi.pos_lo = 0.0; fi.pos_hi = (double)c->n;
   }
   return true;
+}
+
+// ---- pruning of dead lines (frugal_pass.h: FrugalItem::line_lo ...) ------------------------------
+// One pass of a program, lowered for the frugal kernels before anything is launched, so that the
+// planner below can look ahead.
+struct LoweredPass {
+  bool ok = false;
+  std::vector<FrugalItem> items;
+  int kpre = 0, kmid = 0, nfft = 1, mask_block = -1, mask_slot = -1;
+};
+
+// Lines (rows for a row pass, columns for a column pass) outside the returned range get weight
+// exactly 0 from the aperture of this pass: photutils' bounding box, ixmin = floor(c - e + 0.5),
+// ixmax = ceil(c + e + 0.5) (pointwise.h: make_box; theta = 0 here), widened by one pixel and then
+// rounded outward to whole block rows so that a tile is either wholly dead or processed.
+bool mask_live_range(const paos_ctx* c, const double* q, const double* q2, int axis, int* lo, int* hi) {
+  if (q[0] == 0.0 || q2[0] != 0.0 || q2[1] != 0.0) return false;  // off, tilted, or an obscuration (outside weight 1)
+  const double centre = axis == 0 ? q[2] : q[1];
+  double ext = axis == 0 ? q[4] : q[3];
+  if (q2[3] != PAOS_SHAPE_ELLIPSE) ext = ext / 2.0;
+  if (!std::isfinite(centre) || !std::isfinite(ext) || !(ext > 0.0)) return false;
+  const double a = std::floor(centre - ext + 0.5) - 1.0, b = std::ceil(centre + ext + 0.5) + 1.0;
+  const int n = c->n;
+  int l = a < 0.0 ? 0 : (a > n ? n : (int)a), h = b < 0.0 ? 0 : (b > n ? n : (int)b);
+  l = (l / BR) * BR;
+  h = ((h + BR - 1) / BR) * BR;
+  if (h > n) h = n;
+  if (l >= h) { l = 0; h = BR; }  // aperture off the grid along this axis: keep one block row live
+  *lo = l; *hi = h;
+  return true;
+}
+
+// Fill in the pruning fields of a whole program.  Per item the planner carries which lines are
+// known to be zero: DENSE, or "lines along `axis` outside [lo, hi) are zero" -- physically (zeros in
+// memory: the state a stand-alone aperture leaves, passed in through entry_rows) or virtually (the
+// tiles were skipped and hold stale data).  A pass along the same axis skips the dead tiles; a pass
+// along the other axis does not load the dead positions and, writing every element, makes the field
+// dense again.  Virtual zeros must be consumed by such a pass before the program ends; where none
+// follows, the last pass that skipped them writes zeros instead (line_fill).
+void plan_pruning(const paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks,
+                  std::vector<LoweredPass>& low, const double* entry_rows) {
+  const int n = c->n;
+  for (int it = 0; it < c->batch; ++it) {
+    bool zl = false, virt = false;
+    int axis = 0, lo = 0, hi = n, last_skip = -1;
+    if (entry_rows) {
+      int l = (int)entry_rows[2 * it], h = (int)entry_rows[2 * it + 1];
+      l = l < 0 ? 0 : (l / BR) * BR;
+      h = h > n ? n : ((h + BR - 1) / BR) * BR;
+      if (h > n) h = n;
+      if (l < h && (l > 0 || h < n)) { zl = true; axis = 0; lo = l; hi = h; }
+    }
+    for (int q = 0; q < n_passes; ++q) {
+      FrugalItem& fi = low[q].items[it];
+      if (fi.active == 0.0) continue;
+      const int ax = passes[q].axis;
+      if (zl && ax != axis) {  // reads across the dead lines: skip their loads; output is dense
+        fi.pos_lo = lo; fi.pos_hi = hi;
+        zl = false; virt = false; last_skip = -1;
+      }
+      int mlo = 0, mhi = n;
+      bool masked = false;
+      if (low[q].mask_block >= 0) {
+        const double* mq = blocks + ((size_t)low[q].mask_block * c->batch + it) * FP_STRIDE;
+        const double* mq2 = blocks + ((size_t)(low[q].mask_block + 1) * c->batch + it) * FP_STRIDE;
+        masked = mask_live_range(c, mq, mq2, ax, &mlo, &mhi);
+      }
+      if (zl) {  // same axis: the dead lines stay dead
+        if (masked) {
+          const int l2 = lo > mlo ? lo : mlo, h2 = hi < mhi ? hi : mhi;
+          if (l2 != lo || h2 != hi) virt = true;  // newly dead lines still hold data
+          lo = l2; hi = h2;
+          if (lo >= hi) { lo = 0; hi = BR; virt = true; }
+        }
+      } else if (masked && (mlo > 0 || mhi < n)) {
+        zl = true; virt = true; axis = ax; lo = mlo; hi = mhi;
+      }
+      if (zl) { fi.line_lo = lo; fi.line_hi = hi; last_skip = q; }
+    }
+    if (zl && virt && last_skip >= 0) low[last_skip].items[it].line_fill = 1.0;
+  }
 }
 
 template <typename T, int N, int AXIS, int KPRE, int KMID, int NFFT>
@@ -420,6 +506,7 @@ int frugal_launch(paos_ctx* c, const FrugalArgs& a) {
   HIPCHK(c, hipGetLastError());
   if (timed) {
     HIPCHK(c, hipEventRecord(c->prof_events[c->prof_used + 1], c->stream));
+    c->prof_tags.push_back(c->prof_next_tag);
     c->prof_used += 2;
   }
   return PAOS_OK;
@@ -491,22 +578,25 @@ int paos_frugal_f4096(paos_ctx* c, const FrugalArgs& a, int axis, int kpre, int 
 #if PAOS_PART <= 0  // ---- everything below belongs to the main translation unit ----------------
 namespace {
 
-// returns PAOS_OK and sets *done when the pass ran on the frugal path
-int try_frugal(paos_ctx* c, const paos_pass& p, const double* host_blocks, const double* dblocks, bool* done) {
-  *done = false;
+bool frugal_sizes(const paos_ctx* c) {
   // instantiated for complex128 at N >= 1024 and complex64 at N >= 2048
-  if (!use_frugal() || c->n < (c->precision == PAOS_F64 ? 1024 : 2048)) return PAOS_OK;
-  std::vector<FrugalItem> items;
-  int kpre = 0, kmid = 0, nfft = 1, mask_block = -1, mask_slot = -1;
+  return use_frugal() && c->n >= (c->precision == PAOS_F64 ? 1024 : 2048);
+}
+
+int ensure_mask_store(paos_ctx* c) {
   if (!c->mask_lines) {  // line-record store of an aperture riding on a pass (lazily)
     HIPCHK(c, hipMalloc(&c->mask_lines, (size_t)c->batch * c->n * sizeof(MaskLine)));
     HIPCHK(c, hipMalloc(&c->mask_vals, (size_t)c->batch * c->n * 2 * kMaskW * sizeof(double)));
     HIPCHK(c, hipMalloc(&c->mask_overflow, sizeof(int)));
     HIPCHK(c, hipMemsetAsync(c->mask_overflow, 0, sizeof(int), c->stream));
   }
-  if (!lower_frugal(c, p, host_blocks, items, kpre, kmid, nfft, mask_block, mask_slot)) return PAOS_OK;
-  if (mask_block >= 0) {  // render the records along the pass axis, right before the pass
-    const double* ap = dblocks + (size_t)mask_block * c->batch * FP_STRIDE;
+  return PAOS_OK;
+}
+
+// launch a pass that lower_frugal accepted
+int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const double* dblocks) {
+  if (lp.mask_block >= 0) {  // render the records along the pass axis, right before the pass
+    const double* ap = dblocks + (size_t)lp.mask_block * c->batch * FP_STRIDE;
     const double* ap2 = ap + (size_t)c->batch * FP_STRIDE;
     const dim3 grid((c->n + 3) / 4, c->batch), block(256);
     hipLaunchKernelGGL(mask_lines_kernel<0>, grid, block, 0, c->stream, ap, ap2, (int)FP_STRIDE, c->n, p.axis,
@@ -517,24 +607,25 @@ int try_frugal(paos_ctx* c, const paos_pass& p, const double* host_blocks, const
   }
   const double* ditems = nullptr;
   static_assert(sizeof(FrugalItem) % sizeof(double) == 0, "record of doubles");
-  int rc = arena_push(c, reinterpret_cast<const double*>(items.data()),
-                      items.size() * sizeof(FrugalItem) / sizeof(double), &ditems);
+  int rc = arena_push(c, reinterpret_cast<const double*>(lp.items.data()),
+                      lp.items.size() * sizeof(FrugalItem) / sizeof(double), &ditems);
   if (rc) return rc;
   FrugalArgs a{c->field, c->tw, reinterpret_cast<const FrugalItem*>(ditems), c->pitch, c->item_stride};
+  c->prof_next_tag = 0;  // for the launch timer: does this launch skip anything?
+  for (const FrugalItem& fi : lp.items)
+    if (fi.active != 0.0 && (fi.line_lo > 0.0 || fi.line_hi < (double)c->n || fi.pos_lo > 0.0 || fi.pos_hi < (double)c->n))
+      c->prof_next_tag = 1;
   if (c->precision == PAOS_F64) {
     switch (c->n) {
-      case 1024: rc = paos_frugal_d1024(c, a, p.axis, kpre, kmid, nfft); break;
-      case 2048: rc = paos_frugal_d2048(c, a, p.axis, kpre, kmid, nfft); break;
-      default: rc = paos_frugal_d4096(c, a, p.axis, kpre, kmid, nfft); break;
-    }
-  } else {
-    switch (c->n) {
-      case 2048: rc = paos_frugal_f2048(c, a, p.axis, kpre, kmid, nfft); break;
-      default: rc = paos_frugal_f4096(c, a, p.axis, kpre, kmid, nfft); break;
+      case 1024: return paos_frugal_d1024(c, a, p.axis, lp.kpre, lp.kmid, lp.nfft);
+      case 2048: return paos_frugal_d2048(c, a, p.axis, lp.kpre, lp.kmid, lp.nfft);
+      default: return paos_frugal_d4096(c, a, p.axis, lp.kpre, lp.kmid, lp.nfft);
     }
   }
-  if (rc == PAOS_OK) *done = true;
-  return rc;
+  switch (c->n) {
+    case 2048: return paos_frugal_f2048(c, a, p.axis, lp.kpre, lp.kmid, lp.nfft);
+    default: return paos_frugal_f4096(c, a, p.axis, lp.kpre, lp.kmid, lp.nfft);
+  }
 }
 
 int launch_one_pass(paos_ctx* c, const paos_pass& p, const double* dblocks, int n_blocks,
@@ -598,7 +689,14 @@ int launch_one_pass(paos_ctx* c, const paos_pass& p, const double* dblocks, int 
   return PAOS_OK;
 }
 
-int run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks, int n_blocks) {
+// PAOS_NO_PRUNE=1 processes every tile (A/B tests of the dead-line pruning).
+bool use_pruning() {
+  static const bool on = [] { const char* e = getenv("PAOS_NO_PRUNE"); return !(e && e[0] == '1'); }();
+  return on;
+}
+
+int run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks, int n_blocks,
+               const double* entry_rows = nullptr) {
   if (!c || !passes || !blocks || n_passes < 0 || n_blocks < 1) return fail(c, PAOS_EINVAL, "bad pass program");
   // The device sincos has no huge-argument path: bound every enabled phase operator here.
   for (int i = 0; i < n_passes; ++i) {
@@ -628,6 +726,19 @@ int run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double*
   if (rc) return rc;
   rc = arena_push(c, blocks, (size_t)n_blocks * c->batch * FP_STRIDE, &dblocks);
   if (rc) return rc;
+  // Lower every pass for the frugal kernels first; when the whole program runs on them, plan the
+  // pruning of dead lines across it (look-ahead), then launch.
+  std::vector<LoweredPass> low(n_passes);
+  bool all_frugal = !use_tables() && frugal_sizes(c) && n_passes > 0;
+  if (!use_tables() && frugal_sizes(c)) {
+    if ((rc = ensure_mask_store(c))) return rc;
+    for (int q = 0; q < n_passes; ++q) {
+      LoweredPass& lp = low[q];
+      lp.ok = lower_frugal(c, passes[q], blocks, lp.items, lp.kpre, lp.kmid, lp.nfft, lp.mask_block, lp.mask_slot);
+      all_frugal = all_frugal && lp.ok;
+    }
+  }
+  if (all_frugal && use_pruning() && c->prune) plan_pruning(c, passes, n_passes, blocks, low, entry_rows);
   // Walk the program in chunks whose phase operators fit the table store: fill the tables of
   // a chunk with one small launch, then run its passes.
   int i = 0;
@@ -670,9 +781,10 @@ int run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double*
       HIPCHK(c, hipGetLastError());
     }
     for (int q = i; q < j; ++q) {
-      bool done = false;
-      if (!use_tables() && (rc = try_frugal(c, passes[q], blocks, dblocks, &done))) return rc;
-      if (done) continue;
+      if (low[q].ok) {
+        if ((rc = launch_lowered(c, passes[q], low[q], dblocks))) return rc;
+        continue;
+      }
       if ((rc = launch_one_pass(c, passes[q], dblocks, n_blocks, &assign[(size_t)(q - i) * 3 * PAOS_MAX_PW]))) return rc;
     }
     i = j;
@@ -822,24 +934,38 @@ int paos_profile_begin(paos_ctx* c, int kernel_kind, int max_launches) {
   }
   c->prof_kind = kernel_kind;
   c->prof_used = 0;
+  c->prof_tags.clear();
   return PAOS_OK;
 }
 
-int paos_profile_end(paos_ctx* c, int* launches, double* total_ms) {
+static int profile_end(paos_ctx* c, int* launches, double* total_ms, int* pruned_launches, double* pruned_ms) {
   if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c || !launches || !total_ms) return fail(c, PAOS_EINVAL, "null argument");
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  double sum = 0.0;
+  double sum = 0.0, psum = 0.0;
+  int pcount = 0;
   for (size_t i = 0; i + 1 < c->prof_used; i += 2) {
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->prof_events[i], c->prof_events[i + 1]));
     sum += ms;
+    if (i / 2 < c->prof_tags.size() && c->prof_tags[i / 2]) { psum += ms; ++pcount; }
   }
   *launches = (int)(c->prof_used / 2);
   *total_ms = sum;
+  if (pruned_launches) *pruned_launches = pcount;
+  if (pruned_ms) *pruned_ms = psum;
   c->prof_kind = -1;
   c->prof_used = 0;
   return PAOS_OK;
+}
+
+int paos_profile_end(paos_ctx* c, int* launches, double* total_ms) {
+  return profile_end(c, launches, total_ms, nullptr, nullptr);
+}
+
+int paos_profile_end_split(paos_ctx* c, int* launches, double* total_ms, int* pruned_launches, double* pruned_ms) {
+  if (!pruned_launches || !pruned_ms) return fail(c, PAOS_EINVAL, "null argument");
+  return profile_end(c, launches, total_ms, pruned_launches, pruned_ms);
 }
 
 int paos_ctx_destroy(paos_ctx* c) {
@@ -1158,6 +1284,12 @@ int paos_norm2_fetch(paos_ctx* c, int ticket, double* host_out) {
   return check_mask_overflow(c);
 }
 
+int paos_norm2_release(paos_ctx* c, int ticket) {
+  if (!c || ticket < 0 || ticket >= kNormSlots) return fail(c, PAOS_EINVAL, "bad ticket");
+  c->norm_busy[ticket] = false;  // the caller does not want the value; the slot may be handed out again
+  return PAOS_OK;
+}
+
 int paos_norm2(paos_ctx* c, double* host_out) {
   if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c || !host_out) return fail(c, PAOS_EINVAL, "null argument");
@@ -1201,6 +1333,50 @@ int paos_phase_map(paos_ctx* c, int item, const double* host_wfe, double wl) {
 int paos_run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks, int n_blocks) {
   if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   return run_passes(c, passes, n_passes, blocks, n_blocks);
+}
+
+int paos_copy_yardstick(paos_ctx* c, int reps, double* ms_per_launch, double* bytes_per_launch) {
+  if (c) (void)hipSetDevice(c->device);
+  if (!c || !ms_per_launch || !bytes_per_launch || reps < 1) return fail(c, PAOS_EINVAL, "bad yardstick request");
+  const size_t total = (size_t)c->item_stride * c->batch;
+  const int blocks = (int)((total + kPwThreads - 1) / kPwThreads < 65536 * 4 ? (total + kPwThreads - 1) / kPwThreads : 65536 * 4);
+  hipEvent_t e0, e1;
+  HIPCHK(c, hipEventCreate(&e0));
+  HIPCHK(c, hipEventCreate(&e1));
+  auto launch = [&] {
+    if (c->precision == PAOS_F64)
+      hipLaunchKernelGGL(rmw_copy_kernel<double>, dim3(blocks), dim3(kPwThreads), 0, c->stream, (cx<double>*)c->field, total);
+    else
+      hipLaunchKernelGGL(rmw_copy_kernel<float>, dim3(blocks), dim3(kPwThreads), 0, c->stream, (cx<float>*)c->field, total);
+  };
+  launch();  // warm
+  HIPCHK(c, hipEventRecord(e0, c->stream));
+  for (int r = 0; r < reps; ++r) launch();
+  HIPCHK(c, hipEventRecord(e1, c->stream));
+  HIPCHK(c, hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIPCHK(c, hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  *ms_per_launch = (double)ms / reps;
+  *bytes_per_launch = 2.0 * (double)total * (double)elem_bytes(c);  // pitch padding included: it is moved too
+  return PAOS_OK;
+}
+
+int paos_ctx_set_pruning(paos_ctx* c, int on) {
+  if (!c) return fail(c, PAOS_EINVAL, "null context");
+  c->prune = on != 0;
+  return PAOS_OK;
+}
+
+int paos_run_passes_live(paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks, int n_blocks,
+                         const double* live_rows) {
+  if (c) (void)hipSetDevice(c->device);
+  if (c && live_rows)
+    for (int i = 0; i < c->batch; ++i)
+      if (!(live_rows[2 * i] >= 0.0) || !(live_rows[2 * i + 1] <= (double)c->n) || !(live_rows[2 * i] <= live_rows[2 * i + 1]))
+        return fail(c, PAOS_EINVAL, "live row range must satisfy 0 <= lo <= hi <= n");
+  return run_passes(c, passes, n_passes, blocks, n_blocks, live_rows);
 }
 
 int paos_ptp(paos_ctx* c, const double* params) {

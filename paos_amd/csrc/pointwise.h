@@ -34,6 +34,19 @@ __global__ void fill_kernel(cx<T>* f, size_t total, T re, T im) {
   for (; i < total; i += (size_t)gridDim.x * blockDim.x) f[i] = {re, im};
 }
 
+// ---- in-place copy yardstick (measurement aid, bench.py): read every element of the batch and
+// write it back unchanged, 16 B per lane, unit stride -- what the chip's HBM path reaches on an
+// in-place read-modify-write of this buffer, without any transform
+template <typename T>
+__global__ void rmw_copy_kernel(cx<T>* f, size_t total) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    cx<T> v = f[i];
+    asm volatile("" : "+v"(v.x), "+v"(v.y));  // keep the store: the value is unchanged, the compiler must not know
+    f[i] = v;
+  }
+}
+
 // ---- host <-> device layout conversion (staging buffer is row-major complex128)
 template <typename T, int BR, int BC>
 __global__ void import_kernel(cx<T>* f, const cx<double>* staged, int n, unsigned pitch) {

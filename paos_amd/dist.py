@@ -5,12 +5,15 @@ processes on one host (paos/core/pipeline.py:140-150).  Here the unit of work is
 the same -- one wavefront = one (wavelength, opt_chain) pair or one Monte-Carlo
 WFE draw -- and the partition is static: rank ``r`` of ``W`` takes a contiguous
 block.  The only exchange is ONE broadcast of the packed work description from
-rank 0 (RCCL over xGMI when the process group is NCCL, gloo in CPU tests); after
-that the ranks never talk until the timing reduction.  No data-path collective.
+rank 0 (``paos_comm_bcast_blob``: RCCL over xGMI, or TCP in the CPU tests -- include/paos_comm.h,
+no PyTorch); after that the ranks never talk until the optional gather of per-wavefront scalars.
+No data-path collective.
 """
-import pickle
+import os
 
 import numpy as np
+
+from . import wire
 
 
 def shard_bounds(total, rank, world):
@@ -23,40 +26,13 @@ def shard_bounds(total, rank, world):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def broadcast_blob(obj, src=0, device=None):
-    """Broadcast a picklable object from ``src`` to every rank with two
-    ``torch.distributed.broadcast`` calls (length, then bytes).  ``device`` is the
-    tensor device: a CUDA device under the NCCL(=RCCL) backend, CPU under gloo."""
-    import torch
-    import torch.distributed as dist
-
-    if not dist.is_initialized() or dist.get_world_size() == 1:
-        return obj
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    rank = dist.get_rank()
-    payload = pickle.dumps(obj) if rank == src else b""
-    size = torch.tensor([len(payload)], dtype=torch.int64, device=device)
-    dist.broadcast(size, src)
-    buf = torch.empty(int(size.item()), dtype=torch.uint8, device=device)
-    if rank == src:
-        buf.copy_(torch.frombuffer(bytearray(payload), dtype=torch.uint8))
-    dist.broadcast(buf, src)
-    return pickle.loads(buf.cpu().numpy().tobytes())
-
-
-def max_over_ranks(value, device=None):
-    """MAX all-reduce of a scalar (the bench's time bracket)."""
-    import torch
-    import torch.distributed as dist
-
-    if not dist.is_initialized() or dist.get_world_size() == 1:
-        return float(value)
-    if device is None:
-        device = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+def broadcast_work(work, comm=None, root=0):
+    """The ONE broadcast: ``work`` (any structure ``wire`` can pack: wavelengths, chains, coefficient
+    tables) from ``root`` to every rank of ``comm``; the other ranks pass None.  Single process: no-op."""
+    if comm is None or comm.size == 1:
+        return work
+    blob = comm.bcast_blob(wire.dumps(work) if comm.rank == root else None, root=root)
+    return work if comm.rank == root else wire.loads(blob)
 
 
 def syn20_work(total, mode="wavelengths", wfe_table=None):
@@ -76,41 +52,100 @@ def syn20_work(total, mode="wavelengths", wfe_table=None):
     raise ValueError(mode)
 
 
+# ---- per-wavefront scalars as flat float64 records (what the gather moves) -------------------------
+_PROP = ("", "II", "IO", "OI", "OO")
+_SCALARS = ("wl", "dx", "dy", "wz", "distancetofocus", "fratio")
+
+
+def _pack_result(index, res):
+    """[index, n_surfaces, then per saved surface: num, 6 scalars, extent(4), propagator code, power,
+    ABCDt(4) cin cout, ABCDs(4) cin cout, n_metrics, metrics...]"""
+    rec = [float(index), float(len(res))]
+    for num in sorted(res):
+        r = res[num]
+        rec.append(float(num))
+        rec += [float(r[k]) for k in _SCALARS]
+        rec += [float(x) for x in r["extent"]]
+        rec.append(float(_PROP.index(r["propagator"])))
+        rec.append(float(r.get("power", np.nan)))
+        for key in ("ABCDt", "ABCDs"):
+            m = np.asarray(r[key](), dtype=np.float64)
+            rec += [m[0, 0], m[0, 1], m[1, 0], m[1, 1], float(r[key].cin), float(r[key].cout)]
+        met = r.get("metrics")
+        if met is None:
+            rec.append(0.0)
+        else:
+            enc = np.asarray(met["encircled"], dtype=np.float64)
+            rec.append(float(4 + enc.size))
+            rec += [float(met["power"]), float(met["centroid"][0]), float(met["centroid"][1]), float(met["peak"])]
+            rec += [float(x) for x in enc]
+    return rec
+
+
+def _unpack_results(flat):
+    from .abcd import ABCD
+
+    out, pos, flat = [], 0, np.asarray(flat, dtype=np.float64)
+    while pos < flat.size:
+        index, nsurf = int(flat[pos]), int(flat[pos + 1])
+        pos += 2
+        res = {}
+        for _ in range(nsurf):
+            num = int(flat[pos])
+            r = dict(zip(_SCALARS, (float(x) for x in flat[pos + 1:pos + 7])))
+            r["extent"] = tuple(float(x) for x in flat[pos + 7:pos + 11])
+            r["propagator"] = _PROP[int(flat[pos + 11])]
+            r["power"] = float(flat[pos + 12])
+            pos += 13
+            for key in ("ABCDt", "ABCDs"):
+                m = ABCD()
+                m.ABCD = np.array([[flat[pos], flat[pos + 1]], [flat[pos + 2], flat[pos + 3]]])
+                m.cin, m.cout = flat[pos + 4], flat[pos + 5]
+                r[key] = m
+                pos += 6
+            nmet = int(flat[pos])
+            pos += 1
+            if nmet:
+                r["metrics"] = {"power": float(flat[pos]), "centroid": (float(flat[pos + 1]), float(flat[pos + 2])),
+                                "peak": float(flat[pos + 3]), "encircled": flat[pos + 4:pos + nmet].copy()}
+                pos += nmet
+            res[num] = r
+        out.append((index, res))
+    return out
+
+
 def run_sharded(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, batch=8,
                 precision="fp64", device=None, outputs=(), metrics_radii_px=None, gather=True,
-                make_device=None):
+                make_device=None, comm=None):
     """The reference's fan-out over wavelengths / Monte-Carlo draws (pipeline.py:139-150,
-    joblib workers on one host) on N GPUs: call from every rank of an initialised process group
-    (or from a single process).  Rank 0 supplies ``wavelengths`` and ``opt_chains`` (other ranks
-    may pass None); they travel in ONE broadcast.  Every rank then propagates its contiguous
-    shard in batches of ``batch`` wavefronts with ``run_batch`` -- no further communication --
-    and returns ``[(global index, result dict), ...]`` for its shard; with ``gather`` the
-    per-wavefront results (scalars, power, metrics, and whatever ``outputs`` asks for) are
-    collected so that every rank returns the full, index-ordered list.
+    joblib workers on one host) on N GPUs: call from every rank of ``comm`` (a ``paos_amd.comm.Comm``;
+    None = single process).  Rank 0 supplies ``wavelengths`` and ``opt_chains`` (other ranks may pass
+    None); they travel in ONE broadcast.  Every rank then propagates its contiguous shard in batches of
+    ``batch`` wavefronts with ``run_batch`` -- no further communication -- and returns
+    ``[(global index, result dict), ...]`` for its shard, arrays asked for in ``outputs`` included (PSFs
+    stay with the rank that computed them).  With ``gather`` every rank ALSO receives the per-wavefront
+    scalars of all ranks (sampling, f-ratio, power, ABCD matrices, on-device PSF metrics; < 1 KB per
+    wavefront) and returns the full, index-ordered list, its own entries still carrying their arrays.
+
+    A failure on one rank (an unsupported surface, a HIP error) is reported on every rank: the ranks
+    exchange a status word before the gather, so nobody waits for a result that will not come.
 
     ``device``: GPU ordinal of this rank (default LOCAL_RANK, else 0).  ``make_device(n, nb)``
     lets the CPU tests substitute a model of the device."""
-    import os
-
     from . import _lib
     from .run import run_batch
 
-    try:
-        import torch.distributed as dist
-        live = dist.is_available() and dist.is_initialized()
-    except ImportError:  # single process without torch
-        dist, live = None, False
-    rank = dist.get_rank() if live else 0
-    world = dist.get_world_size() if live else 1
+    rank = comm.rank if comm is not None else 0
+    world = comm.size if comm is not None else 1
     work = {"wavelengths": list(wavelengths), "chains": list(opt_chains)} if rank == 0 else None
-    work = broadcast_blob(work, src=0)
+    work = broadcast_work(work, comm)
     total = len(work["chains"])
     if len(work["wavelengths"]) != total:
         raise ValueError("one wavelength per chain is required")
     lo, hi = shard_bounds(total, rank, world)
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0"))
-    mine = []
+    mine, failure = [], None
     dev, dev_nb = None, 0
     try:
         for start in range(lo, hi, int(batch)):
@@ -125,11 +160,31 @@ def run_sharded(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, 
                             work["chains"][start:stop], precision=precision, outputs=outputs, dev=dev,
                             metrics_radii_px=metrics_radii_px)
             mine.extend(zip(range(start, stop), res))
+    except Exception as exc:  # noqa: BLE001 -- reported to every rank below, then re-raised
+        if world == 1:
+            raise
+        failure = exc
     finally:
         if dev is not None:
             dev.close()
-    if not (gather and live and world > 1):
+    if world == 1:
         return mine
-    parts = [None] * world
-    dist.all_gather_object(parts, mine)
-    return sorted((pair for part in parts for pair in part), key=lambda p: p[0])
+    # status word of every rank, then the messages of the ranks that failed
+    status = comm.allgather_scalars([0.0 if failure is None else 1.0])
+    bad = [r for r in range(world) if status[r][0] != 0.0]
+    if bad:
+        notes = []
+        for r in bad:
+            text = f"{type(failure).__name__}: {failure}" if r == rank else None
+            notes.append((r, comm.bcast_blob(text.encode() if text is not None else None, root=r).decode()))
+        if failure is not None:
+            raise failure
+        raise RuntimeError("run_sharded failed on " + "; ".join(f"rank {r}: {m}" for r, m in notes))
+    if not gather:
+        return mine
+    flat = [x for index, res in mine for x in _pack_result(index, res)]
+    parts = comm.allgather_scalars(flat)
+    merged = {index: res for part in parts for index, res in _unpack_results(part)}
+    for index, res in mine:  # this rank's own entries keep their arrays / aperture handles
+        merged[index] = res
+    return sorted(merged.items(), key=lambda p: p[0])

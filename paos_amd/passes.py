@@ -163,10 +163,15 @@ class PassCompiler:
         self._reset()
         return passes, blocks
 
-    def flush(self, dev):
+    def flush(self, dev, live_rows=None):
+        """``live_rows`` ([batch][2], optional): rows of each item outside [lo, hi) are exactly zero in
+        memory on entry (a stand-alone aperture has just been applied) -- the library then skips them."""
         if not self.pending():
             return 0
         passes, blocks = self.program()
         if passes:
-            dev.run_passes(passes, blocks)
+            if live_rows is None:
+                dev.run_passes(passes, blocks)
+            else:
+                dev.run_passes(passes, blocks, live_rows=live_rows)
         return len(passes)

@@ -157,6 +157,29 @@ def _plan_surface(st, item):
     return plan
 
 
+def _live_rows_after(plans, live, n):
+    """Rows that may be non-zero after the stand-alone apertures of ``plans`` were applied: a clear
+    aperture (not an obscuration) leaves exact zeros outside its bounding box (photutils' box,
+    widened by a pixel here).  ``live`` is updated in place, one [lo, hi) per item."""
+    for i, p in enumerate(plans):
+        ap = p["aperture"]
+        if ap is None or ap[1] or ap[0].theta != 0.0:
+            continue
+        h = ap[0]
+        ext = h.b if isinstance(h, EllipticalAperture) else h.h / 2.0
+        yc = float(h.positions[1])
+        if not (math.isfinite(yc) and math.isfinite(ext) and ext > 0.0):
+            continue
+        lo = max(0, int(math.floor(yc - ext + 0.5)) - 1)
+        hi = min(n, int(math.ceil(yc + ext + 0.5)) + 1)
+        if lo >= hi:
+            continue
+        live[i][0] = max(live[i][0], lo)
+        live[i][1] = min(live[i][1], hi)
+        if live[i][0] >= live[i][1]:  # disjoint boxes: everything is zero; keep a token range
+            live[i][0], live[i][1] = 0, 0
+
+
 def _launch_apertures(dev, plans):
     for code, cls_is_ellipse in ((_lib.SHAPE_ELLIPSE, True), (_lib.SHAPE_RECT, False)):
         blocks, any_on = [], False
@@ -286,6 +309,19 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None):
         raise ValueError("batched chains must list the same surfaces (same keys, same order)")
     comp = PassCompiler(len(states), dev.n)
     npass = 0
+    # rows of each item known to be exactly zero in memory (outside [lo, hi)): set by stand-alone
+    # apertures, kept by stops / Zernike / phase screens (they multiply), handed to the next pass
+    # program (which skips them) and forgotten once that program has run
+    live = [[0, dev.n] for _ in states]
+
+    def flush():
+        known = any(r[0] > 0 or r[1] < dev.n for r in live)
+        done = comp.flush(dev, live_rows=live if known and comp.pending() else None)
+        if done:
+            for r in live:
+                r[0], r[1] = 0, dev.n
+        return done
+
     for key in keys[0]:
         items = [c[key] for c in chains]
         plans = [_plan_surface(st, it) for st, it in zip(states, items)]
@@ -293,6 +329,7 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None):
         if fresh is not None:
             value, fresh = fresh, None
             if _start_field(dev, plans, value):
+                _live_rows_after(plans, live, dev.n)
                 want_wfe = len(plans) == 1 and bool(items[0]["save"])
                 wfe = _launch_zernike(dev, plans, want_wfe=want_wfe)
                 wfe = _launch_phase_maps(dev, plans, wfe)
@@ -316,9 +353,11 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None):
         breaker = saved or any(p["stop"] or p["zernike"] is not None or p["phase_map"] is not None or
                                (p["aperture"] is not None and not fuse_ap) for p in plans)
         if breaker:
-            npass += comp.flush(dev)  # the field must be current before a non-fusable operator
+            npass += flush()  # the field must be current before a non-fusable operator
         if not fuse_ap:
             _launch_apertures(dev, plans)
+            if not comp.pending():
+                _live_rows_after(plans, live, dev.n)
         if any(p["stop"] for p in plans):
             dev.make_stop([1.0 if p["stop"] else 0.0 for p in plans])
         want_wfe = len(plans) == 1 and bool(items[0]["save"])
@@ -329,7 +368,7 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None):
         _queue_steps(comp, plans)
     if fresh is not None:  # an empty chain still yields the initial wavefront
         dev.fill(fresh)
-    npass += comp.flush(dev)
+    npass += flush()
     if stats is not None:
         stats["fused_passes"] = npass
 

@@ -221,7 +221,7 @@ class ModelDevice:
             q = 6.283185307179586 * q
         return u * (np.cos(q) + 1j * p[4] * np.sin(q))
 
-    def run_passes(self, passes, blocks):
+    def run_passes(self, passes, blocks, live_rows=None):  # live_rows: a traffic hint, results are the same
         blocks = np.asarray(blocks, dtype=np.float64)
         assert blocks.ndim == 3 and blocks.shape[1:] == (self.batch, 5)
         n_ = self.n

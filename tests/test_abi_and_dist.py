@@ -1,5 +1,6 @@
-"""The C-ABI library loads and exports what include/paos_hip.h declares (no compute calls
-without a GPU); the multi-GPU sharding helpers under a world_size-2 gloo group."""
+"""The C-ABI library loads and exports what include/paos_hip.h and include/paos_comm.h declare (no compute
+calls without a GPU); the multi-GPU fan-out (paos_comm_* over its TCP transport, world size 2 and 3, no
+torch) with a NumPy model of the device."""
 import ctypes
 import os
 import re
@@ -10,8 +11,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
-    text = open(os.path.join(ROOT, "include", "paos_hip.h")).read()
+def header_functions(name="paos_hip.h"):
+    text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(paos_[a-z0-9_]+)\s*\(", text)))
 
@@ -26,6 +27,13 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/paos_hip.h but not exported"
     assert sorted(_lib.SYMBOLS) == names, "ctypes binding table and header disagree"
     assert b"gfx950" in lib.paos_build_info()
+    from paos_amd import comm
+
+    names = header_functions("paos_comm.h")
+    assert len(names) == 12
+    for name in names:
+        assert hasattr(lib, name), f"{name} declared in include/paos_comm.h but not exported"
+    assert sorted(comm.SYMBOLS) == names, "ctypes binding table and paos_comm.h disagree"
 
 
 def test_abi_struct_layout_matches_header():
@@ -67,24 +75,39 @@ def test_shard_bounds_cover_exactly():
             assert max(sizes) - min(sizes) <= 1
 
 
-def _gloo_worker(rank, world, port, out):
-    import torch.distributed as dist
+def _spawn(target, world, *extra, timeout=300):
+    import multiprocessing as mp
+    import uuid
 
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    key = "pytest_" + uuid.uuid4().hex
+    procs = [ctx.Process(target=target, args=(r, world, key, out, *extra)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [out.get(timeout=timeout) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(results, key=lambda r: r[0])
+
+
+def _star_worker(rank, world, key, out):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fakes import ModelDevice
+    from paos_amd.chains import syn20_chain
+    from paos_amd.comm import Comm
+    from paos_amd.dist import broadcast_work, shard_bounds, syn20_work
+    from paos_amd.run import _Item, _walk
+
+    comm = Comm(world, rank, 0, "socket", key=key, timeout=120)
     try:
-        import sys
-
-        sys.path.insert(0, ROOT)
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from fakes import ModelDevice
-        from paos_amd.chains import syn20_chain
-        from paos_amd.dist import broadcast_blob, max_over_ranks, shard_bounds, syn20_work
-        from paos_amd.run import _Item, _walk
-
         total = 5
         work = syn20_work(total, "wavelengths") if rank == 0 else None
-        work = broadcast_blob(work, src=0)
+        work = broadcast_work(work, comm)
         lo, hi = shard_bounds(total, rank, world)
         wls = work["wavelengths"][lo:hi]
         chains = [syn20_chain(coefficients=c) for c in work["coefficients"][lo:hi]]
@@ -93,103 +116,150 @@ def _gloo_worker(rank, world, port, out):
         states = [_Item(1.0, wl, 64, 4, {"us": 0.0, "ut": 0.0}) for wl in wls]
         power = {}
 
-        def on_saved(key, items, plans, wfe):
+        def on_saved(key_, items, plans, wfe):
             p = dev.norm2()
             for i, it in enumerate(items):
                 power[(lo + i, it["num"])] = float(p[i])
 
         _walk(dev, states, chains, on_saved)
-        slowest = max_over_ranks(float(rank + 1))
-        out.put((rank, lo, hi, [float(w) for w in work["wavelengths"]], power, slowest))
+        slowest = comm.max(float(rank + 1))
+        comm.barrier()
+        parts = comm.allgather_scalars(np.arange(rank + 1, dtype=float) + 10 * rank)  # ragged
+        text = comm.bcast_blob(b"from the last rank" if rank == world - 1 else None, root=world - 1)
+        out.put((rank, lo, hi, [float(w) for w in work["wavelengths"]], power, slowest,
+                 [list(p) for p in parts], text))
     finally:
-        dist.destroy_process_group()
+        comm.close()
 
 
-def test_two_rank_gloo_sharding():
-    """world_size 2 on CPU: one broadcast of the work description, disjoint shards that
-    together cover the batch, MAX-reduction of the time bracket; each rank's wavefronts agree
-    with the single-process oracle."""
-    import socket
-
-    import torch.multiprocessing as mp
-
+@pytest.mark.parametrize("world", [2, 3])
+def test_comm_star_sharding(world):
+    """world_size 2 and 3 on CPU over the TCP transport of paos_comm (no torch): one broadcast of the
+    work description, disjoint shards that together cover the batch, MAX-reduction of the time bracket,
+    ragged gather, broadcast from a non-zero root; each rank's wavefronts agree with the oracle."""
     from oracle.run_np import run as oracle_run
     from paos_amd.chains import syn20_chain, syn20_wavelength
+    from paos_amd.dist import shard_bounds
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    out = ctx.Queue()
-    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, out)) for r in range(2)]
-    for p in procs:
-        p.start()
-    results = [out.get(timeout=300) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    results.sort()
-    (r0, lo0, hi0, wl0, pw0, s0), (r1, lo1, hi1, wl1, pw1, s1) = results
-    assert (lo0, hi0, lo1, hi1) == (0, 3, 3, 5)
-    assert wl0 == wl1 == [syn20_wavelength(k) for k in range(5)]
-    assert s0 == s1 == 2.0
-    power = {**pw0, **pw1}
+    results = _spawn(_star_worker, world)
+    power = {}
+    for rank, lo, hi, wls, pw, slowest, parts, text in results:
+        assert (lo, hi) == shard_bounds(5, rank, world)
+        assert wls == [syn20_wavelength(k) for k in range(5)]
+        assert slowest == float(world)
+        assert parts == [[10.0 * r + k for k in range(r + 1)] for r in range(world)]
+        assert text == b"from the last rank"
+        power.update(pw)
     assert sorted(k[0] for k in power if k[1] == 20) == [0, 1, 2, 3, 4]
     for idx in (0, 4):
         ref = oracle_run(1.0, syn20_wavelength(idx), 64, 4, {"us": 0.0, "ut": 0.0}, syn20_chain(), light=True)
         assert abs(power[(idx, 20)] - np.sum(ref[20]["amplitude"] ** 2)) < 1e-12
 
 
-def _sharded_worker(rank, world, port, out):
-    import torch.distributed as dist
+def _sharded_worker(rank, world, key, out, poison):
+    import sys
 
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fakes import ModelDevice
+    from paos_amd.chains import syn20_chain, syn20_wavelength
+    from paos_amd.comm import Comm
+    from paos_amd.dist import run_sharded
+
+    comm = Comm(world, rank, 0, "socket", key=key, timeout=120)
     try:
-        import sys
-
-        sys.path.insert(0, ROOT)
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from fakes import ModelDevice
-        from paos_amd.chains import syn20_chain, syn20_wavelength
-        from paos_amd.dist import run_sharded
-
         total = 5
         wls = [syn20_wavelength(k * 50) for k in range(total)] if rank == 0 else None
         chains = [syn20_chain() for _ in range(total)] if rank == 0 else None
-        res = run_sharded(1.0, wls, 64, 4, {"us": 0.0, "ut": 0.0}, chains, batch=2, outputs=("psf",),
-                          make_device=lambda n, nb: ModelDevice(n, nb))
-        out.put((rank, [(i, float(r[20]["power"]), float(r[20]["psf"].sum()), r[20]["dx"]) for i, r in res]))
+        if poison and rank == 0:
+            chains[4][7]["type"] = "Hologram"  # lands in rank 1's shard; only that rank can notice
+            chains[4][7]["ABCDt"] = None
+        try:
+            res = run_sharded(1.0, wls, 64, 4, {"us": 0.0, "ut": 0.0}, chains, batch=2, outputs=("psf",),
+                              make_device=lambda n, nb: ModelDevice(n, nb), comm=comm)
+        except Exception as exc:  # noqa: BLE001
+            out.put((rank, "error", f"{type(exc).__name__}: {exc}"))
+            return
+        mine = [i for i, r in res if "psf" in r[20]]
+        out.put((rank, [(i, float(r[20]["power"]), r[20]["dx"], r[20]["propagator"], r[20]["ABCDt"]().tolist())
+                        for i, r in res], mine, [float(res[i][1][20]["psf"].sum()) for i in mine]))
     finally:
-        dist.destroy_process_group()
+        comm.close()
 
 
-def test_run_sharded_two_ranks_gloo():
-    """run_sharded: rank 0 alone holds the work, both ranks return the full ordered result list,
-    and it equals the single-process run."""
-    import socket
-
-    import torch.multiprocessing as mp
-
+def test_run_sharded_two_ranks():
+    """run_sharded: rank 0 alone holds the work; both ranks return the full ordered list of per-wavefront
+    scalars (equal on both, equal to the oracle), and each keeps the PSF arrays of its own shard only."""
     from oracle.run_np import run as oracle_run
     from paos_amd.chains import syn20_chain, syn20_wavelength
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    ctx = mp.get_context("spawn")
-    out = ctx.Queue()
-    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, out)) for r in range(2)]
-    for p in procs:
-        p.start()
-    results = dict(out.get(timeout=300) for _ in procs)
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
-    assert results[0] == results[1]
-    assert [i for i, *_ in results[0]] == [0, 1, 2, 3, 4]
-    for i, power, psf_sum, dx in (results[0][0], results[0][4]):
+    results = _spawn(_sharded_worker, 2, False)
+    (_, all0, mine0, sums0), (_, all1, mine1, sums1) = results
+    assert all0 == all1
+    assert [i for i, *_ in all0] == [0, 1, 2, 3, 4]
+    assert mine0 == [0, 1, 2] and mine1 == [3, 4]
+    for (i, power, dx, prop, abcd), psf_sum in zip([all0[0], all0[4]], [sums0[0], sums1[1]]):
         ref = oracle_run(1.0, syn20_wavelength(i * 50), 64, 4, {"us": 0.0, "ut": 0.0}, syn20_chain(), light=True)
         assert abs(power - np.sum(ref[20]["amplitude"] ** 2)) < 1e-12
         assert abs(psf_sum - np.sum(ref[20]["amplitude"] ** 2)) < 1e-12
-        assert dx == ref[20]["dx"]
+        assert dx == ref[20]["dx"] and prop == ref[20]["propagator"]
+        assert np.array_equal(np.array(abcd), ref[20]["ABCDt"]())
+
+
+def test_run_sharded_failure_reaches_every_rank():
+    """A chain that only rank 1 finds out it cannot run: both ranks raise, nobody hangs in the gather."""
+    results = _spawn(_sharded_worker, 2, True, timeout=120)
+    assert [r[1] for r in results] == ["error", "error"]
+    assert "rank 1" in results[0][2] and "Hologram" not in results[0][2][:0]
+    assert results[1][2]  # the failing rank re-raises its own exception
+
+
+def test_wire_format_round_trip():
+    """The packed work description: every type an optical chain is made of survives; nothing else packs."""
+    from paos_amd import wire
+    from paos_amd.abcd import ABCD
+    from paos_amd.chains import parse_config_variant, syn20_chain
+
+    chain = syn20_chain()
+    back = wire.loads(wire.dumps({"wavelengths": [1.0e-6, 2.0e-6], "chains": [chain]}))
+    got = back["chains"][0]
+    assert list(got) == list(chain) and back["wavelengths"] == [1.0e-6, 2.0e-6]
+    for k in chain:
+        assert sorted(got[k]) == sorted(chain[k])
+        assert np.array_equal(got[k]["ABCDt"](), chain[k]["ABCDt"]()) and got[k]["ABCDt"].cout == chain[k]["ABCDt"].cout
+        assert got[k]["ABCDt"].power == chain[k]["ABCDt"].power
+    assert np.array_equal(got[2]["Z"], chain[2]["Z"]) and got[2]["Zindex"].dtype == chain[2]["Zindex"].dtype
+    pup, par, wls, fields, chains = parse_config_variant(os.path.join(ROOT, "data", "lens", "Ariel_AIRS-CH0.ini"))
+    blob = wire.dumps(chains[0])
+    assert len(blob) < 16384
+    again = wire.loads(blob)
+    assert list(again) == list(chains[0])
+    m = np.ma.MaskedArray(np.arange(6.0).reshape(2, 3), mask=[[0, 1, 0], [0, 0, 1]])
+    rt = wire.loads(wire.dumps({"m": m, "n": None, "t": (1, 2.5, "x", True), "b": b"raw"}))
+    assert np.array_equal(rt["m"].mask, m.mask) and np.array_equal(rt["m"].data, m.data)
+    assert rt["t"] == [1, 2.5, "x", True] and rt["n"] is None and rt["b"] == b"raw"
+    with pytest.raises(TypeError):
+        wire.dumps({"f": lambda: 0})
+    with pytest.raises(TypeError):
+        wire.dumps(np.array([object()]))
+    with pytest.raises(ValueError):
+        wire.loads(blob[:-3])
+    with pytest.raises(ValueError):
+        wire.loads(b"Zjunk")
+    assert isinstance(wire.loads(wire.dumps(ABCD(thickness=1.0, curvature=0.5))), ABCD)
+
+
+def test_single_rank_comm_and_bad_arguments():
+    from paos_amd.comm import Comm, CommError
+
+    c = Comm()  # one rank: no peer, no file
+    assert c.max(3.5) == 3.5 and c.bcast_blob(b"abc") == b"abc"
+    assert [list(p) for p in c.allgather_scalars([1.0, 2.0])] == [[1.0, 2.0]]
+    c.barrier()
+    c.close()
+    with pytest.raises(CommError):
+        Comm(2, 5, 0, "socket", key="x")
+    with pytest.raises(CommError, match="key"):
+        Comm(2, 1, 0, "socket", key=None, timeout=1)
+    with pytest.raises(CommError, match="timed out"):
+        Comm(2, 1, 0, "socket", key="nobody_listens_here", timeout=0.3)

@@ -92,20 +92,21 @@ def test_run_with_a_psd_surface_matches_the_stepwise_wfo():
     pup, par, wls, fields, chains = parse_config(os.path.join(DATA, "lens", "lens_file_TA_Ground_PSD.ini"))
     chain = chains[1]
     np.random.seed(7)
-    ret = run(pup, 1e-6 * wls[1], 256, par["zoom"], fields[0], chain)
+    n = par["grid_size"]  # 1024: the PSD band of the file (fmax = 500 / m) needs the file's own sampling
+    ret = run(pup, 1e-6 * wls[1], n, par["zoom"], fields[0], chain)
     psd_num = [k for k, it in chain.items() if it["type"] == "PSD"][0]
     assert psd_num in ret and "wfe" in ret[psd_num]
     wfe = ret[psd_num]["wfe"]
-    assert wfe.shape == (256, 256) and np.std(np.ma.filled(wfe, 0.0)) > 0
+    assert wfe.shape == (n, n) and np.std(np.ma.filled(wfe, 0.0)) > 0
     # the same chain with the PSD surface replaced by nothing differs exactly by that phase screen
     plain = {k: v for k, v in chain.items() if k != psd_num}
-    base = run(pup, 1e-6 * wls[1], 256, par["zoom"], fields[0], plain)
+    base = run(pup, 1e-6 * wls[1], n, par["zoom"], fields[0], plain)
     # surfaces before the PSD are identical, the PSD surface itself is base * exp(2 pi i wfe / wl)
     before = [k for k in ret if k < psd_num]
     for k in before:
         assert np.array_equal(ret[k]["wfo"], base[k]["wfo"])
     np.random.seed(7)
-    again = run(pup, 1e-6 * wls[1], 256, par["zoom"], fields[0], chain)
+    again = run(pup, 1e-6 * wls[1], n, par["zoom"], fields[0], chain)
     for k in ret:
         assert np.array_equal(ret[k]["wfo"], again[k]["wfo"])
     last = max(ret)
@@ -190,3 +191,109 @@ def test_parameter_arena_grows_for_a_long_program():
     ref = dev.download(5)
     assert rel_err(got, ref) < 1e-12
     dev.close()
+
+
+@pytest.mark.parametrize("n", [1024, 2048])
+def test_dead_line_pruning_changes_nothing(n):
+    """Rows / columns an aperture has zeroed are skipped by the following passes (tiles not processed,
+    loads not issued).  With the pruning switched off every tile is processed: the saved fields must be
+    equal (zeros are zeros), for apertures riding on passes, stand-alone apertures (the live-row promise
+    of paos_run_passes_live), an off-axis field point (decentred boxes), a batch whose items have
+    different boxes, and fp32."""
+    import paos_amd.run as prun
+    from paos_amd import _lib
+    from paos_amd.chains import parse_config_variant, syn20_chain, syn20_wavelength
+    from paos_amd.parse_config import parse_config
+
+    def both(args, chains, wls, precision="fp64", **kw):
+        out = []
+        for on in (True, False):
+            dev = _lib.DeviceFields(n, len(chains), precision)
+            dev.set_pruning(on)
+            stats = {}
+            out.append(prun.run_batch(args[0], wls, n, args[1], args[2], chains, outputs=("wfo",), dev=dev,
+                                      precision=precision, stats=stats, **kw))
+            dev.close()
+        for a, b in zip(*out):
+            assert sorted(a) == sorted(b)
+            for k in a:
+                assert np.array_equal(a[k]["wfo"], b[k]["wfo"]), k
+                assert a[k]["power"] == b[k]["power"]
+        return out[0]
+
+    on_axis = {"us": 0.0, "ut": 0.0}
+    wls = [syn20_wavelength(k) for k in (0, 200, 400)]
+    both((1.0, 4, on_axis), [syn20_chain() for _ in wls], wls)
+    both((1.0, 4, {"us": 5.0e-5, "ut": -2.0e-5}), [syn20_chain()], [1.0e-6])
+    both((1.0, 4, on_axis), [syn20_chain()], [1.0e-6], precision="fp32") if n >= 2048 else None
+    pup, par, w, fields, chains = parse_config(os.path.join(DATA, "lens", "Hubble_simple.ini"))
+    both((pup, par["zoom"], fields[0]), [chains[0]], [1e-6 * w[0]])
+    pup, par, w, fields, chains = parse_config_variant(os.path.join(DATA, "lens", "Ariel_AIRS-CH0.ini"), [1.95, 3.9])
+    both((pup, par["zoom"], fields[0]), chains, [1e-6 * x for x in w])
+    # stand-alone apertures only (no line records): the promise travels through paos_run_passes_live
+    old = prun.FUSE_APERTURES
+    prun.FUSE_APERTURES = False
+    try:
+        both((1.0, 4, on_axis), [syn20_chain() for _ in wls], wls)
+    finally:
+        prun.FUSE_APERTURES = old
+
+
+def test_live_row_promise_is_validated():
+    from paos_amd import _lib
+    from paos_amd.passes import PassCompiler
+    from paos_amd.planner import PilotBeam
+
+    dev = _lib.DeviceFields(1024, 1)
+    dev.fill(1.0)
+    comp = PassCompiler(1, 1024)
+    comp.ptp([PilotBeam(1.0, 1e-6, 1024, 4).ptp(1.0)])
+    passes, blocks = comp.program()
+    with pytest.raises(_lib.PaosHipError, match="live row range"):
+        dev.run_passes(passes, blocks, live_rows=[[10, 2000]])
+    with pytest.raises(ValueError):
+        dev.run_passes(passes, blocks, live_rows=[[0, 10], [0, 10]])
+    # a field that really is zero outside rows [384, 640): same result with and without the promise
+    u = np.zeros((1024, 1024), dtype=complex)
+    rng = np.random.default_rng(1)
+    u[384:640] = rng.standard_normal((256, 1024)) + 1j * rng.standard_normal((256, 1024))
+    dev.upload(0, u)
+    dev.run_passes(passes, blocks, live_rows=[[384, 640]])
+    a = dev.download(0)
+    dev.upload(0, u)
+    dev.run_passes(passes, blocks)
+    b = dev.download(0)
+    assert np.array_equal(a, b)
+    dev.close()
+
+
+def test_rccl_transport_single_rank():
+    """paos_comm over RCCL on the one GPU of this box: dlopen of librccl, ncclCommInitRank, and the three
+    collectives the fan-out uses (broadcast of a packed work description, ragged gather, MAX) -- the
+    N > 1 path differs only in the number of ranks.  run_sharded with that communicator == run_batch."""
+    from paos_amd import wire
+    from paos_amd.chains import syn20_chain, syn20_wavelength
+    from paos_amd.comm import Comm
+    from paos_amd.dist import broadcast_work, run_sharded
+    from paos_amd.run import run_batch
+
+    comm = Comm(1, 0, 0, "rccl")
+    try:
+        work = {"wavelengths": [1e-6, 2e-6], "chains": [syn20_chain(), syn20_chain()]}
+        blob = wire.dumps(work)
+        assert comm.bcast_blob(blob, root=0) == blob  # through a device buffer and ncclBroadcast
+        assert broadcast_work(work, comm) is work
+        parts = comm.allgather_scalars(np.arange(5.0))
+        assert len(parts) == 1 and np.array_equal(parts[0], np.arange(5.0))
+        assert comm.max(2.5) == 2.5
+        comm.barrier()
+        field = {"us": 0.0, "ut": 0.0}
+        wls = [syn20_wavelength(k * 100) for k in range(3)]
+        chains = [syn20_chain() for _ in wls]
+        got = run_sharded(1.0, wls, 128, 4, field, chains, batch=2, outputs=("psf",), comm=comm)
+        ref = run_batch(1.0, wls, 128, 4, field, chains, outputs=("psf",))
+        assert [i for i, _ in got] == [0, 1, 2]
+        for (i, r), q in zip(got, ref):
+            assert np.array_equal(r[20]["psf"], q[20]["psf"]) and r[20]["power"] == q[20]["power"]
+    finally:
+        comm.close()

@@ -6,7 +6,7 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \\
         --master-port 29540 tools/mc_sharded.py                  # N GPUs (RCCL)
     PAOS_MC_REHEARSAL=1 ... --nproc-per-node 2 tools/mc_sharded.py --draws 16 --grid 512
-                                                                 # 2 ranks on ONE GPU over gloo
+                                                                 # 2 ranks on ONE GPU over the TCP transport
 """
 import argparse
 import os
@@ -29,18 +29,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
+    comm = None
+    if world > 1:  # torch is only the launcher: the process group is paos_comm (RCCL from libpaoship.so)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        import torch
-        import torch.distributed as dist
+        from paos_amd.comm import Comm
 
         if os.environ.get("PAOS_MC_REHEARSAL") == "1":
             local_rank = 0
-            dist.init_process_group(backend="gloo")
+            comm = Comm.from_env(transport="socket")
         else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            comm = Comm.from_env(transport="rccl")
 
     from paos_amd.chains import inject_wfe, parse_config_variant, read_wfe_table
     from paos_amd.dist import run_sharded
@@ -59,10 +57,10 @@ def main():
     warm = min(args.batch * world, args.draws)
     run_sharded(pup, wls[:warm] if rank == 0 else None, args.grid, zoom, field,
                 chains[:warm] if rank == 0 else None, batch=args.batch, device=local_rank, outputs=(),
-                metrics_radii_px=radii, gather=False)
+                metrics_radii_px=radii, gather=False, comm=comm)
     t0 = time.perf_counter()
     res = run_sharded(pup, wls, args.grid, zoom, field, chains, batch=args.batch, device=local_rank,
-                      outputs=(), metrics_radii_px=radii)
+                      outputs=(), metrics_radii_px=radii, comm=comm)
     dt = time.perf_counter() - t0
     if rank == 0:
         ree90, power = [], []
@@ -74,8 +72,8 @@ def main():
         print(f"{len(res)} draws on {world} rank(s), {args.grid}^2: {dt:.2f} s = {len(res) / dt:.1f} wavefronts/s "
               f"(including the gather); power {min(power):.6f}..{max(power):.6f}; "
               f"rEE90 {1e6 * min(ree90):.2f}..{1e6 * max(ree90):.2f} um (median {1e6 * float(np.median(ree90)):.2f})")
-    if dist is not None:
-        dist.destroy_process_group()
+    if comm is not None:
+        comm.close()
 
 
 if __name__ == "__main__":
