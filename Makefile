@@ -12,7 +12,13 @@ all: $(LIB)
 # part 0 = everything but the frugal pass-kernel families, parts 1..5 = one (type, N) family each.
 DEPS = $(CSRC)/paos_hip.hip $(CSRC)/fft_core.h $(CSRC)/fft_kernels.h $(CSRC)/frugal_pass.h $(CSRC)/pointwise.h include/paos_hip.h
 PARTS = 0 1 2 3 4 5
-OBJS = $(foreach k,$(PARTS),build/obj/part$(k).o) build/obj/comm.o
+OBJS = $(foreach k,$(PARTS),build/obj/part$(k).o) build/obj/comm.o build/obj/plan.o
+
+# the scalar half of the propagation loop for a batch (include/paos_plan.h): plain C++, the
+# reference's operation order, no FMA contraction
+build/obj/plan.o: $(CSRC)/paos_plan.cpp include/paos_plan.h
+	mkdir -p build/obj
+	g++ -O2 -fPIC -std=c++17 -Wall -ffp-contract=off -c $(CSRC)/paos_plan.cpp -o $@
 
 # the multi-GPU fan-out (include/paos_comm.h): host code only, RCCL is dlopen'ed at run time
 build/obj/comm.o: $(CSRC)/paos_comm.cpp include/paos_comm.h include/paos_hip.h

@@ -41,14 +41,17 @@ ON_AXIS = {"us": 0.0, "ut": 0.0}
 def chain_fft_counts(wavelength, gridsize):
     """(n_ptp, n_stw, n_wts) the planner executes for SYN20 at this wavelength."""
     from paos_amd.chains import syn20_chain
-    from paos_amd.run import _Item, _plan_surface
+    from paos_amd.planner import BeamBatch
+    from paos_amd.run import _surface_gates
 
-    st = _Item(1.0, wavelength, gridsize, 4, ON_AXIS)
-    counts = {"ptp": 0, "stw": 0, "wts": 0}
+    beams = BeamBatch(1.0, [wavelength], gridsize, 4)
+    n_ptp = n_stw = n_wts = 0
     for item in syn20_chain().values():
-        for step in _plan_surface(st, item)["steps"]:
-            counts[step[0]] += 1
-    return counts["ptp"], counts["stw"], counts["wts"]
+        _, stw, ptp, wts, _, _ = beams.surface(*_surface_gates([item]))
+        n_stw += int(stw[0, 0] != 0.0)
+        n_ptp += int(ptp[0, 0] != 0.0)
+        n_wts += int(wts[0, 0] != 0.0)
+    return n_ptp, n_stw, n_wts
 
 
 def _oracle_seconds(task):

@@ -62,6 +62,17 @@ class ABCD:
     @cout.setter
     def cout(self, value):
         self._cout = value
+        self._cache.pop("gates", None)
+
+    def gates(self):
+        """(M, fl, T, n1n2) the way the propagation loop derives them from a surface's matrix
+        (run.py:181-190): fl = cout / power (inf for a powerless surface), T = cout * thickness."""
+        g = self._cache.get("gates")
+        if g is None:
+            power = self.power
+            g = (self.M, np.inf if power == 0 else self.cout / power, self.cout * self.thickness, self.n1n2)
+            self._cache["gates"] = g
+        return g
 
     # factorisation read-outs (abcd.py:98-116,142-144) ------------------------
     def _readout(self, name):

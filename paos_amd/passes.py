@@ -27,26 +27,43 @@ from . import _lib
 _OFF = [0.0, 0.0, 0.0, 0.0, 0.0]
 
 
+def _rows(rows, batch):
+    """[batch][5] array of parameter blocks from either such an array (enable = 0: step off) or a list
+    of 5-double rows with None for "off"."""
+    if isinstance(rows, np.ndarray):
+        if rows.shape != (batch, 5):
+            raise ValueError(f"expected blocks of shape {(batch, 5)}, got {rows.shape}")
+        return rows
+    if len(rows) != batch:
+        raise ValueError("one block (or None) per batch item is required")
+    return np.array([r if r is not None else _OFF for r in rows], dtype=np.float64).reshape(batch, 5)
+
+
 class PassCompiler:
     def __init__(self, batch, n):
         self.batch, self.n = int(batch), int(n)
         self._reset()
 
     def _reset(self):
-        self.blocks = []    # each: list of `batch` 5-double rows
+        self.blocks = []    # each: [batch][5] array
         self.passes = []    # emitted, in order
         self.open = None    # last pass, if its second transform slot is still free
         self.tail = []      # pointwise operators not yet attached to a pass
 
     # ---- helpers -------------------------------------------------------------------
     def _block(self, rows):
-        self.blocks.append([list(r) if r is not None else _OFF for r in rows])
+        self.blocks.append(_rows(rows, self.batch))
         return len(self.blocks) - 1
 
-    def _derived(self, rows, v1=0.0, v2=0.0, v3=0.0, v4=0.0):
-        """Block with the enable flags of ``rows`` and a fixed payload."""
-        return self._block([[1.0, v1, v2, v3, v4] if (r is not None and r[0] != 0.0) else None
-                            for r in rows])
+    def _derived(self, arr, v1=0.0, v2=0.0, v3=0.0, v4=0.0):
+        """Block with the enable flags of ``arr`` and a payload (scalars, or one value per item)."""
+        out = np.zeros((self.batch, 5), dtype=np.float64)
+        on = arr[:, 0] != 0.0
+        for col, v in ((1, v1), (2, v2), (3, v3), (4, v4)):
+            out[:, col] = v
+        out[:, 0] = 1.0
+        out[~on] = 0.0
+        return self._block(out)
 
     def _standalone(self, ops):
         for i in range(0, len(ops), _lib.MAX_PW):
@@ -98,23 +115,24 @@ class PassCompiler:
         if any(op[0] == _lib.PW_MASK for op in self.tail) or (
                 self.open is not None and any(op[0] == _lib.PW_MASK for op in self.open["mid"])):
             self._close_open()  # one aperture per pass
-        first = self._block([r[0][:5] if r is not None else None for r in records])
+        first = self._block([list(r[0][:5]) if r is not None else None for r in records])
         self._block([[r[0][5], r[0][6], r[0][7], float(r[1]), 0.0] if r is not None else None
                      for r in records])
         self.tail.append((_lib.PW_MASK, 0, first))
 
     def lens(self, rows):
-        if all(r is None for r in rows):
+        arr = _rows(rows, self.batch)
+        if not arr[:, 0].any():
             return
-        self.tail.append((_lib.PW_QPHASE_CENTRED, _lib.PWF_MUL2PI, self._block(rows)))
+        self.tail.append((_lib.PW_QPHASE_CENTRED, _lib.PWF_MUL2PI, self._block(arr)))
 
     def _single(self, rows, inverse, kind):
-        if all(r is None for r in rows):
+        arr = _rows(rows, self.batch)
+        if not arr[:, 0].any():
             return
-        par = self._block(rows)
-        ctl = self._block([[1.0, 1.0 if inv else 0.0, 0, 0, 0] if r is not None else None
-                           for r, inv in zip(rows, inverse)])
-        scl = self._derived(rows, v3=1.0 / self.n)
+        par = self._block(arr)
+        ctl = self._derived(arr, v1=np.where(np.asarray(inverse, dtype=bool), 1.0, 0.0))
+        scl = self._derived(arr, v3=1.0 / self.n)
         sign = (_lib.PW_SIGN, 0, par)
         phase = (_lib.PW_QPHASE_CENTRED, 0, par)
         pre = [phase, sign] if kind == "wts" else [sign]
@@ -129,12 +147,13 @@ class PassCompiler:
         self._single(rows, inverse, "wts")
 
     def ptp(self, rows):
-        if all(r is None for r in rows):
+        arr = _rows(rows, self.batch)
+        if not arr[:, 0].any():
             return
-        par = self._block(rows)
-        fwd = self._derived(rows, v1=0.0)
-        inv = self._derived(rows, v1=1.0)
-        scl = self._derived(rows, v3=1.0 / self.n)
+        par = self._block(arr)
+        fwd = self._derived(arr, v1=0.0)
+        inv = self._derived(arr, v1=1.0)
+        scl = self._derived(arr, v3=1.0 / self.n)
         axis = self._first_pass([], fwd)
         self.passes.append({"axis": 1 - axis, "fft1": fwd, "fft2": inv, "pre": [], "post": [],
                             "mid": [(_lib.PW_QPHASE_NATURAL, 0, par), (_lib.PW_SCALE, 0, scl)]})
@@ -159,7 +178,8 @@ class PassCompiler:
     def program(self):
         """Finish the current stretch; returns (passes, blocks[n][batch][5])."""
         self._close_open()
-        passes, blocks = self.passes, np.asarray(self.blocks, dtype=np.float64).reshape(-1, self.batch, 5)
+        passes = self.passes
+        blocks = np.stack(self.blocks) if self.blocks else np.zeros((0, self.batch, 5), dtype=np.float64)
         self._reset()
         return passes, blocks
 

@@ -193,6 +193,97 @@ class PilotBeam:
         return steps
 
 
+# ---- the same scalars for a whole batch, in C (include/paos_plan.h) ------------------------------------
+_PROP_NAMES = ("", "II", "IO", "OI", "OO")
+_PLAN_ERRORS = {
+    1: (AssertionError, "Negative magnification not implemented yet."),
+    2: (ValueError, "PTP wavefront should be planar"),
+    3: (ValueError, "STW wavefront should not be planar"),
+    4: (ValueError, "WTS wavefront should be planar"),
+}
+_plan_lib = None
+
+
+def _plan():
+    global _plan_lib
+    if _plan_lib is None:
+        import ctypes
+
+        from . import _lib
+
+        lib = _lib.load()
+        dp = ctypes.POINTER(ctypes.c_double)
+        lib.paos_plan_init.restype = ctypes.c_int
+        lib.paos_plan_init.argtypes = [ctypes.c_int, ctypes.c_double, dp, ctypes.c_int, ctypes.c_double, dp]
+        lib.paos_plan_readout.restype = ctypes.c_int
+        lib.paos_plan_readout.argtypes = [ctypes.c_int, dp, dp, dp]
+        lib.paos_plan_surface.restype = ctypes.c_int
+        lib.paos_plan_surface.argtypes = [ctypes.c_int, ctypes.c_int, dp] + [dp] * 5 + [dp] * 6 + [ctypes.POINTER(ctypes.c_int)]
+        _plan_lib = (lib, dp, ctypes)
+    return _plan_lib
+
+
+class BeamBatch:
+    """``PilotBeam`` for B wavefronts at once: the state lives in one [B][10] array, one C call per
+    surface does what B x (magnification, change_medium, lens, propagate) calls do in Python
+    (include/paos_plan.h; bit-identical to ``PilotBeam``, tests/test_r2_host.py)."""
+    WL, Z, W0, ZW0, ZR, DX, DY, C, FRATIO, PROP = range(10)
+
+    def __init__(self, beam_diameter, wavelengths, grid_size, zoom):
+        assert np.log2(grid_size).is_integer(), "Grid size should be 2**n"
+        assert zoom > 0, "zoom factor should be positive"
+        assert beam_diameter > 0, "beam diameter should be positive"
+        wl = np.ascontiguousarray(wavelengths, dtype=np.float64).reshape(-1)
+        assert np.all(wl > 0), "a wavelength should be positive"
+        self.n, self.batch = int(grid_size), int(wl.size)
+        self.state = np.empty((self.batch, 10), dtype=np.float64)
+        lib, dp, _ = _plan()
+        if lib.paos_plan_init(self.batch, float(beam_diameter), wl.ctypes.data_as(dp), self.n, float(zoom),
+                              self.state.ctypes.data_as(dp)) != 0:
+            raise ValueError("paos_plan_init rejected its arguments")
+        b = self.batch
+        self._lens, self._stw, self._ptp, self._wts = (np.empty((b, 5)) for _ in range(4))
+        self._inv_stw, self._inv_wts = np.empty(b), np.empty(b)
+        self._status = np.empty(b, dtype=np.int32)
+
+    def column(self, k):
+        return self.state[:, k]
+
+    def readout(self):
+        """(wz, distancetofocus) arrays -- wfo.py:142-150."""
+        lib, dp, _ = _plan()
+        wz, dtf = np.empty(self.batch), np.empty(self.batch)
+        lib.paos_plan_readout(self.batch, self.state.ctypes.data_as(dp), wz.ctypes.data_as(dp), dtf.ctypes.data_as(dp))
+        return wz, dtf
+
+    def propagators(self):
+        return [_PROP_NAMES[int(c)] for c in self.state[:, self.PROP]]
+
+    def extents(self):
+        n = self.n
+        return [(-n // 2 * dx, (n // 2 - 1) * dx, -n // 2 * dy, (n // 2 - 1) * dy)
+                for dx, dy in zip(self.state[:, self.DX].tolist(), self.state[:, self.DY].tolist())]
+
+    def surface(self, Mt, Ms, fl, T, n1n2):
+        """run.py:181-207 for every item.  Returns fresh arrays (lens, stw, ptp, wts blocks [B][5] with
+        enable = 0 where the step does not run; inverse flags of stw and wts [B])."""
+        lib, dp, ctypes = _plan()
+        args = [np.ascontiguousarray(a, dtype=np.float64) for a in (Mt, Ms, fl, T, n1n2)]
+        if any(a.shape != (self.batch,) for a in args):
+            raise ValueError("one value per wavefront is required")
+        lens, stw, ptp, wts = (np.empty((self.batch, 5)) for _ in range(4))
+        inv_stw, inv_wts = np.empty(self.batch), np.empty(self.batch)
+        bad = lib.paos_plan_surface(self.batch, self.n, self.state.ctypes.data_as(dp), *[a.ctypes.data_as(dp) for a in args],
+                                    lens.ctypes.data_as(dp), stw.ctypes.data_as(dp), ptp.ctypes.data_as(dp),
+                                    wts.ctypes.data_as(dp), inv_stw.ctypes.data_as(dp), inv_wts.ctypes.data_as(dp),
+                                    self._status.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+        if bad:
+            code = int(self._status[np.nonzero(self._status)[0][0]])
+            exc, msg = _PLAN_ERRORS[code]
+            raise exc(msg)
+        return lens, stw, ptp, wts, inv_stw, inv_wts
+
+
 # ---- Zernike tables -------------------------------------------------------------------
 def jacobi_recurrence(nmax):
     """Constants of P_k^{(a,0)}(x) = (A x + B) P_{k-1} - C P_{k-2} for a = 0..nmax,

@@ -28,7 +28,7 @@ from .aperture import EllipticalAperture, bbox_misses_grid, make_aperture
 from .coordinate_break import coordinate_break
 from .passes import PassCompiler
 from .phase_maps import grid_sag_map, psd_map
-from .planner import (PilotBeam, gram_polynomials, jacobi_recurrence, orthonorm_matrix,
+from .planner import (BeamBatch, gram_polynomials, jacobi_recurrence, orthonorm_matrix,
                       zernike_block)
 from .zernike import zernike_tables
 
@@ -59,28 +59,51 @@ _OFF_APERTURE = [0.0] * _lib.APERTURE_STRIDE
 
 
 class _Item:
-    """Host state of one wavefront while it walks the chain."""
+    """Host state of one wavefront while it walks the chain: the two paraxial rays of the field
+    point and the ray-transfer factors met so far.  (The pilot beams of all wavefronts live together
+    in a ``planner.BeamBatch``.)"""
 
     def __init__(self, pupil_diameter, wavelength, gridsize, zoom, field):
-        self.beam = PilotBeam(pupil_diameter, wavelength, gridsize, zoom)
+        self.pupil_diameter, self.wavelength, self.gridsize, self.zoom = pupil_diameter, wavelength, gridsize, zoom
         self.vt = np.array([0.0, field["ut"]])
         self.vs = np.array([0.0, field["us"]])
-        self.acc_t = ABCD()
-        self.acc_s = ABCD()
+        # an on-axis field point: both rays are [0, 0] and stay so under every ABCD matrix (A @ 0 = 0)
+        # until a coordinate break moves them -- no need to multiply
+        self.still = field["ut"] == 0.0 and field["us"] == 0.0
+        self.factors_t, self.factors_s = [], []
 
 
-def _plan_surface(st, item):
-    """Host half of one loop iteration of run.py:77-224 for one wavefront.  Returns the
-    device work as a dict of slots and advances the host state."""
-    beam = st.beam
-    plan = {"aperture": None, "stop": False, "zernike": None, "lens": None, "steps": [], "phase_map": None}
+class ABCDProduct(ABCD):
+    """The accumulated ray-transfer matrix ``f_k * ... * f_1 * ABCD()`` of a saved surface
+    (run.py:215-219), multiplied out when it is first read -- most callers never look at it."""
 
-    if item["type"] == "Coordinate Break":
+    def __init__(self, factors):  # noqa: D107 -- deliberately does not build a matrix
+        object.__setattr__(self, "_factors", factors)
+
+    def __getattr__(self, name):  # only reached while the product has not been formed
+        if name in ("_mat", "_cin", "_cout", "_cache"):
+            acc = ABCD()
+            for f in object.__getattribute__(self, "_factors"):
+                acc = f * acc
+            self._mat, self._cin, self._cout, self._cache = acc._mat, acc._cin, acc._cout, {}
+            return object.__getattribute__(self, name)
+        raise AttributeError(name)
+
+
+def _plan_host(st, item, n, dx, dy, wl, wz_of):
+    """Host half of one loop iteration of run.py:77-178 for one wavefront -- everything but the
+    pilot-beam scalars (those are advanced for the whole batch in one C call, planner.BeamBatch).
+    ``dx, dy, wl`` are the wavefront's current sampling and wavelength, ``wz_of()`` its beam radius."""
+    plan = {"aperture": None, "stop": bool(item["is_stop"]), "zernike": None, "phase_map": None}
+    kind = item["type"]
+
+    if kind == "Coordinate Break":
         st.vt, st.vs = coordinate_break(st.vt, st.vs, item["xdec"], item["ydec"], item["xrot"],
                                         item["yrot"], 0.0)
+        st.still = not (np.any(st.vt) or np.any(st.vs))
 
-    if "aperture" in item:
-        ap = item["aperture"]
+    ap = item.get("aperture")
+    if ap is not None:
         xdec = ap["xc"] if math.isfinite(ap["xc"]) else st.vs[0]
         ydec = ap["yc"] if math.isfinite(ap["yc"]) else st.vt[0]
         xrad = ap["xrad"]
@@ -89,18 +112,14 @@ def _plan_surface(st, item):
         yrad *= math.sqrt(1 / (st.vt[1] ** 2 + 1))
         xaper = xdec - st.vs[0]
         yaper = ydec - st.vt[0]
-        obscuration = ap["type"] != "aperture"
         if math.isfinite(xrad) and math.isfinite(yrad):
-            handle = make_aperture(beam.n, beam.dx, beam.dy, xaper, yaper, hx=xrad, hy=yrad,
-                                   shape=ap["shape"])
-            if bbox_misses_grid(handle, beam.n):
+            handle = make_aperture(n, dx, dy, xaper, yaper, hx=xrad, hy=yrad, shape=ap["shape"])
+            if bbox_misses_grid(handle, n):
                 raise TypeError("aperture does not overlap the grid (mask is None in the reference)")
-            plan["aperture"] = (handle, obscuration)
+            plan["aperture"] = (handle, ap["type"] != "aperture")
 
-    plan["stop"] = bool(item["is_stop"])
-
-    if item["type"] == "Zernike":
-        radius = item["Zradius"] if math.isfinite(item["Zradius"]) else beam.wz
+    if kind == "Zernike":
+        radius = item["Zradius"] if math.isfinite(item["Zradius"]) else wz_of()
         pupil = None
         if item["Zorthonorm"]:  # run.py:133-141: orthonormal over THIS surface's aperture object
             assert "aperture" in item, "Zorthonorm requires aperture"
@@ -115,46 +134,28 @@ def _plan_surface(st, item):
         ordering = item["Zordering"]
         if ordering not in ("ansi", "noll", "fringe", "standard"):
             raise AssertionError("Unrecognised ordering scheme.")
-        m, n, norm = zernike_tables(len(index), ordering, bool(item["Znormalize"]))
-        plan["zernike"] = dict(m=m, n=n, norm=norm,
-                               Z=np.asarray(item["Z"], dtype=np.float64), dx=beam.dx, dy=beam.dy,
-                               radius=radius, wl=beam.wl, origin=item["Zorigin"], pupil=pupil)
-    if item["type"] == "Grid Sag":  # run.py:154-164
+        m, nn, norm = zernike_tables(len(index), ordering, bool(item["Znormalize"]))
+        plan["zernike"] = dict(m=m, n=nn, norm=norm, Z=np.asarray(item["Z"], dtype=np.float64), dx=dx, dy=dy,
+                               radius=radius, wl=wl, origin=item["Zorigin"], pupil=pupil)
+    elif kind == "Grid Sag":  # run.py:154-164
         plan["phase_map"] = (grid_sag_map(item["grid_sag"], item["nx"], item["ny"], item["delx"], item["dely"],
-                                          item["xdec"], item["ydec"], (beam.n, beam.n), beam.dx, beam.dy), beam.wl)
-    if item["type"] == "PSD":  # run.py:166-177
-        plan["phase_map"] = (psd_map((beam.n, beam.n), beam.dx, beam.dy, item["A"], item["B"], item["C"],
-                                     item["fknee"], item["fmin"], item["fmax"], item["SR"], item["units"]), beam.wl)
-
-    # push_results scalars (run.py:12-27) are those BEFORE magnification / lens / propagate
-    if item["save"]:
-        plan["scalars"] = {
-            "wz": beam.wz, "distancetofocus": beam.distancetofocus, "fratio": beam.fratio,
-            "dx": beam.dx, "dy": beam.dy, "wl": beam.wl, "extent": beam.extent,
-            "propagator": beam.propagator,
-        }
-
-    Ms = item["ABCDs"].M
-    Mt = item["ABCDt"].M
-    fl = np.inf if (item["ABCDt"].power == 0) else item["ABCDt"].cout / item["ABCDt"].power
-    T = item["ABCDt"].cout * item["ABCDt"].thickness
-    n1n2 = item["ABCDt"].n1n2
-    if Mt != 1.0 or Ms != 1.0:
-        beam.magnification(Mt, Ms)
-    if abs(n1n2) != 1.0:
-        beam.change_medium(n1n2)
-    if math.isfinite(fl):
-        plan["lens"] = beam.lens(fl)
-    if math.isfinite(T) and abs(T) > 1e-10:
-        plan["steps"] = beam.propagate(T)
-
-    st.vt = item["ABCDt"]() @ st.vt
-    st.vs = item["ABCDs"]() @ st.vs
-    st.acc_t = item["ABCDt"] * st.acc_t
-    st.acc_s = item["ABCDs"] * st.acc_s
-    plan["ABCDt"] = st.acc_t
-    plan["ABCDs"] = st.acc_s
+                                          item["xdec"], item["ydec"], (n, n), dx, dy), wl)
+    elif kind == "PSD":  # run.py:166-177
+        plan["phase_map"] = (psd_map((n, n), dx, dy, item["A"], item["B"], item["C"], item["fknee"], item["fmin"],
+                                     item["fmax"], item["SR"], item["units"]), wl)
     return plan
+
+
+def _surface_gates(items):
+    """Mt, Ms, fl, T, n1n2 of one surface for every item -- the quantities run.py:181-190 reads off the
+    surface's ABCD matrices (fl = cout / power, inf for a powerless surface; T = cout * thickness)."""
+    gt = [it["ABCDt"].gates() for it in items]
+    Mt = [g[0] for g in gt]
+    Ms = [it["ABCDs"].M for it in items]
+    fl = [g[1] for g in gt]
+    T = [g[2] for g in gt]
+    n1n2 = [g[3] for g in gt]
+    return Mt, Ms, fl, T, n1n2
 
 
 def _live_rows_after(plans, live, n):
@@ -267,23 +268,15 @@ def _queue_apertures(comp, plans):
     comp.aperture(recs)
 
 
-def _queue_steps(comp, plans):
+def _queue_steps(comp, lens, stw, ptp, wts, inv_stw, inv_wts):
     """Lens and stw / ptp / wts of one surface go to the pass compiler, in the fixed slot
     order every regime respects (OI: stw, ptp; IO: ptp, wts; OO: stw, wts; II: ptp --
-    wfo.py:560-570).  Nothing is launched here: consecutive surfaces fuse (passes.py)."""
-    comp.lens([p["lens"] for p in plans])
-    for kind in ("stw", "ptp", "wts"):
-        rows, inverse = [], []
-        for p in plans:
-            hit = [s for s in p["steps"] if s[0] == kind]
-            rows.append(hit[0][1] if hit else None)
-            inverse.append(bool(hit[0][2]) if hit else False)
-        if kind == "ptp":
-            comp.ptp(rows)
-        elif kind == "stw":
-            comp.stw(rows, inverse)
-        else:
-            comp.wts(rows, inverse)
+    wfo.py:560-570).  Blocks are [batch][5] arrays with enable = 0 where an item skips the step.
+    Nothing is launched here: consecutive surfaces fuse (passes.py)."""
+    comp.lens(lens)
+    comp.stw(stw, inv_stw != 0.0)
+    comp.ptp(ptp)
+    comp.wts(wts, inv_wts != 0.0)
 
 
 def _start_field(dev, plans, value):
@@ -307,6 +300,11 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None):
     keys = [list(c.keys()) for c in chains]
     if any(k != keys[0] for k in keys[1:]):
         raise ValueError("batched chains must list the same surfaces (same keys, same order)")
+    st0 = states[0]
+    if any((st.pupil_diameter, st.gridsize, st.zoom) != (st0.pupil_diameter, st0.gridsize, st0.zoom) for st in states):
+        raise ValueError("the wavefronts of a batch share beam diameter, grid and zoom")
+    beams = BeamBatch(st0.pupil_diameter, [st.wavelength for st in states], st0.gridsize, st0.zoom)
+    state, n = beams.state, beams.n
     comp = PassCompiler(len(states), dev.n)
     npass = 0
     # rows of each item known to be exactly zero in memory (outside [lo, hi)): set by stand-alone
@@ -324,8 +322,38 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None):
 
     for key in keys[0]:
         items = [c[key] for c in chains]
-        plans = [_plan_surface(st, it) for st, it in zip(states, items)]
+        dxs, dys, wls = state[:, beams.DX].tolist(), state[:, beams.DY].tolist(), state[:, beams.WL].tolist()
+        readout = []
+
+        def wz_dtf():
+            if not readout:
+                readout.extend(beams.readout())
+            return readout
+
+        plans = [_plan_host(st, it, n, dxs[i], dys[i], wls[i], lambda i=i: wz_dtf()[0][i])
+                 for i, (st, it) in enumerate(zip(states, items))]
         saved = any(it["save"] for it in items)
+        if saved:  # push_results scalars (run.py:12-27) are those BEFORE magnification / lens / propagate
+            wz, dtf = wz_dtf()
+            fr, props, ext = state[:, beams.FRATIO].tolist(), beams.propagators(), beams.extents()
+            for i, (it, p) in enumerate(zip(items, plans)):
+                if it["save"]:
+                    p["scalars"] = {"wz": float(wz[i]), "distancetofocus": float(dtf[i]), "fratio": fr[i],
+                                    "dx": dxs[i], "dy": dys[i], "wl": wls[i], "extent": ext[i],
+                                    "propagator": props[i]}
+        # the pilot beams of the whole batch through this surface (one C call), the rays and the
+        # accumulated ABCD factors of each item
+        lens, stw, ptp, wts, inv_stw, inv_wts = beams.surface(*_surface_gates(items))
+        for st, it, p in zip(states, items, plans):
+            if not st.still:
+                st.vt = it["ABCDt"]() @ st.vt
+                st.vs = it["ABCDs"]() @ st.vs
+            st.factors_t.append(it["ABCDt"])
+            st.factors_s.append(it["ABCDs"])
+            if it["save"]:
+                p["ABCDt"] = ABCDProduct(tuple(st.factors_t))
+                p["ABCDs"] = ABCDProduct(tuple(st.factors_s))
+
         if fresh is not None:
             value, fresh = fresh, None
             if _start_field(dev, plans, value):
@@ -335,7 +363,7 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None):
                 wfe = _launch_phase_maps(dev, plans, wfe)
                 if saved:
                     on_saved(key, items, plans, wfe)
-                _queue_steps(comp, plans)
+                _queue_steps(comp, lens, stw, ptp, wts, inv_stw, inv_wts)
                 continue
         fuse_ap = FUSE_APERTURES
         own_breaker = saved or any(p["stop"] or p["zernike"] is not None or p["phase_map"] is not None
@@ -365,7 +393,7 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None):
         wfe = _launch_phase_maps(dev, plans, wfe)
         if saved:
             on_saved(key, items, plans, wfe)
-        _queue_steps(comp, plans)
+        _queue_steps(comp, lens, stw, ptp, wts, inv_stw, inv_wts)
     if fresh is not None:  # an empty chain still yields the initial wavefront
         dev.fill(fresh)
     npass += flush()

@@ -143,3 +143,83 @@ def test_psd_maps_match_reference():
     b = _beam(False)
     with pytest.raises(AssertionError, match="fmax"):
         psd_map((64, 64), b.dx, b.dy, fmax=1e9)
+
+
+def test_beam_batch_is_bitwise_the_pilot_beam():
+    """include/paos_plan.h (C, whole batch) against planner.PilotBeam (Python, one wavefront), which the
+    round-1 fixtures pin to the reference: random sequences of surfaces through every regime, with
+    magnifications, medium changes, negative focal lengths and tiny propagation steps -- every state
+    variable, every block, every flag must be EQUAL (x**2 is libm pow in both)."""
+    from paos_amd.planner import BeamBatch, PilotBeam
+
+    rng = np.random.default_rng(42)
+    nb = 64
+    wls = rng.uniform(0.4e-6, 12e-6, nb)
+    seen = set()
+    for trial in range(6):
+        grid = int(rng.choice([64, 512, 4096]))
+        zoom = int(rng.choice([1, 4, 8]))
+        dia = float(rng.uniform(0.1, 2.5))
+        batch = BeamBatch(dia, wls, grid, zoom)
+        singles = [PilotBeam(dia, wl, grid, zoom) for wl in wls]
+        names = ("wl", "z", "w0", "zw0", "zr", "dx", "dy", "C", "fratio")
+        for step in range(40):
+            Mt = np.where(rng.random(nb) < 0.2, rng.uniform(0.5, 2.0, nb), 1.0)
+            Ms = np.where(rng.random(nb) < 0.2, rng.uniform(0.5, 2.0, nb), Mt)
+            n1n2 = np.where(rng.random(nb) < 0.25, rng.uniform(0.6, 1.6, nb), 1.0)
+            n1n2[rng.random(nb) < 0.05] = -1.0  # a mirror: |n1n2| == 1, no medium change
+            fl = np.where(rng.random(nb) < 0.6, rng.uniform(0.05, 30.0, nb) * rng.choice([-1.0, 1.0], nb), np.inf)
+            T = np.where(rng.random(nb) < 0.8, 10.0 ** rng.uniform(-11, 2, nb) * rng.choice([-1.0, 1.0], nb, p=[0.2, 0.8]), 0.0)
+            # every other step some items travel (almost) to their waist, or away from it: OI and IO regimes
+            if step % 2:
+                to_waist = np.array([b.zw0 - b.z for b in singles]) * rng.choice([1.0, 0.999, 1.5], nb)
+                pick = (rng.random(nb) < 0.5) & np.isfinite(to_waist)
+                T = np.where(pick, to_waist, T)
+                fl = np.where(pick, np.inf, fl)
+            want = []
+            ok = True
+            for i, b in enumerate(singles):
+                try:
+                    if Mt[i] != 1.0 or Ms[i] != 1.0:
+                        b.magnification(Mt[i], Ms[i])
+                    if abs(n1n2[i]) != 1.0:
+                        b.change_medium(n1n2[i])
+                    lens = b.lens(fl[i]) if np.isfinite(fl[i]) else None
+                    steps = b.propagate(T[i]) if np.isfinite(T[i]) and abs(T[i]) > 1e-10 else []
+                    want.append((lens, steps))
+                except ValueError:
+                    ok = False
+                    break
+            if not ok:
+                with pytest.raises(ValueError):
+                    batch.surface(Mt, Ms, fl, T, n1n2)
+                break
+            lens, stw, ptp, wts, inv_stw, inv_wts = batch.surface(Mt, Ms, fl, T, n1n2)
+            for i, (wl_, steps) in enumerate(want):
+                assert list(lens[i]) == (wl_ if wl_ is not None else [0.0] * 5), (trial, step, i)
+                by = {s[0]: s for s in steps}
+                for kind, blk, inv in (("stw", stw, inv_stw), ("ptp", ptp, None), ("wts", wts, inv_wts)):
+                    if kind in by:
+                        assert list(blk[i]) == list(by[kind][1]), (trial, step, i, kind)
+                        if inv is not None:
+                            assert bool(inv[i]) == bool(by[kind][2])
+                    else:
+                        assert blk[i][0] == 0.0
+            got = batch.state
+            for k, name in enumerate(names):
+                ref = np.array([getattr(b, name) for b in singles], dtype=np.float64)
+                assert np.array_equal(got[:, k], ref, equal_nan=True), (trial, step, name)
+            wz, dtf = batch.readout()
+            assert np.array_equal(wz, np.array([b.wz for b in singles]), equal_nan=True)
+            assert np.array_equal(dtf, np.array([b.distancetofocus for b in singles]))
+            assert batch.propagators() == [b.propagator for b in singles]
+            assert batch.extents() == [b.extent for b in singles]
+            seen.update(batch.propagators())
+        assert {"II", "OO"} <= seen
+    assert {"II", "IO", "OI", "OO"} <= seen
+    with pytest.raises(AssertionError, match="Negative magnification"):
+        BeamBatch(1.0, [1e-6], 64, 4).surface([-1.0], [1.0], [np.inf], [0.0], [1.0])
+    with pytest.raises(ValueError, match="PTP wavefront should be planar"):
+        b = BeamBatch(1.0, [1e-6], 64, 4)
+        b.state[0, BeamBatch.C] = 0.3  # a curved reference surface inside the Rayleigh range
+        b.surface([1.0], [1.0], [np.inf], [1.0], [1.0])
