@@ -188,7 +188,9 @@ static __global__ void phase_table_kernel(TableArgs a) {  // static: the header 
 // time -- each thread owns the same position of SEQ lines and walks them one after the other
 // (smaller workgroups, two of them resident per CU, and the loads of line s+1 are in flight
 // while line s is transformed).
-template <int N, int E, int LINES, int TILES, int AXIS, int BR, int BC, int SEQ = 1>
+// COLSIB > 1 (complex64: a block is 64 B, so two column tiles share every 128-byte line): column tiles
+// are renumbered like the half-block row tiles, siblings 8 workgroups apart = on one XCD.
+template <int N, int E, int LINES, int TILES, int AXIS, int BR, int BC, int SEQ = 1, int COLSIB = 1>
 struct TileMap {
   static constexpr int kAxis = AXIS;
   static constexpr int TL = N / E;
@@ -226,6 +228,10 @@ struct TileMap {
       stride = (unsigned)TL * BR;
       seq_stride = (BR == 1) ? (unsigned)PAR * pitch : (unsigned)PAR * BC;  // next rows of the block
     } else {
+      if constexpr (COLSIB > 1 && TILES == 1 && (N / LINES) % (8 * COLSIB) == 0) {
+        const int grp = tile / (8 * COLSIB), in = tile % (8 * COLSIB);
+        tile = (grp * 8 + in % 8) * COLSIB + in / 8;
+      }
       row0 = 0; col0 = tile * LINES;
       if constexpr (BR == 1) {
         line = tid % LINES; t = tid / LINES;
@@ -250,10 +256,16 @@ struct TileMap {
 // lines whose areas start a multiple of 256 B apart hit the same banks on every read
 // (SQ_LDS_BANK_CONFLICT = half of the LDS cycles, profiles/r01_sq_counters_frugal.txt);
 // a 128-B skew puts the second line on the other half of the 64 read banks.
-template <typename T, int N, bool SPLIT>
+// With LINES lines interleaved among the lanes of a wave (LINES = 4: N = 1024 row tiles), each line's
+// lanes read 256 / LINES consecutive bytes per 32-lane group, so the areas must start 256 / LINES bytes
+// apart (mod 256) to cover all 64 banks: measured at N = 1024, rows (4 lines, 128-B skew: lines 0/2 and
+// 1/3 collided) ran a two-transform pass in 1.31 ms against 1.09 ms for columns (2 lines).
+template <typename T, int N, bool SPLIT, int LINES = 2>
 constexpr size_t line_lds_bytes() {
   const size_t b = (size_t)lds_line_slots<N>() * (SPLIT ? sizeof(T) : 2 * sizeof(T));
-  return (b % 256 == 0) ? b + 128 : b;
+  if (LINES == 2) return (b % 256 == 0) ? b + 128 : b;  // the round-1 rule (kept bit for bit: generic kernels)
+  const size_t want = LINES >= 4 ? 64 : 0;
+  return b + (want + 256 - b % 256) % 256;
 }
 
 template <typename T, int E, int FR, int FEAT, typename Map>

@@ -128,15 +128,21 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
   const int line = Map::kAxis == 0 ? m.row(0) : m.col(0);  // this thread's row (column): constant
   if (sl.mask_on != 0.0) {  // wave-uniform: an aperture rides on this slot
     const MaskLine ml = sl.lines[line];
-    const double* vals = sl.vals + (size_t)line * (2 * kMaskW);
+    // weights by a wave-uniform base and a 32-bit byte offset (one VGPR per load instead of a pointer pair)
+    const char* vb = reinterpret_cast<const char*>(sl.vals);
+    const unsigned vlo = (unsigned)line * (unsigned)(2 * kMaskW * sizeof(double));
+    auto val = [&](int idx) { return *reinterpret_cast<const double*>(vb + (vlo + (unsigned)idx * (unsigned)sizeof(double))); };
 #pragma unroll
     for (int k = 0; k < E; ++k) {
       const int pos = m.t + k * TL;
       double w = (pos >= ml.p1 && pos < ml.p2) ? sl.w_in : sl.w_out;
-      if (pos >= ml.p0 && pos < ml.p1) w = vals[pos - ml.p0];
-      if (pos >= ml.p2 && pos < ml.p3) w = vals[kMaskW + pos - ml.p2];
+      if (pos >= ml.p0 && pos < ml.p1) w = val(pos - ml.p0);
+      if (pos >= ml.p2 && pos < ml.p3) w = val(kMaskW + pos - ml.p2);
       w *= ml.lm;
       v[k] = {(T)__dmul_rn((double)v[k].x, w), (T)__dmul_rn((double)v[k].y, w)};
+      // a few elements at a time: unfenced, the scheduler issues all sixteen weight loads first and
+      // this rarely taken branch sets the register allocation of the whole kernel
+      if ((k + 1) % PAOS_FENCE_EVERY == 0) __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -147,8 +153,10 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
   // the scale ALONG it.  Coordinates are exact integers times the sampling step, formed like the
   // reference's (g * dx, one rounding); centred index g = i - N/2, natural order g = i or i - N.
   constexpr int KK = K > 0 ? K : 1;
-  double across2[KK], step[KK];
-  const double td = (double)m.t;
+  // Along the line, element k sits at position t + k TL, which is < N/2 exactly when k < E/2 (t < TL):
+  // its signed index is (t + base) + k TL with base = -N/2 (centred), or 0 / -N for the two halves of
+  // the natural order -- two per-thread doubles per phase, picked per k at compile time.
+  double across2[KK], step[KK], g_lo[KK], g_hi[KK];
 #pragma unroll
   for (int j = 0; j < K; ++j) {
     const bool nat = ph[j].natural != 0.0;
@@ -156,30 +164,46 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
     const double a = (double)ga * (Map::kAxis == 0 ? ph[j].sy : ph[j].sx);
     across2[j] = __dmul_rn(a, a);
     step[j] = Map::kAxis == 0 ? ph[j].sx : ph[j].sy;
+    g_lo[j] = (double)(nat ? m.t : m.t - N / 2);
+    g_hi[j] = (double)(nat ? m.t - N : m.t - N / 2);
+  }
+  if constexpr (sizeof(T) == 4) {
+    // fp32 mode: the field carries ~1e-7, so the phase needs no more than that -- but its ARGUMENT
+    // reaches 1e6 rad and is still formed in fp64: in turns, s * (m2 coef / 2 pi), one fraction
+    // instruction, then the hardware sin / cos (inputs in revolutions) and an fp32 rotation.  No
+    // fp64 copy of the element: 8 temporaries instead of 14, which is what lets the kernel keep to
+    // the register budget of three workgroups per CU.
+    double turn_coef[KK];
+#pragma unroll
+    for (int j = 0; j < K; ++j) turn_coef[j] = ph[j].m2 * ph[j].coef * 0.15915494309189535 * ph[j].sgn;  // / 2 pi, signed
+    const float ff = (float)f, ffy = (float)fy;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+      float xr = v[k].x, xi = v[k].y;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const double x = ((k < E / 2 ? g_lo[j] : g_hi[j]) + (double)(k * TL)) * step[j];
+        const double turns = fma(x, x, across2[j]) * turn_coef[j];
+        const float frac = (float)(turns - floor(turns));
+        const float snf = __builtin_amdgcn_sinf(frac), csf = __builtin_amdgcn_cosf(frac);
+        const float nr = fmaf(xr, csf, -(xi * snf));
+        xi = fmaf(xr, snf, xi * csf);
+        xr = nr;
+      }
+      v[k] = {(T)(xr * ff), (T)(xi * ffy)};
+      if ((k + 1) % PAOS_FENCE_EVERY == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
   }
 #pragma unroll
   for (int k = 0; k < E; ++k) {
     cx<double> vd = {(double)v[k].x, (double)v[k].y};
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      // element k sits at position t + k TL < N/2 exactly when k < E/2 (t < TL): the index offset
-      // is a compile-time constant per k, picked by the wave-uniform order flag
-      const double off = (ph[j].natural != 0.0) ? (double)(k * TL - (k >= E / 2 ? N : 0)) : (double)(k * TL - N / 2);
-      const double x = __dmul_rn(td + off, step[j]);
+      const double x = __dmul_rn((k < E / 2 ? g_lo[j] : g_hi[j]) + (double)(k * TL), step[j]);
       // x^2 + y^2 in the reference's order (addition commutes, so which of the two is "x" is moot)
       const double s = __dadd_rn(__dmul_rn(x, x), across2[j]);
       const double q = __dmul_rn(ph[j].m2, __dmul_rn(ph[j].coef, s));
-      if constexpr (sizeof(T) == 4) {
-        // fp32 mode: the argument is still formed in fp64 like the reference's, reduced to a
-        // fraction of a turn in fp64, and only then handed to the hardware sin / cos (inputs in
-        // revolutions, ~1e-7 absolute) -- the field itself carries no more than that
-        const double turns = q * 0.15915494309189535;  // 1 / (2 pi)
-        const float frac = (float)(turns - rint(turns));
-        const float snf = __builtin_amdgcn_sinf(frac) * (float)ph[j].sgn, csf = __builtin_amdgcn_cosf(frac);
-        const float xr = (float)vd.x, xi = (float)vd.y;
-        vd = {(double)fmaf(xr, csf, -(xi * snf)), (double)fmaf(xr, snf, xi * csf)};
-        continue;
-      }
       double sn, cs;
       sincos_tab(q, circle, &sn, &cs);
       sn *= ph[j].sgn;
@@ -238,7 +262,7 @@ __device__ __forceinline__ void frugal_fft(cx<T>* v, void* lds, int t, const cx<
 // dynamic LDS of one workgroup: exchange areas | stage twiddles | (c128 with phases) circle table
 template <typename T, int N, int LINES, int TILES, bool SPLIT, int KPRE, int KMID>
 constexpr size_t frugal_lds_bytes() {
-  return (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT>() + kTwiddleLds * sizeof(cx<T>) +
+  return (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT, LINES>() + kTwiddleLds * sizeof(cx<T>) +
          (sizeof(T) == 8 ? kCircleLds * sizeof(cx<double>) : 0);
 }
 
@@ -252,12 +276,21 @@ constexpr size_t frugal_lds_bytes() {
 #ifndef PAOS_MINW_SMALL
 #define PAOS_MINW_SMALL 3
 #endif
-template <int N, int THREADS>
-constexpr int frugal_min_waves() { return THREADS >= 512 ? 4 : PAOS_MINW_SMALL; }
+// complex64 tiles hold half the registers of complex128 ones: with the exchange split into real and
+// imaginary halves (35 KiB per 512-thread workgroup) THREE workgroups fit a CU if the kernel keeps to
+// 80 VGPRs (6 waves per SIMD) -- a third actor to overlap the memory phases with (PAOS_F32_MINW).
+#ifndef PAOS_F32_MINW
+#define PAOS_F32_MINW 4
+#endif
+template <typename T, int N, int THREADS>
+constexpr int frugal_min_waves() {
+  if (sizeof(T) == 4 && THREADS >= 512) return PAOS_F32_MINW;
+  return THREADS >= 512 ? 4 : PAOS_MINW_SMALL;
+}
 
 template <typename T, int N, int E, int LINES, int TILES, int AXIS, int BR, int BC, bool SPLIT,
           int KPRE, int KMID, int NFFT>
-__global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<N, TILES * LINES * N / E>()))
+__global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, TILES * LINES * N / E>()))
     frugal_pass_kernel(FrugalArgs a) {
   const int item = blockIdx.y;
   // constant address space: the per-item records are invariant during the kernel, so the scalar
@@ -266,24 +299,31 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<N, TILE
   const FrugalItem& it = *(const FrugalItem*)((ConstItemPtr)a.items + item);
   if (it.active == 0.0) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const TileMap<N, E, LINES, TILES, AXIS, BR, BC> m(blockIdx.x, threadIdx.x, a.pitch);
+  // a block of BR x BC elements is a whole 128-byte line for complex128, half of one for complex64
+  constexpr bool kBlockIsLine = BR * BC * sizeof(cx<T>) >= 128;
+  constexpr int COLSIB = kBlockIsLine ? 1 : (int)(128 / (BR * BC * sizeof(cx<T>)));
+  const TileMap<N, E, LINES, TILES, AXIS, BR, BC, 1, COLSIB> m(blockIdx.x, threadIdx.x, a.pitch);
   cx<T>* f = reinterpret_cast<cx<T>*>(a.field) + (size_t)item * a.item_stride;
-  constexpr bool NT = PAOS_NT_FULL_LINES ? (AXIS == 1 || LINES == BR) : (AXIS == 1);
-  if constexpr (TILES == 1) {  // a tile of dead lines: nothing to transform
-    const int l0 = AXIS == 0 ? m.row0 : m.col0;
-    if (l0 + LINES <= (int)it.line_lo || l0 >= (int)it.line_hi) {
+  // tiles that own whole 128-byte lines (c128 column tiles; row tiles that span a full block row) stream
+  // around the caches; tiles that share lines with a sibling need the L2 to merge the halves
+  constexpr bool NT = kBlockIsLine && (PAOS_NT_FULL_LINES ? (AXIS == 1 || LINES == BR) : (AXIS == 1));
+  {  // a workgroup of dead lines only: nothing to transform (its tiles are consecutive lines)
+    const int l0 = TILES == 1 ? (AXIS == 0 ? m.row0 : m.col0) : (int)blockIdx.x * (TILES * LINES);
+    if (l0 + TILES * LINES <= (int)it.line_lo || l0 >= (int)it.line_hi) {
       if (it.line_fill != 0.0) {
 #pragma unroll
-        for (int k = 0; k < E; ++k) stream_store<NT>(&f[m.base + (unsigned)k * m.stride], cx<T>{(T)0, (T)0});
+        for (int k = 0; k < E; ++k)
+          stream_store<NT>(reinterpret_cast<cx<T>*>(reinterpret_cast<char*>(f) + (m.base + (unsigned)k * m.stride) * (unsigned)sizeof(cx<T>)),
+                           cx<T>{(T)0, (T)0});
       }
       return;
     }
   }
-  void* lds = smem + (size_t)m.lds_line * line_lds_bytes<T, N, SPLIT>();
+  void* lds = smem + (size_t)m.lds_line * line_lds_bytes<T, N, SPLIT, LINES>();
   // The stage twiddles (indices < 256 of the table for every supported N) sit in LDS behind the
   // exchange areas: the load that follows each exchange barrier is then a ~100-cycle ds_read
   // instead of a dependent global load.  Published by the first exchange's barriers.
-  cx<T>* tw_lds = reinterpret_cast<cx<T>*>(smem + (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT>());
+  cx<T>* tw_lds = reinterpret_cast<cx<T>*>(smem + (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT, LINES>());
   for (int i = threadIdx.x; i < kTwiddleLds; i += TILES * LINES * N / E)
     tw_lds[i] = reinterpret_cast<const cx<T>*>(a.tw)[i];
   const cx<T>* tw = tw_lds;
@@ -309,17 +349,22 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<N, TILE
 
   // tiles that own whole 128-byte lines (column tiles; row tiles that span a full block row) stream
   // around the caches (NT); row tiles that share lines with a sibling need the L2 to merge the halves
+  // Addresses as a wave-uniform base (SGPRs) plus a 32-bit byte offset per element (an item is < 4 GiB):
+  // 64-bit pointers for the sixteen elements would sit in 32 VGPRs from the loads to the stores.
+  const char* fb = reinterpret_cast<const char*>(f);
+  const unsigned boff = m.base * (unsigned)sizeof(cx<T>), bstride = m.stride * (unsigned)sizeof(cx<T>);
+  auto at = [&](int k) { return reinterpret_cast<cx<T>*>(const_cast<char*>(fb) + (boff + (unsigned)k * bstride)); };
   cx<T> v[E];
   const int plo = (int)it.pos_lo, phi = (int)it.pos_hi;
   if (plo <= 0 && phi >= N) {  // wave-uniform: the whole line is live
 #pragma unroll
-    for (int k = 0; k < E; ++k) v[k] = stream_load<NT>(&f[m.base + (unsigned)k * m.stride]);
+    for (int k = 0; k < E; ++k) v[k] = stream_load<NT>(at(k));
   } else {
 #pragma unroll
     for (int k = 0; k < E; ++k) {
       const int pos = m.t + k * (N / E);
       v[k] = cx<T>{(T)0, (T)0};
-      if (pos >= plo && pos < phi) v[k] = stream_load<NT>(&f[m.base + (unsigned)k * m.stride]);
+      if (pos >= plo && pos < phi) v[k] = stream_load<NT>(at(k));
     }
   }
   __builtin_amdgcn_sched_barrier(0);
@@ -342,7 +387,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<N, TILE
   }
   PAOS_STAMP(5);
 #pragma unroll
-  for (int k = 0; k < E; ++k) stream_store<NT>(&f[m.base + (unsigned)k * m.stride], v[k]);
+  for (int k = 0; k < E; ++k) stream_store<NT>(at(k), v[k]);
   PAOS_STAMP(6);
   PAOS_STAMP_WAIT_VM();
   PAOS_STAMP(7);

@@ -64,6 +64,11 @@ class _Item:
     in a ``planner.BeamBatch``.)"""
 
     def __init__(self, pupil_diameter, wavelength, gridsize, zoom, field):
+        # the argument checks of WFO.__init__ (wfo.py:100-103)
+        assert np.log2(gridsize).is_integer(), "Grid size should be 2**n"
+        assert zoom > 0, "zoom factor should be positive"
+        assert pupil_diameter > 0, "beam diameter should be positive"
+        assert wavelength > 0, "a wavelength should be positive"
         self.pupil_diameter, self.wavelength, self.gridsize, self.zoom = pupil_diameter, wavelength, gridsize, zoom
         self.vt = np.array([0.0, field["ut"]])
         self.vs = np.array([0.0, field["us"]])

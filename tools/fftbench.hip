@@ -141,7 +141,7 @@ void bench_variant(const char* name, int batch, int reps, int pad_blocks = 0) {
   CK(hipFree(dtw));
 }
 
-template <typename T, int N, int AXIS, int KPRE, int KMID, int NFFT, int LINES = 2>
+template <typename T, int N, int AXIS, int KPRE, int KMID, int NFFT, int LINES = 2, int TILES = 1>
 void bench_frugal(const char* name, int batch, int reps, int pad_blocks) {
   constexpr int E = 16, BR = 4, BC = 2;
   const unsigned pitch = (unsigned)N * BR + (unsigned)pad_blocks * BR * BC;
@@ -173,18 +173,21 @@ void bench_frugal(const char* name, int batch, int reps, int pad_blocks) {
   CK(hipMalloc(&ditems, items.size() * sizeof(FrugalItem)));
   CK(hipMemcpy(ditems, items.data(), items.size() * sizeof(FrugalItem), hipMemcpyHostToDevice));
   FrugalArgs a{d, dtw, ditems, pitch, item_stride};
-  const dim3 grid(N / LINES, batch), block(LINES * N / E);
-  constexpr bool SPLIT = true;
-  const size_t lds = frugal_lds_bytes<T, N, LINES, 1, SPLIT, KPRE, KMID>();
-  auto kf = frugal_pass_kernel<T, N, E, LINES, 1, AXIS, BR, BC, SPLIT, KPRE, KMID, NFFT>;
+  const dim3 grid(N / LINES / TILES, batch), block(TILES * LINES * N / E);
+#ifndef PAOS_F32_SPLIT
+#define PAOS_F32_SPLIT 0
+#endif
+  constexpr bool SPLIT = sizeof(T) == 8 || PAOS_F32_SPLIT;
+  const size_t lds = frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID>();
+  auto kf = frugal_pass_kernel<T, N, E, LINES, TILES, AXIS, BR, BC, SPLIT, KPRE, KMID, NFFT>;
   CK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   Timer tm;
   float ms = tm.run([&] { hipLaunchKernelGGL(kf, grid, block, lds, 0, a); }, reps);
   int nb = 0;
   CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kf, block.x, lds));
   const double bytes = 2.0 * (double)N * N * batch * sizeof(cx<T>);
-  printf("%-34s N=%d b=%d ax=%d kpre=%d kmid=%d nfft=%d thr=%d lds=%zuK occ=%d  %8.3f ms  %7.1f GB/s\n", name, N, batch,
-         AXIS, KPRE, KMID, NFFT, block.x, lds / 1024, nb, ms, bytes / ms * 1e-6);
+  printf("%-40s %s N=%d b=%d ax=%d k=%d,%d nfft=%d thr=%d lds=%zuK occ=%d  %8.3f ms  %7.1f GB/s\n", name, sizeof(T) == 8 ? "c128" : "c64 ",
+         N, batch, AXIS, KPRE, KMID, NFFT, block.x, lds / 1024, nb, ms, bytes / ms * 1e-6);
   fflush(stdout);
   CK(hipFree(d)); CK(hipFree(dtw)); CK(hipFree(ditems));
 }
@@ -206,29 +209,36 @@ void bench_copy(int n, int batch, int reps) {
 int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 10;
   const int b4 = 8, pad = 3;
-  // NOTE: only instantiate the shapes the library builds (2-line tiles): a 4-line (1024-thread)
-  // instantiation in the same translation unit changes the register allocation of the 2-line ones
-  // (148 B of scratch instead of 0-28, measured in round 2) and the numbers stop describing the library.
+  // NOTE: only instantiate 512-or-fewer-thread shapes: a 1024-thread instantiation in the same translation unit
+  // changes the register allocation of the others (measured in round 2).
   bench_copy<double>(4096, b4, reps);
-  bench_frugal<double, 4096, 0, 0, 0, 1>("frugal rows single", b4, reps, pad);
-  bench_frugal<double, 4096, 1, 0, 0, 1>("frugal cols single", b4, reps, pad);
-  bench_frugal<double, 4096, 0, 0, 1, 2>("frugal rows double 1 phase", b4, reps, pad);
-  bench_frugal<double, 4096, 1, 0, 1, 2>("frugal cols double 1 phase", b4, reps, pad);
-  bench_frugal<double, 4096, 1, 0, 0, 2>("frugal cols double 0 phases", b4, reps, pad);
-  bench_frugal<double, 4096, 0, 1, 0, 1>("frugal rows single 1 pre phase", b4, reps, pad);
-  bench_frugal<double, 4096, 0, 1, 2, 2>("frugal rows double 1+2 phases", b4, reps, pad);
-  bench_frugal<double, 4096, 0, 2, 3, 2>("frugal rows double 2+3 phases", b4, reps, pad);
-  bench_frugal<double, 2048, 0, 0, 1, 2>("frugal rows double 1 phase", 32, reps, pad);
-#ifdef PAOS_BENCH_ROWS4
-  bench_frugal<double, 2048, 0, 0, 1, 2, 4>("frugal rows double 1 phase 4-row tiles", 32, reps, pad);
-  bench_frugal<double, 2048, 0, 0, 0, 1, 4>("frugal rows single 4-row tiles", 32, reps, pad);
-#endif
-  bench_frugal<double, 2048, 0, 0, 0, 1>("frugal rows single", 32, reps, pad);
-  bench_frugal<double, 2048, 1, 0, 0, 1>("frugal cols single", 32, reps, pad);
-  bench_frugal<double, 2048, 1, 0, 1, 2>("frugal cols double 1 phase", 32, reps, pad);
-  bench_frugal<double, 1024, 0, 0, 1, 2, 4>("frugal rows double 1 phase", 128, reps, pad);
-  bench_frugal<double, 1024, 1, 0, 1, 2>("frugal cols double 1 phase", 128, reps, pad);
-  bench_frugal<double, 1024, 0, 0, 0, 1, 4>("frugal rows single", 128, reps, pad);
-  bench_frugal<double, 1024, 1, 0, 0, 1>("frugal cols single", 128, reps, pad);
+  bench_frugal<double, 4096, 0, 0, 0, 1>("rows single", b4, reps, pad);
+  bench_frugal<double, 4096, 1, 0, 0, 1>("cols single", b4, reps, pad);
+  bench_frugal<double, 4096, 0, 0, 1, 2>("rows double 1 phase", b4, reps, pad);
+  bench_frugal<double, 4096, 1, 0, 1, 2>("cols double 1 phase", b4, reps, pad);
+  // N = 2048: 256-thread workgroups (library, round 2a) against 512-thread ones (two tiles per workgroup)
+  bench_frugal<double, 2048, 0, 0, 1, 2, 2, 1>("rows double 1 phase 256 thr", 32, reps, pad);
+  bench_frugal<double, 2048, 0, 0, 1, 2, 2, 2>("rows double 1 phase 512 thr (2 tiles)", 32, reps, pad);
+  bench_frugal<double, 2048, 1, 0, 1, 2, 2, 1>("cols double 1 phase 256 thr", 32, reps, pad);
+  bench_frugal<double, 2048, 1, 0, 1, 2, 2, 2>("cols double 1 phase 512 thr (2 tiles)", 32, reps, pad);
+  bench_frugal<double, 2048, 0, 0, 0, 1, 2, 1>("rows single 256 thr", 32, reps, pad);
+  bench_frugal<double, 2048, 0, 0, 0, 1, 2, 2>("rows single 512 thr (2 tiles)", 32, reps, pad);
+  bench_frugal<double, 2048, 1, 0, 0, 1, 2, 1>("cols single 256 thr", 32, reps, pad);
+  bench_frugal<double, 2048, 1, 0, 0, 1, 2, 2>("cols single 512 thr (2 tiles)", 32, reps, pad);
+  // N = 1024
+  bench_frugal<double, 1024, 0, 0, 1, 2, 4, 1>("rows double 1 phase 256 thr", 128, reps, pad);
+  bench_frugal<double, 1024, 0, 0, 1, 2, 4, 2>("rows double 1 phase 512 thr (2 tiles)", 128, reps, pad);
+  bench_frugal<double, 1024, 1, 0, 1, 2, 2, 1>("cols double 1 phase 128 thr", 128, reps, pad);
+  bench_frugal<double, 1024, 1, 0, 1, 2, 2, 2>("cols double 1 phase 256 thr (2 tiles)", 128, reps, pad);
+  bench_frugal<double, 1024, 1, 0, 1, 2, 2, 4>("cols double 1 phase 512 thr (4 tiles)", 128, reps, pad);
+  bench_frugal<double, 1024, 0, 0, 0, 1, 4, 1>("rows single 256 thr", 128, reps, pad);
+  bench_frugal<double, 1024, 0, 0, 0, 1, 4, 2>("rows single 512 thr (2 tiles)", 128, reps, pad);
+  bench_frugal<double, 1024, 1, 0, 0, 1, 2, 1>("cols single 128 thr", 128, reps, pad);
+  bench_frugal<double, 1024, 1, 0, 0, 1, 2, 4>("cols single 512 thr (4 tiles)", 128, reps, pad);
+  // complex64 (fp32 mode): 8 B elements, 4 x 2 blocks of 64 B
+  bench_frugal<float, 4096, 0, 0, 0, 1>("rows single", 16, reps, pad);
+  bench_frugal<float, 4096, 1, 0, 0, 1>("cols single", 16, reps, pad);
+  bench_frugal<float, 4096, 0, 0, 1, 2>("rows double 1 phase", 16, reps, pad);
+  bench_frugal<float, 4096, 1, 0, 1, 2>("cols double 1 phase", 16, reps, pad);
   return 0;
 }
