@@ -252,7 +252,12 @@ def main():
         n_ptp, n_stw, n_wts = chain_fft_counts(wavelengths[0], n)
         ffts = 2 * n_ptp + n_stw + n_wts
         survey_bytes = (ffts * 4 * esz + 8) * n * n  # 2 passes x (read + write) per 2-D FFT + the 8 B/px PSF write
-        moved_bytes = (m["fused_passes"] * 2 * esz + 85) * n * n  # fused passes + start / Zernike / reductions / PSF
+        # bytes the fused path moves: full passes at 32 B/px (c128), pruned passes at about half of that (PMC:
+        # profiles/r02_pmc_hbm_traffic_bench.txt -- a row pass behind an aperture moves ~0.3 of a full pass, the
+        # column pass after it ~0.75), plus ~85 B/px of start / Zernike / reductions / PSF write
+        per_step = max(args.steps, 1) * nb
+        full_p, pruned_p = (m["launches"] - m["pruned"]) / per_step * nb, m["pruned"] / per_step * nb
+        moved_bytes = ((full_p + 0.5 * pruned_p) * 2 * esz + 85) * n * n
         per_gpu = value / world
         dtype = "c128 (f64)" if args.precision == "fp64" else "c64 (f32, f64 phase arguments)"
         out = {
