@@ -337,6 +337,102 @@ __device__ __forceinline__ void fft_stages(cx<T>* v, void* lds, int t,
   }
 }
 
+// ---- 4096-point transforms with a digit-swapped side (the two transforms of a fused pass) ----------
+// A pass that runs FFT | pointwise | FFT needs natural order only at its two ends (global memory).  In
+// between, the 256 threads of a line may hold the 4096 points in any order as long as each thread knows
+// which positions it owns.  That freedom removes the barriers of one exchange per transform:
+//
+//   index digits  n = t0 + 16 t1 + 256 s  (thread t = t0 + 16 t1 holds slots s = 0..15)
+//   NAT -> SWP (decimation in frequency):
+//     DFT16 over s -> a | * W4096^(t a) | X1: (t0, t1; a) -> (t0, a; t1)   cross-wave: LDS + barriers
+//     DFT16 over slots  -> b | * W256^(t0 b) | X2: (t0, a; b) -> (b, a; t0)    inside the 16 lanes of a group:
+//     DFT16 over slots  -> c                                                 LDS, no barrier
+//     thread (t0 = b, t1 = a), slot c holds X[a + 16 b + 256 c]: position sigma(t) + 256 c, sigma = nibble swap
+//   SWP -> NAT is the transposed flow (the DFT matrix is symmetric): the same three DFT16s, the same two
+//   diagonal twiddles at the same (thread, slot) places, the exchanges inverted and in reverse order.
+//
+// X1 moves slot a of thread t to row a of a 16 x 272 table (272 = 16 * 17: the second digit of a row is
+// padded to 17 so that the in-group transposition X2 reads and writes it without bank conflicts; rows 272
+// apart put the two groups of a 32-lane LDS cycle on the two halves of the banks).  Row a is read -- and
+// later reused for X2 -- only by the 16 threads of group a, which sit in one wave: X2 needs no barrier.
+// Real and imaginary parts take turns (SPLIT) like in fft_stages.  Seven barriers per transform become three.
+constexpr int kSwapRow = 272;
+
+__device__ __forceinline__ int swap_nibbles(int t) { return ((t & 15) << 4) | (t >> 4); }
+
+// scatter ``v[r]`` to ``lds[wbase + r * wstride]``, [barrier], gather ``v[r]`` from ``lds[rbase + r * rstride]``
+template <typename T, bool BARRIER>
+__device__ __forceinline__ void swap_exchange(cx<T>* v, T* lds, int wbase, int wstride, int rbase, int rstride, bool first) {
+#pragma unroll
+  for (int part = 0; part < 2; ++part) {
+    if (BARRIER && (part == 1 || !first)) __syncthreads();  // the area may still be read (previous round / transform)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lds[wbase + r * wstride] = part ? v[r].y : v[r].x;
+    if (BARRIER) __syncthreads();
+    else __builtin_amdgcn_wave_barrier();  // same wave: LDS operations execute in order; keep the compiler from reordering
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const T val = lds[rbase + r * rstride];
+      if (part) v[r].y = val; else v[r].x = val;
+    }
+    if (!BARRIER) __builtin_amdgcn_wave_barrier();
+  }
+}
+
+// v[b] *= W256^(t0 b) = conj(circle[t0 b]), two table reads in flight
+template <typename T>
+__device__ __forceinline__ void swap_twiddle256(cx<T>* v, const cx<double>* circle, int t0) {
+  cx<double> wa = circle[t0], wb = circle[2 * t0];
+#pragma unroll
+  for (int r = 1; r < 16; ++r) {
+    const cx<double> w = wa;
+    wa = wb;
+    if (r + 2 < 16) wb = circle[t0 * (r + 2)];
+    v[r] = cmul(v[r], cx<T>{(T)w.x, (T)-w.y});
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+// natural order in (slot s = x[t + 256 s]) -> digit-swapped out (slot c = X[swap_nibbles(t) + 256 c])
+template <typename T>
+__device__ __forceinline__ void fft4096_nat_to_swapped(cx<T>* v, T* lds, int t, const cx<T>* tw, const cx<double>* circle,
+                                                       bool area_idle) {
+  const int t0 = t & 15, t1 = t >> 4;
+  dft<16, +1>(v);
+  __builtin_amdgcn_sched_barrier(0);
+  apply_twiddle_chain<16>(v, tw[t]);
+  __builtin_amdgcn_sched_barrier(0);
+  swap_exchange<T, true>(v, lds, t, kSwapRow, t1 * kSwapRow + t0, 16, area_idle);
+  __builtin_amdgcn_sched_barrier(0);
+  dft<16, +1>(v);
+  __builtin_amdgcn_sched_barrier(0);
+  swap_twiddle256(v, circle, t0);
+  swap_exchange<T, false>(v, lds, t1 * kSwapRow + t0, 17, t1 * kSwapRow + t0 * 17, 1, false);
+  __builtin_amdgcn_sched_barrier(0);
+  dft<16, +1>(v);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// digit-swapped in -> natural order out: the transposed flow
+template <typename T>
+__device__ __forceinline__ void fft4096_swapped_to_nat(cx<T>* v, T* lds, int t, const cx<T>* tw, const cx<double>* circle) {
+  const int t0 = t & 15, t1 = t >> 4;
+  dft<16, +1>(v);
+  __builtin_amdgcn_sched_barrier(0);
+  // X2 transposed: (b = t0, a = t1; r) -> (r, a; b); row t1 is private to this group
+  swap_exchange<T, false>(v, lds, t1 * kSwapRow + t0, 17, t1 * kSwapRow + t0 * 17, 1, false);
+  swap_twiddle256(v, circle, t0);
+  dft<16, +1>(v);
+  __builtin_amdgcn_sched_barrier(0);
+  // X1 transposed: (t0, a = t1; s') -> (t0 + 16 s'; a): writes stay in the group's own row
+  swap_exchange<T, true>(v, lds, t1 * kSwapRow + t0, 16, t, kSwapRow, true);
+  __builtin_amdgcn_sched_barrier(0);
+  apply_twiddle_chain<16>(v, tw[t]);
+  __builtin_amdgcn_sched_barrier(0);
+  dft<16, +1>(v);
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 // Undo the output slot permutation in registers (compile-time renaming), so
 // that slot k holds X[t + k * TL] again -- lets a forward transform feed an
 // inverse one with no LDS trip in between (fused ptp column pass).

@@ -63,7 +63,11 @@ struct FrugalItem {
   FrugalPhase mid_ph[kFrugalMaxMid];
 };
 
-constexpr int kTwiddleLds = 256;  // table entries the stage twiddles can address: k N / (NS R) < N / R <= 256
+// table entries the stage twiddles can address: the base twiddle of a stage is tw[k N / (NS R)] with
+// k < NS, i.e. an index below N / R <= N / 4; with 16 points per thread every supported N stays below 256,
+// with 32 points per thread (complex64) below 1024
+template <int N, int E>
+constexpr int twiddle_lds_entries() { return E <= 16 ? 256 : (N / 4 < 1024 ? N / 4 : 1024); }
 
 // PAOS_STAMPS (tools/fftbench.hip timeline builds only): wave 0 of every workgroup records
 // s_memtime at the phase boundaries plus where it ran (HW_ID, XCC_ID) into FrugalArgs::stamps.
@@ -121,7 +125,9 @@ __device__ __forceinline__ void sincos_tab(double a, const cx<double>* circle, d
 
 template <typename T, int N, int E, int K, typename Map>
 __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, const FrugalPhase* ph,
-                                            const Map& m, const cx<double>* circle, bool conj_out) {
+                                            const Map& m, const cx<double>* circle, bool conj_out, int tpos) {
+  // tpos: position along the line of the thread's element 0 (its elements are TL apart): m.t in natural
+  // order, swap_nibbles(m.t) between the two transforms of a digit-swapped pass
   constexpr int TL = N / E;
   static_assert(TL % 2 == 0, "the checkerboard sign is constant along a thread's elements");
   const double sc = sl.scale;
@@ -134,7 +140,7 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
     auto val = [&](int idx) { return *reinterpret_cast<const double*>(vb + (vlo + (unsigned)idx * (unsigned)sizeof(double))); };
 #pragma unroll
     for (int k = 0; k < E; ++k) {
-      const int pos = m.t + k * TL;
+      const int pos = tpos + k * TL;
       double w = (pos >= ml.p1 && pos < ml.p2) ? sl.w_in : sl.w_out;
       if (pos >= ml.p0 && pos < ml.p1) w = val(pos - ml.p0);
       if (pos >= ml.p2 && pos < ml.p3) w = val(kMaskW + pos - ml.p2);
@@ -147,7 +153,7 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
     __builtin_amdgcn_sched_barrier(0);
   }
   // (-1)^(row+col): the position along the line advances by TL (even) from element to element
-  const double f = (sl.sign_on != 0.0 && ((line + m.t) & 1)) ? -sc : sc;
+  const double f = (sl.sign_on != 0.0 && ((line + tpos) & 1)) ? -sc : sc;
   const double fy = conj_out ? -f : f;  // the conjugation in front of an inverse transform rides on the scale
   // Per phase, what does not depend on the element: the squared coordinate ACROSS the line and
   // the scale ALONG it.  Coordinates are exact integers times the sampling step, formed like the
@@ -164,8 +170,8 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
     const double a = (double)ga * (Map::kAxis == 0 ? ph[j].sy : ph[j].sx);
     across2[j] = __dmul_rn(a, a);
     step[j] = Map::kAxis == 0 ? ph[j].sx : ph[j].sy;
-    g_lo[j] = (double)(nat ? m.t : m.t - N / 2);
-    g_hi[j] = (double)(nat ? m.t - N : m.t - N / 2);
+    g_lo[j] = (double)(nat ? tpos : tpos - N / 2);
+    g_hi[j] = (double)(nat ? tpos - N : tpos - N / 2);
   }
   if constexpr (sizeof(T) == 4) {
     // fp32 mode: the field carries ~1e-7, so the phase needs no more than that -- but its ARGUMENT
@@ -260,9 +266,9 @@ __device__ __forceinline__ void frugal_fft(cx<T>* v, void* lds, int t, const cx<
 }
 
 // dynamic LDS of one workgroup: exchange areas | stage twiddles | (c128 with phases) circle table
-template <typename T, int N, int LINES, int TILES, bool SPLIT, int KPRE, int KMID>
+template <typename T, int N, int LINES, int TILES, bool SPLIT, int KPRE, int KMID, int E = 16>
 constexpr size_t frugal_lds_bytes() {
-  return (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT, LINES>() + kTwiddleLds * sizeof(cx<T>) +
+  return (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT, LINES>() + twiddle_lds_entries<N, E>() * sizeof(cx<T>) +
          (sizeof(T) == 8 ? kCircleLds * sizeof(cx<double>) : 0);
 }
 
@@ -324,6 +330,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   // exchange areas: the load that follows each exchange barrier is then a ~100-cycle ds_read
   // instead of a dependent global load.  Published by the first exchange's barriers.
   cx<T>* tw_lds = reinterpret_cast<cx<T>*>(smem + (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT, LINES>());
+  constexpr int kTwiddleLds = twiddle_lds_entries<N, E>();
   for (int i = threadIdx.x; i < kTwiddleLds; i += TILES * LINES * N / E)
     tw_lds[i] = reinterpret_cast<const cx<T>*>(a.tw)[i];
   const cx<T>* tw = tw_lds;
@@ -371,13 +378,42 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   PAOS_STAMP_WAIT_VM();
   PAOS_STAMP(1);
 
+  if constexpr (NFFT == 3) {
+    // two transforms with a digit-swapped layout in between (fft_core.h: fft4096_nat_to_swapped): the host
+    // launches this shape only when both transforms run for every active item of the batch
+    static_assert(N == 4096 && E == 16 && sizeof(T) == 8 && SPLIT, "digit-swapped passes: 4096-point complex128 lines");
+    T* area = reinterpret_cast<T*>(lds);
+    frugal_slot<T, N, E, KPRE>(v, it.pre, it.pre_ph, m, circle, it.fft1_inv != 0.0, m.t);
+    PAOS_STAMP(2);
+    fft4096_nat_to_swapped<T>(v, area, m.t, tw, circle, true);
+    {
+      const unsigned mask = it.fft1_inv != 0.0 ? 0x80000000u : 0u;
+#pragma unroll
+      for (int k = 0; k < E; ++k) v[k].y = flip_sign(v[k].y, mask);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    PAOS_STAMP(3);
+    frugal_slot<T, N, E, KMID>(v, it.mid, it.mid_ph, m, circle, it.fft2_inv != 0.0, swap_nibbles(m.t));
+    PAOS_STAMP(4);
+    fft4096_swapped_to_nat<T>(v, area, m.t, tw, circle);
+    {
+      const unsigned mask = it.fft2_inv != 0.0 ? 0x80000000u : 0u;
+#pragma unroll
+      for (int k = 0; k < E; ++k) v[k].y = flip_sign(v[k].y, mask);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    PAOS_STAMP(5);
+#pragma unroll
+    for (int k = 0; k < E; ++k) stream_store<NT>(at(k), v[k]);
+    return;
+  }
   const bool ran1 = it.fft1_on != 0.0;
   const bool ran2 = NFFT == 2 && it.fft2_on != 0.0;
-  frugal_slot<T, N, E, KPRE>(v, it.pre, it.pre_ph, m, circle, ran1 && it.fft1_inv != 0.0);
+  frugal_slot<T, N, E, KPRE>(v, it.pre, it.pre_ph, m, circle, ran1 && it.fft1_inv != 0.0, m.t);
   PAOS_STAMP(2);
   if (ran1) frugal_fft<T, N, E, SPLIT>(v, lds, m.t, tw, circle, it.fft1_inv);
   PAOS_STAMP(3);
-  frugal_slot<T, N, E, KMID>(v, it.mid, it.mid_ph, m, circle, ran2 && it.fft2_inv != 0.0);
+  frugal_slot<T, N, E, KMID>(v, it.mid, it.mid_ph, m, circle, ran2 && it.fft2_inv != 0.0, m.t);
   PAOS_STAMP(4);
   if constexpr (NFFT == 2) {
     if (ran2) {

@@ -492,7 +492,7 @@ int frugal_launch(paos_ctx* c, const FrugalArgs& a) {
   // fits whole (the same 35 KiB) and so needs half the barriers
   constexpr bool SPLIT = sizeof(T) == 8;
   const dim3 grid(N / LINES / TILES, c->batch), block(TILES * LINES * N / C::E);
-  const size_t lds = frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID>();
+  const size_t lds = frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, C::E>();
   auto kern = frugal_pass_kernel<T, N, C::E, LINES, TILES, AXIS, BR, C::BC, SPLIT, KPRE, KMID, NFFT>;
   {
     int rc = opt_in_lds(c, (const void*)kern, lds);
@@ -514,7 +514,10 @@ int frugal_launch(paos_ctx* c, const FrugalArgs& a) {
 
 template <typename T, int N, int AXIS, int KPRE, int KMID>
 int frugal_nfft(paos_ctx* c, const FrugalArgs& a, int nfft) {
-  return nfft == 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1>(c, a);
+  if constexpr (sizeof(T) == 8 && N == 4096) {  // 3: two transforms, digit-swapped in between (fft_core.h)
+    if (nfft == 3) return frugal_launch<T, N, AXIS, KPRE, KMID, 3>(c, a);
+  }
+  return nfft >= 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1>(c, a);
 }
 template <typename T, int N, int AXIS, int KPRE>
 int frugal_kmid(paos_ctx* c, const FrugalArgs& a, int kmid, int nfft) {
@@ -611,20 +614,34 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const
                       lp.items.size() * sizeof(FrugalItem) / sizeof(double), &ditems);
   if (rc) return rc;
   FrugalArgs a{c->field, c->tw, reinterpret_cast<const FrugalItem*>(ditems), c->pitch, c->item_stride};
+  // Two transforms in one pass need natural order only at the ends: with PAOS_SWAP=1, when both run for
+  // every active item, the 4096-point complex128 shape keeps a digit-swapped layout in between, whose second
+  // exchange stays inside a wave (three workgroup barriers per transform instead of seven).  Measured in round
+  // 2: parity unchanged, speed unchanged to slightly worse (201 vs 203 wavefronts/s,
+  // profiles/r02_fftbench_digit_swapped_experiment.txt) -- the barriers are not what bounds the pass -- so
+  // the natural-order transforms stay the default.
+  int nfft = lp.nfft;
+  static const bool swap = [] { const char* e = getenv("PAOS_SWAP"); return e && e[0] == '1'; }();
+  if (nfft == 2 && c->precision == PAOS_F64 && c->n == 4096 && swap) {
+    bool all = true, any = false;
+    for (const FrugalItem& fi : lp.items)
+      if (fi.active != 0.0) { any = true; all = all && fi.fft1_on != 0.0 && fi.fft2_on != 0.0; }
+    if (any && all) nfft = 3;
+  }
   c->prof_next_tag = 0;  // for the launch timer: does this launch skip anything?
   for (const FrugalItem& fi : lp.items)
     if (fi.active != 0.0 && (fi.line_lo > 0.0 || fi.line_hi < (double)c->n || fi.pos_lo > 0.0 || fi.pos_hi < (double)c->n))
       c->prof_next_tag = 1;
   if (c->precision == PAOS_F64) {
     switch (c->n) {
-      case 1024: return paos_frugal_d1024(c, a, p.axis, lp.kpre, lp.kmid, lp.nfft);
-      case 2048: return paos_frugal_d2048(c, a, p.axis, lp.kpre, lp.kmid, lp.nfft);
-      default: return paos_frugal_d4096(c, a, p.axis, lp.kpre, lp.kmid, lp.nfft);
+      case 1024: return paos_frugal_d1024(c, a, p.axis, lp.kpre, lp.kmid, nfft);
+      case 2048: return paos_frugal_d2048(c, a, p.axis, lp.kpre, lp.kmid, nfft);
+      default: return paos_frugal_d4096(c, a, p.axis, lp.kpre, lp.kmid, nfft);
     }
   }
   switch (c->n) {
-    case 2048: return paos_frugal_f2048(c, a, p.axis, lp.kpre, lp.kmid, lp.nfft);
-    default: return paos_frugal_f4096(c, a, p.axis, lp.kpre, lp.kmid, lp.nfft);
+    case 2048: return paos_frugal_f2048(c, a, p.axis, lp.kpre, lp.kmid, nfft);
+    default: return paos_frugal_f4096(c, a, p.axis, lp.kpre, lp.kmid, nfft);
   }
 }
 

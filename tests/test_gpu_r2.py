@@ -297,3 +297,53 @@ def test_rccl_transport_single_rank():
             assert np.array_equal(r[20]["psf"], q[20]["psf"]) and r[20]["power"] == q[20]["power"]
     finally:
         comm.close()
+
+
+def test_line_records_never_overflow_when_the_host_accepts_an_aperture():
+    """An aperture rides on a pass as per-line records with room for 192 partial pixels per side
+    (csrc/frugal_pass.h: kMaskW).  The host accepts an ellipse only if 2 a sqrt(3 / b) + 8 <= 192 (and the
+    same with a, b swapped) -- the tip row of an ellipse holds at most 2 a sqrt(2 / b) partial pixels, so the
+    test is conservative.  Scan ellipses right at that limit, decentred and at grid edges, along both pass
+    axes: the overflow counter the kernel keeps must stay zero (paos_sync raises otherwise), and the result
+    must equal the stand-alone aperture kernel's."""
+    import math
+
+    from paos_amd import _lib
+    from paos_amd.aperture import EllipticalAperture
+    from paos_amd.passes import PassCompiler
+    from paos_amd.planner import PilotBeam
+    from paos_amd.run import _aperture_fits_line_records
+
+    n, nb = 4096, 8
+    rng = np.random.default_rng(11)
+    dev = _lib.DeviceFields(n, nb)
+    tried = 0
+    for trial in range(6):
+        handles = []
+        while len(handles) < nb:
+            b = float(rng.choice([2.0, 2.5, 4.0, 9.0, 30.0, 200.0, 1500.0]))
+            a_max = (192.0 - 8.0) / (2.0 * math.sqrt(3.0 / b))
+            a = float(min(a_max * rng.uniform(0.97, 1.0), 1900.0))
+            if trial % 2:
+                a, b = b, a
+            xc, yc = rng.uniform(-100.0, n + 100.0), rng.uniform(-100.0, n + 100.0)
+            if rng.random() < 0.5:
+                xc, yc = n / 2 + rng.uniform(-3, 3), n / 2 + rng.uniform(-3, 3)
+            h = EllipticalAperture((xc, yc), a, b)
+            if _aperture_fits_line_records(h, False, n, "fp64"):
+                handles.append(h)
+        tried += nb
+        dev.fill(1.0 + 0.5j)
+        comp = PassCompiler(nb, n)
+        comp.aperture([(h.block(obscuration=False), _lib.SHAPE_ELLIPSE) for h in handles])
+        blk = [PilotBeam(1.0, 1.0e-6, n, 4).ptp(0.25)] * nb
+        comp.ptp(blk)
+        comp.flush(dev)
+        dev.sync()  # raises if a line record overflowed
+        got = dev.download(trial % nb)
+        dev.fill(1.0 + 0.5j)
+        dev.aperture(_lib.SHAPE_ELLIPSE, [h.block(obscuration=False) for h in handles])
+        dev.ptp(blk)
+        assert rel_err(got, dev.download(trial % nb)) < 1e-13
+    assert tried == 48
+    dev.close()

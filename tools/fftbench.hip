@@ -141,9 +141,9 @@ void bench_variant(const char* name, int batch, int reps, int pad_blocks = 0) {
   CK(hipFree(dtw));
 }
 
-template <typename T, int N, int AXIS, int KPRE, int KMID, int NFFT, int LINES = 2, int TILES = 1>
+template <typename T, int N, int AXIS, int KPRE, int KMID, int NFFT, int LINES = 2, int TILES = 1, int E = 16, int BC = 2>
 void bench_frugal(const char* name, int batch, int reps, int pad_blocks) {
-  constexpr int E = 16, BR = 4, BC = 2;
+  constexpr int BR = 4;
   const unsigned pitch = (unsigned)N * BR + (unsigned)pad_blocks * BR * BC;
   const unsigned item_stride = pitch * (N / BR);
   cx<T>* d;
@@ -177,8 +177,8 @@ void bench_frugal(const char* name, int batch, int reps, int pad_blocks) {
 #ifndef PAOS_F32_SPLIT
 #define PAOS_F32_SPLIT 0
 #endif
-  constexpr bool SPLIT = sizeof(T) == 8 || PAOS_F32_SPLIT;
-  const size_t lds = frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID>();
+  constexpr bool SPLIT = sizeof(T) == 8 || PAOS_F32_SPLIT || E == 32;
+  const size_t lds = frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, E>();
   auto kf = frugal_pass_kernel<T, N, E, LINES, TILES, AXIS, BR, BC, SPLIT, KPRE, KMID, NFFT>;
   CK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   Timer tm;
@@ -186,8 +186,8 @@ void bench_frugal(const char* name, int batch, int reps, int pad_blocks) {
   int nb = 0;
   CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kf, block.x, lds));
   const double bytes = 2.0 * (double)N * N * batch * sizeof(cx<T>);
-  printf("%-40s %s N=%d b=%d ax=%d k=%d,%d nfft=%d thr=%d lds=%zuK occ=%d  %8.3f ms  %7.1f GB/s\n", name, sizeof(T) == 8 ? "c128" : "c64 ",
-         N, batch, AXIS, KPRE, KMID, NFFT, block.x, lds / 1024, nb, ms, bytes / ms * 1e-6);
+  printf("%-40s %s N=%d b=%d ax=%d k=%d,%d nfft=%d E=%d thr=%d lds=%zuK occ=%d  %8.3f ms  %7.1f GB/s\n", name, sizeof(T) == 8 ? "c128" : "c64 ",
+         N, batch, AXIS, KPRE, KMID, NFFT, E, block.x, lds / 1024, nb, ms, bytes / ms * 1e-6);
   fflush(stdout);
   CK(hipFree(d)); CK(hipFree(dtw)); CK(hipFree(ditems));
 }
@@ -216,6 +216,10 @@ int main(int argc, char** argv) {
   bench_frugal<double, 4096, 1, 0, 0, 1>("cols single", b4, reps, pad);
   bench_frugal<double, 4096, 0, 0, 1, 2>("rows double 1 phase", b4, reps, pad);
   bench_frugal<double, 4096, 1, 0, 1, 2>("cols double 1 phase", b4, reps, pad);
+  bench_frugal<double, 4096, 0, 0, 1, 3>("rows double 1 phase, digit-swapped", b4, reps, pad);
+  bench_frugal<double, 4096, 1, 0, 1, 3>("cols double 1 phase, digit-swapped", b4, reps, pad);
+  bench_frugal<double, 4096, 1, 0, 0, 3>("cols double 0 phases, digit-swapped", b4, reps, pad);
+  bench_frugal<double, 4096, 1, 0, 0, 2>("cols double 0 phases", b4, reps, pad);
   // N = 2048: 256-thread workgroups (library, round 2a) against 512-thread ones (two tiles per workgroup)
   bench_frugal<double, 2048, 0, 0, 1, 2, 2, 1>("rows double 1 phase 256 thr", 32, reps, pad);
   bench_frugal<double, 2048, 0, 0, 1, 2, 2, 2>("rows double 1 phase 512 thr (2 tiles)", 32, reps, pad);
@@ -240,5 +244,12 @@ int main(int argc, char** argv) {
   bench_frugal<float, 4096, 1, 0, 0, 1>("cols single", 16, reps, pad);
   bench_frugal<float, 4096, 0, 0, 1, 2>("rows double 1 phase", 16, reps, pad);
   bench_frugal<float, 4096, 1, 0, 1, 2>("cols double 1 phase", 16, reps, pad);
+#ifdef PAOS_BENCH_E32
+  // complex64 with 32 points per thread over 4 x 4 blocks (128 B): 4-line tiles, 512 threads, whole lines on both axes
+  bench_frugal<float, 4096, 0, 0, 0, 1, 4, 1, 32, 4>("rows single E=32 4x4 blocks", 16, reps, pad);
+  bench_frugal<float, 4096, 1, 0, 0, 1, 4, 1, 32, 4>("cols single E=32 4x4 blocks", 16, reps, pad);
+  bench_frugal<float, 4096, 0, 0, 1, 2, 4, 1, 32, 4>("rows double 1 phase E=32 4x4 blocks", 16, reps, pad);
+  bench_frugal<float, 4096, 1, 0, 1, 2, 4, 1, 32, 4>("cols double 1 phase E=32 4x4 blocks", 16, reps, pad);
+#endif
   return 0;
 }
