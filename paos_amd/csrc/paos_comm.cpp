@@ -231,32 +231,31 @@ int connect_star(paos_comm* c, const std::string& path, double timeout_s) {
     ::unlink(path.c_str());
     return PAOS_OK;
   }
-  int port = -1;
-  while (port < 0) {
+  // The rendezvous file is re-read on every attempt: a file left behind by a job that died (same key) names
+  // a port nobody listens on any more; rank 0 of THIS job replaces it as soon as it is up.
+  for (;;) {
+    int port = -1;
     if (FILE* fh = std::fopen(path.c_str(), "r")) {
       if (std::fscanf(fh, "%d", &port) != 1) port = -1;
       std::fclose(fh);
     }
-    if (port >= 0) break;
-    if (now_s() > deadline) return cfail(PAOS_EHIP, "timed out waiting for rank 0's rendezvous file " + path);
-    std::this_thread::sleep_for(std::chrono::milliseconds(5));
-  }
-  for (;;) {
-    const int fd = ::socket(AF_INET, SOCK_STREAM, 0);
-    if (fd < 0) return cfail(PAOS_EHIP, "socket() failed");
-    sockaddr_in addr{};
-    addr.sin_family = AF_INET;
-    addr.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
-    addr.sin_port = htons((uint16_t)port);
-    if (::connect(fd, reinterpret_cast<sockaddr*>(&addr), sizeof(addr)) == 0) {
-      int one = 1;
-      ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-      if (!send_all(fd, &c->rank, sizeof(c->rank))) { ::close(fd); return cfail(PAOS_EHIP, "announcing the rank to rank 0 failed"); }
-      c->fds.assign(1, fd);
-      return PAOS_OK;
+    if (port > 0) {
+      const int fd = ::socket(AF_INET, SOCK_STREAM, 0);
+      if (fd < 0) return cfail(PAOS_EHIP, "socket() failed");
+      sockaddr_in addr{};
+      addr.sin_family = AF_INET;
+      addr.sin_addr.s_addr = htonl(INADDR_LOOPBACK);
+      addr.sin_port = htons((uint16_t)port);
+      if (::connect(fd, reinterpret_cast<sockaddr*>(&addr), sizeof(addr)) == 0) {
+        int one = 1;
+        ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+        if (!send_all(fd, &c->rank, sizeof(c->rank))) { ::close(fd); return cfail(PAOS_EHIP, "announcing the rank to rank 0 failed"); }
+        c->fds.assign(1, fd);
+        return PAOS_OK;
+      }
+      ::close(fd);
     }
-    ::close(fd);
-    if (now_s() > deadline) return cfail(PAOS_EHIP, "timed out connecting to rank 0");
+    if (now_s() > deadline) return cfail(PAOS_EHIP, "timed out waiting for rank 0 (rendezvous file " + path + ")");
     std::this_thread::sleep_for(std::chrono::milliseconds(5));
   }
 }
