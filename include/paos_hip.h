@@ -103,6 +103,10 @@ int paos_export(paos_ctx* ctx, int item, int what, void* host_out);
  * (row-major doubles): the final intensity write of a propagation whose results are consumed on
  * the GPU or fetched later.  paos_psf_fetch copies one item's PSF to the host (synchronises). */
 int paos_psf_keep(paos_ctx* ctx);
+/* paos_psf_keep and paos_norm2_enqueue of the same field in one sweep (the saved last surface of a chain:
+ * |u|^2 is written and summed while the field is read once); *ticket as paos_norm2_enqueue, the sum is
+ * bit-identical to it. */
+int paos_psf_keep_power(paos_ctx* ctx, int* ticket);
 int paos_psf_fetch(paos_ctx* ctx, int item, double* host_out);
 /* Page-locked host memory for results (no reference counterpart).  paos_export into pageable
  * memory is bounded by first-touch page faults and on-the-fly pinning (~3 GB/s); into a buffer from

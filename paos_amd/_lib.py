@@ -74,6 +74,7 @@ SYMBOLS = {
     "paos_run_passes_live": (ctypes.c_int, [_c_ctx, ctypes.POINTER(Pass), ctypes.c_int, _dbl_p, ctypes.c_int, _dbl_p]),
     "paos_zernike": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, _dbl_p, _dbl_p, ctypes.c_int, _dbl_p]),
     "paos_psf_keep": (ctypes.c_int, [_c_ctx]),
+    "paos_psf_keep_power": (ctypes.c_int, [_c_ctx, ctypes.POINTER(ctypes.c_int)]),
     "paos_psf_fetch": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p]),
     "paos_host_alloc": (ctypes.c_int, [ctypes.c_ulonglong, ctypes.POINTER(ctypes.c_void_p)]),
     "paos_host_free": (ctypes.c_int, [ctypes.c_void_p]),
@@ -287,6 +288,12 @@ class DeviceFields:
     def psf_keep(self):
         """|u|^2 of every item into the context's device-resident PSF buffer (no host copy)."""
         self._check(self._lib.paos_psf_keep(self._ctx), "paos_psf_keep")
+
+    def psf_keep_power(self):
+        """``psf_keep`` and ``norm2_enqueue`` in one sweep over the field; returns the power ticket."""
+        t = ctypes.c_int(-1)
+        self._check(self._lib.paos_psf_keep_power(self._ctx, ctypes.byref(t)), "paos_psf_keep_power")
+        return t.value
 
     def psf_fetch(self, item=0):
         out = np.empty((self.n, self.n), dtype=np.float64)

@@ -324,7 +324,7 @@ bool use_frugal() {
 
 // Express pass p as   load | sign*scale*K phases | FFT | sign*scale*K phases | [FFT] | store.
 bool lower_frugal(const paos_ctx* c, const paos_pass& p, const double* blocks /*host*/, std::vector<FrugalItem>& items,
-                  int& kpre, int& kmid, int& nfft, int& mask_block, int& mask_slot) {
+                  int& kpre, int& kmid, int& nfft, int& mask_block, int& mask_slot, std::vector<double>& mask_shared) {
   if (p.axis != 0 && p.axis != 1) return false;
   if (p.fft1 < 0 || p.n_post != 0) return false;
   const paos_pw_op* lists[2] = {p.pre, p.mid};
@@ -360,6 +360,7 @@ bool lower_frugal(const paos_ctx* c, const paos_pass& p, const double* blocks /*
   }
   kpre = k[0]; kmid = k[1]; nfft = p.fft2 >= 0 ? 2 : 1;
   items.assign(c->batch, FrugalItem{});
+  mask_shared.assign(c->batch, 0.0);
   auto blk = [&](int b, int it) { return blocks + ((size_t)b * c->batch + it) * FP_STRIDE; };
   for (int it = 0; it < c->batch; ++it) {
     FrugalItem& fi = items[it];
@@ -384,8 +385,15 @@ bool lower_frugal(const paos_ctx* c, const paos_pass& p, const double* blocks /*
           slots[l]->mask_on = on ? 1.0 : 0.0;
           const bool obsc = q2[1] != 0.0 && q2[3] == PAOS_SHAPE_ELLIPSE;
           slots[l]->w_in = obsc ? 0.0 : 1.0; slots[l]->w_out = obsc ? 1.0 : 0.0;
-          slots[l]->lines = c->mask_lines + (size_t)it * c->n;
-          slots[l]->vals = c->mask_vals + (size_t)it * c->n * 2 * kMaskW;
+          // items with the same aperture on the same sampling (a Monte-Carlo batch: one wavelength, many
+          // wavefront-error draws) share one set of line records: only the first of them is rendered
+          int rep = it;
+          for (int j = 0; j < it; ++j)
+            if (!std::memcmp(blk(op.block, j), q, FP_STRIDE * sizeof(double)) &&
+                !std::memcmp(blk(op.block + 1, j), q2, FP_STRIDE * sizeof(double))) { rep = j; break; }
+          mask_shared[it] = rep != it ? 1.0 : 0.0;
+          slots[l]->lines = c->mask_lines + (size_t)rep * c->n;
+          slots[l]->vals = c->mask_vals + (size_t)rep * c->n * 2 * kMaskW;
         } else if (op.kind == PAOS_PW_SIGN) { if (on) slots[l]->sign_on = slots[l]->sign_on != 0.0 ? 0.0 : 1.0; }
         else if (op.kind == PAOS_PW_SCALE) { if (on) slots[l]->scale *= q[FP_COEF]; }
         else {
@@ -409,6 +417,7 @@ struct LoweredPass {
   bool ok = false;
   std::vector<FrugalItem> items;
   int kpre = 0, kmid = 0, nfft = 1, mask_block = -1, mask_slot = -1;
+  std::vector<double> mask_shared;  // [batch] 1: the item reads the line records of an earlier, identical item
 };
 
 // Lines (rows for a row pass, columns for a column pass) outside the returned range get weight
@@ -602,10 +611,13 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const
     const double* ap = dblocks + (size_t)lp.mask_block * c->batch * FP_STRIDE;
     const double* ap2 = ap + (size_t)c->batch * FP_STRIDE;
     const dim3 grid((c->n + 3) / 4, c->batch), block(256);
+    const double* dshared = nullptr;
+    int rcs = arena_push(c, lp.mask_shared.data(), lp.mask_shared.size(), &dshared);
+    if (rcs) return rcs;
     hipLaunchKernelGGL(mask_lines_kernel<0>, grid, block, 0, c->stream, ap, ap2, (int)FP_STRIDE, c->n, p.axis,
-                       c->mask_lines, c->mask_vals, c->mask_overflow);
+                       c->mask_lines, c->mask_vals, c->mask_overflow, dshared);
     hipLaunchKernelGGL(mask_lines_kernel<1>, grid, block, 0, c->stream, ap, ap2, (int)FP_STRIDE, c->n, p.axis,
-                       c->mask_lines, c->mask_vals, c->mask_overflow);
+                       c->mask_lines, c->mask_vals, c->mask_overflow, dshared);
     HIPCHK(c, hipGetLastError());
   }
   const double* ditems = nullptr;
@@ -751,7 +763,7 @@ int run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double*
     if ((rc = ensure_mask_store(c))) return rc;
     for (int q = 0; q < n_passes; ++q) {
       LoweredPass& lp = low[q];
-      lp.ok = lower_frugal(c, passes[q], blocks, lp.items, lp.kpre, lp.kmid, lp.nfft, lp.mask_block, lp.mask_slot);
+      lp.ok = lower_frugal(c, passes[q], blocks, lp.items, lp.kpre, lp.kmid, lp.nfft, lp.mask_block, lp.mask_slot, lp.mask_shared);
       all_frugal = all_frugal && lp.ok;
     }
   }
@@ -1058,18 +1070,30 @@ int paos_start(paos_ctx* c, double re, double im, int shape, const double* apert
   bool any_stop = false;
   if (stop)
     for (int i = 0; i < c->batch; ++i) { flags[i] = stop[i] != 0.0 ? 1.0 : 0.0; any_stop |= flags[i] != 0.0; }
-  const double *dp = nullptr, *ds = nullptr;
+  // items with identical aperture records (a wavelength sweep at the entrance pupil, a Monte-Carlo batch)
+  // have identical power sums: stage 1 runs for the first of them, stage 2 sums ITS partials for all
+  std::vector<double> power_of(c->batch), compute(c->batch);
+  for (int i = 0; i < c->batch; ++i) {
+    int rep = i;
+    for (int j = 0; j < i; ++j)
+      if (flags[j] != 0.0 && !std::memcmp(aperture + (size_t)j * AP_STRIDE, aperture + (size_t)i * AP_STRIDE, AP_STRIDE * sizeof(double))) { rep = j; break; }
+    power_of[i] = (double)rep;
+    compute[i] = (flags[i] != 0.0 && rep == i) ? 1.0 : 0.0;
+  }
+  const double *dp = nullptr, *ds = nullptr, *dcompute = nullptr, *dpower_of = nullptr;
   int rc;
   if ((rc = arena_push(c, aperture, (size_t)c->batch * AP_STRIDE, &dp))) return rc;
   if ((rc = arena_push(c, flags.data(), flags.size(), &ds))) return rc;
+  if ((rc = arena_push(c, compute.data(), compute.size(), &dcompute))) return rc;
+  if ((rc = arena_push(c, power_of.data(), power_of.size(), &dpower_of))) return rc;
   const dim3 block(kPwThreads);
 #define START_LAUNCH(T, S)                                                                              \
   do {                                                                                                  \
     if (any_stop) {                                                                                     \
       hipLaunchKernelGGL((start_power_kernel<T, BR, Lay<T>::BC, S>), dim3(c->nparts, c->batch), block, 0, \
-                         c->stream, dp, c->n, c->pitch, c->item_stride, re, im, c->partial, ds);        \
+                         c->stream, dp, c->n, c->pitch, c->item_stride, re, im, c->partial, dcompute);  \
       hipLaunchKernelGGL(norm2_final_kernel, dim3(c->batch), block, 0, c->stream, c->partial, c->norm2,   \
-                         c->nparts, ds, 1);                                                             \
+                         c->nparts, ds, 1, dpower_of);                                                  \
     }                                                                                                   \
     hipLaunchKernelGGL((start_write_kernel<T, BR, Lay<T>::BC, S>), dim3(pw_blocks(c), c->batch), block, 0, \
                        c->stream, (cx<T>*)c->field, dp, c->n, c->pitch, c->item_stride, re, im,          \
@@ -1283,6 +1307,32 @@ int paos_norm2_enqueue(paos_ctx* c, int* ticket) {
     return fail(c, PAOS_EINVAL, "64 power reductions outstanding: fetch earlier tickets (paos_norm2_fetch) first");
   int rc = norm2_launch(c, nullptr);
   if (rc) return rc;
+  c->norm_busy[slot] = true;
+  c->norm_slot = (slot + 1) % kNormSlots;
+  HIPCHK(c, hipMemcpyAsync(c->norm2_host + (size_t)slot * c->batch, c->norm2, (size_t)c->batch * sizeof(double),
+                           hipMemcpyDeviceToHost, c->stream));
+  *ticket = slot;
+  return PAOS_OK;
+}
+
+int paos_psf_keep_power(paos_ctx* c, int* ticket) {
+  if (c) (void)hipSetDevice(c->device);
+  if (!c || !ticket) return fail(c, PAOS_EINVAL, "null argument");
+  const int slot = c->norm_slot;
+  if (c->norm_busy[slot])
+    return fail(c, PAOS_EINVAL, "64 power reductions outstanding: fetch earlier tickets (paos_norm2_fetch) first");
+  if (!c->psf) HIPCHK(c, hipMalloc(&c->psf, (size_t)c->batch * c->n * c->n * sizeof(double)));
+  const dim3 grid(c->nparts, c->batch), block(kPwThreads);
+  if (c->precision == PAOS_F64)
+    hipLaunchKernelGGL((intensity_power_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream,
+                       (const cx<double>*)c->field, c->psf, c->partial, c->n, c->pitch, c->item_stride);
+  else
+    hipLaunchKernelGGL((intensity_power_kernel<float, BR, Lay<float>::BC>), grid, block, 0, c->stream,
+                       (const cx<float>*)c->field, c->psf, c->partial, c->n, c->pitch, c->item_stride);
+  HIPCHK(c, hipGetLastError());
+  hipLaunchKernelGGL(norm2_final_kernel, dim3(c->batch), block, 0, c->stream, c->partial, c->norm2, c->nparts,
+                     (const double*)nullptr, 1);
+  HIPCHK(c, hipGetLastError());
   c->norm_busy[slot] = true;
   c->norm_slot = (slot + 1) % kNormSlots;
   HIPCHK(c, hipMemcpyAsync(c->norm2_host + (size_t)slot * c->batch, c->norm2, (size_t)c->batch * sizeof(double),

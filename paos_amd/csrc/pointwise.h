@@ -180,13 +180,40 @@ __global__ void norm2_partial_kernel(const cx<T>* field, double* partial, int n,
   if (threadIdx.x == 0) partial[(size_t)item * gridDim.x + blockIdx.x] = s;
 }
 
+// intensity_kernel that also leaves the partial sums of sum |u|^2 norm2_partial_kernel would (same grid,
+// same walk, same order of additions: the power of a saved last surface comes out bit-identical without
+// reading the field a second time)
+template <typename T, int BR, int BC>
+__global__ void intensity_power_kernel(const cx<T>* field, double* out, double* partial, int n, unsigned pitch,
+                                       unsigned item_stride) {
+  const int item = blockIdx.y;
+  __shared__ double sh[kPwThreads / 64];
+  const cx<T>* f = field + (size_t)item * item_stride;
+  double* o = out + (size_t)item * n * n;
+  const size_t total = item_stride;
+  double acc = 0.0;
+  size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
+    int r, c;
+    if (!layout_unmap<BR, BC>(m, n, pitch, r, c)) continue;
+    const double x = (double)f[m].x, y = (double)f[m].y;
+    const double v = __dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y));
+    o[(size_t)r * n + c] = v;
+    acc += v;
+  }
+  const double s = block_sum(acc, sh);
+  if (threadIdx.x == 0) partial[(size_t)item * gridDim.x + blockIdx.x] = s;
+}
+
+// ``source`` (optional): item whose partial sums make up this item's result (identical inputs, summed once)
 static __global__ void norm2_final_kernel(const double* partial, double* norm2, int nparts,
-                                   const double* enable, int enable_stride) {
+                                   const double* enable, int enable_stride, const double* source = nullptr) {
   const int item = blockIdx.x;
   if (enable && enable[(size_t)item * enable_stride] == 0.0) return;
   __shared__ double sh[kPwThreads / 64];
   double acc = 0.0;
-  for (int i = threadIdx.x; i < nparts; i += blockDim.x) acc += partial[(size_t)item * nparts + i];
+  const int src = source ? (int)source[item] : item;
+  for (int i = threadIdx.x; i < nparts; i += blockDim.x) acc += partial[(size_t)src * nparts + i];
   const double s = block_sum(acc, sh);
   if (threadIdx.x == 0) norm2[item] = s;
 }
@@ -552,8 +579,9 @@ constexpr int kMaskWaves = 4;  // waves (= lines) per workgroup of mask_lines_ke
 
 template <int SHAPE>
 __global__ void __launch_bounds__(kMaskWaves * 64) mask_lines_kernel(const double* params, const double* params2, int param_stride, int n,
-                                  int axis, MaskLine* lines, double* vals, int* overflow) {
+                                  int axis, MaskLine* lines, double* vals, int* overflow, const double* shared) {
   const int item = blockIdx.y;
+  if (shared[item] != 0.0) return;  // reads the records of an earlier, identical item
   const int line = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (line >= n) return;

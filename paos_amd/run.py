@@ -553,12 +553,14 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
             met = dev.psf_metrics(metrics_radii_px)
             for i, rec in pending:
                 rec["metrics"] = met[i]
-        if keep_psf and key == last_key:
-            dev.psf_keep()
+        keep = keep_psf and key == last_key
         if power:
             if len(tickets) - drained[0] >= _lib.NORM_SLOTS - 1:
                 drain()  # the ticket ring of the library is about to fill: fetch what is pending
-            tickets.append((dev.norm2_enqueue(), pending))
+            # the saved last surface of a run that keeps its PSFs: |u|^2 written and summed in one sweep
+            tickets.append((dev.psf_keep_power() if keep else dev.norm2_enqueue(), pending))
+        elif keep:
+            dev.psf_keep()
 
     try:
         _walk(dev, states, list(opt_chains), on_saved, stats=stats, fresh=1.0 + 0.0j)

@@ -77,6 +77,10 @@ class ModelDevice:
 
     def psf_keep(self):
         self.log.append(("psf_keep", None))
+
+    def psf_keep_power(self):
+        self.psf_keep()
+        return self.norm2_enqueue()
         self.psf = np.abs(self.u) ** 2
 
     def psf_fetch(self, item=0):

@@ -347,3 +347,56 @@ def test_line_records_never_overflow_when_the_host_accepts_an_aperture():
         assert rel_err(got, dev.download(trial % nb)) < 1e-13
     assert tried == 48
     dev.close()
+
+
+def test_items_with_identical_apertures_share_their_records():
+    """A batch whose items see the same aperture on the same sampling (Monte-Carlo draws at one wavelength;
+    every item at the entrance pupil) renders one set of line records and sums the stop power once.
+    Each item of a mixed batch -- three at one wavelength with different wavefront errors, one at another
+    wavelength -- must equal the same item propagated alone."""
+    import paos_amd.run as prun
+    from paos_amd.chains import syn20_chain, syn20_coefficients, syn20_wavelength
+
+    n = 1024
+    on_axis = {"us": 0.0, "ut": 0.0}
+    wls = [1.0e-6, 1.0e-6, syn20_wavelength(300), 1.0e-6]
+    chains = []
+    for k in range(4):
+        ch = syn20_chain()
+        coef = np.array(syn20_coefficients(), dtype=float) * (1.0 + 0.25 * k)
+        for item in ch.values():
+            if item.get("type") == "Zernike":
+                item["Z"] = coef.copy()
+        chains.append(ch)
+    together = prun.run_batch(1.0, wls, n, 4, on_axis, [copy.deepcopy(c) for c in chains], outputs=("wfo",))
+    for k in range(4):
+        alone = prun.run_batch(1.0, [wls[k]], n, 4, on_axis, [copy.deepcopy(chains[k])], outputs=("wfo",))[0]
+        assert sorted(alone) == sorted(together[k])
+        for num in alone:
+            assert np.array_equal(alone[num]["wfo"], together[k][num]["wfo"]), (k, num)
+            assert alone[num]["power"] == together[k][num]["power"], (k, num)
+    assert not np.array_equal(together[0][max(together[0])]["wfo"], together[1][max(together[1])]["wfo"])
+
+
+@pytest.mark.parametrize("precision", ["fp64", "fp32"])
+def test_psf_keep_power_equals_the_two_separate_sweeps(precision):
+    """paos_psf_keep_power = paos_psf_keep + paos_norm2_enqueue with one read of the field: same PSF, and the
+    same sum to the last bit (same grid, same order of additions)."""
+    from paos_amd import _lib
+
+    n, nb = 1024, 3
+    rng = np.random.default_rng(5)
+    dev = _lib.DeviceFields(n, nb, precision)
+    try:
+        for i in range(nb):
+            dev.upload(i, (rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))) * (i + 1))
+        dev.psf_keep()
+        separate = [dev.psf_fetch(i) for i in range(nb)]
+        power = dev.norm2_fetch(dev.norm2_enqueue())
+        fused_power = dev.norm2_fetch(dev.psf_keep_power())
+        assert np.array_equal(power, fused_power)
+        for i in range(nb):
+            assert np.array_equal(dev.psf_fetch(i), separate[i])
+        assert abs(power[0] - separate[0].sum()) <= 1e-12 * power[0]
+    finally:
+        dev.close()

@@ -220,6 +220,7 @@ int main(int argc, char** argv) {
   bench_frugal<double, 4096, 1, 0, 1, 3>("cols double 1 phase, digit-swapped", b4, reps, pad);
   bench_frugal<double, 4096, 1, 0, 0, 3>("cols double 0 phases, digit-swapped", b4, reps, pad);
   bench_frugal<double, 4096, 1, 0, 0, 2>("cols double 0 phases", b4, reps, pad);
+  if (getenv("PAOS_BENCH_CORE")) return 0;  // the 4096^2 complex128 shapes only (counter runs)
   // N = 2048: 256-thread workgroups (library, round 2a) against 512-thread ones (two tiles per workgroup)
   bench_frugal<double, 2048, 0, 0, 1, 2, 2, 1>("rows double 1 phase 256 thr", 32, reps, pad);
   bench_frugal<double, 2048, 0, 0, 1, 2, 2, 2>("rows double 1 phase 512 thr (2 tiles)", 32, reps, pad);

@@ -16,7 +16,7 @@ with open(path) as f:
                 inside, name = True, m.group(1)
             continue
         s = line.strip()
-        if s.startswith("s_endpgm"):
+        if s.startswith(".Lfunc_end"):  # a kernel may hold several s_endpgm (early exits)
             break
         m = re.match(r"^([vs]_\w+|ds_\w+|global_\w+|buffer_\w+|scratch_\w+)", s)
         if m:
