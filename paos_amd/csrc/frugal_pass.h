@@ -328,14 +328,14 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   void* lds = smem + (size_t)m.lds_line * line_lds_bytes<T, N, SPLIT, LINES>();
   // The stage twiddles (indices < 256 of the table for every supported N) sit in LDS behind the
   // exchange areas: the load that follows each exchange barrier is then a ~100-cycle ds_read
-  // instead of a dependent global load.  Published by the first exchange's barriers.
+  // instead of a dependent global load.  Published by the barrier behind the tile's loads.
   cx<T>* tw_lds = reinterpret_cast<cx<T>*>(smem + (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT, LINES>());
   constexpr int kTwiddleLds = twiddle_lds_entries<N, E>();
   for (int i = threadIdx.x; i < kTwiddleLds; i += TILES * LINES * N / E)
     tw_lds[i] = reinterpret_cast<const cx<T>*>(a.tw)[i];
   const cx<T>* tw = tw_lds;
   // the unit circle in 256 steps for the phase factors (sincos_tab) and the twiddles of the second
-  // stage: conj of every (N/256)-th entry of the twiddle table.  Published by the first exchange's barriers.
+  // stage: conj of every (N/256)-th entry of the twiddle table.  Published by the same barrier.
   const cx<double>* circle = nullptr;
   if constexpr (sizeof(T) == 8) {
     cx<double>* cl = reinterpret_cast<cx<double>*>(tw_lds + kTwiddleLds);
@@ -375,6 +375,10 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
     }
   }
   __builtin_amdgcn_sched_barrier(0);
+  // The LDS tables above are read before the first exchange barrier when a phase sits in front of the first
+  // transform (sincos_tab in the pre slot), or when the first transform is switched off: publish them here,
+  // with the tile's loads already in flight.  LDS only -- a __syncthreads() would also wait for those loads.
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   PAOS_STAMP_WAIT_VM();
   PAOS_STAMP(1);
 
