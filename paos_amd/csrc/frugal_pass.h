@@ -125,7 +125,7 @@ __device__ __forceinline__ void sincos_tab(double a, const cx<double>* circle, d
 
 template <typename T, int N, int E, int K, typename Map>
 __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, const FrugalPhase* ph,
-                                            const Map& m, const cx<double>* circle, bool conj_out, int tpos) {
+                                            const Map& m, const cx<double>* circle, bool conj_in, bool conj_out, int tpos) {
   // tpos: position along the line of the thread's element 0 (its elements are TL apart): m.t in natural
   // order, swap_nibbles(m.t) between the two transforms of a digit-swapped pass
   constexpr int TL = N / E;
@@ -154,7 +154,13 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
   }
   // (-1)^(row+col): the position along the line advances by TL (even) from element to element
   const double f = (sl.sign_on != 0.0 && ((line + tpos) & 1)) ? -sc : sc;
-  const double fy = conj_out ? -f : f;  // the conjugation in front of an inverse transform rides on the scale
+  // The conjugations around an inverse transform (IFFT x = conj FFT conj x) ride on this slot: the one in
+  // front of the transform that FOLLOWS flips the sign of the imaginary scale; the one behind the transform
+  // that PRECEDES (conj_in: the values in ``v`` are the conjugates of the true ones) does too, since
+  //   conj(v) w e^{iq} = conj(v w e^{-iq})        (w: real mask weight)
+  // -- and the phases run with -q, a sign flip of the (wave-uniform) coefficient.
+  const double fy = (conj_out != conj_in) ? -f : f;
+  const int qflip = conj_in ? (int)0x80000000 : 0;
   // Per phase, what does not depend on the element: the squared coordinate ACROSS the line and
   // the scale ALONG it.  Coordinates are exact integers times the sampling step, formed like the
   // reference's (g * dx, one rounding); centred index g = i - N/2, natural order g = i or i - N.
@@ -162,9 +168,10 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
   // Along the line, element k sits at position t + k TL, which is < N/2 exactly when k < E/2 (t < TL):
   // its signed index is (t + base) + k TL with base = -N/2 (centred), or 0 / -N for the two halves of
   // the natural order -- two per-thread doubles per phase, picked per k at compile time.
-  double across2[KK], step[KK], g_lo[KK], g_hi[KK];
+  double across2[KK], step[KK], g_lo[KK], g_hi[KK], coefq[KK];
 #pragma unroll
   for (int j = 0; j < K; ++j) {
+    coefq[j] = __hiloint2double(__double2hiint(ph[j].coef) ^ qflip, __double2loint(ph[j].coef));
     const bool nat = ph[j].natural != 0.0;
     const int ga = nat ? ((line < N / 2) ? line : line - N) : line - N / 2;
     const double a = (double)ga * (Map::kAxis == 0 ? ph[j].sy : ph[j].sx);
@@ -181,7 +188,7 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
     // the register budget of three workgroups per CU.
     double turn_coef[KK];
 #pragma unroll
-    for (int j = 0; j < K; ++j) turn_coef[j] = ph[j].m2 * ph[j].coef * 0.15915494309189535 * ph[j].sgn;  // / 2 pi, signed
+    for (int j = 0; j < K; ++j) turn_coef[j] = ph[j].m2 * coefq[j] * 0.15915494309189535;  // / 2 pi; coef carries the sign
     const float ff = (float)f, ffy = (float)fy;
 #pragma unroll
     for (int k = 0; k < E; ++k) {
@@ -209,10 +216,11 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
       const double x = __dmul_rn((k < E / 2 ? g_lo[j] : g_hi[j]) + (double)(k * TL), step[j]);
       // x^2 + y^2 in the reference's order (addition commutes, so which of the two is "x" is moot)
       const double s = __dadd_rn(__dmul_rn(x, x), across2[j]);
-      const double q = __dmul_rn(ph[j].m2, __dmul_rn(ph[j].coef, s));
+      // the host stores coef * sgn (lower_frugal): fl(-c s) = -fl(c s), so the argument is the reference's up to
+      // its sign, and sin is odd -- no multiply by sgn here
+      const double q = __dmul_rn(ph[j].m2, __dmul_rn(coefq[j], s));
       double sn, cs;
       sincos_tab(q, circle, &sn, &cs);
-      sn *= ph[j].sgn;
       // only the phase ARGUMENT is rounded like the reference's; the product itself may use FMA
       vd = {fma(vd.x, cs, -(vd.y * sn)), fma(vd.x, sn, vd.y * cs)};
     }
@@ -254,14 +262,17 @@ __device__ __forceinline__ T flip_sign(T x, unsigned mask_hi) {
   else
     return __uint_as_float(__float_as_uint(x) ^ mask_hi);
 }
-template <typename T, int N, int E, bool SPLIT>
+// FLIP = false: the conjugation behind the transform is left to the slot that follows (frugal_slot: conj_in)
+template <typename T, int N, int E, bool SPLIT, bool FLIP = true>
 __device__ __forceinline__ void frugal_fft(cx<T>* v, void* lds, int t, const cx<T>* tw, const cx<double>* circle,
                                            double inv) {
   fft_stages<T, N, E, +1, SPLIT, 1, 1>(v, lds, t, tw, circle);
   unpermute_slots<N, E>(v);
-  const unsigned mask = inv != 0.0 ? 0x80000000u : 0u;
+  if constexpr (FLIP) {
+    const unsigned mask = inv != 0.0 ? 0x80000000u : 0u;
 #pragma unroll
-  for (int k = 0; k < E; ++k) v[k].y = flip_sign(v[k].y, mask);
+    for (int k = 0; k < E; ++k) v[k].y = flip_sign(v[k].y, mask);
+  }
   __builtin_amdgcn_sched_barrier(0);
 }
 
@@ -359,8 +370,23 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   // Addresses as a wave-uniform base (SGPRs) plus a 32-bit byte offset per element (an item is < 4 GiB):
   // 64-bit pointers for the sixteen elements would sit in 32 VGPRs from the loads to the stores.
   const char* fb = reinterpret_cast<const char*>(f);
-  const unsigned boff = m.base * (unsigned)sizeof(cx<T>), bstride = m.stride * (unsigned)sizeof(cx<T>);
-  auto at = [&](int k) { return reinterpret_cast<cx<T>*>(const_cast<char*>(fb) + (boff + (unsigned)k * bstride)); };
+  // element k sits k * stride further on: that part is wave-uniform and is added to the base on the scalar unit
+  const unsigned boff = m.base * (unsigned)sizeof(cx<T>);
+  // (readfirstlane pins the sum to a scalar register pair: otherwise it is reassociated into a 64-bit vector add
+  // per access; with it the access is "scalar base + 32-bit vector offset" and costs no vector instruction)
+  const size_t bstride = (size_t)(m.stride * (unsigned)sizeof(cx<T>));
+  auto at = [&](int k) {
+    const unsigned long long u = (unsigned long long)(fb + (size_t)k * bstride);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32));
+    typedef __attribute__((address_space(1))) char* GlobalBytes;  // keeps the access a global_*, not a flat_* one
+    // the zero-extension of the offset has to sit in the basic block of the access for the instruction selector to
+    // see "scalar base + 32-bit offset"; hoisted to the entry block (it is common to all 48 accesses) it is a 64-bit
+    // register pair and every access pays a 64-bit vector add.  The empty asm keeps it local.
+    unsigned bo = boff;
+    asm volatile("" : "+v"(bo));
+    return (cx<T>*)((GlobalBytes)(((unsigned long long)hi << 32) | lo) + bo);
+  };
   cx<T> v[E];
   const int plo = (int)it.pos_lo, phi = (int)it.pos_hi;
   if (plo <= 0 && phi >= N) {  // wave-uniform: the whole line is live
@@ -387,7 +413,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
     // launches this shape only when both transforms run for every active item of the batch
     static_assert(N == 4096 && E == 16 && sizeof(T) == 8 && SPLIT, "digit-swapped passes: 4096-point complex128 lines");
     T* area = reinterpret_cast<T*>(lds);
-    frugal_slot<T, N, E, KPRE>(v, it.pre, it.pre_ph, m, circle, it.fft1_inv != 0.0, m.t);
+    frugal_slot<T, N, E, KPRE>(v, it.pre, it.pre_ph, m, circle, false, it.fft1_inv != 0.0, m.t);
     PAOS_STAMP(2);
     fft4096_nat_to_swapped<T>(v, area, m.t, tw, circle, true);
     {
@@ -397,7 +423,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
       __builtin_amdgcn_sched_barrier(0);
     }
     PAOS_STAMP(3);
-    frugal_slot<T, N, E, KMID>(v, it.mid, it.mid_ph, m, circle, it.fft2_inv != 0.0, swap_nibbles(m.t));
+    frugal_slot<T, N, E, KMID>(v, it.mid, it.mid_ph, m, circle, false, it.fft2_inv != 0.0, swap_nibbles(m.t));
     PAOS_STAMP(4);
     fft4096_swapped_to_nat<T>(v, area, m.t, tw, circle);
     {
@@ -413,11 +439,12 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   }
   const bool ran1 = it.fft1_on != 0.0;
   const bool ran2 = NFFT == 2 && it.fft2_on != 0.0;
-  frugal_slot<T, N, E, KPRE>(v, it.pre, it.pre_ph, m, circle, ran1 && it.fft1_inv != 0.0, m.t);
+  const bool inv1 = ran1 && it.fft1_inv != 0.0;
+  frugal_slot<T, N, E, KPRE>(v, it.pre, it.pre_ph, m, circle, false, inv1, m.t);
   PAOS_STAMP(2);
-  if (ran1) frugal_fft<T, N, E, SPLIT>(v, lds, m.t, tw, circle, it.fft1_inv);
+  if (ran1) frugal_fft<T, N, E, SPLIT, false>(v, lds, m.t, tw, circle, it.fft1_inv);
   PAOS_STAMP(3);
-  frugal_slot<T, N, E, KMID>(v, it.mid, it.mid_ph, m, circle, ran2 && it.fft2_inv != 0.0, m.t);
+  frugal_slot<T, N, E, KMID>(v, it.mid, it.mid_ph, m, circle, inv1, ran2 && it.fft2_inv != 0.0, m.t);
   PAOS_STAMP(4);
   if constexpr (NFFT == 2) {
     if (ran2) {

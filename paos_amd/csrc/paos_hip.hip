@@ -334,7 +334,13 @@ bool lower_frugal(const paos_ctx* c, const paos_pass& p, const double* blocks /*
   for (int l = 0; l < 2; ++l)
     for (int o = 0; o < counts[l]; ++o) {
       const int kind = lists[l][o].kind;
-      if (kind == PAOS_PW_QPHASE_CENTRED || kind == PAOS_PW_QPHASE_NATURAL) ++k[l];
+      if (kind == PAOS_PW_QPHASE_CENTRED || kind == PAOS_PW_QPHASE_NATURAL) {
+        ++k[l];
+        for (int it = 0; it < c->batch; ++it) {  // the kernels fold the sign into the coefficient: it must be +-1
+          const double* q = blocks + ((size_t)lists[l][o].block * c->batch + it) * FP_STRIDE;
+          if (q[FP_ENABLE] != 0.0 && std::fabs(q[FP_SGN]) != 1.0) return false;
+        }
+      }
       else if (kind == PAOS_PW_MASK) {
         if (mask_block >= 0) return false;  // one aperture per pass (one set of line records)
         mask_block = lists[l][o].block; mask_slot = l;
@@ -399,7 +405,8 @@ bool lower_frugal(const paos_ctx* c, const paos_pass& p, const double* blocks /*
         else {
           FrugalPhase& ph = phases[l][j++];
           ph.natural = op.kind == PAOS_PW_QPHASE_NATURAL ? 1.0 : 0.0;
-          if (on) { ph.sx = q[FP_SX]; ph.sy = q[FP_SY]; ph.coef = q[FP_COEF]; ph.sgn = q[FP_SGN]; ph.m2 = (op.flags & PAOS_PWF_MUL2PI) ? 6.283185307179586 : 1.0; }
+          // the sign rides on the coefficient: exp(i sgn m2 fl(coef s)) = exp(i m2 fl((sgn coef) s)), sgn = +-1
+          if (on) { ph.sx = q[FP_SX]; ph.sy = q[FP_SY]; ph.coef = q[FP_COEF] * q[FP_SGN]; ph.sgn = 1.0; ph.m2 = (op.flags & PAOS_PWF_MUL2PI) ? 6.283185307179586 : 1.0; }
           else { ph.sx = ph.sy = 0.0; ph.coef = 0.0; ph.sgn = 1.0; ph.m2 = 1.0; }  // exp(i 0) = 1 exactly
         }
       }
