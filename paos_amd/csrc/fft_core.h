@@ -84,12 +84,12 @@ __device__ constexpr double kCos32[9] = {
     0.19509032201612826785,
     0.0};
 
-__device__ constexpr double cos32(int m) {
+__host__ __device__ constexpr double cos32(int m) {
   m &= 31;
   if (m > 16) m = 32 - m;
   return (m > 8) ? -kCos32[16 - m] : kCos32[m];
 }
-__device__ constexpr double sin32(int m) { return cos32(m - 8); }
+__host__ __device__ constexpr double sin32(int m) { return cos32(m - 8); }
 
 // v * W_R^m with W_R = exp(-2 pi i / R) for DIR = +1 (forward) and its
 // conjugate for DIR = -1.  m is a compile-time constant after unrolling, so
@@ -106,10 +106,102 @@ __device__ __forceinline__ cx<T> mulw(cx<T> v, int m) {
   return {fma(v.x, c, -(v.y * s)), fma(v.x, s, v.y * c)};
 }
 
+// ---- 16-point DFT with the inner twiddles folded into the butterflies (Linzer-Feig) ---------------
+// The 4 x 4 decomposition below multiplies nine of the sixteen intermediate values by W16^m between its two
+// layers: 8 non-trivial complex products, 32 of the 160 fp64 instructions.  With w = c (1 + i tau), tau = tan,
+//   w b = c u,  u = (b.x - tau b.y, b.y + tau b.x)           2 FMA instead of 4 instructions,
+// and the factor c rides on the FMA that replaces the butterfly's addition:  a +- w b = fma(+-c, u, a).
+// For the pair  w1 b1 +- w3 b3 = c1 (u1 +- (c3 / c1) u3)  the factor c1 moves one level down the same way.
+// A radix-4 butterfly with three twiddled inputs costs 22 FMA instead of 28 instructions; the DFT 144 instead
+// of 160 -- 16 fewer per transform stage, six stages per two-transform pass, in kernels that run at the rate of
+// the fp64 pipe (profiles/r02_valu_mix_fftbench.txt).  All constants are compile-time; cos(2 pi m / 16) is never
+// zero for the m used here (m = 4, the multiplication by -+i, is kept exact and free).
+#ifndef PAOS_LF16
+#define PAOS_LF16 1
+#endif
+template <int M16, int DIR>
+struct W16 {  // W16^M16 for DIR = +1 (exp(-2 pi i M16 / 16)), its conjugate for DIR = -1
+  static constexpr int m32 = (M16 * 2) & 31;
+  static constexpr bool quarter = m32 == 8 || m32 == 24;  // * -+i: exact, no arithmetic
+  static constexpr bool times_minus_i = (m32 == 8) == (DIR > 0);
+  static constexpr double c = cos32(m32);
+  static constexpr double s = (DIR > 0) ? -sin32(m32) : sin32(m32);
+  static constexpr double tau = quarter ? 0.0 : s / c;
+};
+template <typename T>
+__device__ __forceinline__ cx<T> lf_u(cx<T> b, double tau) {
+  return {fma((T)-tau, b.y, b.x), fma((T)tau, b.x, b.y)};
+}
+// out[k2], k2 = 0..3, of the radix-4 butterfly over (b0, W^K1 b1, W^2K1 b2, W^3K1 b3), W = W16
+template <int K1, int DIR, typename T>
+__device__ __forceinline__ void lf_twiddled_dft4(const cx<T>* b, cx<T>* out) {
+  using W1 = W16<K1, DIR>;
+  using W2 = W16<2 * K1, DIR>;
+  using W3 = W16<3 * K1, DIR>;
+  static_assert(!W1::quarter && !W3::quarter, "K1 and 3 K1 are never multiples of 4 here");
+  cx<T> t0, t1;
+  if constexpr (W2::quarter) {
+    const cx<T> wb = W2::times_minus_i ? cx<T>{b[2].y, -b[2].x} : cx<T>{-b[2].y, b[2].x};
+    t0 = cadd(b[0], wb);
+    t1 = csub(b[0], wb);
+  } else {
+    const cx<T> u2 = lf_u(b[2], W2::tau);
+    t0 = {fma((T)W2::c, u2.x, b[0].x), fma((T)W2::c, u2.y, b[0].y)};
+    t1 = {fma((T)-W2::c, u2.x, b[0].x), fma((T)-W2::c, u2.y, b[0].y)};
+  }
+  const cx<T> u1 = lf_u(b[1], W1::tau), u3 = lf_u(b[3], W3::tau);
+  constexpr double rho = W3::c / W1::c;
+  const cx<T> t2 = {fma((T)rho, u3.x, u1.x), fma((T)rho, u3.y, u1.y)};    // (w1 b1 + w3 b3) / c1
+  const cx<T> t3 = {fma((T)-rho, u3.x, u1.x), fma((T)-rho, u3.y, u1.y)};  // (w1 b1 - w3 b3) / c1
+  constexpr T c1 = (T)W1::c;
+  out[0] = {fma(c1, t2.x, t0.x), fma(c1, t2.y, t0.y)};
+  out[2] = {fma(-c1, t2.x, t0.x), fma(-c1, t2.y, t0.y)};
+  if constexpr (DIR > 0) {  // t1 -+ i c1 t3
+    out[1] = {fma(c1, t3.y, t1.x), fma(-c1, t3.x, t1.y)};
+    out[3] = {fma(-c1, t3.y, t1.x), fma(c1, t3.x, t1.y)};
+  } else {
+    out[1] = {fma(-c1, t3.y, t1.x), fma(c1, t3.x, t1.y)};
+    out[3] = {fma(c1, t3.y, t1.x), fma(-c1, t3.x, t1.y)};
+  }
+}
+
+template <int R, int DIR, typename T>
+__device__ __forceinline__ void dft(cx<T>* v);
+
+template <int DIR, typename T>
+__device__ __forceinline__ void dft16_lf(cx<T>* v) {
+  cx<T> y[16];
+#pragma unroll
+  for (int n2 = 0; n2 < 4; ++n2) {  // first layer: n = 4 n1 + n2 -> a[k1], untwiddled
+    cx<T> a[4] = {v[n2], v[4 + n2], v[8 + n2], v[12 + n2]};
+    dft<4, DIR>(a);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) y[k1 * 4 + n2] = a[k1];
+  }
+  cx<T> o[4];
+  {
+    cx<T> b[4] = {y[0], y[1], y[2], y[3]};
+    dft<4, DIR>(b);
+#pragma unroll
+    for (int k2 = 0; k2 < 4; ++k2) v[4 * k2] = b[k2];
+  }
+  lf_twiddled_dft4<1, DIR>(y + 4, o);
+#pragma unroll
+  for (int k2 = 0; k2 < 4; ++k2) v[1 + 4 * k2] = o[k2];
+  lf_twiddled_dft4<2, DIR>(y + 8, o);
+#pragma unroll
+  for (int k2 = 0; k2 < 4; ++k2) v[2 + 4 * k2] = o[k2];
+  lf_twiddled_dft4<3, DIR>(y + 12, o);
+#pragma unroll
+  for (int k2 = 0; k2 < 4; ++k2) v[3 + 4 * k2] = o[k2];
+}
+
 // In-place DFT of R points held in registers, natural order in and out.
 template <int R, int DIR, typename T>
 __device__ __forceinline__ void dft(cx<T>* v) {
-  if constexpr (R == 2) {
+  if constexpr (R == 16 && PAOS_LF16 != 0) {
+    dft16_lf<DIR>(v);
+  } else if constexpr (R == 2) {
     cx<T> a = v[0], b = v[1];
     v[0] = cadd(a, b);
     v[1] = csub(a, b);
