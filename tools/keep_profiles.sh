@@ -1,0 +1,14 @@
+#!/bin/bash
+# Copy the summaries of gpurun_out/profile_round (tools/profile_round.sh) into profiles/ under this round's names.
+R=${1:-r02}
+S=gpurun_out/profile_round
+cp $S/kernel_stats.txt profiles/${R}_rocprof_kernel_stats_bench.txt
+{ head -3 profiles/${R}_pmc_hbm_traffic_bench.txt 2>/dev/null | grep '^#' ; echo "## FETCH"; cat $S/pmc_fetch.txt; echo "## WRITE"; cat $S/pmc_write.txt; } > /tmp/pmc_$$.txt && mv /tmp/pmc_$$.txt profiles/${R}_pmc_hbm_traffic_bench.txt
+{ echo "# rocprofv3 --pmc SQ_* on bench.py --steps 1 (4096^2 c128 batch 8), per-kernel averages per launch (131072 waves per launch)"; cat $S/pmc_sq.txt; } > profiles/${R}_sq_counters.txt
+cp $S/fftbench.txt profiles/${R}_fftbench_pass_shapes.txt
+cp $S/timeline.txt profiles/${R}_timeline_workgroup_phases.txt
+cp $S/bench_default.json profiles/${R}_bench_4096_default.json
+cp $S/bench_fp32.json profiles/${R}_bench_4096_fp32.json
+cp $S/bench_noprune.json profiles/${R}_bench_4096_noprune.json
+cp $S/parity_gpu_vs_oracle.txt profiles/${R}_parity_gpu_vs_oracle.txt
+cp $S/baseline_configs.txt profiles/${R}_baseline_configs.txt
