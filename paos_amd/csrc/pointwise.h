@@ -626,7 +626,28 @@ __global__ void __launch_bounds__(kMaskWaves * 64) mask_lines_kernel(const doubl
     const int pos = base + lane;
     const int c = axis == 0 ? pos : line, r = axis == 0 ? line : pos;
     double mask = 0.0;
-    if (c >= box.ixmin && c < box.ixmax && r >= box.iymin && r < box.iymax) {
+    // Whole chunks inside or outside the ellipse (wave-uniform tests on the chunk's rectangle, theta = 0):
+    //  * inside: ellipse_pixel returns exactly 1 when the four corners of a pixel pass x'^2 + y'^2 <= 1; along a
+    //    row edge that sum is a monotone function of |x'| also in floating point (every operation rounds
+    //    monotonically), so when the chunk's four outer corners pass, every pixel corner in between does;
+    //  * outside: the point of the rectangle nearest the centre lies outside by a margin no rounding bridges,
+    //    so no pixel touches the ellipse and none contains its centre: ellipse_pixel returns 0.
+    // A line through the middle of a 1024-pixel pupil evaluates 2-4 chunks instead of 16.
+    int chunk = 0;  // 0: per pixel, 1: all inside, 2: all outside
+    if (SHAPE == 0) {
+      const double lo_a = __dsub_rn((double)base - 0.5, axis == 0 ? xc : yc), hi_a = __dsub_rn((double)(base + 63) + 0.5, axis == 0 ? xc : yc);
+      const double lo_c = __dsub_rn((double)line - 0.5, axis == 0 ? yc : xc), hi_c = __dsub_rn((double)line + 0.5, axis == 0 ? yc : xc);
+      const double sa = axis == 0 ? a : b, sc = axis == 0 ? b : a;  // semi-axes along / across the line
+      auto sum2 = [&](double al, double ac) { const double u = al / sa, v = ac / sc; return axis == 0 ? __dadd_rn(__dmul_rn(u, u), __dmul_rn(v, v)) : __dadd_rn(__dmul_rn(v, v), __dmul_rn(u, u)); };
+      const bool whole = base >= (axis == 0 ? box.ixmin : box.iymin) && base + 64 <= (axis == 0 ? box.ixmax : box.iymax);
+      if (whole && sum2(lo_a, lo_c) <= 1.0 && sum2(hi_a, lo_c) <= 1.0 && sum2(lo_a, hi_c) <= 1.0 && sum2(hi_a, hi_c) <= 1.0) chunk = 1;
+      else {
+        const double na = lo_a > 0.0 ? lo_a : (hi_a < 0.0 ? hi_a : 0.0), nc = lo_c > 0.0 ? lo_c : (hi_c < 0.0 ? hi_c : 0.0);
+        if (sum2(na, nc) > 1.0 + 1.0e-9) chunk = 2;
+      }
+    }
+    if (chunk == 1) mask = 1.0;
+    else if (chunk == 0 && c >= box.ixmin && c < box.ixmax && r >= box.iymin && r < box.iymax) {
       if (SHAPE == 0) mask = ellipse_pixel(c, r, xc, yc, a, b, 1.0, 0.0, full_disk);
       else mask = (double)(axis == 0 ? subpixel_count_1d(c, xc, hw, subpix) : subpixel_count_1d(r, yc, hh, subpix)) / (double)subpix;
     }
