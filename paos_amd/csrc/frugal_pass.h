@@ -123,9 +123,29 @@ __device__ __forceinline__ void sincos_tab(double a, const cx<double>* circle, d
   *sn = fma(c.y, c1, c.x * s1);
 }
 
-template <typename T, int N, int E, int K, typename Map>
+// sign flip as an XOR on the sign bit (an integer instruction instead of an fp64 multiply)
+template <typename T>
+__device__ __forceinline__ T flip_sign(T x, unsigned mask_hi) {
+  if constexpr (sizeof(T) == 8)
+    return __hiloint2double(__double2hiint(x) ^ (int)mask_hi, __double2loint(x));
+  else
+    return __uint_as_float(__float_as_uint(x) ^ mask_hi);
+}
+
+// PLAIN (the slot in front of the first transform when the pass has no phase there): the host guarantees that
+// the slot carries no sign, no scale and no aperture for any item (lower_frugal routes the rare pass that does
+// to the KPRE = 1 shape with a null phase), so all that is left is the conjugation in front of an inverse
+// transform -- 16 sign flips instead of 32 multiplications by +-1, in 43 of the 44 passes of the SYN20 chain.
+template <typename T, int N, int E, int K, typename Map, bool PLAIN = false>
 __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, const FrugalPhase* ph,
                                             const Map& m, const cx<double>* circle, bool conj_in, bool conj_out, int tpos) {
+  if constexpr (PLAIN) {
+    static_assert(K == 0, "a plain slot has no phases");
+    const unsigned mask = (conj_out != conj_in) ? 0x80000000u : 0u;
+#pragma unroll
+    for (int k = 0; k < E; ++k) v[k].y = flip_sign(v[k].y, mask);
+    return;
+  }
   // tpos: position along the line of the thread's element 0 (its elements are TL apart): m.t in natural
   // order, swap_nibbles(m.t) between the two transforms of a digit-swapped pass
   constexpr int TL = N / E;
@@ -255,13 +275,6 @@ __device__ __forceinline__ void stream_store(cx<T>* p, cx<T> v) {
 // the direction stays data and the conjugations are made cheap instead: the one in FRONT of the
 // transform is folded into the slot that precedes it (frugal_slot multiplies the imaginary part by
 // -f instead of f), the one BEHIND it is an XOR on the sign bit (half the issue cost of an fp64 multiply).
-template <typename T>
-__device__ __forceinline__ T flip_sign(T x, unsigned mask_hi) {
-  if constexpr (sizeof(T) == 8)
-    return __hiloint2double(__double2hiint(x) ^ (int)mask_hi, __double2loint(x));
-  else
-    return __uint_as_float(__float_as_uint(x) ^ mask_hi);
-}
 // FLIP = false: the conjugation behind the transform is left to the slot that follows (frugal_slot: conj_in)
 template <typename T, int N, int E, bool SPLIT, bool FLIP = true>
 __device__ __forceinline__ void frugal_fft(cx<T>* v, void* lds, int t, const cx<T>* tw, const cx<double>* circle,
@@ -387,6 +400,11 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
     asm volatile("" : "+v"(bo));
     return (cx<T>*)((GlobalBytes)(((unsigned long long)hi << 32) | lo) + bo);
   };
+  // The empty slot in front of the first transform as 16 sign flips instead of 32 multiplications: column passes
+  // gain 1-2 %; row passes LOSE 2 % with it (measured three times over, profiles/r02_fftbench_plain_slot.txt --
+  // their tiles share every 128-byte line with a sibling workgroup, and the shorter prologue seems to upset
+  // that pairing), so they keep the general slot.
+  constexpr bool kPlainPre = KPRE == 0 && AXIS == 1;
   cx<T> v[E];
   const int plo = (int)it.pos_lo, phi = (int)it.pos_hi;
   if (plo <= 0 && phi >= N) {  // wave-uniform: the whole line is live
@@ -413,7 +431,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
     // launches this shape only when both transforms run for every active item of the batch
     static_assert(N == 4096 && E == 16 && sizeof(T) == 8 && SPLIT, "digit-swapped passes: 4096-point complex128 lines");
     T* area = reinterpret_cast<T*>(lds);
-    frugal_slot<T, N, E, KPRE>(v, it.pre, it.pre_ph, m, circle, false, it.fft1_inv != 0.0, m.t);
+    frugal_slot<T, N, E, KPRE, decltype(m), kPlainPre>(v, it.pre, it.pre_ph, m, circle, false, it.fft1_inv != 0.0, m.t);
     PAOS_STAMP(2);
     fft4096_nat_to_swapped<T>(v, area, m.t, tw, circle, true);
     {
@@ -440,7 +458,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   const bool ran1 = it.fft1_on != 0.0;
   const bool ran2 = NFFT == 2 && it.fft2_on != 0.0;
   const bool inv1 = ran1 && it.fft1_inv != 0.0;
-  frugal_slot<T, N, E, KPRE>(v, it.pre, it.pre_ph, m, circle, false, inv1, m.t);
+  frugal_slot<T, N, E, KPRE, decltype(m), kPlainPre>(v, it.pre, it.pre_ph, m, circle, false, inv1, m.t);
   PAOS_STAMP(2);
   if (ran1) frugal_fft<T, N, E, SPLIT, false>(v, lds, m.t, tw, circle, it.fft1_inv);
   PAOS_STAMP(3);

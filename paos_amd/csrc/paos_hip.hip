@@ -414,6 +414,12 @@ bool lower_frugal(const paos_ctx* c, const paos_pass& p, const double* blocks /*
     fi.active = active ? 1.0 : 0.0;
     fi.line_lo = 0.0; fi.line_hi = (double)c->n; fi.line_fill = 0.0; fi.pos_lo = 0.0; fi.pos_hi = (double)c->n;
   }
+  // The KPRE = 0 shapes take the slot in front of the first transform to be empty (frugal_slot: PLAIN).  The
+  // rare pass that has a sign, a scale or an aperture there but no phase runs on the KPRE = 1 shape; its
+  // phase record is all zeros: exp(i 0) = 1 exactly.
+  if (kpre == 0)
+    for (const FrugalItem& fi : items)
+      if (fi.active != 0.0 && (fi.pre.sign_on != 0.0 || fi.pre.scale != 1.0 || fi.pre.mask_on != 0.0)) { kpre = 1; break; }
   return true;
 }
 
@@ -614,6 +620,15 @@ int ensure_mask_store(paos_ctx* c) {
 
 // launch a pass that lower_frugal accepted
 int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const double* dblocks) {
+  // PAOS_DUMP_PASSES=1: one line per pass launch on stderr (shape and what item 0's two slots carry)
+  static const bool dump = [] { const char* e = getenv("PAOS_DUMP_PASSES"); return e && e[0] == '1'; }();
+  if (dump && !lp.items.empty()) {
+    const FrugalItem& f = lp.items[0];
+    std::fprintf(stderr, "pass axis %d kpre %d kmid %d nfft %d | pre: sign %g scale %g mask %g | fft1 on %g inv %g | mid: sign %g scale %g mask %g | "
+                 "fft2 on %g inv %g | lines [%g, %g) fill %g positions [%g, %g)\n", p.axis, lp.kpre, lp.kmid, lp.nfft, f.pre.sign_on,
+                 f.pre.scale, f.pre.mask_on, f.fft1_on, f.fft1_inv, f.mid.sign_on, f.mid.scale, f.mid.mask_on, f.fft2_on, f.fft2_inv,
+                 f.line_lo, f.line_hi, f.line_fill, f.pos_lo, f.pos_hi);
+  }
   if (lp.mask_block >= 0) {  // render the records along the pass axis, right before the pass
     const double* ap = dblocks + (size_t)lp.mask_block * c->batch * FP_STRIDE;
     const double* ap2 = ap + (size_t)c->batch * FP_STRIDE;
