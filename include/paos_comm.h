@@ -33,7 +33,10 @@ enum { PAOS_COMM_SOCKET = 0, PAOS_COMM_RCCL = 1 };
 
 /* Join the job: `nranks` processes call this with ranks 0..nranks-1.  `device` is the HIP device of
  * this rank (RCCL transport only).  `rendezvous_dir` may be NULL (= "/tmp"); timeout_s bounds the
- * wait for the other ranks.  nranks == 1 needs no peer and no file. */
+ * wait for the other ranks.  nranks == 1 needs no peer and no file.
+ * PAOS_COMM_RCCL is a request: the ranks agree over the control plane whether RCCL came up on ALL of them
+ * (library found, device usable, ncclCommInitRank succeeded); if not, every rank continues on the TCP
+ * transport, says so on stderr, and paos_comm_transport reports PAOS_COMM_SOCKET. */
 int paos_comm_init_rank(int nranks, int rank, int device, int transport, const char* key,
                         const char* rendezvous_dir, double timeout_s, paos_comm** out);
 int paos_comm_destroy(paos_comm* comm);

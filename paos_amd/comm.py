@@ -64,7 +64,9 @@ class Comm:
         if rc != 0:
             self._h = _c_comm()
             raise CommError(f"paos_comm_init_rank failed ({rc}): {self._lib.paos_comm_last_error().decode()}")
-        self.rank, self.size, self.transport, self.device = int(rank), int(nranks), transport, int(device)
+        # the transport in use: "rccl" falls back to "socket" on every rank when RCCL cannot come up on all of them
+        actual = {SOCKET: "socket", RCCL: "rccl"}[self._lib.paos_comm_transport(self._h)]
+        self.rank, self.size, self.transport, self.device = int(rank), int(nranks), actual, int(device)
 
     @classmethod
     def from_env(cls, transport=None, timeout=300.0):

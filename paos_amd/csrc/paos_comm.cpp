@@ -305,20 +305,41 @@ int paos_comm_init_rank(int nranks, int rank, int device, int transport, const c
     if (rc) { paos_comm_destroy(c); return rc; }
   }
   if (transport == PAOS_COMM_RCCL) {
+    // RCCL is the data plane when every rank can bring it up; the ranks agree over the control plane after each
+    // step that may fail on some of them only, and otherwise ALL continue on the TCP transport -- a rank that
+    // skipped ncclCommInitRank would leave the others waiting in it.
+    auto everyone_ok = [&](bool mine) {
+      if (nranks == 1) return mine;
+      const double flag = mine ? 0.0 : 1.0;
+      std::vector<double> all((size_t)nranks, 1.0);
+      if (sock_allgather(c, &flag, 1, all.data()) != PAOS_OK) return false;
+      for (double v : all)
+        if (v != 0.0) return false;
+      return true;
+    };
     std::string why;
-    if (!load_rccl(c->rccl, why)) { paos_comm_destroy(c); return cfail(PAOS_EHIP, why); }
-    hipError_t e = hipSetDevice(device);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) {
-      const std::string msg = std::string("HIP device setup for RCCL: ") + hipGetErrorString(e);
-      paos_comm_destroy(c);
-      return cfail(PAOS_EHIP, msg);
+    bool ok = load_rccl(c->rccl, why);
+    if (ok) {
+      hipError_t e = hipSetDevice(device);
+      if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+      if (e != hipSuccess) { ok = false; why = std::string("HIP device setup for RCCL: ") + hipGetErrorString(e); }
     }
     UniqueId id{};
-    if (rank == 0) rc = nccl_check(c, c->rccl.GetUniqueId(&id), "ncclGetUniqueId");
-    if (!rc) rc = sock_bcast(c, &id, sizeof(id), 0);  // the id travels over the control plane
-    if (!rc) rc = nccl_check(c, c->rccl.CommInitRank(&c->nccl, nranks, id, rank), "ncclCommInitRank");
-    if (rc) { const std::string keep = g_comm_err; paos_comm_destroy(c); return cfail(rc, keep); }
+    if (ok && rank == 0 && nccl_check(c, c->rccl.GetUniqueId(&id), "ncclGetUniqueId")) { ok = false; why = g_comm_err; }
+    bool all_ok = everyone_ok(ok);
+    if (all_ok && nranks > 1 && sock_bcast(c, &id, sizeof(id), 0) != PAOS_OK) {  // the id travels over the control plane
+      const std::string keep = g_comm_err; paos_comm_destroy(c); return cfail(PAOS_EHIP, keep);
+    }
+    if (all_ok) {
+      if (nccl_check(c, c->rccl.CommInitRank(&c->nccl, nranks, id, rank), "ncclCommInitRank")) { ok = false; why = g_comm_err; c->nccl = nullptr; }
+      all_ok = everyone_ok(ok);
+    }
+    if (!all_ok) {
+      if (c->nccl) { (void)c->rccl.CommDestroy(c->nccl); c->nccl = nullptr; }
+      c->transport = PAOS_COMM_SOCKET;
+      std::fprintf(stderr, "paos_comm: rank %d of %d continues on the TCP transport, RCCL is not usable on every rank%s%s\n", rank, nranks,
+                   ok ? "" : " -- here: ", ok ? "" : why.c_str());
+    }
   }
   *out = c;
   return PAOS_OK;

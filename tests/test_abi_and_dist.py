@@ -263,3 +263,27 @@ def test_single_rank_comm_and_bad_arguments():
         Comm(2, 1, 0, "socket", key=None, timeout=1)
     with pytest.raises(CommError, match="timed out"):
         Comm(2, 1, 0, "socket", key="nobody_listens_here", timeout=0.3)
+
+
+def _fallback_worker(rank, world, key, out):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    from paos_amd.comm import Comm
+
+    comm = Comm(world, rank, rank, "rccl", key=key, timeout=120)  # no GPU here: RCCL cannot come up
+    try:
+        text = comm.bcast_blob(b"still here" if rank == 0 else None, root=0)
+        out.put((rank, comm.transport, text, comm.max(float(rank))))
+    finally:
+        comm.close()
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="needs a machine where RCCL cannot initialise")
+def test_rccl_bring_up_failure_falls_back_to_tcp_on_every_rank():
+    """Where RCCL cannot come up on every rank (here: no GPU), all ranks agree over the control plane and
+    continue on the TCP transport instead of leaving each other waiting in ncclCommInitRank."""
+    for rank, transport, text, slowest in _spawn(_fallback_worker, 2):
+        assert transport == "socket"
+        assert text == b"still here"
+        assert slowest == 1.0
