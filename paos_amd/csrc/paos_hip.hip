@@ -536,9 +536,8 @@ int frugal_launch(paos_ctx* c, const FrugalArgs& a) {
 
 template <typename T, int N, int AXIS, int KPRE, int KMID>
 int frugal_nfft(paos_ctx* c, const FrugalArgs& a, int nfft) {
-  if constexpr (sizeof(T) == 8 && N == 4096) {  // 3: two transforms, digit-swapped in between (fft_core.h)
-    if (nfft == 3) return frugal_launch<T, N, AXIS, KPRE, KMID, 3>(c, a);
-  }
+  // (the digit-swapped two-transform variant NFFT = 3 of frugal_pass.h is built by tools/fftbench.hip only:
+  // measured in round 2 with parity unchanged and no gain, profiles/r02_fftbench_digit_swapped_experiment.txt)
   return nfft >= 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1>(c, a);
 }
 template <typename T, int N, int AXIS, int KPRE>
@@ -648,20 +647,7 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const
                       lp.items.size() * sizeof(FrugalItem) / sizeof(double), &ditems);
   if (rc) return rc;
   FrugalArgs a{c->field, c->tw, reinterpret_cast<const FrugalItem*>(ditems), c->pitch, c->item_stride};
-  // Two transforms in one pass need natural order only at the ends: with PAOS_SWAP=1, when both run for
-  // every active item, the 4096-point complex128 shape keeps a digit-swapped layout in between, whose second
-  // exchange stays inside a wave (three workgroup barriers per transform instead of seven).  Measured in round
-  // 2: parity unchanged, speed unchanged to slightly worse (201 vs 203 wavefronts/s,
-  // profiles/r02_fftbench_digit_swapped_experiment.txt) -- the barriers are not what bounds the pass -- so
-  // the natural-order transforms stay the default.
-  int nfft = lp.nfft;
-  static const bool swap = [] { const char* e = getenv("PAOS_SWAP"); return e && e[0] == '1'; }();
-  if (nfft == 2 && c->precision == PAOS_F64 && c->n == 4096 && swap) {
-    bool all = true, any = false;
-    for (const FrugalItem& fi : lp.items)
-      if (fi.active != 0.0) { any = true; all = all && fi.fft1_on != 0.0 && fi.fft2_on != 0.0; }
-    if (any && all) nfft = 3;
-  }
+  const int nfft = lp.nfft;
   c->prof_next_tag = 0;  // for the launch timer: does this launch skip anything?
   for (const FrugalItem& fi : lp.items)
     if (fi.active != 0.0 && (fi.line_lo > 0.0 || fi.line_hi < (double)c->n || fi.pos_lo > 0.0 || fi.pos_hi < (double)c->n))
