@@ -31,6 +31,89 @@ __device__ __forceinline__ cx<T> cmul(cx<T> a, cx<T> b) {
 }
 template <typename T>
 __device__ __forceinline__ cx<T> cconj(cx<T> a) { return {a.x, -a.y}; }
+// a - i b, a + i b, and (re, im) -> (p.x re + q.x im_or_re ...) helpers used by the butterflies:
+template <typename T>
+__device__ __forceinline__ cx<T> sub_ib(cx<T> a, cx<T> b) { return {a.x + b.y, a.y - b.x}; }
+template <typename T>
+__device__ __forceinline__ cx<T> add_ib(cx<T> a, cx<T> b) { return {a.x - b.y, a.y + b.x}; }
+// a + c b and a - c b for a real c (FMA)
+template <typename T>
+__device__ __forceinline__ cx<T> fma_real(T c, cx<T> b, cx<T> a) { return {fma(c, b.x, a.x), fma(c, b.y, a.y)}; }
+// (b.x - tau b.y, b.y + tau b.x) = b (1 + i tau)
+template <typename T>
+__device__ __forceinline__ cx<T> rot_tau(cx<T> b, T tau) { return {fma(-tau, b.y, b.x), fma(tau, b.x, b.y)}; }
+// a - i c b and a + i c b for a real c
+template <typename T>
+__device__ __forceinline__ cx<T> fma_mic(T c, cx<T> b, cx<T> a) { return {fma(c, b.y, a.x), fma(-c, b.x, a.y)}; }
+template <typename T>
+__device__ __forceinline__ cx<T> fma_pic(T c, cx<T> b, cx<T> a) { return {fma(-c, b.y, a.x), fma(c, b.x, a.y)}; }
+// v (c + i s) for compile-time c, s
+template <typename T>
+__device__ __forceinline__ cx<T> cmul_const(cx<T> v, T c, T s) { return {fma(v.x, c, -(v.y * s)), fma(v.x, s, v.y * c)}; }
+// (v.x p, v.y q)
+template <typename T>
+__device__ __forceinline__ cx<T> scale2(cx<T> v, T p, T q) { return {v.x * p, v.y * q}; }
+
+// ---- complex64 on the packed fp32 pipe --------------------------------------------------------
+// A complex64 value is a (re, im) register pair, and gfx950 has packed fp32 arithmetic on such pairs
+// (v_pk_add / mul / fma_f32) whose operand modifiers pick halves (op_sel) and flip signs (neg_lo / neg_hi) per
+// lane: a complex sum is ONE instruction, a complex product two, a +- i b one.  Left to itself the compiler
+// vectorises across unrelated values instead and spends a quarter of the vector instructions of a complex64
+// pass on register moves (546 v_mov_b32 of 2316, round 2).  These overloads spell the operations out; the two
+// with lane-wise negation of a variable operand -- which the compiler does not fold into the modifiers -- are
+// two lines of assembly.  Per byte moved a complex64 pass has twice the points of a complex128 one, so this is
+// what lets the fp32 mode approach 2x instead of 1.5x.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 pk(cx<float> a) { return f2{a.x, a.y}; }
+__device__ __forceinline__ cx<float> unpk(f2 v) { return {v.x, v.y}; }
+__device__ __forceinline__ cx<float> cadd(cx<float> a, cx<float> b) { return unpk(pk(a) + pk(b)); }
+__device__ __forceinline__ cx<float> csub(cx<float> a, cx<float> b) { return unpk(pk(a) - pk(b)); }
+__device__ __forceinline__ cx<float> cmul(cx<float> a, cx<float> b) {
+  f2 t, r;
+  const f2 av = pk(a), bv = pk(b);
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(av), "v"(bv));                       // (a.x b.x, a.x b.y)
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]"                    // (-a.y b.y, a.y b.x) + t
+      : "=v"(r) : "v"(av), "v"(bv), "v"(t));
+  return unpk(r);
+}
+// The same product where ``b`` may come straight out of the transcendental unit (v_sin_f32 / v_cos_f32): gfx950
+// wants one wait state between such an instruction and a consumer of its result.  The compiler inserts it for the
+// instructions it emits itself but does not look into inline assembly, so the wait state is part of the text.
+__device__ __forceinline__ cx<float> cmul_after_trans(cx<float> a, cx<float> b) {
+  f2 t, r;
+  const f2 av = pk(a), bv = pk(b);
+  asm("s_nop 0\n\tv_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(av), "v"(bv));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(av), "v"(bv), "v"(t));
+  return unpk(r);
+}
+__device__ __forceinline__ cx<float> sub_ib(cx<float> a, cx<float> b) {  // (a.x + b.y, a.y - b.x)
+  f2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(pk(a)), "v"(pk(b)));
+  return unpk(r);
+}
+__device__ __forceinline__ cx<float> add_ib(cx<float> a, cx<float> b) {  // (a.x - b.y, a.y + b.x)
+  f2 r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(pk(a)), "v"(pk(b)));
+  return unpk(r);
+}
+__device__ __forceinline__ cx<float> fma_real(float c, cx<float> b, cx<float> a) {
+  return unpk(__builtin_elementwise_fma(f2{c, c}, pk(b), pk(a)));
+}
+__device__ __forceinline__ cx<float> rot_tau(cx<float> b, float tau) {
+  const f2 bv = pk(b);
+  return unpk(__builtin_elementwise_fma(bv.yx, f2{-tau, tau}, bv));
+}
+__device__ __forceinline__ cx<float> fma_mic(float c, cx<float> b, cx<float> a) {
+  return unpk(__builtin_elementwise_fma(pk(b).yx, f2{c, -c}, pk(a)));
+}
+__device__ __forceinline__ cx<float> fma_pic(float c, cx<float> b, cx<float> a) {
+  return unpk(__builtin_elementwise_fma(pk(b).yx, f2{-c, c}, pk(a)));
+}
+__device__ __forceinline__ cx<float> cmul_const(cx<float> v, float c, float s) {
+  const f2 vv = pk(v);
+  return unpk(__builtin_elementwise_fma(vv.yy, f2{-s, c}, vv.xx * f2{c, s}));
+}
+__device__ __forceinline__ cx<float> scale2(cx<float> v, float p, float q) { return unpk(pk(v) * f2{p, q}); }
 
 // sin and cos of a double: three-term Cody-Waite reduction by pi/2 + the classic minimax
 // kernels on [-pi/4, pi/4].  With FMA the first reduction step a - n*pio2_1 is exact for any
@@ -103,7 +186,7 @@ __device__ __forceinline__ cx<T> mulw(cx<T> v, int m) {
   if (m32 == 24) return (DIR > 0) ? cx<T>{-v.y, v.x} : cx<T>{v.y, -v.x};   // * +/- i
   const T c = (T)cos32(m32);
   const T s = (T)((DIR > 0) ? -sin32(m32) : sin32(m32));
-  return {fma(v.x, c, -(v.y * s)), fma(v.x, s, v.y * c)};
+  return cmul_const(v, c, s);
 }
 
 // ---- 16-point DFT with the inner twiddles folded into the butterflies (Linzer-Feig) ---------------
@@ -129,9 +212,7 @@ struct W16 {  // W16^M16 for DIR = +1 (exp(-2 pi i M16 / 16)), its conjugate for
   static constexpr double tau = quarter ? 0.0 : s / c;
 };
 template <typename T>
-__device__ __forceinline__ cx<T> lf_u(cx<T> b, double tau) {
-  return {fma((T)-tau, b.y, b.x), fma((T)tau, b.x, b.y)};
-}
+__device__ __forceinline__ cx<T> lf_u(cx<T> b, double tau) { return rot_tau(b, (T)tau); }
 // out[k2], k2 = 0..3, of the radix-4 butterfly over (b0, W^K1 b1, W^2K1 b2, W^3K1 b3), W = W16
 template <int K1, int DIR, typename T>
 __device__ __forceinline__ void lf_twiddled_dft4(const cx<T>* b, cx<T>* out) {
@@ -146,22 +227,22 @@ __device__ __forceinline__ void lf_twiddled_dft4(const cx<T>* b, cx<T>* out) {
     t1 = csub(b[0], wb);
   } else {
     const cx<T> u2 = lf_u(b[2], W2::tau);
-    t0 = {fma((T)W2::c, u2.x, b[0].x), fma((T)W2::c, u2.y, b[0].y)};
-    t1 = {fma((T)-W2::c, u2.x, b[0].x), fma((T)-W2::c, u2.y, b[0].y)};
+    t0 = fma_real((T)W2::c, u2, b[0]);
+    t1 = fma_real((T)-W2::c, u2, b[0]);
   }
   const cx<T> u1 = lf_u(b[1], W1::tau), u3 = lf_u(b[3], W3::tau);
   constexpr double rho = W3::c / W1::c;
-  const cx<T> t2 = {fma((T)rho, u3.x, u1.x), fma((T)rho, u3.y, u1.y)};    // (w1 b1 + w3 b3) / c1
-  const cx<T> t3 = {fma((T)-rho, u3.x, u1.x), fma((T)-rho, u3.y, u1.y)};  // (w1 b1 - w3 b3) / c1
+  const cx<T> t2 = fma_real((T)rho, u3, u1);   // (w1 b1 + w3 b3) / c1
+  const cx<T> t3 = fma_real((T)-rho, u3, u1);  // (w1 b1 - w3 b3) / c1
   constexpr T c1 = (T)W1::c;
-  out[0] = {fma(c1, t2.x, t0.x), fma(c1, t2.y, t0.y)};
-  out[2] = {fma(-c1, t2.x, t0.x), fma(-c1, t2.y, t0.y)};
+  out[0] = fma_real(c1, t2, t0);
+  out[2] = fma_real(-c1, t2, t0);
   if constexpr (DIR > 0) {  // t1 -+ i c1 t3
-    out[1] = {fma(c1, t3.y, t1.x), fma(-c1, t3.x, t1.y)};
-    out[3] = {fma(-c1, t3.y, t1.x), fma(c1, t3.x, t1.y)};
+    out[1] = fma_mic(c1, t3, t1);
+    out[3] = fma_pic(c1, t3, t1);
   } else {
-    out[1] = {fma(-c1, t3.y, t1.x), fma(c1, t3.x, t1.y)};
-    out[3] = {fma(c1, t3.y, t1.x), fma(-c1, t3.x, t1.y)};
+    out[1] = fma_pic(c1, t3, t1);
+    out[3] = fma_mic(c1, t3, t1);
   }
 }
 
@@ -211,11 +292,11 @@ __device__ __forceinline__ void dft(cx<T>* v) {
     v[0] = cadd(t0, t2);
     v[2] = csub(t0, t2);
     if constexpr (DIR > 0) {
-      v[1] = {t1.x + t3.y, t1.y - t3.x};
-      v[3] = {t1.x - t3.y, t1.y + t3.x};
+      v[1] = sub_ib(t1, t3);
+      v[3] = add_ib(t1, t3);
     } else {
-      v[1] = {t1.x - t3.y, t1.y + t3.x};
-      v[3] = {t1.x + t3.y, t1.y - t3.x};
+      v[1] = add_ib(t1, t3);
+      v[3] = sub_ib(t1, t3);
     }
   } else if constexpr (R > 4) {
     // R = A * B, n = B n1 + n2, k = k1 + A k2:

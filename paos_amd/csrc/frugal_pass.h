@@ -212,18 +212,17 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
     const float ff = (float)f, ffy = (float)fy;
 #pragma unroll
     for (int k = 0; k < E; ++k) {
-      float xr = v[k].x, xi = v[k].y;
+      cx<float> z = {(float)v[k].x, (float)v[k].y};
 #pragma unroll
       for (int j = 0; j < K; ++j) {
         const double x = ((k < E / 2 ? g_lo[j] : g_hi[j]) + (double)(k * TL)) * step[j];
         const double turns = fma(x, x, across2[j]) * turn_coef[j];
         const float frac = (float)(turns - floor(turns));
         const float snf = __builtin_amdgcn_sinf(frac), csf = __builtin_amdgcn_cosf(frac);
-        const float nr = fmaf(xr, csf, -(xi * snf));
-        xi = fmaf(xr, snf, xi * csf);
-        xr = nr;
+        z = cmul_after_trans(z, cx<float>{csf, snf});  // two packed instructions (fft_core.h)
       }
-      v[k] = {(T)(xr * ff), (T)(xi * ffy)};
+      const cx<float> zs = scale2(z, ff, ffy);
+      v[k] = {(T)zs.x, (T)zs.y};
       if ((k + 1) % PAOS_FENCE_EVERY == 0) __builtin_amdgcn_sched_barrier(0);
     }
     return;
