@@ -136,14 +136,32 @@ __device__ __forceinline__ T flip_sign(T x, unsigned mask_hi) {
 // the slot carries no sign, no scale and no aperture for any item (lower_frugal routes the rare pass that does
 // to the KPRE = 1 shape with a null phase), so all that is left is the conjugation in front of an inverse
 // transform -- 16 sign flips instead of 32 multiplications by +-1, in 43 of the 44 passes of the SYN20 chain.
-template <typename T, int N, int E, int K, typename Map, bool PLAIN = false>
+template <typename T, int N, int E, int K, typename Map, int PLAIN = 0>
 __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, const FrugalPhase* ph,
                                             const Map& m, const cx<double>* circle, bool conj_in, bool conj_out, int tpos) {
-  if constexpr (PLAIN) {
+  if constexpr (PLAIN == 1) {  // column passes: the conjugation, nothing else
     static_assert(K == 0, "a plain slot has no phases");
     const unsigned mask = (conj_out != conj_in) ? 0x80000000u : 0u;
 #pragma unroll
     for (int k = 0; k < E; ++k) v[k].y = flip_sign(v[k].y, mask);
+    return;
+  }
+  if constexpr (PLAIN == 2) {
+    // Row passes.  Measured (profiles/r02_fftbench_plain_slot.txt): with the 16 flips alone they run 2 % SLOWER
+    // than with the general slot's 32 multiplications, and so do the multiplications without the aperture branch
+    // around them; 32 integer instructions consumed in load order, two elements per scheduling fence like the
+    // general slot, are 1 % faster than it.  Their tiles share every 128-byte line with a sibling workgroup and
+    // the pace at which the prologue drains the loads evidently matters; the flip of the real part is by a mask
+    // that is zero under the host's guarantee (sign_on == 0) but not known to the compiler.
+    static_assert(K == 0, "a plain slot has no phases");
+    const unsigned mask = (conj_out != conj_in) ? 0x80000000u : 0u;
+    const unsigned none = (sl.sign_on != 0.0) ? 0x80000000u : 0u;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+      v[k].x = flip_sign(v[k].x, none);
+      v[k].y = flip_sign(v[k].y, mask);
+      if ((k + 1) % PAOS_FENCE_EVERY == 0) __builtin_amdgcn_sched_barrier(0);
+    }
     return;
   }
   // tpos: position along the line of the thread's element 0 (its elements are TL apart): m.t in natural
@@ -399,11 +417,9 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
     asm volatile("" : "+v"(bo));
     return (cx<T>*)((GlobalBytes)(((unsigned long long)hi << 32) | lo) + bo);
   };
-  // The empty slot in front of the first transform as 16 sign flips instead of 32 multiplications: column passes
-  // gain 1-2 %; row passes LOSE 2 % with it (measured three times over, profiles/r02_fftbench_plain_slot.txt --
-  // their tiles share every 128-byte line with a sibling workgroup, and the shorter prologue seems to upset
-  // that pairing), so they keep the general slot.
-  constexpr bool kPlainPre = KPRE == 0 && AXIS == 1;
+  // The empty slot in front of the first transform without its 32 multiplications by +-1 (frugal_slot: PLAIN):
+  // 16 sign flips in column passes, a paced variant in row passes.
+  constexpr int kPlainPre = KPRE != 0 ? 0 : (AXIS == 1 ? 1 : 2);
   cx<T> v[E];
   const int plo = (int)it.pos_lo, phi = (int)it.pos_hi;
   if (plo <= 0 && phi >= N) {  // wave-uniform: the whole line is live
