@@ -136,6 +136,13 @@ __device__ __forceinline__ T flip_sign(T x, unsigned mask_hi) {
 // the slot carries no sign, no scale and no aperture for any item (lower_frugal routes the rare pass that does
 // to the KPRE = 1 shape with a null phase), so all that is left is the conjugation in front of an inverse
 // transform -- 16 sign flips instead of 32 multiplications by +-1, in 43 of the 44 passes of the SYN20 chain.
+// which form the empty slot takes per axis (0: the general slot): tuning knobs, defaults = measured best
+#ifndef PAOS_ROW_PRE
+#define PAOS_ROW_PRE 2
+#endif
+#ifndef PAOS_COL_PRE
+#define PAOS_COL_PRE 1
+#endif
 template <typename T, int N, int E, int K, typename Map, int PLAIN = 0>
 __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, const FrugalPhase* ph,
                                             const Map& m, const cx<double>* circle, bool conj_in, bool conj_out, int tpos) {
@@ -419,7 +426,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   };
   // The empty slot in front of the first transform without its 32 multiplications by +-1 (frugal_slot: PLAIN):
   // 16 sign flips in column passes, a paced variant in row passes.
-  constexpr int kPlainPre = KPRE != 0 ? 0 : (AXIS == 1 ? 1 : 2);
+  constexpr int kPlainPre = KPRE != 0 ? 0 : (AXIS == 1 ? PAOS_COL_PRE : PAOS_ROW_PRE);
   cx<T> v[E];
   const int plo = (int)it.pos_lo, phi = (int)it.pos_hi;
   if (plo <= 0 && phi >= N) {  // wave-uniform: the whole line is live
