@@ -43,7 +43,7 @@ struct FrugalSlot {
   const double* vals;             // [N][2 * kMaskW]
 };
 static_assert(sizeof(FrugalSlot) == 7 * sizeof(double), "record of 8-byte fields");
-// per-item record, doubles: [fft1_on, fft1_inv, fft2_on, fft2_inv, pre slot, pre phases[2],
+// per-item record, doubles: [fft1_on, fft1_inv, fft2_on, fft2_inv, pruning ranges, pre slot, pre phases[2],
 // mid slot, mid phases[3]]
 struct FrugalItem {
   double active;  // 0: the item takes no part in this pass (no load, no store)
@@ -57,6 +57,9 @@ struct FrugalItem {
   //     data): they are not loaded.
   // Full ranges [0, N) switch all of it off.  Bounds are multiples of the block height.
   double line_lo, line_hi, line_fill, pos_lo, pos_hi;
+  // positions along a line outside [spos_lo, spos_hi) need not be STORED: the next pass (along the other axis)
+  // does not process the tiles of those lines -- an aperture in it is about to zero them
+  double spos_lo, spos_hi;
   FrugalSlot pre;
   FrugalPhase pre_ph[kFrugalMaxPre];
   FrugalSlot mid;
@@ -493,8 +496,17 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
     }
   }
   PAOS_STAMP(5);
+  const int slo = (int)it.spos_lo, shi = (int)it.spos_hi;
+  if (slo <= 0 && shi >= N) {  // wave-uniform: everything is stored
 #pragma unroll
-  for (int k = 0; k < E; ++k) stream_store<NT>(at(k), v[k]);
+    for (int k = 0; k < E; ++k) stream_store<NT>(at(k), v[k]);
+  } else {
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+      const int pos = m.t + k * (N / E);
+      if (pos >= slo && pos < shi) stream_store<NT>(at(k), v[k]);
+    }
+  }
   PAOS_STAMP(6);
   PAOS_STAMP_WAIT_VM();
   PAOS_STAMP(7);

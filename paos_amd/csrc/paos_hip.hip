@@ -413,6 +413,7 @@ bool lower_frugal(const paos_ctx* c, const paos_pass& p, const double* blocks /*
     }
     fi.active = active ? 1.0 : 0.0;
     fi.line_lo = 0.0; fi.line_hi = (double)c->n; fi.line_fill = 0.0; fi.pos_lo = 0.0; fi.pos_hi = (double)c->n;
+    fi.spos_lo = 0.0; fi.spos_hi = (double)c->n;
   }
   // The KPRE = 0 shapes take the slot in front of the first transform to be empty (frugal_slot: PLAIN).  The
   // rare pass that has a sign, a scale or an aperture there but no phase runs on the KPRE = 1 shape; its
@@ -502,6 +503,19 @@ void plan_pruning(const paos_ctx* c, const paos_pass* passes, int n_passes, cons
       if (zl) { fi.line_lo = lo; fi.line_hi = hi; last_skip = q; }
     }
     if (zl && virt && last_skip >= 0) low[last_skip].items[it].line_fill = 1.0;
+    // Stores nobody reads: when the next pass the item takes part in runs along the other axis and does not
+    // process the tiles of the lines outside [line_lo, line_hi) (its aperture zeroes them whatever they hold; it
+    // writes zeros there itself if somebody will read them), this pass need not store those positions.
+    int prev = -1;
+    for (int q = 0; q < n_passes; ++q) {
+      FrugalItem& fi = low[q].items[it];
+      if (fi.active == 0.0) continue;
+      if (prev >= 0 && passes[prev].axis != passes[q].axis && (fi.line_lo > 0.0 || fi.line_hi < (double)n)) {
+        low[prev].items[it].spos_lo = fi.line_lo;
+        low[prev].items[it].spos_hi = fi.line_hi;
+      }
+      prev = q;
+    }
   }
 }
 
@@ -624,9 +638,9 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const
   if (dump && !lp.items.empty()) {
     const FrugalItem& f = lp.items[0];
     std::fprintf(stderr, "pass axis %d kpre %d kmid %d nfft %d | pre: sign %g scale %g mask %g | fft1 on %g inv %g | mid: sign %g scale %g mask %g | "
-                 "fft2 on %g inv %g | lines [%g, %g) fill %g positions [%g, %g)\n", p.axis, lp.kpre, lp.kmid, lp.nfft, f.pre.sign_on,
+                 "fft2 on %g inv %g | lines [%g, %g) fill %g loads [%g, %g) stores [%g, %g)\n", p.axis, lp.kpre, lp.kmid, lp.nfft, f.pre.sign_on,
                  f.pre.scale, f.pre.mask_on, f.fft1_on, f.fft1_inv, f.mid.sign_on, f.mid.scale, f.mid.mask_on, f.fft2_on, f.fft2_inv,
-                 f.line_lo, f.line_hi, f.line_fill, f.pos_lo, f.pos_hi);
+                 f.line_lo, f.line_hi, f.line_fill, f.pos_lo, f.pos_hi, f.spos_lo, f.spos_hi);
   }
   if (lp.mask_block >= 0) {  // render the records along the pass axis, right before the pass
     const double* ap = dblocks + (size_t)lp.mask_block * c->batch * FP_STRIDE;
@@ -650,7 +664,8 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const
   const int nfft = lp.nfft;
   c->prof_next_tag = 0;  // for the launch timer: does this launch skip anything?
   for (const FrugalItem& fi : lp.items)
-    if (fi.active != 0.0 && (fi.line_lo > 0.0 || fi.line_hi < (double)c->n || fi.pos_lo > 0.0 || fi.pos_hi < (double)c->n))
+    if (fi.active != 0.0 && (fi.line_lo > 0.0 || fi.line_hi < (double)c->n || fi.pos_lo > 0.0 || fi.pos_hi < (double)c->n ||
+                              fi.spos_lo > 0.0 || fi.spos_hi < (double)c->n))
       c->prof_next_tag = 1;
   if (c->precision == PAOS_F64) {
     switch (c->n) {

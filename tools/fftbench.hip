@@ -165,7 +165,7 @@ void bench_frugal(const char* name, int batch, int reps, int pad_blocks) {
     std::memset(&it, 0, sizeof(it));
     it.active = 1; it.fft1_on = 1; it.fft1_inv = 0; it.fft2_on = 1; it.fft2_inv = 1;
     it.pre.scale = 1.0; it.mid.scale = 1.0 / N; it.mid.sign_on = 0;
-    it.line_lo = 0; it.line_hi = N; it.pos_lo = 0; it.pos_hi = N;  // no pruning
+    it.line_lo = 0; it.line_hi = N; it.pos_lo = 0; it.pos_hi = N; it.spos_lo = 0; it.spos_hi = N;  // no pruning
     for (int j = 0; j < kFrugalMaxPre; ++j) it.pre_ph[j] = {0.01, 0.01, 0.21, 1.0, 1.0, 0.0};
     for (int j = 0; j < kFrugalMaxMid; ++j) it.mid_ph[j] = {0.01, 0.01, 0.37, -1.0, 1.0, 1.0};
   }
