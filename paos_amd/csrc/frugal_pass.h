@@ -354,7 +354,21 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   // loads of their fields may be kept or merged across the workgroup barriers instead of re-issued
   typedef const __attribute__((address_space(4))) FrugalItem* ConstItemPtr;
   const FrugalItem& it = *(const FrugalItem*)((ConstItemPtr)a.items + item);
-  if (it.active == 0.0) return;
+  // The prologue is what a tile pays before its first load is in flight, with a CU slot already taken.  As the
+  // compiler laid it out it was a chain of five dependent scalar loads (one item field, wait, branch, the next
+  // field, ...) plus -- for the waves that fill the LDS tables -- a full global round trip (table load, wait,
+  // ds_write) in front of the tile loads.  Now the item's pruning header is fetched in one go (the empty asm needs
+  // all of it in scalar registers at this point, so the loads are merged into wide ones and waited for once), and
+  // the table fill has moved behind the tile loads (below).
+  constexpr int kThreads = TILES * LINES * N / E;
+  constexpr int kTwiddleLds = twiddle_lds_entries<N, E>();
+  constexpr int kTwIt = (kTwiddleLds + kThreads - 1) / kThreads;
+  constexpr int kClIt = sizeof(T) == 8 ? (kCircleLds + kThreads - 1) / kThreads : 1;
+  const double h_active = it.active, h_line_lo = it.line_lo, h_line_hi = it.line_hi, h_line_fill = it.line_fill,
+               h_pos_lo = it.pos_lo, h_pos_hi = it.pos_hi, h_spos_lo = it.spos_lo, h_spos_hi = it.spos_hi;
+  asm volatile("" ::"s"(h_active), "s"(h_line_lo), "s"(h_line_hi), "s"(h_line_fill), "s"(h_pos_lo), "s"(h_pos_hi), "s"(h_spos_lo),
+               "s"(h_spos_hi));
+  if (h_active == 0.0) return;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // a block of BR x BC elements is a whole 128-byte line for complex128, half of one for complex64
   constexpr bool kBlockIsLine = BR * BC * sizeof(cx<T>) >= 128;
@@ -366,8 +380,8 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   constexpr bool NT = kBlockIsLine && (PAOS_NT_FULL_LINES ? (AXIS == 1 || LINES == BR) : (AXIS == 1));
   {  // a workgroup of dead lines only: nothing to transform (its tiles are consecutive lines)
     const int l0 = TILES == 1 ? (AXIS == 0 ? m.row0 : m.col0) : (int)blockIdx.x * (TILES * LINES);
-    if (l0 + TILES * LINES <= (int)it.line_lo || l0 >= (int)it.line_hi) {
-      if (it.line_fill != 0.0) {
+    if (l0 + TILES * LINES <= (int)h_line_lo || l0 >= (int)h_line_hi) {
+      if (h_line_fill != 0.0) {
 #pragma unroll
         for (int k = 0; k < E; ++k)
           stream_store<NT>(reinterpret_cast<cx<T>*>(reinterpret_cast<char*>(f) + (m.base + (unsigned)k * m.stride) * (unsigned)sizeof(cx<T>)),
@@ -381,21 +395,11 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   // exchange areas: the load that follows each exchange barrier is then a ~100-cycle ds_read
   // instead of a dependent global load.  Published by the barrier behind the tile's loads.
   cx<T>* tw_lds = reinterpret_cast<cx<T>*>(smem + (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT, LINES>());
-  constexpr int kTwiddleLds = twiddle_lds_entries<N, E>();
-  for (int i = threadIdx.x; i < kTwiddleLds; i += TILES * LINES * N / E)
-    tw_lds[i] = reinterpret_cast<const cx<T>*>(a.tw)[i];
   const cx<T>* tw = tw_lds;
   // the unit circle in 256 steps for the phase factors (sincos_tab) and the twiddles of the second
-  // stage: conj of every (N/256)-th entry of the twiddle table.  Published by the same barrier.
-  const cx<double>* circle = nullptr;
-  if constexpr (sizeof(T) == 8) {
-    cx<double>* cl = reinterpret_cast<cx<double>*>(tw_lds + kTwiddleLds);
-    for (int i = threadIdx.x; i < kCircleLds; i += TILES * LINES * N / E) {
-      const cx<T> w = reinterpret_cast<const cx<T>*>(a.tw)[i * (N / kCircleLds)];
-      cl[i] = {(double)w.x, -(double)w.y};
-    }
-    circle = cl;
-  }
+  // stage: conj of every (N/256)-th entry of the twiddle table
+  cx<double>* cl = reinterpret_cast<cx<double>*>(tw_lds + kTwiddleLds);
+  const cx<double>* circle = sizeof(T) == 8 ? cl : nullptr;
 #if PAOS_STAMPS
   if (threadIdx.x == 0) {
     unsigned long long* st = a.stamps + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * kStampSlots;
@@ -431,7 +435,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   // 16 sign flips in column passes, a paced variant in row passes.
   constexpr int kPlainPre = KPRE != 0 ? 0 : (AXIS == 1 ? PAOS_COL_PRE : PAOS_ROW_PRE);
   cx<T> v[E];
-  const int plo = (int)it.pos_lo, phi = (int)it.pos_hi;
+  const int plo = (int)h_pos_lo, phi = (int)h_pos_hi;
   if (plo <= 0 && phi >= N) {  // wave-uniform: the whole line is live
 #pragma unroll
     for (int k = 0; k < E; ++k) v[k] = stream_load<NT>(at(k));
@@ -444,6 +448,35 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
     }
   }
   __builtin_amdgcn_sched_barrier(0);
+  // The LDS tables are fetched BEHIND the tile's loads (they are L2 hits and return in order right after the
+  // tile) and written once everything has arrived: nothing stands between the prologue and the first tile load.
+  cx<T> tw_fetch[kTwIt], cl_fetch[kClIt];
+#pragma unroll
+  for (int j = 0; j < kTwIt; ++j) {
+    const int i = (int)threadIdx.x + j * kThreads;
+    tw_fetch[j] = cx<T>{(T)0, (T)0};
+    if (i < kTwiddleLds) tw_fetch[j] = reinterpret_cast<const cx<T>*>(a.tw)[i];
+  }
+  if constexpr (sizeof(T) == 8) {
+#pragma unroll
+    for (int j = 0; j < kClIt; ++j) {
+      const int i = (int)threadIdx.x + j * kThreads;
+      cl_fetch[j] = cx<T>{(T)0, (T)0};
+      if (i < kCircleLds) cl_fetch[j] = reinterpret_cast<const cx<T>*>(a.tw)[i * (N / kCircleLds)];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < kTwIt; ++j) {
+    const int i = (int)threadIdx.x + j * kThreads;
+    if (i < kTwiddleLds) tw_lds[i] = tw_fetch[j];
+  }
+  if constexpr (sizeof(T) == 8) {
+#pragma unroll
+    for (int j = 0; j < kClIt; ++j) {
+      const int i = (int)threadIdx.x + j * kThreads;
+      if (i < kCircleLds) cl[i] = {(double)cl_fetch[j].x, -(double)cl_fetch[j].y};
+    }
+  }
   // The LDS tables above are read before the first exchange barrier when a phase sits in front of the first
   // transform (sincos_tab in the pre slot), or when the first transform is switched off: publish them here,
   // with the tile's loads already in flight.  LDS only -- a __syncthreads() would also wait for those loads.
@@ -496,7 +529,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
     }
   }
   PAOS_STAMP(5);
-  const int slo = (int)it.spos_lo, shi = (int)it.spos_hi;
+  const int slo = (int)h_spos_lo, shi = (int)h_spos_hi;
   if (slo <= 0 && shi >= N) {  // wave-uniform: everything is stored
 #pragma unroll
     for (int k = 0; k < E; ++k) stream_store<NT>(at(k), v[k]);
