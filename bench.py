@@ -166,8 +166,8 @@ def roofline_block(m, n, nb, esz, dev, kernel_name):
                         "under rocprofv3: profiles/r02_pmc_hbm_traffic_bench.txt",
         "launches": full, "avg_launch_ms": full_ms, "algorithmic_bytes_per_launch": pass_bytes,
         "pruned": {"launches": m["pruned"], "avg_launch_ms": m["pruned_ms"] / max(m["pruned"], 1),
-                   "what": "pass launches behind an aperture that skip the tiles / loads of rows or columns the aperture "
-                           "has zeroed (they move fewer bytes and are kept out of `achieved`)"},
+                   "what": "pass launches next to an aperture that skip the tiles / loads of rows or columns it has zeroed, "
+                           "or the stores of rows it is about to zero (they move fewer bytes and are kept out of `achieved`)"},
         "all_pass_launches_avg_ms": m["kern_ms"] / max(m["launches"], 1),
         "fused_passes_per_wavefront": m["fused_passes"],
         "copy_yardstick": {"ms_per_launch": y_ms, "GBps": y_bytes / (y_ms * 1e-3) / 1e9,
