@@ -21,7 +21,7 @@ imported here).  Rank 0 prints one JSON line (contract in the task statement) wi
                      per 2-D FFT) next to the bytes the fused passes really move (`frac_bytes_moved`).
   extra              the same chain at 2048^2 and 1024^2 (the north star's sweep), value + roofline each.
   cpu_baseline       the NumPy oracle ("port") on the host: one wavefront of the workload at the benchmark grid
-                     on one core, and `cpu_baseline_parallel`: min(batch, cores, memory) worker processes over
+                     on one core, and `cpu_baseline_parallel`: min(batch, cores, memory, 8) worker processes over
                      wavelengths at the benchmark grid -- the reference's own joblib scheme (pipeline.py:140).
 """
 import argparse
@@ -88,6 +88,13 @@ def cpu_baseline_parallel(gridsize, batch):
     import multiprocessing as mp
 
     cores = os.cpu_count() or 1
+    try:  # the CPUs this process may actually use, and the cgroup's share of them
+        cores = min(cores, len(os.sched_getaffinity(0)))
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            cores = max(1, min(cores, int(int(quota) / int(period))))
+    except Exception:  # noqa: BLE001
+        pass
     per_worker_gb = 17.0 * (gridsize / 4096.0) ** 2 + 0.5
     try:
         import psutil
@@ -95,8 +102,18 @@ def cpu_baseline_parallel(gridsize, batch):
         avail_gb = psutil.virtual_memory().available / 1e9
     except Exception:  # noqa: BLE001
         avail_gb = 64.0
-    by_memory = max(1, int(0.6 * avail_gb / per_worker_gb))
-    workers = max(1, min(batch, cores, by_memory))
+    try:  # a container's memory limit is not in /proc/meminfo
+        limit = open("/sys/fs/cgroup/memory.max").read().strip()
+        if limit != "max":
+            used = int(open("/sys/fs/cgroup/memory.current").read())
+            avail_gb = min(avail_gb, (int(limit) - used) / 1e9)
+    except Exception:  # noqa: BLE001
+        pass
+    by_memory = max(1, int(0.5 * avail_gb / per_worker_gb))
+    # Never more than kMaxWorkers: a GPU box is a slice of a host whose /proc numbers describe the whole machine
+    # (round 2 lost a box to 32 workers x 17 GB that the host-wide figures allowed); 8 is the measured-safe count.
+    kMaxWorkers = 8
+    workers = max(1, min(batch, cores, by_memory, kMaxWorkers))
     t0 = time.perf_counter()
     with mp.get_context("fork").Pool(workers) as pool:
         each = pool.map(_oracle_seconds, [(64 * k, gridsize) for k in range(workers)])
@@ -106,7 +123,7 @@ def cpu_baseline_parallel(gridsize, batch):
         "unit": "wavefronts/s",
         "cores": workers,
         "kind": "port",
-        "sample": f"{workers} worker processes = min(batch {batch}, {cores} logical CPUs, memory: {avail_gb:.0f} GB free at "
+        "sample": f"{workers} worker processes = min(batch {batch}, {cores} usable CPUs, 8, memory: {avail_gb:.0f} GB free at "
                   f"~{per_worker_gb:.0f} GB per worker) over wavelengths (pipeline.py:140), one SYN20 wavefront each at "
                   f"{gridsize}x{gridsize}: {wall:.1f} s wall ({min(each):.1f}-{max(each):.1f} s per worker)",
     }
@@ -182,13 +199,14 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid", type=int, default=4096)
-    ap.add_argument("--batch", type=int, default=0, help="wavefronts per GPU per step (default: 8 at 4096^2, 2 GiB of fields)")
+    ap.add_argument("--batch", type=int, default=0, help="wavefronts per GPU per step (default: 32 at 4096^2 = 8 GiB of fields + 4 GiB of PSFs of the 288 GB)")
     ap.add_argument("--precision", default="fp64", choices=["fp64", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the 2048^2 / 1024^2 entries")
     args = ap.parse_args()
     if args.batch <= 0:
-        args.batch = max(8, 8 * (4096 // args.grid) ** 2)
+        # 8 -> 32 wavefronts per step is +3 % (launch tails and host work amortised; 64: +0.3 % more): 217 -> 224 at 4096^2
+        args.batch = max(32, 32 * (4096 // args.grid) ** 2)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -298,7 +316,7 @@ def main():
         dev.close()
         if world == 1 and not args.no_extras and n == 4096:
             extra = {}
-            for n2, nb2 in ((2048, 16), (1024, 64)):
+            for n2, nb2 in ((2048, 64), (1024, 256)):
                 w2 = syn20_work(nb2, "wavelengths")
                 ch2 = [syn20_chain(coefficients=c) for c in w2["coefficients"]]
                 dev2 = _lib.DeviceFields(n2, nb2, args.precision)
