@@ -164,6 +164,7 @@ void bench_frugal(const char* name, int batch, int reps, int pad_blocks) {
   for (auto& it : items) {
     std::memset(&it, 0, sizeof(it));
     it.active = 1; it.fft1_on = 1; it.fft1_inv = 0; it.fft2_on = 1; it.fft2_inv = 1;
+    if (getenv("PAOS_BENCH_NOFFT")) it.fft1_on = it.fft2_on = 0;  // tile yardstick: the pass's loads and stores, no transform
     it.pre.scale = 1.0; it.mid.scale = 1.0 / N; it.mid.sign_on = 0;
     it.line_lo = 0; it.line_hi = N; it.pos_lo = 0; it.pos_hi = N; it.spos_lo = 0; it.spos_hi = N;  // no pruning
     for (int j = 0; j < kFrugalMaxPre; ++j) it.pre_ph[j] = {0.01, 0.01, 0.21, 1.0, 1.0, 0.0};
@@ -208,7 +209,7 @@ void bench_copy(int n, int batch, int reps) {
 
 int main(int argc, char** argv) {
   const int reps = argc > 1 ? atoi(argv[1]) : 10;
-  const int b4 = 8, pad = 3;
+  const int b4 = 8, pad = getenv("PAOS_BENCH_PAD") ? atoi(getenv("PAOS_BENCH_PAD")) : 3;  // pitch padding in blocks
   // NOTE: only instantiate 512-or-fewer-thread shapes: a 1024-thread instantiation in the same translation unit
   // changes the register allocation of the others (measured in round 2).
   bench_copy<double>(4096, b4, reps);
