@@ -179,8 +179,8 @@ def roofline_block(m, n, nb, esz, dev, kernel_name):
     return {
         "bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-        "traffic_note": "PMC counters are not readable in-process; per-kernel FETCH_SIZE / WRITE_SIZE of this command "
-                        "under rocprofv3: profiles/r02_pmc_hbm_traffic_bench.txt",
+        "traffic_note": "PMC counters are not readable in-process; per-kernel FETCH_SIZE / WRITE_SIZE of the default "
+                        "command (4096^2 fp64, 32 wavefronts per step) under rocprofv3: profiles/r02_pmc_hbm_traffic_bench.txt",
         "launches": full, "avg_launch_ms": full_ms, "algorithmic_bytes_per_launch": pass_bytes,
         "pruned": {"launches": m["pruned"], "avg_launch_ms": m["pruned_ms"] / max(m["pruned"], 1),
                    "what": "pass launches next to an aperture that skip the tiles / loads of rows or columns it has zeroed, "

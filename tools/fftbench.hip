@@ -143,7 +143,10 @@ void bench_variant(const char* name, int batch, int reps, int pad_blocks = 0) {
 
 template <typename T, int N, int AXIS, int KPRE, int KMID, int NFFT, int LINES = 2, int TILES = 1, int E = 16, int BC = 2>
 void bench_frugal(const char* name, int batch, int reps, int pad_blocks) {
-  constexpr int BR = 4;
+#ifndef PAOS_BENCH_BR
+#define PAOS_BENCH_BR 4
+#endif
+  constexpr int BR = PAOS_BENCH_BR;
   const unsigned pitch = (unsigned)N * BR + (unsigned)pad_blocks * BR * BC;
   const unsigned item_stride = pitch * (N / BR);
   cx<T>* d;
