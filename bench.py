@@ -15,8 +15,9 @@ imported here).  Rank 0 prints one JSON line (contract in the task statement) wi
                      bracketed by HIP events on the context's stream; `achieved` = 32 B/px x N^2 x batch (one read
                      and one write of every element) / mean duration of the launches that process every tile
                      (launches that skip dead tiles behind an aperture move fewer bytes and are listed apart under
-                     `pruned`); `copy_yardstick` is measured in this run (paos_copy_yardstick); `traffic` is null
-                     here -- PMC counters cannot be read from inside the process; profiles/r02_pmc_* holds them.
+                     `pruned`); `copy_yardstick` is measured in this run (paos_copy_yardstick); `traffic` = HBM bytes
+                     per full launch from FETCH_SIZE / WRITE_SIZE, collected by two child runs of this script under
+                     rocprofv3 --pmc (measure_traffic; N = 1 only, --no-traffic skips it).
   chain_vs_survey_model / ptp_step   the whole chain and one ptp priced with SURVEY 8d's UNFUSED byte model (2 passes
                      per 2-D FFT) next to the bytes the fused passes really move (`frac_bytes_moved`).
   extra              the same chain at 2048^2 and 1024^2 (the north star's sweep), value + roofline each.
@@ -170,6 +171,62 @@ def measure(dev, n, nb, precision, wavelengths, chains, steps, warmup, comm=None
             "fused_passes": stats.get("fused_passes"), "res": res}
 
 
+def measure_traffic(grid, batch, precision, alg_bytes):
+    """HBM bytes per full pass launch from the PMC counters, collected the way MI355X_MICROARCH.md prescribes: this
+    script once under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and once under `... --pmc WRITE_SIZE` (separate
+    passes, one chain step each, as child processes), FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE doubled (gfx950
+    reports half of the bytes of wide coalesced reads).  Launches are matched by dispatch order; "full" launches are
+    those that read AND write at least 90 % of the algorithmic bytes ``alg_bytes`` / 2 each (the ones next to an
+    aperture skip loads or stores and stay far below).  Returns (bytes or None, note)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not found"
+    series = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        tmp = tempfile.mkdtemp(prefix="paos_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", tmp, "-o", "pmc", "--output-format", "csv", "--",
+                   sys.executable, os.path.abspath(__file__), "--grid", str(grid), "--batch", str(batch),
+                   "--precision", precision, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras",
+                   "--no-traffic"]
+            run = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                                 stderr=subprocess.PIPE, timeout=600)
+            files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
+            if run.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (exit {run.returncode})"
+            per_dispatch = {}
+            with open(files[0]) as fh:
+                for row in csv.DictReader(fh):
+                    if "_pass_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                        k = int(row["Dispatch_Id"])
+                        per_dispatch[k] = per_dispatch.get(k, 0.0) + float(row["Counter_Value"])
+            series[counter] = [per_dispatch[k] for k in sorted(per_dispatch)]
+        except Exception as exc:  # noqa: BLE001 -- the bench line must come out whatever the profiler does
+            return None, f"rocprofv3 --pmc {counter}: {type(exc).__name__}: {exc}"
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    f, w = series["FETCH_SIZE"], series["WRITE_SIZE"]
+    if not f or len(f) != len(w):
+        return None, f"pass launches seen: {len(f)} (FETCH_SIZE run) vs {len(w)} (WRITE_SIZE run)"
+    half = 0.9 * alg_bytes / 2.0
+    pairs = [(2.0 * a * 1024.0, b * 1024.0) for a, b in zip(f, w)]
+    full = [r + wr for r, wr in pairs if r >= half and wr >= half]
+    reads = [r for r, wr in pairs if r >= half and wr >= half]
+    if not full:
+        return None, "no pass launch moved the algorithmic bytes (unexpected counter values)"
+    note = (f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE on one chain step of this workload (two child runs, "
+            f"counters in KiB, FETCH_SIZE x2 per MI355X_MICROARCH.md): mean over the {len(full)} of {len(f)} pass launches "
+            f"that skip nothing; read {sum(reads) / len(reads) / 1e9:.3f} GB + written "
+            f"{(sum(full) - sum(reads)) / len(full) / 1e9:.3f} GB per launch")
+    return sum(full) / len(full), note
+
+
 def roofline_block(m, n, nb, esz, dev, kernel_name):
     pass_bytes = 2 * esz * n * n * nb  # one pass over the batch: every element read + written once
     full = m["launches"] - m["pruned"]
@@ -179,8 +236,8 @@ def roofline_block(m, n, nb, esz, dev, kernel_name):
     return {
         "bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-        "traffic_note": "PMC counters are not readable in-process; per-kernel FETCH_SIZE / WRITE_SIZE of the default "
-                        "command (4096^2 fp64, 32 wavefronts per step) under rocprofv3: profiles/r02_pmc_hbm_traffic_bench.txt",
+        "traffic_note": "not measured in this run (--no-traffic, an `extra` entry, or N > 1); per-kernel FETCH_SIZE / WRITE_SIZE "
+                        "of the default command under rocprofv3: profiles/r02_pmc_hbm_traffic_bench.txt",
         "launches": full, "avg_launch_ms": full_ms, "algorithmic_bytes_per_launch": pass_bytes,
         "pruned": {"launches": m["pruned"], "avg_launch_ms": m["pruned_ms"] / max(m["pruned"], 1),
                    "what": "pass launches next to an aperture that skip the tiles / loads of rows or columns it has zeroed, "
@@ -196,6 +253,7 @@ def roofline_block(m, n, nb, esz, dev, kernel_name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC child runs that measure roofline.traffic")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--grid", type=int, default=4096)
@@ -329,6 +387,13 @@ def main():
                                                ("frugal_pass_kernel" if fr2 else "fused_pass_kernel") + " (every FFT pass launch)")}
                 dev2.close()
             out["extra"] = extra
+        if world == 1 and not args.no_traffic:
+            # every context of this process is closed by now; the child runs get the GPU to themselves
+            traffic, note = measure_traffic(n, nb, args.precision, out["roofline"]["algorithmic_bytes_per_launch"])
+            out["roofline"]["traffic"] = traffic
+            out["roofline"]["traffic_note"] = note
+            if traffic is not None:
+                out["roofline"]["traffic_over_algorithmic"] = traffic / out["roofline"]["algorithmic_bytes_per_launch"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n)
             out["cpu_baseline_parallel"] = cpu_parallel

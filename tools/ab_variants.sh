@@ -6,7 +6,7 @@ cp paos_amd/libpaoship.so $OUT/shipped.so
 for r in $(seq $ROUNDS); do
   for v in "$@"; do
     cp build/variants/$v.so paos_amd/libpaoship.so
-    python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras > $OUT/${v}_$r.json 2>/dev/null || exit 1
+    python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-traffic > $OUT/${v}_$r.json 2>/dev/null || exit 1
     python - $OUT/${v}_$r.json $v $r <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1])); r=d["roofline"]

@@ -8,14 +8,14 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profile_round
 rm -rf "$OUT" && mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras"
+BENCH="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --no-traffic"
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats --output-format csv -- $BENCH > "$OUT/bench_under_rocprof.log" 2>&1
 python3 "$ROOT/tools/kernel_stats_summary.py" "$OUT/stats" "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras (4096^2 c128, batch 32; 6 chain steps + ptp probe + copy yardstick)" > "$OUT/kernel_stats.txt"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o fetch --output-format csv -- python3 "$ROOT/bench.py" --steps 2 --warmup 0 --no-cpu-baseline --no-extras > "$OUT/bench_fetch.log" 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/write" -o write --output-format csv -- python3 "$ROOT/bench.py" --steps 2 --warmup 0 --no-cpu-baseline --no-extras > "$OUT/bench_write.log" 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o fetch --output-format csv -- python3 "$ROOT/bench.py" --steps 2 --warmup 0 --no-cpu-baseline --no-extras --no-traffic > "$OUT/bench_fetch.log" 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/write" -o write --output-format csv -- python3 "$ROOT/bench.py" --steps 2 --warmup 0 --no-cpu-baseline --no-extras --no-traffic > "$OUT/bench_write.log" 2>&1
 python3 "$ROOT/tools/pmc_summary.py" $(find "$OUT/fetch" -name "*counter_collection.csv" | head -1) > "$OUT/pmc_fetch.txt"
 python3 "$ROOT/tools/pmc_summary.py" $(find "$OUT/write" -name "*counter_collection.csv" | head -1) > "$OUT/pmc_write.txt"
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT -d "$OUT/sq" -o sq --output-format csv -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-extras > "$OUT/bench_sq.log" 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT -d "$OUT/sq" -o sq --output-format csv -- python3 "$ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-extras --no-traffic > "$OUT/bench_sq.log" 2>&1
 python3 "$ROOT/tools/pmc_summary.py" $(find "$OUT/sq" -name "*counter_collection.csv" | head -1) > "$OUT/pmc_sq.txt" 2>&1
 # keep the merge-back small
 find "$OUT" -name "*.csv" -size +8M -delete
@@ -23,8 +23,8 @@ cd "$ROOT"
 ./build/fftbench_new 10 > "$OUT/fftbench.txt" 2>&1
 ./build/timeline > "$OUT/timeline.txt" 2>&1
 python3 bench.py --steps 20 --warmup 5 > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
-python3 bench.py --precision fp32 --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_fp32.json" 2>&1
-PAOS_NO_PRUNE=1 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > "$OUT/bench_noprune.json" 2>&1
+python3 bench.py --precision fp32 --steps 10 --warmup 2 --no-cpu-baseline --no-traffic > "$OUT/bench_fp32.json" 2>&1
+PAOS_NO_PRUNE=1 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --no-traffic > "$OUT/bench_noprune.json" 2>&1
 python3 tests/reports/parity_report.py --sizes 1024 2048 > "$OUT/parity_gpu_vs_oracle.txt" 2>&1
 python3 tests/reports/run_configs.py > "$OUT/baseline_configs.txt" 2>&1
 head -14 "$OUT/kernel_stats.txt"
