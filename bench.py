@@ -278,6 +278,11 @@ def main():
     cpu_parallel = None
     if world == 1 and not args.no_cpu_baseline:
         cpu_parallel = cpu_baseline_parallel(args.grid, args.batch)
+    # the PMC child runs too: no process is started from one that holds a GPU context
+    traffic_result = None
+    if world == 1 and not args.no_traffic:
+        esz0 = 16 if args.precision == "fp64" else 8
+        traffic_result = measure_traffic(args.grid, args.batch, args.precision, 2 * esz0 * args.grid * args.grid * args.batch)
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     from paos_amd import _lib
@@ -387,9 +392,8 @@ def main():
                                                ("frugal_pass_kernel" if fr2 else "fused_pass_kernel") + " (every FFT pass launch)")}
                 dev2.close()
             out["extra"] = extra
-        if world == 1 and not args.no_traffic:
-            # every context of this process is closed by now; the child runs get the GPU to themselves
-            traffic, note = measure_traffic(n, nb, args.precision, out["roofline"]["algorithmic_bytes_per_launch"])
+        if traffic_result is not None:
+            traffic, note = traffic_result
             out["roofline"]["traffic"] = traffic
             out["roofline"]["traffic_note"] = note
             if traffic is not None:
