@@ -249,6 +249,11 @@ int main(int argc, char** argv) {
   bench_frugal<float, 4096, 1, 0, 0, 1>("cols single", 16, reps, pad);
   bench_frugal<float, 4096, 0, 0, 1, 2>("rows double 1 phase", 16, reps, pad);
   bench_frugal<float, 4096, 1, 0, 1, 2>("cols double 1 phase", 16, reps, pad);
+#ifdef PAOS_BENCH_ROWS4_F32
+  // complex64 row tiles of 4 rows (1024 threads, 64-byte pieces of 8 x 2 blocks when PAOS_BENCH_BR=8)
+  bench_frugal<float, 4096, 0, 0, 0, 1, 4, 1>("rows single 4-row tiles", 16, reps, pad);
+  bench_frugal<float, 4096, 0, 0, 1, 2, 4, 1>("rows double 1 phase 4-row tiles", 16, reps, pad);
+#endif
 #ifdef PAOS_BENCH_E32
   // complex64 with 32 points per thread over 4 x 4 blocks (128 B): 4-line tiles, 512 threads, whole lines on both axes
   bench_frugal<float, 4096, 0, 0, 0, 1, 4, 1, 32, 4>("rows single E=32 4x4 blocks", 16, reps, pad);
