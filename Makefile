@@ -2,7 +2,8 @@
 # runs the same commands.
 HIPCC ?= hipcc
 ARCH ?= gfx950
-HIPFLAGS = -O3 --offload-arch=$(ARCH) -ffp-contract=off -fPIC -std=c++17 -Wall -Wno-unused-function
+# EXTRA: experiment flags for every translation unit of the library, e.g. make EXTRA=-DPAOS_BR=8
+HIPFLAGS = -O3 --offload-arch=$(ARCH) -ffp-contract=off -fPIC -std=c++17 -Wall -Wno-unused-function $(EXTRA)
 CSRC = paos_amd/csrc
 LIB = paos_amd/libpaoship.so
 
