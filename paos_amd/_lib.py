@@ -12,7 +12,9 @@ import weakref
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpaoship.so")
+# PAOS_LIB: another build of the same library (an experiment variant from tools/build_variant.sh) -- for A/B runs
+# of bench.py; the shipped library is never overwritten.  The path is printed once so that no run uses one unawares.
+LIB_PATH = os.environ.get("PAOS_LIB") or os.path.join(_HERE, "libpaoship.so")
 
 PAOS_F64, PAOS_F32 = 0, 1
 SHAPE_ELLIPSE, SHAPE_RECT = 0, 1
@@ -105,6 +107,10 @@ def load():
             "`python -c 'import __graft_entry__ as g; g.build()'` (there is no CPU fallback)"
         )
     lib = ctypes.CDLL(LIB_PATH)
+    if os.environ.get("PAOS_LIB"):
+        import sys
+
+        print(f"paos_amd: using the library variant {LIB_PATH} (PAOS_LIB)", file=sys.stderr)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the header and the library disagree
         fn.restype = res

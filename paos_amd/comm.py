@@ -77,9 +77,15 @@ class Comm:
         rank = int(os.environ.get("RANK", "0"))
         local = int(os.environ.get("LOCAL_RANK", "0"))
         transport = transport or os.environ.get("PAOS_COMM_TRANSPORT", "rccl")
-        key = os.environ.get("PAOS_COMM_KEY") or "_".join(
-            [os.environ.get("TORCHELASTIC_RUN_ID", "job"), os.environ.get("MASTER_PORT", "0"),
-             os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")])
+        key = os.environ.get("PAOS_COMM_KEY")
+        if not key:
+            # the launcher's rendezvous port is what makes the key unique on the host (two jobs cannot both listen
+            # on it); without it concurrent jobs would meet in the same rendezvous file
+            if world > 1 and "MASTER_PORT" not in os.environ:
+                raise CommError("set PAOS_COMM_KEY (the same on every rank, unique per job on the host): the environment "
+                                "has no MASTER_PORT to derive a job key from")
+            key = "_".join([os.environ.get("TORCHELASTIC_RUN_ID", "job"), os.environ.get("MASTER_PORT", "0"),
+                            os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")])
         return cls(world, rank, local, transport, key=key, timeout=timeout)
 
     def _check(self, rc, what):

@@ -10,6 +10,7 @@
 
 #include <arpa/inet.h>
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <hip/hip_runtime_api.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
@@ -23,7 +24,10 @@
 #include <cerrno>
 #include <chrono>
 #include <cstdio>
+#include <condition_variable>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -68,6 +72,27 @@ bool recv_all(int fd, void* buf, size_t bytes) {
     bytes -= (size_t)k;
   }
   return true;
+}
+
+// receive timeout of a control-plane socket (0 = block for ever): a peer that never speaks must not stall a rank
+void set_recv_timeout(int fd, double seconds) {
+  timeval tv{};
+  tv.tv_sec = (long)seconds;
+  tv.tv_usec = (long)((seconds - (double)(long)seconds) * 1e6);
+  ::setsockopt(fd, SOL_SOCKET, SO_RCVTIMEO, &tv, sizeof(tv));
+}
+
+// What the two ends of a fresh control-plane connection tell each other, so that a stale rendezvous file whose
+// port now belongs to an unrelated listener (or a stray connect to rank 0's port) is noticed instead of trusted.
+constexpr unsigned kHelloMagic = 0x50414f53u;  // "PAOS"
+struct Hello {
+  unsigned magic, key_hash;
+  int nranks, rank;
+};
+unsigned fnv1a(const std::string& s) {
+  unsigned h = 2166136261u;
+  for (unsigned char ch : s) { h ^= ch; h *= 16777619u; }
+  return h;
 }
 
 // ---- the slice of the RCCL API this file uses, resolved at run time --------------------------
@@ -188,7 +213,7 @@ int sock_allgather(paos_comm* c, const double* send, int count, double* recv) {
   return sock_allgatherv(c, send, count, recv, std::vector<int>(c->nranks, count));
 }
 
-int connect_star(paos_comm* c, const std::string& path, double timeout_s) {
+int connect_star(paos_comm* c, const std::string& path, unsigned key_hash, double timeout_s) {
   const double deadline = now_s() + timeout_s;
   if (c->rank == 0) {
     c->listen_fd = ::socket(AF_INET, SOCK_STREAM, 0);
@@ -201,32 +226,48 @@ int connect_star(paos_comm* c, const std::string& path, double timeout_s) {
       return cfail(PAOS_EHIP, std::string("bind/listen on 127.0.0.1 failed: ") + strerror(errno));
     socklen_t len = sizeof(addr);
     ::getsockname(c->listen_fd, reinterpret_cast<sockaddr*>(&addr), &len);
-    const std::string tmp = path + ".tmp";
-    FILE* fh = std::fopen(tmp.c_str(), "w");
-    if (!fh) return cfail(PAOS_EINVAL, "cannot write the rendezvous file " + tmp);
-    std::fprintf(fh, "%d\n", (int)ntohs(addr.sin_port));
-    std::fclose(fh);
-    if (std::rename(tmp.c_str(), path.c_str()) != 0) return cfail(PAOS_EINVAL, "cannot publish the rendezvous file " + path);
+    // the port goes into a file of our own making (O_EXCL | O_NOFOLLOW: no symlink somebody planted is followed, mode
+    // 0600), published under the agreed name by rename
+    const std::string tmp = path + "." + std::to_string((long)::getpid()) + ".tmp";
+    ::unlink(tmp.c_str());
+    const int tfd = ::open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
+    if (tfd < 0) return cfail(PAOS_EINVAL, "cannot create the rendezvous file " + tmp + ": " + strerror(errno));
+    char text[32];
+    const int tlen = std::snprintf(text, sizeof(text), "%d\n", (int)ntohs(addr.sin_port));
+    const bool wrote = ::write(tfd, text, (size_t)tlen) == (ssize_t)tlen;
+    ::close(tfd);
+    if (!wrote) { ::unlink(tmp.c_str()); return cfail(PAOS_EINVAL, "cannot write the rendezvous file " + tmp); }
+    if (std::rename(tmp.c_str(), path.c_str()) != 0) { ::unlink(tmp.c_str()); return cfail(PAOS_EINVAL, "cannot publish the rendezvous file " + path); }
     c->fds.assign(c->nranks, -1);
     timeval tv{};
-    for (int got = 1; got < c->nranks; ++got) {
+    for (int got = 1; got < c->nranks;) {
       const double left = deadline - now_s();
       if (left <= 0) { ::unlink(path.c_str()); return cfail(PAOS_EHIP, "timed out waiting for the other ranks to connect"); }
       tv.tv_sec = (long)left; tv.tv_usec = (long)((left - (long)left) * 1e6);
       fd_set set;
       FD_ZERO(&set);
       FD_SET(c->listen_fd, &set);
-      if (::select(c->listen_fd + 1, &set, nullptr, nullptr, &tv) <= 0) { --got; continue; }
+      if (::select(c->listen_fd + 1, &set, nullptr, nullptr, &tv) <= 0) continue;
       const int fd = ::accept(c->listen_fd, nullptr, nullptr);
-      if (fd < 0) { --got; continue; }
-      int one = 1, peer = -1;
+      if (fd < 0) continue;
+      int one = 1;
       ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-      if (!recv_all(fd, &peer, sizeof(peer)) || peer <= 0 || peer >= c->nranks || c->fds[peer] != -1) {
+      set_recv_timeout(fd, 2.0);  // a connection that does not introduce itself at once is not a rank of this job
+      Hello hi{};
+      if (!recv_all(fd, &hi, sizeof(hi)) || hi.magic != kHelloMagic || hi.key_hash != key_hash || hi.nranks != c->nranks) {
+        ::close(fd);  // a stranger (port scan, a rank of another job reading a stale file): keep waiting
+        continue;
+      }
+      if (hi.rank <= 0 || hi.rank >= c->nranks || c->fds[hi.rank] != -1) {
         ::close(fd);
         ::unlink(path.c_str());
         return cfail(PAOS_EINVAL, "a peer announced an invalid or duplicate rank");
       }
-      c->fds[peer] = fd;
+      const Hello reply{kHelloMagic, key_hash, c->nranks, 0};
+      if (!send_all(fd, &reply, sizeof(reply))) { ::close(fd); continue; }
+      set_recv_timeout(fd, 0.0);
+      c->fds[hi.rank] = fd;
+      ++got;
     }
     ::unlink(path.c_str());
     return PAOS_OK;
@@ -249,9 +290,17 @@ int connect_star(paos_comm* c, const std::string& path, double timeout_s) {
       if (::connect(fd, reinterpret_cast<sockaddr*>(&addr), sizeof(addr)) == 0) {
         int one = 1;
         ::setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-        if (!send_all(fd, &c->rank, sizeof(c->rank))) { ::close(fd); return cfail(PAOS_EHIP, "announcing the rank to rank 0 failed"); }
-        c->fds.assign(1, fd);
-        return PAOS_OK;
+        // introduce ourselves and insist on rank 0's answer: whoever listens on a port named by a stale file
+        // does not know the job's key, and the connection is dropped and retried
+        const Hello hi{kHelloMagic, key_hash, c->nranks, c->rank};
+        Hello reply{};
+        set_recv_timeout(fd, 2.0);
+        if (send_all(fd, &hi, sizeof(hi)) && recv_all(fd, &reply, sizeof(reply)) && reply.magic == kHelloMagic &&
+            reply.key_hash == key_hash && reply.nranks == c->nranks && reply.rank == 0) {
+          set_recv_timeout(fd, 0.0);
+          c->fds.assign(1, fd);
+          return PAOS_OK;
+        }
       }
       ::close(fd);
     }
@@ -271,7 +320,7 @@ int paos_comm_transport(const paos_comm* c) { return c ? c->transport : -1; }
 
 int paos_comm_destroy(paos_comm* c) {
   if (!c) return PAOS_OK;
-  if (c->transport == PAOS_COMM_RCCL) {
+  if (c->stream || c->dbuf || c->nccl) {  // whatever the transport ended up being: a fall-back keeps its stream
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->nccl) (void)c->rccl.CommDestroy(c->nccl);
@@ -301,7 +350,7 @@ int paos_comm_init_rank(int nranks, int rank, int device, int transport, const c
     std::string safe;
     for (const char* p = key; *p; ++p) safe += (std::isalnum((unsigned char)*p) || *p == '-' || *p == '_' || *p == '.') ? *p : '_';
     const std::string path = std::string(rendezvous_dir && rendezvous_dir[0] ? rendezvous_dir : "/tmp") + "/paos_comm_" + safe;
-    rc = connect_star(c, path, timeout_s);
+    rc = connect_star(c, path, fnv1a(safe), timeout_s);
     if (rc) { paos_comm_destroy(c); return rc; }
   }
   if (transport == PAOS_COMM_RCCL) {
@@ -331,8 +380,48 @@ int paos_comm_init_rank(int nranks, int rank, int device, int transport, const c
       const std::string keep = g_comm_err; paos_comm_destroy(c); return cfail(PAOS_EHIP, keep);
     }
     if (all_ok) {
-      if (nccl_check(c, c->rccl.CommInitRank(&c->nccl, nranks, id, rank), "ncclCommInitRank")) { ok = false; why = g_comm_err; c->nccl = nullptr; }
+      // ncclCommInitRank is a collective without a timeout: if one rank never enters it (it died after the id
+      // broadcast, its device is wedged) the others would sit in it for ever and the vote below would never be
+      // reached.  It runs on a helper thread under a watchdog; on expiry this rank gives up with an error (the
+      // thread cannot be cancelled: it is left behind and the process is expected to exit).
+      struct InitState {
+        std::mutex mu;
+        std::condition_variable cv;
+        bool done = false;
+        int rc = 0;
+        void* comm = nullptr;
+      };
+      auto st = std::make_shared<InitState>();
+      auto init_fn = c->rccl.CommInitRank;
+      std::thread([st, init_fn, nranks, id, rank, device] {
+        (void)hipSetDevice(device);
+        void* comm = nullptr;
+        const int rc_init = init_fn(&comm, nranks, id, rank);
+        std::lock_guard<std::mutex> lock(st->mu);
+        st->rc = rc_init; st->comm = comm; st->done = true;
+        st->cv.notify_all();
+      }).detach();
+      bool finished;
+      {
+        std::unique_lock<std::mutex> lock(st->mu);
+        finished = st->cv.wait_for(lock, std::chrono::duration<double>(timeout_s), [&] { return st->done; });
+      }
+      if (!finished) {
+        // the communicator object stays allocated: the helper thread may still touch what it was given
+        for (int fd : c->fds)
+          if (fd >= 0) ::close(fd);
+        c->fds.clear();
+        return cfail(PAOS_EHIP, "ncclCommInitRank did not return within " + std::to_string((int)timeout_s) +
+                                    " s (a rank is missing or its device is stuck): giving up");
+      }
+      if (nccl_check(c, st->rc, "ncclCommInitRank")) { ok = false; why = g_comm_err; c->nccl = nullptr; }
+      else c->nccl = st->comm;
+      // the vote: bounded too, a rank whose watchdog fired will not take part
+      for (int fd : c->fds)
+        if (fd >= 0) set_recv_timeout(fd, timeout_s);
       all_ok = everyone_ok(ok);
+      for (int fd : c->fds)
+        if (fd >= 0) set_recv_timeout(fd, 0.0);
     }
     if (!all_ok) {
       if (c->nccl) { (void)c->rccl.CommDestroy(c->nccl); c->nccl = nullptr; }

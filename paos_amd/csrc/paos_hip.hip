@@ -773,7 +773,9 @@ int run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double*
   const double* dblocks = nullptr;
   // everything this program pushes stays live until its last pass has run: the block table and,
   // per pass, one FrugalItem record per batch item (each push is rounded up to 16 doubles)
-  const size_t per_pass = ((size_t)c->batch * sizeof(FrugalItem) / sizeof(double) + 15) & ~size_t(15);
+  // plus, for a pass that carries an aperture, the [batch] "shares its line records" vector (launch_lowered)
+  const size_t per_pass = (((size_t)c->batch * sizeof(FrugalItem) / sizeof(double) + 15) & ~size_t(15)) +
+                          (((size_t)c->batch + 15) & ~size_t(15));
   int rc = arena_reserve(c, (size_t)n_blocks * c->batch * FP_STRIDE + 16 + (size_t)n_passes * per_pass);
   if (rc) return rc;
   rc = arena_push(c, blocks, (size_t)n_blocks * c->batch * FP_STRIDE, &dblocks);

@@ -77,11 +77,11 @@ class ModelDevice:
 
     def psf_keep(self):
         self.log.append(("psf_keep", None))
+        self.psf = self.u.real**2 + self.u.imag**2
 
     def psf_keep_power(self):
         self.psf_keep()
         return self.norm2_enqueue()
-        self.psf = np.abs(self.u) ** 2
 
     def psf_fetch(self, item=0):
         return self.psf[item].copy()

@@ -287,3 +287,122 @@ def test_rccl_bring_up_failure_falls_back_to_tcp_on_every_rank():
         assert transport == "socket"
         assert text == b"still here"
         assert slowest == 1.0
+
+
+def _late_pair_worker(rank, world, key, out, rdv):
+    import sys
+    import time
+
+    sys.path.insert(0, ROOT)
+    from paos_amd.comm import Comm
+
+    if rank == 0:
+        time.sleep(1.0)  # rank 1 meets the stale file (and its unrelated listener) first
+    comm = Comm(world, rank, 0, "socket", key=key, rendezvous_dir=rdv, timeout=60)
+    try:
+        out.put((rank, comm.bcast_blob(b"fresh" if rank == 0 else None, root=0), comm.max(float(rank))))
+    finally:
+        comm.close()
+
+
+def test_stale_rendezvous_file_and_stray_connections_are_not_trusted(tmp_path):
+    """A rendezvous file left behind by a dead job may name a port that now belongs to somebody else: a peer
+    that connects there gets no valid handshake and keeps looking until rank 0 of ITS job has published the
+    real port.  A stranger connecting to rank 0's port (and saying nothing) does not stall or fail rank 0."""
+    import multiprocessing as mp
+    import socket
+    import threading
+    import uuid
+
+    key = "pytest_" + uuid.uuid4().hex
+    stranger = socket.socket()
+    stranger.bind(("127.0.0.1", 0))
+    stranger.listen(8)
+    stale_port = stranger.getsockname()[1]
+    (tmp_path / f"paos_comm_{key}").write_text(f"{stale_port}\n")
+    stop = threading.Event()
+    visits = []
+
+    def serve():  # accepts, answers with junk, hangs up
+        stranger.settimeout(0.2)
+        while not stop.is_set():
+            try:
+                conn, _ = stranger.accept()
+            except OSError:
+                continue
+            visits.append(1)
+            try:
+                conn.sendall(b"\x00" * 16)
+            finally:
+                conn.close()
+
+    th = threading.Thread(target=serve, daemon=True)
+    th.start()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_late_pair_worker, args=(r, 2, key, out, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+
+    def poke():  # while rank 0 waits for its peer: connect to whatever port the file names now, say nothing
+        import time
+
+        for _ in range(200):
+            try:
+                port = int((tmp_path / f"paos_comm_{key}").read_text())
+            except (OSError, ValueError):
+                time.sleep(0.01)
+                continue
+            if port != stale_port:
+                try:
+                    s = socket.create_connection(("127.0.0.1", port), timeout=1)
+                    time.sleep(0.5)
+                    s.close()
+                except OSError:
+                    pass
+                return
+            time.sleep(0.01)
+
+    pk = threading.Thread(target=poke, daemon=True)
+    pk.start()
+    results = sorted(out.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    stop.set()
+    th.join(timeout=5)
+    stranger.close()
+    assert visits, "rank 1 never met the stale port: the test did not exercise the handshake"
+    assert results == [(0, b"fresh", 1.0), (1, b"fresh", 1.0)]
+
+
+def test_from_env_wants_a_job_key(monkeypatch):
+    from paos_amd.comm import Comm, CommError
+
+    for name in ("PAOS_COMM_KEY", "MASTER_PORT", "TORCHELASTIC_RUN_ID"):
+        monkeypatch.delenv(name, raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "1")
+    with pytest.raises(CommError, match="PAOS_COMM_KEY"):
+        Comm.from_env(transport="socket", timeout=1)
+
+
+def test_model_device_keeps_the_psf():
+    """run_batch(keep_psf=True) on the NumPy model of the device: the PSF of the last surface is what
+    psf_fetch returns (the model mirrors paos_psf_keep / paos_psf_keep_power)."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from fakes import ModelDevice
+    from paos_amd.chains import syn20_chain, syn20_wavelength
+    from paos_amd.run import run_batch
+
+    wls = [syn20_wavelength(0), syn20_wavelength(200)]
+    for power in (True, False):
+        dev = ModelDevice(64, 2)
+        res = run_batch(1.0, wls, 64, 4, {"us": 0.0, "ut": 0.0}, [syn20_chain(), syn20_chain()], outputs=("psf",),
+                        dev=dev, keep_psf=True, power=power)
+        for i in range(2):
+            assert np.array_equal(dev.psf_fetch(i), res[i][20]["psf"])
+            if power:
+                assert abs(res[i][20]["power"] - res[i][20]["psf"].sum()) < 1e-13

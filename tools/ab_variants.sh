@@ -1,12 +1,11 @@
 #!/bin/bash
 # ab_variants.sh ROUNDS NAME...: bench.py (4096^2 complex128, 20 steps) with each build/variants/NAME.so in turn, ROUNDS times.
+# The variant is selected through PAOS_LIB (paos_amd/_lib.py), the shipped library is never overwritten.
 ROUNDS=$1; shift
 OUT=gpurun_out/ab; mkdir -p $OUT
-cp paos_amd/libpaoship.so $OUT/shipped.so
 for r in $(seq $ROUNDS); do
   for v in "$@"; do
-    cp build/variants/$v.so paos_amd/libpaoship.so
-    python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-traffic > $OUT/${v}_$r.json 2>/dev/null || exit 1
+    PAOS_LIB=$PWD/build/variants/$v.so python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras --no-traffic > $OUT/${v}_$r.json 2>$OUT/${v}_$r.err || { tail -3 $OUT/${v}_$r.err; exit 1; }
     python - $OUT/${v}_$r.json $v $r <<'PY'
 import json,sys
 d=json.load(open(sys.argv[1])); r=d["roofline"]
@@ -14,4 +13,3 @@ print(f"{sys.argv[2]:10s} round {sys.argv[3]}: {d['value']:.1f} wavefronts/s  fu
 PY
   done
 done
-cp $OUT/shipped.so paos_amd/libpaoship.so; rm -f $OUT/shipped.so
