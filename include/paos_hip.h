@@ -62,6 +62,24 @@ typedef struct {
   paos_pw_op pre[PAOS_MAX_PW], mid[PAOS_MAX_PW], post[PAOS_MAX_PW];
 } paos_pass;
 
+/* Options of paos_run_program (round 3); a NULL pointer or all zeros = paos_run_passes.
+ *   live_rows      [batch][2] or NULL: on entry the rows of item i outside [lo, hi) are zero (see
+ *                  paos_run_passes_live) ...
+ *   rows_stale     != 0: ... or rather, they hold old data that STANDS for zeros (what paos_start_rows leaves):
+ *                  no pass reads them; the program consumes them (a pass along columns rewrites the whole field) or,
+ *                  where it cannot, writes the zeros itself before it ends.
+ *   final_intensity  != 0: the caller wants |u|^2 (the PSF, plot.py:125-130) and its sum of the field the program
+ *                  ends with, not the field: the last pass stores |u|^2 into the context's PSF buffer (as
+ *                  paos_psf_keep_power would afterwards) and *power_ticket receives a ticket for paos_norm2_fetch.
+ *                  The field content is UNDEFINED after the call.  (Saves writing the last field and reading it
+ *                  back: 32 B/px.) */
+typedef struct {
+  const double* live_rows;
+  int rows_stale;
+  int final_intensity;
+  int* power_ticket;
+} paos_program_opts;
+
 /* ---- lifetime -------------------------------------------------------------------- */
 /* WFO.__init__ (wfo.py:99-120): allocates `batch` n x n fields (n = 2^k, 64..4096).
  * The field content is undefined until paos_fill / paos_import. */
@@ -92,6 +110,15 @@ int paos_fill(paos_ctx* ctx, double re, double im);
  * is summed from the weights alone and the field is written once (16 B/px instead of ~72).
  * aperture: [batch][PAOS_APERTURE_STRIDE] (enable = 0: no aperture on that item); stop may be NULL. */
 int paos_start(paos_ctx* ctx, double re, double im, int shape, const double* aperture, const double* stop);
+/* paos_start that writes only the rows [write_rows[2 i], write_rows[2 i + 1]) of item i (rounded outward to
+ * whole blocks of rows; they must contain every row the aperture leaves non-zero).  The other rows keep whatever
+ * they held and merely STAND for the zeros wfo.py:273-276 would have put there: until a pass program has
+ * consumed them (paos_run_program with rows_stale) only paos_zernike, paos_norm2_enqueue_rows and
+ * paos_zero_outside_rows may touch the field.  Saves three quarters of the first field write at zoom 4. */
+int paos_start_rows(paos_ctx* ctx, double re, double im, int shape, const double* aperture, const double* stop,
+                    const double* write_rows);
+/* make such rows real zeros (whole blocks of rows outside [lo, hi) of every item are cleared) */
+int paos_zero_outside_rows(paos_ctx* ctx, const double* live_rows);
 /* host row-major complex128 -> batch item (WFO._wfo assignment in notebooks/tests) */
 int paos_import(paos_ctx* ctx, int item, const void* host_c128);
 /* batch item -> host.  what = FIELD: complex128 copy (wfo.py:162-164); AMPLITUDE: |u|
@@ -100,7 +127,7 @@ int paos_import(paos_ctx* ctx, int item, const void* host_c128);
 int paos_export(paos_ctx* ctx, int item, int what, void* host_out);
 
 /* PSF = |u|^2 (plot.py:125-130) of EVERY batch item written to a device buffer and kept there
- * (row-major doubles): the final intensity write of a propagation whose results are consumed on
+ * (doubles, laid out like the field; paos_psf_fetch hands out row-major arrays): the final intensity write of a propagation whose results are consumed on
  * the GPU or fetched later.  paos_psf_fetch copies one item's PSF to the host (synchronises). */
 int paos_psf_keep(paos_ctx* ctx);
 /* paos_psf_keep and paos_norm2_enqueue of the same field in one sweep (the saved last surface of a chain:
@@ -133,6 +160,9 @@ int paos_norm2(paos_ctx* ctx, double* host_out);
  * outstanding: one more paos_norm2_enqueue fails with PAOS_EINVAL until a ticket is fetched, and
  * a ticket can be fetched once. */
 int paos_norm2_enqueue(paos_ctx* ctx, int* ticket);
+/* paos_norm2_enqueue that reads only the rows [lo, hi) of each item: the caller knows the others to be zero
+ * (or to stand for zeros, paos_start_rows).  Bit-identical to the full sum of the zero-filled field. */
+int paos_norm2_enqueue_rows(paos_ctx* ctx, const double* live_rows, int* ticket);
 int paos_norm2_fetch(paos_ctx* ctx, int ticket, double* host_out);
 /* give a ticket back without reading it (no synchronisation) */
 int paos_norm2_release(paos_ctx* ctx, int ticket);
@@ -182,6 +212,10 @@ int paos_copy_yardstick(paos_ctx* ctx, int reps, double* ms_per_launch, double* 
 int paos_ctx_set_pruning(paos_ctx* ctx, int on);
 int paos_run_passes_live(paos_ctx* ctx, const paos_pass* passes, int n_passes, const double* blocks,
                          int n_blocks, const double* live_rows);
+/* paos_run_passes with options (paos_program_opts above): entry rows that are zero or stand for zeros, and the
+ * PSF + power of the final field instead of the field itself (run.py:222-224 -> plot.py:125-130 in one sweep). */
+int paos_run_program(paos_ctx* ctx, const paos_pass* passes, int n_passes, const double* blocks, int n_blocks,
+                     const paos_program_opts* opts);
 /* WFO.zernikes (wfo.py:620-652) with Zernike polynomials (zernike.py:85-109,245-247):
  * u *= exp(2 pi i wfe / wl) inside rho <= 1.  `table` holds the Jacobi recurrence
  * constants [(nmax+1)][kdim][3]; `params` the per-item blocks (PAOS_ZERNIKE_HEAD +

@@ -31,6 +31,12 @@ class PwOp(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int), ("flags", ctypes.c_int), ("block", ctypes.c_int)]
 
 
+class ProgramOpts(ctypes.Structure):
+    """paos_program_opts of include/paos_hip.h"""
+    _fields_ = [("live_rows", ctypes.POINTER(ctypes.c_double)), ("rows_stale", ctypes.c_int),
+                ("final_intensity", ctypes.c_int), ("power_ticket", ctypes.POINTER(ctypes.c_int))]
+
+
 class Pass(ctypes.Structure):
     """paos_pass of include/paos_hip.h"""
     _fields_ = [("axis", ctypes.c_int), ("fft1", ctypes.c_int), ("fft2", ctypes.c_int),
@@ -87,6 +93,11 @@ SYMBOLS = {
     "paos_zernike_gram": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, _dbl_p, _dbl_p, ctypes.c_int,
                                          ctypes.c_int, _dbl_p, ctypes.c_int, _dbl_p]),
     "paos_zernike_pupil": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, _dbl_p, _dbl_p, ctypes.c_int, _dbl_p]),
+    "paos_start_rows": (ctypes.c_int, [_c_ctx, ctypes.c_double, ctypes.c_double, ctypes.c_int, _dbl_p, _dbl_p, _dbl_p]),
+    "paos_zero_outside_rows": (ctypes.c_int, [_c_ctx, _dbl_p]),
+    "paos_norm2_enqueue_rows": (ctypes.c_int, [_c_ctx, _dbl_p, ctypes.POINTER(ctypes.c_int)]),
+    "paos_run_program": (ctypes.c_int, [_c_ctx, ctypes.POINTER(Pass), ctypes.c_int, _dbl_p, ctypes.c_int,
+                                        ctypes.POINTER(ProgramOpts)]),
 }
 
 _lib = None
@@ -330,10 +341,25 @@ class DeviceFields:
         self._check(self._lib.paos_norm2(self._ctx, _dptr(out)), "paos_norm2")
         return out
 
-    def norm2_enqueue(self):
+    def _rows(self, rows):
+        lr = np.ascontiguousarray(rows, dtype=np.float64)
+        if lr.shape != (self.batch, 2):
+            raise ValueError("row ranges must be [batch][2]")
+        return lr
+
+    def norm2_enqueue(self, live_rows=None):
+        """``live_rows`` ([batch][2], optional): rows outside [lo, hi) are zero (or stand for zeros) and are not read."""
         t = ctypes.c_int(-1)
+        if live_rows is not None:
+            self._check(self._lib.paos_norm2_enqueue_rows(self._ctx, _dptr(self._rows(live_rows)), ctypes.byref(t)),
+                        "paos_norm2_enqueue_rows")
+            return t.value
         self._check(self._lib.paos_norm2_enqueue(self._ctx, ctypes.byref(t)), "paos_norm2_enqueue")
         return t.value
+
+    def zero_outside_rows(self, live_rows):
+        """Rows that merely stand for zeros (``start(..., write_rows=...)``) become zeros."""
+        self._check(self._lib.paos_zero_outside_rows(self._ctx, _dptr(self._rows(live_rows))), "paos_zero_outside_rows")
 
     def norm2_fetch(self, ticket):
         out = np.empty(self.batch, dtype=np.float64)
@@ -392,10 +418,12 @@ class DeviceFields:
         """Dead-line pruning of the pass programs on (default) / off -- results are identical."""
         self._check(self._lib.paos_ctx_set_pruning(self._ctx, 1 if on else 0), "paos_ctx_set_pruning")
 
-    def run_passes(self, passes, blocks, live_rows=None):
+    def run_passes(self, passes, blocks, live_rows=None, rows_stale=False, final_intensity=False):
         """passes: list of dicts {axis, fft1, fft2, pre, mid, post} with operator tuples
         (kind, flags, block); blocks: array [n_blocks][batch][PHASE_STRIDE].  ``live_rows``
-        ([batch][2], optional): rows outside [lo, hi) of item i are exactly zero in memory."""
+        ([batch][2], optional): rows outside [lo, hi) of item i are exactly zero in memory -- or, with
+        ``rows_stale``, hold old data that stands for zeros.  ``final_intensity``: the last pass writes |u|^2 to
+        the PSF buffer instead of the field (which is undefined afterwards); returns the power ticket."""
         b = np.ascontiguousarray(blocks, dtype=np.float64)
         if b.ndim != 3 or b.shape[1:] != (self.batch, PHASE_STRIDE):
             raise ValueError("blocks must be [n_blocks][batch][5]")
@@ -410,15 +438,22 @@ class DeviceFields:
                 lst = getattr(dst, name)
                 for i, (kind, flags, block) in enumerate(ops):
                     lst[i].kind, lst[i].flags, lst[i].block = kind, flags, block
+        if rows_stale or final_intensity:
+            lr = self._rows(live_rows) if live_rows is not None else None
+            ticket = ctypes.c_int(-1)
+            opts = ProgramOpts(_dptr(lr) if lr is not None else None, 1 if (rows_stale and lr is not None) else 0,
+                               1 if final_intensity else 0, ctypes.pointer(ticket))
+            self._check(self._lib.paos_run_program(self._ctx, arr, len(passes), _dptr(b), b.shape[0], ctypes.byref(opts)),
+                        "paos_run_program")
+            return ticket.value if final_intensity else None
         if live_rows is not None:
-            lr = np.ascontiguousarray(live_rows, dtype=np.float64)
-            if lr.shape != (self.batch, 2):
-                raise ValueError("live_rows must be [batch][2]")
+            lr = self._rows(live_rows)
             self._check(self._lib.paos_run_passes_live(self._ctx, arr, len(passes), _dptr(b), b.shape[0], _dptr(lr)),
                         "paos_run_passes_live")
-            return
+            return None
         self._check(self._lib.paos_run_passes(self._ctx, arr, len(passes), _dptr(b), b.shape[0]),
                     "paos_run_passes")
+        return None
 
     def zernike(self, nmax, kdim, table, blocks, want_wfe=False, pupil=False):
         """``pupil=True``: only pixels inside the pupil set by pupil_aperture / pupil_upload."""
@@ -433,8 +468,9 @@ class DeviceFields:
                     "paos_zernike_pupil" if pupil else "paos_zernike")
         return out
 
-    def start(self, value, shape, blocks, stop=None):
-        """fill(value) + aperture(shape, blocks) + make_stop(stop) in one write of the field."""
+    def start(self, value, shape, blocks, stop=None, write_rows=None):
+        """fill(value) + aperture(shape, blocks) + make_stop(stop) in one write of the field.  ``write_rows``
+        ([batch][2]): only these rows are written, the others stand for zeros (see paos_start_rows)."""
         b = np.ascontiguousarray(blocks, dtype=np.float64)
         if b.shape != (self.batch, APERTURE_STRIDE):
             raise ValueError("aperture blocks must be [batch][8]")
@@ -442,6 +478,11 @@ class DeviceFields:
         if st is not None and st.shape != (self.batch,):
             raise ValueError("stop flags must be [batch]")
         v = complex(value)
+        if write_rows is not None:
+            self._check(self._lib.paos_start_rows(self._ctx, v.real, v.imag, int(shape), _dptr(b),
+                                                  _dptr(st) if st is not None else None, _dptr(self._rows(write_rows))),
+                        "paos_start_rows")
+            return
         self._check(self._lib.paos_start(self._ctx, v.real, v.imag, int(shape), _dptr(b),
                                          _dptr(st) if st is not None else None), "paos_start")
 

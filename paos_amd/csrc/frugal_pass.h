@@ -84,6 +84,11 @@ struct FrugalArgs {
   const void* tw;
   const FrugalItem* items;  // [batch]
   unsigned pitch, item_stride;
+  // STORE = 1 (the last pass of a program whose caller wants the PSF, not the field -- plot.py:125-130): |u|^2 goes
+  // to `psf` (doubles, the field's own blocked layout and item stride) and its sum over the workgroup's tile to
+  // `psf_partial[item * gridDim.x + blockIdx.x]`; the field itself is not written
+  double* psf;
+  double* psf_partial;
 #if PAOS_STAMPS
   unsigned long long* stamps;  // [gridDim.y][gridDim.x][kStampSlots]
 #endif
@@ -317,10 +322,11 @@ __device__ __forceinline__ void frugal_fft(cx<T>* v, void* lds, int t, const cx<
 }
 
 // dynamic LDS of one workgroup: exchange areas | stage twiddles | (c128 with phases) circle table
-template <typename T, int N, int LINES, int TILES, bool SPLIT, int KPRE, int KMID, int E = 16>
+constexpr size_t kStoreScratch = 16 * sizeof(double);  // one partial sum per wave (<= 16 waves) of a STORE = 1 workgroup
+template <typename T, int N, int LINES, int TILES, bool SPLIT, int KPRE, int KMID, int E = 16, int STORE = 0>
 constexpr size_t frugal_lds_bytes() {
   return (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT, LINES>() + twiddle_lds_entries<N, E>() * sizeof(cx<T>) +
-         (sizeof(T) == 8 ? kCircleLds * sizeof(cx<double>) : 0);
+         (sizeof(T) == 8 ? kCircleLds * sizeof(cx<double>) : 0) + (STORE ? kStoreScratch : 0);
 }
 
 // Waves per SIMD the kernel is compiled for.  N = 4096: 512-thread workgroups, two per CU (their
@@ -345,8 +351,23 @@ constexpr int frugal_min_waves() {
   return THREADS >= 512 ? 4 : PAOS_MINW_SMALL;
 }
 
+// sum |u|^2 of the tile, one value per workgroup (STORE = 1): lanes by shuffles, waves through the scratch doubles
+template <int THREADS>
+__device__ __forceinline__ void tile_power_out(double acc, double* scratch, double* out) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < THREADS / 64; ++w) s += scratch[w];
+    *out = s;
+  }
+}
+
 template <typename T, int N, int E, int LINES, int TILES, int AXIS, int BR, int BC, bool SPLIT,
-          int KPRE, int KMID, int NFFT>
+          int KPRE, int KMID, int NFFT, int STORE = 0>
 __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, TILES * LINES * N / E>()))
     frugal_pass_kernel(FrugalArgs a) {
   const int item = blockIdx.y;
@@ -381,6 +402,13 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   {  // a workgroup of dead lines only: nothing to transform (its tiles are consecutive lines)
     const int l0 = TILES == 1 ? (AXIS == 0 ? m.row0 : m.col0) : (int)blockIdx.x * (TILES * LINES);
     if (l0 + TILES * LINES <= (int)h_line_lo || l0 >= (int)h_line_hi) {
+      if constexpr (STORE == 1) {  // the PSF of a dead tile is zero (and so is its share of the power)
+        double* ps = a.psf + (size_t)item * a.item_stride;
+#pragma unroll
+        for (int k = 0; k < E; ++k) ps[m.base + (unsigned)k * m.stride] = 0.0;
+        if (threadIdx.x == 0) a.psf_partial[(size_t)item * gridDim.x + blockIdx.x] = 0.0;
+        return;
+      }
       if (h_line_fill != 0.0) {
 #pragma unroll
         for (int k = 0; k < E; ++k)
@@ -529,6 +557,22 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
     }
   }
   PAOS_STAMP(5);
+  if constexpr (STORE == 1) {
+    // |u|^2 as export_kernel forms it (x x + y y, unfused), 8 B per element at the element's own offset; the sum in
+    // a fixed order: element by element per thread, lanes, waves
+    double* ps = a.psf + (size_t)item * a.item_stride;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+      const double x = (double)v[k].x, y = (double)v[k].y;
+      const double w = __dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y));
+      ps[m.base + (unsigned)k * m.stride] = w;
+      acc += w;
+    }
+    double* scratch = reinterpret_cast<double*>(smem + frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, E, 0>());
+    tile_power_out<TILES * LINES * N / E>(acc, scratch, a.psf_partial + (size_t)item * gridDim.x + blockIdx.x);
+    return;
+  }
   const int slo = (int)h_spos_lo, shi = (int)h_spos_hi;
   if (slo <= 0 && shi >= N) {  // wave-uniform: everything is stored
 #pragma unroll

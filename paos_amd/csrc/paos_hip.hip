@@ -69,7 +69,9 @@ struct paos_ctx {
   int device = 0, n = 0, batch = 0, precision = 0;
   unsigned pitch = 0, item_stride = 0;
   hipStream_t stream = nullptr;
-  double* psf = nullptr;  // batch x n x n intensities kept on the device (paos_psf_keep)
+  double* psf = nullptr;  // batch x item_stride intensities kept on the device, blocked like the field (paos_psf_keep)
+  double* psf_partial = nullptr;  // per-workgroup sums of a pass that stores the PSF (paos_run_program: final_intensity)
+  int psf_nparts = 0;
   void* bounce[2] = {nullptr, nullptr};  // pinned host buffers for device -> pageable host copies
   hipEvent_t bounce_ev[2] = {nullptr, nullptr};
   void* field = nullptr;
@@ -463,7 +465,7 @@ bool mask_live_range(const paos_ctx* c, const double* q, const double* q2, int a
 // dense again.  Virtual zeros must be consumed by such a pass before the program ends; where none
 // follows, the last pass that skipped them writes zeros instead (line_fill).
 void plan_pruning(const paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks,
-                  std::vector<LoweredPass>& low, const double* entry_rows) {
+                  std::vector<LoweredPass>& low, const double* entry_rows, bool entry_stale) {
   const int n = c->n;
   for (int it = 0; it < c->batch; ++it) {
     bool zl = false, virt = false;
@@ -473,7 +475,8 @@ void plan_pruning(const paos_ctx* c, const paos_pass* passes, int n_passes, cons
       l = l < 0 ? 0 : (l / BR) * BR;
       h = h > n ? n : ((h + BR - 1) / BR) * BR;
       if (h > n) h = n;
-      if (l < h && (l > 0 || h < n)) { zl = true; axis = 0; lo = l; hi = h; }
+      // entry_stale: the rows outside hold old data that STANDS for zeros (paos_start_rows): virtual from the start
+      if (l < h && (l > 0 || h < n)) { zl = true; axis = 0; lo = l; hi = h; virt = entry_stale; }
     }
     for (int q = 0; q < n_passes; ++q) {
       FrugalItem& fi = low[q].items[it];
@@ -519,7 +522,7 @@ void plan_pruning(const paos_ctx* c, const paos_pass* passes, int n_passes, cons
   }
 }
 
-template <typename T, int N, int AXIS, int KPRE, int KMID, int NFFT>
+template <typename T, int N, int AXIS, int KPRE, int KMID, int NFFT, int STORE = 0>
 int frugal_launch(paos_ctx* c, const FrugalArgs& a) {
   using C = FftCfg<T, N>;
   constexpr int LINES = AXIS == 0 ? C::ROW_LINES : C::COL_LINES;
@@ -528,8 +531,8 @@ int frugal_launch(paos_ctx* c, const FrugalArgs& a) {
   // fits whole (the same 35 KiB) and so needs half the barriers
   constexpr bool SPLIT = sizeof(T) == 8;
   const dim3 grid(N / LINES / TILES, c->batch), block(TILES * LINES * N / C::E);
-  const size_t lds = frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, C::E>();
-  auto kern = frugal_pass_kernel<T, N, C::E, LINES, TILES, AXIS, BR, C::BC, SPLIT, KPRE, KMID, NFFT>;
+  const size_t lds = frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, C::E, STORE>();
+  auto kern = frugal_pass_kernel<T, N, C::E, LINES, TILES, AXIS, BR, C::BC, SPLIT, KPRE, KMID, NFFT, STORE>;
   {
     int rc = opt_in_lds(c, (const void*)kern, lds);
     if (rc) return rc;
@@ -548,10 +551,22 @@ int frugal_launch(paos_ctx* c, const FrugalArgs& a) {
   return PAOS_OK;
 }
 
+// workgroups per batch item of a frugal pass along `axis` (the partial sums of a PSF-storing pass)
+template <typename T, int N>
+int frugal_groups(int axis) {
+  using C = FftCfg<T, N>;
+  return axis == 0 ? N / C::ROW_LINES / C::ROW_TILES : N / C::COL_LINES / C::COL_TILES;
+}
+
 template <typename T, int N, int AXIS, int KPRE, int KMID>
 int frugal_nfft(paos_ctx* c, const FrugalArgs& a, int nfft) {
   // (the digit-swapped two-transform variant NFFT = 3 of frugal_pass.h is built by tools/fftbench.hip only:
   // measured in round 2 with parity unchanged and no gain, profiles/r02_fftbench_digit_swapped_experiment.txt)
+  if constexpr (KPRE == 0 && KMID <= 1) {  // the shapes a chain can end on: also built with the PSF store
+    if (a.psf) return nfft >= 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2, 1>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1, 1>(c, a);
+  } else {
+    if (a.psf) return fail(c, PAOS_EUNSUPPORTED, "no PSF-storing build of this pass shape");
+  }
   return nfft >= 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1>(c, a);
 }
 template <typename T, int N, int AXIS, int KPRE>
@@ -632,7 +647,7 @@ int ensure_mask_store(paos_ctx* c) {
 }
 
 // launch a pass that lower_frugal accepted
-int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const double* dblocks) {
+int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const double* dblocks, bool store_psf = false) {
   // PAOS_DUMP_PASSES=1: one line per pass launch on stderr (shape and what item 0's two slots carry)
   static const bool dump = [] { const char* e = getenv("PAOS_DUMP_PASSES"); return e && e[0] == '1'; }();
   if (dump && !lp.items.empty()) {
@@ -660,7 +675,8 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const
   int rc = arena_push(c, reinterpret_cast<const double*>(lp.items.data()),
                       lp.items.size() * sizeof(FrugalItem) / sizeof(double), &ditems);
   if (rc) return rc;
-  FrugalArgs a{c->field, c->tw, reinterpret_cast<const FrugalItem*>(ditems), c->pitch, c->item_stride};
+  FrugalArgs a{c->field, c->tw, reinterpret_cast<const FrugalItem*>(ditems), c->pitch, c->item_stride, nullptr, nullptr};
+  if (store_psf) { a.psf = c->psf; a.psf_partial = c->psf_partial; }
   const int nfft = lp.nfft;
   c->prof_next_tag = 0;  // for the launch timer: does this launch skip anything?
   for (const FrugalItem& fi : lp.items)
@@ -747,8 +763,14 @@ bool use_pruning() {
   return on;
 }
 
+int zero_outside_rows(paos_ctx* c, const double* live_rows);
+int psf_power_ticket(paos_ctx* c, const double* partial, int nparts, int* ticket);
+int psf_keep_power_impl(paos_ctx* c, int* ticket);
+
+// entry_rows / entry_stale: see paos_program_opts.  final_ticket != nullptr: the caller wants |u|^2 and its sum of
+// the field the program ends with, not the field.
 int run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks, int n_blocks,
-               const double* entry_rows = nullptr) {
+               const double* entry_rows = nullptr, bool entry_stale = false, int* final_ticket = nullptr) {
   if (!c || !passes || !blocks || n_passes < 0 || n_blocks < 1) return fail(c, PAOS_EINVAL, "bad pass program");
   // The device sincos has no huge-argument path: bound every enabled phase operator here.
   for (int i = 0; i < n_passes; ++i) {
@@ -792,7 +814,43 @@ int run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double*
       all_frugal = all_frugal && lp.ok;
     }
   }
-  if (all_frugal && use_pruning() && c->prune) plan_pruning(c, passes, n_passes, blocks, low, entry_rows);
+  const bool pruned = all_frugal && use_pruning() && c->prune;
+  if (pruned) plan_pruning(c, passes, n_passes, blocks, low, entry_rows, entry_stale);
+  if (entry_stale && entry_rows) {
+    // Rows that merely stand for zeros must become zeros wherever the program will not consume them: everywhere when
+    // the planner is off, and for an item no pass of the program touches.
+    bool need = !pruned;
+    for (int it = 0; it < c->batch && !need; ++it) {
+      bool active = false;
+      for (int q = 0; q < n_passes; ++q) active = active || low[q].items[it].active != 0.0;
+      need = !active;
+    }
+    if (need) {
+      // (all items at once: the ones the planner handles lose nothing but a little time, and the planner was told
+      // "stale", which is also right for zeros)
+      if ((rc = zero_outside_rows(c, entry_rows))) return rc;
+    }
+  }
+  // The PSF instead of the field: the last pass stores |u|^2 and its per-workgroup sums (frugal_pass.h: STORE) when
+  // it runs on the frugal kernels in a shape built for it and every item takes part; otherwise the program runs as
+  // usual and the intensity sweep follows.
+  bool fused_store = false;
+  if (final_ticket) {
+    if (!c->psf) HIPCHK(c, hipMalloc(&c->psf, (size_t)c->batch * c->item_stride * sizeof(double)));
+    fused_store = n_passes > 0 && low[n_passes - 1].ok && low[n_passes - 1].kpre == 0 && low[n_passes - 1].kmid <= 1;
+    if (fused_store)
+      for (const FrugalItem& fi : low[n_passes - 1].items) fused_store = fused_store && fi.active != 0.0;
+    if (fused_store) {
+      const int lines = passes[n_passes - 1].axis == 0 ? (c->n >= 2048 ? BR / 2 : BR) : 2;  // FftCfg: ROW_LINES / COL_LINES
+      const int groups = c->n / lines;
+      if (c->psf_nparts < groups) {
+        if (c->psf_partial) (void)hipFree(c->psf_partial);
+        c->psf_partial = nullptr; c->psf_nparts = 0;
+        HIPCHK(c, hipMalloc(&c->psf_partial, (size_t)c->batch * groups * sizeof(double)));
+        c->psf_nparts = groups;
+      }
+    }
+  }
   // Walk the program in chunks whose phase operators fit the table store: fill the tables of
   // a chunk with one small launch, then run its passes.
   int i = 0;
@@ -836,12 +894,19 @@ int run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double*
     }
     for (int q = i; q < j; ++q) {
       if (low[q].ok) {
-        if ((rc = launch_lowered(c, passes[q], low[q], dblocks))) return rc;
+        if ((rc = launch_lowered(c, passes[q], low[q], dblocks, fused_store && q == n_passes - 1))) return rc;
         continue;
       }
       if ((rc = launch_one_pass(c, passes[q], dblocks, n_blocks, &assign[(size_t)(q - i) * 3 * PAOS_MAX_PW]))) return rc;
     }
     i = j;
+  }
+  if (final_ticket) {
+    if (fused_store) {
+      const int lines = passes[n_passes - 1].axis == 0 ? (c->n >= 2048 ? BR / 2 : BR) : 2;
+      return psf_power_ticket(c, c->psf_partial, c->n / lines, final_ticket);
+    }
+    return psf_keep_power_impl(c, final_ticket);
   }
   return PAOS_OK;
 }
@@ -1042,6 +1107,7 @@ int paos_ctx_destroy(paos_ctx* c) {
   if (c->norm2) (void)hipFree(c->norm2);
   if (c->norm2_host) (void)hipHostFree(c->norm2_host);
   if (c->psf) (void)hipFree(c->psf);
+  if (c->psf_partial) (void)hipFree(c->psf_partial);
   for (int i = 0; i < 2; ++i) {
     if (c->bounce[i]) (void)hipHostFree(c->bounce[i]);
     if (c->bounce_ev[i]) (void)hipEventDestroy(c->bounce_ev[i]);
@@ -1087,7 +1153,15 @@ int paos_fill(paos_ctx* c, double re, double im) {
   return PAOS_OK;
 }
 
-int paos_start(paos_ctx* c, double re, double im, int shape, const double* aperture, const double* stop) {
+static int check_rows(paos_ctx* c, const double* rows) {
+  for (int i = 0; i < c->batch; ++i)
+    if (!(rows[2 * i] >= 0.0) || !(rows[2 * i + 1] <= (double)c->n) || !(rows[2 * i] <= rows[2 * i + 1]))
+      return fail(c, PAOS_EINVAL, "row range must satisfy 0 <= lo <= hi <= n");
+  return PAOS_OK;
+}
+
+static int start_impl(paos_ctx* c, double re, double im, int shape, const double* aperture, const double* stop,
+                      const double* write_rows) {
   if (c) (void)hipSetDevice(c->device);
   if (!c || !aperture) return fail(c, PAOS_EINVAL, "null argument");
   if (shape != PAOS_SHAPE_ELLIPSE && shape != PAOS_SHAPE_RECT) return fail(c, PAOS_EINVAL, "unknown aperture shape");
@@ -1111,6 +1185,11 @@ int paos_start(paos_ctx* c, double re, double im, int shape, const double* apert
   if ((rc = arena_push(c, flags.data(), flags.size(), &ds))) return rc;
   if ((rc = arena_push(c, compute.data(), compute.size(), &dcompute))) return rc;
   if ((rc = arena_push(c, power_of.data(), power_of.size(), &dpower_of))) return rc;
+  const double* drows = nullptr;
+  if (write_rows) {
+    if ((rc = check_rows(c, write_rows))) return rc;
+    if ((rc = arena_push(c, write_rows, (size_t)2 * c->batch, &drows))) return rc;
+  }
   const dim3 block(kPwThreads);
 #define START_LAUNCH(T, S)                                                                              \
   do {                                                                                                  \
@@ -1122,7 +1201,7 @@ int paos_start(paos_ctx* c, double re, double im, int shape, const double* apert
     }                                                                                                   \
     hipLaunchKernelGGL((start_write_kernel<T, BR, Lay<T>::BC, S>), dim3(pw_blocks(c), c->batch), block, 0, \
                        c->stream, (cx<T>*)c->field, dp, c->n, c->pitch, c->item_stride, re, im,          \
-                       (const double*)c->norm2, ds);                                                    \
+                       (const double*)c->norm2, ds, drows);                                             \
   } while (0)
   if (c->precision == PAOS_F64) {
     if (shape == PAOS_SHAPE_ELLIPSE) START_LAUNCH(double, 0); else START_LAUNCH(double, 1);
@@ -1132,6 +1211,23 @@ int paos_start(paos_ctx* c, double re, double im, int shape, const double* apert
 #undef START_LAUNCH
   HIPCHK(c, hipGetLastError());
   return PAOS_OK;
+}
+
+int paos_start(paos_ctx* c, double re, double im, int shape, const double* aperture, const double* stop) {
+  return start_impl(c, re, im, shape, aperture, stop, nullptr);
+}
+
+int paos_start_rows(paos_ctx* c, double re, double im, int shape, const double* aperture, const double* stop,
+                    const double* write_rows) {
+  return start_impl(c, re, im, shape, aperture, stop, write_rows);
+}
+
+int paos_zero_outside_rows(paos_ctx* c, const double* live_rows) {
+  if (c) (void)hipSetDevice(c->device);
+  if (!c || !live_rows) return fail(c, PAOS_EINVAL, "null argument");
+  int rc = check_rows(c, live_rows);
+  if (rc) return rc;
+  return zero_outside_rows(c, live_rows);
 }
 
 int paos_import(paos_ctx* c, int item, const void* host) {
@@ -1188,7 +1284,7 @@ int paos_export_pinned(paos_ctx* c, int item, int what, void* pinned_out) {
 int paos_psf_keep(paos_ctx* c) {
   if (c) (void)hipSetDevice(c->device);
   if (!c) return fail(c, PAOS_EINVAL, "null context");
-  if (!c->psf) HIPCHK(c, hipMalloc(&c->psf, (size_t)c->batch * c->n * c->n * sizeof(double)));
+  if (!c->psf) HIPCHK(c, hipMalloc(&c->psf, (size_t)c->batch * c->item_stride * sizeof(double)));
   const dim3 grid(pw_blocks(c), c->batch), block(kPwThreads);
   if (c->precision == PAOS_F64)
     hipLaunchKernelGGL((intensity_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream,
@@ -1204,7 +1300,15 @@ int paos_psf_fetch(paos_ctx* c, int item, double* host_out) {
   if (c) (void)hipSetDevice(c->device);
   if (!c || !host_out || item < 0 || item >= c->batch) return fail(c, PAOS_EINVAL, "bad item or null buffer");
   if (!c->psf) return fail(c, PAOS_EINVAL, "no PSF kept (paos_psf_keep)");
-  return copy_to_host(c, host_out, c->psf + (size_t)item * c->n * c->n, (size_t)c->n * c->n * sizeof(double));
+  // the PSF buffer is blocked like the field: row-major through the staging buffer
+  if (c->precision == PAOS_F64)
+    hipLaunchKernelGGL((psf_unblock_kernel<BR, Lay<double>::BC>), dim3(pw_blocks(c)), dim3(kPwThreads), 0, c->stream,
+                       (const double*)c->psf + (size_t)item * c->item_stride, (double*)c->staging, c->n, c->pitch);
+  else
+    hipLaunchKernelGGL((psf_unblock_kernel<BR, Lay<float>::BC>), dim3(pw_blocks(c)), dim3(kPwThreads), 0, c->stream,
+                       (const double*)c->psf + (size_t)item * c->item_stride, (double*)c->staging, c->n, c->pitch);
+  HIPCHK(c, hipGetLastError());
+  return copy_to_host(c, host_out, c->staging, (size_t)c->n * c->n * sizeof(double));
 }
 
 int paos_host_alloc(unsigned long long bytes, void** out) {
@@ -1340,22 +1444,16 @@ int paos_norm2_enqueue(paos_ctx* c, int* ticket) {
   return PAOS_OK;
 }
 
-int paos_psf_keep_power(paos_ctx* c, int* ticket) {
-  if (c) (void)hipSetDevice(c->device);
-  if (!c || !ticket) return fail(c, PAOS_EINVAL, "null argument");
+}  // extern "C"
+
+namespace {
+
+// partial sums -> norm2 -> a ticket of the power ring
+int psf_power_ticket(paos_ctx* c, const double* partial, int nparts, int* ticket) {
   const int slot = c->norm_slot;
   if (c->norm_busy[slot])
     return fail(c, PAOS_EINVAL, "64 power reductions outstanding: fetch earlier tickets (paos_norm2_fetch) first");
-  if (!c->psf) HIPCHK(c, hipMalloc(&c->psf, (size_t)c->batch * c->n * c->n * sizeof(double)));
-  const dim3 grid(c->nparts, c->batch), block(kPwThreads);
-  if (c->precision == PAOS_F64)
-    hipLaunchKernelGGL((intensity_power_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream,
-                       (const cx<double>*)c->field, c->psf, c->partial, c->n, c->pitch, c->item_stride);
-  else
-    hipLaunchKernelGGL((intensity_power_kernel<float, BR, Lay<float>::BC>), grid, block, 0, c->stream,
-                       (const cx<float>*)c->field, c->psf, c->partial, c->n, c->pitch, c->item_stride);
-  HIPCHK(c, hipGetLastError());
-  hipLaunchKernelGGL(norm2_final_kernel, dim3(c->batch), block, 0, c->stream, c->partial, c->norm2, c->nparts,
+  hipLaunchKernelGGL(norm2_final_kernel, dim3(c->batch), dim3(kPwThreads), 0, c->stream, partial, c->norm2, nparts,
                      (const double*)nullptr, 1);
   HIPCHK(c, hipGetLastError());
   c->norm_busy[slot] = true;
@@ -1364,6 +1462,80 @@ int paos_psf_keep_power(paos_ctx* c, int* ticket) {
                            hipMemcpyDeviceToHost, c->stream));
   *ticket = slot;
   return PAOS_OK;
+}
+
+int psf_keep_power_impl(paos_ctx* c, int* ticket) {
+  if (c->norm_busy[c->norm_slot])
+    return fail(c, PAOS_EINVAL, "64 power reductions outstanding: fetch earlier tickets (paos_norm2_fetch) first");
+  if (!c->psf) HIPCHK(c, hipMalloc(&c->psf, (size_t)c->batch * c->item_stride * sizeof(double)));
+  const dim3 grid(c->nparts, c->batch), block(kPwThreads);
+  if (c->precision == PAOS_F64)
+    hipLaunchKernelGGL((intensity_power_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream,
+                       (const cx<double>*)c->field, c->psf, c->partial, c->n, c->pitch, c->item_stride);
+  else
+    hipLaunchKernelGGL((intensity_power_kernel<float, BR, Lay<float>::BC>), grid, block, 0, c->stream,
+                       (const cx<float>*)c->field, c->psf, c->partial, c->n, c->pitch, c->item_stride);
+  HIPCHK(c, hipGetLastError());
+  return psf_power_ticket(c, c->partial, c->nparts, ticket);
+}
+
+// rows outside [lo, hi) of every item := 0 (whole block rows, which are contiguous in memory)
+int zero_outside_rows(paos_ctx* c, const double* live_rows) {
+  const size_t eb = elem_bytes(c);
+  for (int i = 0; i < c->batch; ++i) {
+    int lo = ((int)live_rows[2 * i] / BR) * BR, hi = (((int)live_rows[2 * i + 1] + BR - 1) / BR) * BR;
+    if (hi > c->n) hi = c->n;
+    if (lo >= hi) { lo = 0; hi = 0; }
+    char* base = (char*)c->field + (size_t)i * c->item_stride * eb;
+    const size_t row_bytes = (size_t)c->pitch / BR * eb;  // one row's share of a block row
+    if (lo > 0) HIPCHK(c, hipMemsetAsync(base, 0, (size_t)lo * row_bytes, c->stream));
+    if (hi < c->n) HIPCHK(c, hipMemsetAsync(base + (size_t)hi * row_bytes, 0, (size_t)(c->n - hi) * row_bytes, c->stream));
+  }
+  return PAOS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int paos_psf_keep_power(paos_ctx* c, int* ticket) {
+  if (c) (void)hipSetDevice(c->device);
+  if (!c || !ticket) return fail(c, PAOS_EINVAL, "null argument");
+  return psf_keep_power_impl(c, ticket);
+}
+
+int paos_run_program(paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks, int n_blocks,
+                     const paos_program_opts* opts) {
+  if (c) (void)hipSetDevice(c->device);
+  if (!opts) return run_passes(c, passes, n_passes, blocks, n_blocks);
+  if (c && opts->live_rows) {
+    int rc = check_rows(c, opts->live_rows);
+    if (rc) return rc;
+  }
+  if (opts->final_intensity && !opts->power_ticket) return fail(c, PAOS_EINVAL, "final_intensity needs a place for the power ticket");
+  return run_passes(c, passes, n_passes, blocks, n_blocks, opts->live_rows, opts->live_rows && opts->rows_stale != 0,
+                    opts->final_intensity ? opts->power_ticket : nullptr);
+}
+
+int paos_norm2_enqueue_rows(paos_ctx* c, const double* live_rows, int* ticket) {
+  if (c) (void)hipSetDevice(c->device);
+  if (!c || !ticket || !live_rows) return fail(c, PAOS_EINVAL, "null argument");
+  int rc = check_rows(c, live_rows);
+  if (rc) return rc;
+  const int slot = c->norm_slot;
+  if (c->norm_busy[slot])
+    return fail(c, PAOS_EINVAL, "64 power reductions outstanding: fetch earlier tickets (paos_norm2_fetch) first");
+  const double* drows = nullptr;
+  if ((rc = arena_push(c, live_rows, (size_t)2 * c->batch, &drows))) return rc;
+  const dim3 grid(c->nparts, c->batch), block(kPwThreads);
+  if (c->precision == PAOS_F64)
+    hipLaunchKernelGGL((norm2_partial_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream,
+                       (const cx<double>*)c->field, c->partial, c->n, c->pitch, c->item_stride, (const double*)nullptr, 1, drows);
+  else
+    hipLaunchKernelGGL((norm2_partial_kernel<float, BR, Lay<float>::BC>), grid, block, 0, c->stream,
+                       (const cx<float>*)c->field, c->partial, c->n, c->pitch, c->item_stride, (const double*)nullptr, 1, drows);
+  HIPCHK(c, hipGetLastError());
+  return psf_power_ticket(c, c->partial, c->nparts, ticket);
 }
 
 int paos_norm2_fetch(paos_ctx* c, int ticket, double* host_out) {
@@ -1498,12 +1670,35 @@ static int zernike_apply(paos_ctx* c, int nmax, int kdim, const double* table, c
   const dim3 grid(pw_blocks(c), c->batch), block(kPwThreads);
   double* wfe = host_wfe ? (double*)c->staging : nullptr;
   const double* pupil = use_pupil ? c->mask : nullptr;
+  // The kernel changes pixels with rho <= 1 only: |row - n/2| dy <= radius.  Bound the rows of the union of the
+  // items' disks (two pixels of margin, whole block rows) and walk only that part of memory -- unless the caller
+  // wants the wfe map, which is written (NaN) outside the disk too.
+  unsigned m_first = 0, m_end = c->item_stride;
+  if (!host_wfe) {
+    double half = -1.0;
+    bool known = true;
+    for (int i = 0; i < c->batch; ++i) {
+      const double* q = params + (size_t)i * param_stride;
+      if (q[ZP_ENABLE] == 0.0) continue;
+      const double h = q[ZP_RADIUS] / q[ZP_DY];
+      if (!(h >= 0.0) || !std::isfinite(h)) { known = false; break; }
+      if (h > half) half = h;
+    }
+    if (known && half >= 0.0 && half < (double)c->n) {
+      int lo = (int)std::floor((double)(c->n / 2) - half) - 2, hi = (int)std::ceil((double)(c->n / 2) + half) + 3;
+      lo = lo < 0 ? 0 : (lo / BR) * BR;
+      hi = hi > c->n ? c->n : ((hi + BR - 1) / BR) * BR;
+      if (hi > c->n) hi = c->n;
+      m_first = (unsigned)(lo / BR) * c->pitch;
+      m_end = (unsigned)(hi / BR) * c->pitch;
+    }
+  }
   if (c->precision == PAOS_F64)
     hipLaunchKernelGGL((zernike_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream, (cx<double>*)c->field,
-                       dt, dp, param_stride, c->n, c->pitch, c->item_stride, nmax, kdim, wfe, pupil);
+                       dt, dp, param_stride, c->n, c->pitch, c->item_stride, nmax, kdim, wfe, pupil, m_first, m_end);
   else
     hipLaunchKernelGGL((zernike_kernel<float, BR, Lay<float>::BC>), grid, block, 0, c->stream, (cx<float>*)c->field, dt,
-                       dp, param_stride, c->n, c->pitch, c->item_stride, nmax, kdim, wfe, pupil);
+                       dp, param_stride, c->n, c->pitch, c->item_stride, nmax, kdim, wfe, pupil, m_first, m_end);
   HIPCHK(c, hipGetLastError());
   if (host_wfe) return copy_to_host(c, host_wfe, c->staging, (size_t)c->n * c->n * 8);
   return PAOS_OK;

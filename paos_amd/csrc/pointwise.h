@@ -83,20 +83,30 @@ __global__ void export_kernel(const cx<T>* f, double* out, int n, unsigned pitch
   }
 }
 
-// |u|^2 of every batch item, row-major doubles, into a device buffer: the PSF of plot.py:125-130
-// kept in HBM (24 B/px: 16 read + 8 written)
+// |u|^2 of every batch item into a device buffer, in the FIELD'S OWN blocked layout and item stride (doubles): the PSF
+// of plot.py:125-130 kept in HBM (24 B/px: 16 read + 8 written).  psf_unblock_kernel turns one item row-major.
 template <typename T, int BR, int BC>
 __global__ void intensity_kernel(const cx<T>* field, double* out, int n, unsigned pitch, unsigned item_stride) {
   const int item = blockIdx.y;
   const cx<T>* f = field + (size_t)item * item_stride;
-  double* o = out + (size_t)item * n * n;
+  double* o = out + (size_t)item * item_stride;
   const size_t total = item_stride;
+  size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
+    if ((unsigned)(m % pitch) >= (unsigned)n * BR) continue;  // pitch padding
+    const double x = (double)f[m].x, y = (double)f[m].y;
+    o[m] = __dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y));
+  }
+}
+
+template <int BR, int BC>
+__global__ void psf_unblock_kernel(const double* psf_item, double* out, int n, unsigned pitch) {
+  const size_t total = (size_t)pitch * (n / BR);
   size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
     int r, c;
     if (!layout_unmap<BR, BC>(m, n, pitch, r, c)) continue;
-    const double x = (double)f[m].x, y = (double)f[m].y;
-    o[(size_t)r * n + c] = __dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y));
+    out[(size_t)r * n + c] = psf_item[m];
   }
 }
 
@@ -161,17 +171,28 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
   return s;  // valid in thread 0
 }
 
+// ``rows`` (optional, [batch][2]): rows of the item outside [lo, hi) are exact zeros (or hold stale data standing for
+// zeros) and are not read.  Block rows are contiguous in memory, so that is a window of the walk; every thread keeps
+// the elements it would have had, in the same order, and a zero adds nothing: the sum is bit-identical.
 template <typename T, int BR, int BC>
 __global__ void norm2_partial_kernel(const cx<T>* field, double* partial, int n, unsigned pitch,
-                                     unsigned item_stride, const double* enable, int enable_stride) {
+                                     unsigned item_stride, const double* enable, int enable_stride,
+                                     const double* rows = nullptr) {
   const int item = blockIdx.y;
   if (enable && enable[(size_t)item * enable_stride] == 0.0) return;
   __shared__ double sh[kPwThreads / 64];
   const cx<T>* f = field + (size_t)item * item_stride;
-  const size_t total = item_stride;
+  size_t total = item_stride, first = 0;
+  if (rows) {
+    first = (size_t)((int)rows[2 * item] / BR) * pitch;
+    total = (size_t)(((int)rows[2 * item + 1] + BR - 1) / BR) * pitch;
+    if (total > item_stride) total = item_stride;
+  }
   double acc = 0.0;
+  const size_t step = (size_t)gridDim.x * blockDim.x;
   size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
+  if (m < first) m += (first - m + step - 1) / step * step;
+  for (; m < total; m += step) {
     if ((unsigned)(m % pitch) >= (unsigned)n * BR) continue;  // pitch padding
     const double x = (double)f[m].x, y = (double)f[m].y;
     acc += __dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y));
@@ -189,16 +210,15 @@ __global__ void intensity_power_kernel(const cx<T>* field, double* out, double* 
   const int item = blockIdx.y;
   __shared__ double sh[kPwThreads / 64];
   const cx<T>* f = field + (size_t)item * item_stride;
-  double* o = out + (size_t)item * n * n;
+  double* o = out + (size_t)item * item_stride;  // blocked like the field (intensity_kernel)
   const size_t total = item_stride;
   double acc = 0.0;
   size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
-    int r, c;
-    if (!layout_unmap<BR, BC>(m, n, pitch, r, c)) continue;
+    if ((unsigned)(m % pitch) >= (unsigned)n * BR) continue;  // pitch padding
     const double x = (double)f[m].x, y = (double)f[m].y;
     const double v = __dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y));
-    o[(size_t)r * n + c] = v;
+    o[m] = v;
     acc += v;
   }
   const double s = block_sum(acc, sh);
@@ -540,7 +560,7 @@ __global__ void start_power_kernel(const double* params, int n, unsigned pitch, 
 template <typename T, int BR, int BC, int SHAPE>
 __global__ void start_write_kernel(cx<T>* field, const double* params, int n, unsigned pitch,
                                    unsigned item_stride, double vre, double vim, const double* norm2,
-                                   const double* stop) {
+                                   const double* stop, const double* rows = nullptr) {
   const int item = blockIdx.y;
   const double* p = params + (size_t)item * AP_STRIDE;
   ApertureEval<SHAPE> ap;
@@ -550,8 +570,15 @@ __global__ void start_write_kernel(cx<T>* field, const double* params, int n, un
   const double s = scaled ? 1.0 / sqrt(norm2[item]) : 1.0;
   const double v0re = (double)(T)vre, v0im = (double)(T)vim;
   cx<T>* f = field + (size_t)item * item_stride;
-  const size_t total = item_stride;
-  size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // ``rows`` ([batch][2], optional): only the rows [lo, hi) are written; the others are left as they are and stand
+  // for zeros (paos_start_rows: the caller promises that nobody reads them before a pass program consumes them)
+  size_t total = item_stride, first = 0;
+  if (rows) {
+    first = (size_t)((int)rows[2 * item] / BR) * pitch;
+    total = (size_t)(((int)rows[2 * item + 1] + BR - 1) / BR) * pitch;
+    if (total > item_stride) total = item_stride;
+  }
+  size_t m = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
     int r, c;
     double x = 0.0, y = 0.0;
@@ -713,7 +740,8 @@ enum : int { ZP_ENABLE = 0, ZP_DX, ZP_DY, ZP_RADIUS, ZP_ORIGIN_Y, ZP_COS_OFF, ZP
 template <typename T, int BR, int BC>
 __global__ void zernike_kernel(cx<T>* field, const double* table, const double* params,
                                int param_stride, int n, unsigned pitch, unsigned item_stride,
-                               int nmax, int kdim, double* wfe_out, const double* pupil) {
+                               int nmax, int kdim, double* wfe_out, const double* pupil,
+                               unsigned m_first = 0, unsigned m_end = 0xffffffffu) {
   const int item = blockIdx.y;
   const double* p = params + (size_t)item * param_stride;
   if (p[ZP_ENABLE] == 0.0) return;
@@ -723,8 +751,10 @@ __global__ void zernike_kernel(cx<T>* field, const double* table, const double* 
   const double* coef_c = p + ZP_HEAD;
   const double* coef_s = coef_c + (size_t)(nmax + 1) * kdim;
   cx<T>* f = field + (size_t)item * item_stride;
-  const size_t total = item_stride;
-  size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // [m_first, m_end): the block rows that meet the unit disk of some item (the host bounds them); outside, the
+  // kernel changes nothing
+  const size_t total = m_end < item_stride ? m_end : item_stride;
+  size_t m = (size_t)m_first + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
     int r, c;
     if (!layout_unmap<BR, BC>(m, n, pitch, r, c)) continue;

@@ -183,15 +183,23 @@ class PassCompiler:
         self._reset()
         return passes, blocks
 
-    def flush(self, dev, live_rows=None):
+    def flush(self, dev, live_rows=None, rows_stale=False, final_intensity=False):
         """``live_rows`` ([batch][2], optional): rows of each item outside [lo, hi) are exactly zero in
-        memory on entry (a stand-alone aperture has just been applied) -- the library then skips them."""
+        memory on entry (a stand-alone aperture has just been applied) -- the library then skips them;
+        ``rows_stale``: they hold old data standing for zeros instead.  ``final_intensity``: the last pass
+        stores |u|^2 (PSF buffer) instead of the field; returns (passes run, power ticket)."""
         if not self.pending():
-            return 0
+            return (0, None) if final_intensity else 0
         passes, blocks = self.program()
+        ticket = None
         if passes:
-            if live_rows is None:
+            if rows_stale or final_intensity:
+                ticket = dev.run_passes(passes, blocks, live_rows=live_rows, rows_stale=rows_stale,
+                                        final_intensity=final_intensity)
+            elif live_rows is None:
                 dev.run_passes(passes, blocks)
             else:
                 dev.run_passes(passes, blocks, live_rows=live_rows)
-        return len(passes)
+        elif final_intensity:
+            raise RuntimeError("a program without passes cannot store the PSF")
+        return (len(passes), ticket) if final_intensity else len(passes)

@@ -284,24 +284,42 @@ def _queue_steps(comp, lens, stw, ptp, wts, inv_stw, inv_wts):
     comp.wts(wts, inv_wts != 0.0)
 
 
-def _start_field(dev, plans, value):
+def _start_field(dev, plans, value, write_rows=None):
     """The wavefront is still the constant ``value`` (wfo.py:118).  When every item opens with a
     stand-alone aperture of one shape, ones -> aperture -> [make_stop] is a single write of the
     field (paos_start); otherwise fill and let the surface run as usual.  Returns True when the
-    first surface's aperture and stop are done."""
+    first surface's aperture and stop are done.  ``write_rows`` ([lo, hi) per item): only these rows are
+    written, the others are left standing for zeros (paos_start_rows)."""
     aps = [p["aperture"] for p in plans]
     if any(a is None for a in aps) or len({isinstance(a[0], EllipticalAperture) for a in aps}) != 1:
         dev.fill(value)
         return False
     code = _lib.SHAPE_ELLIPSE if isinstance(aps[0][0], EllipticalAperture) else _lib.SHAPE_RECT
-    dev.start(value, code, [a[0].block(obscuration=a[1]) for a in aps],
-              [1.0 if p["stop"] else 0.0 for p in plans])
+    blocks = [a[0].block(obscuration=a[1]) for a in aps]
+    stops = [1.0 if p["stop"] else 0.0 for p in plans]
+    if write_rows is None:
+        dev.start(value, code, blocks, stops)
+    else:
+        dev.start(value, code, blocks, stops, write_rows=write_rows)
     return True
 
 
-def _walk(dev, states, chains, on_saved, stats=None, fresh=None):
+class _WalkState:
+    """What ``on_saved`` may want to know about the field at a saved surface of a lean walk:
+    ``rows`` -- per item [lo, hi) outside which the field is zero (or stands for zero), or None;
+    ``psf_ticket`` -- set when the pass program that ended at this surface has already written |u|^2 to the
+    PSF buffer and enqueued its sum (the field itself is then undefined)."""
+
+    def __init__(self):
+        self.rows, self.psf_ticket = None, None
+
+
+def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_at=None):
     """Drive all items through their chains in lock-step, one surface at a time.  ``fresh``: the
-    constant the field is meant to hold but has not been filled with yet (see _start_field)."""
+    constant the field is meant to hold but has not been filled with yet (see _start_field).
+    ``lean`` (a _WalkState, optional): the caller reads no arrays at saved surfaces, only powers (through
+    ``lean.rows`` / ``lean.psf_ticket``) -- the walk may then leave dead rows unwritten at the start and, when
+    ``psf_at`` names the last surface, have the last pass store the PSF instead of the field."""
     keys = [list(c.keys()) for c in chains]
     if any(k != keys[0] for k in keys[1:]):
         raise ValueError("batched chains must list the same surfaces (same keys, same order)")
@@ -316,11 +334,33 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None):
     # apertures, kept by stops / Zernike / phase screens (they multiply), handed to the next pass
     # program (which skips them) and forgotten once that program has run
     live = [[0, dev.n] for _ in states]
+    stale = [False]  # rows outside ``live`` hold old data that stands for zeros (lean start)
+    dead = [False]   # the field has been given up for its PSF (lean end): nothing may run on it any more
 
-    def flush():
-        known = any(r[0] > 0 or r[1] < dev.n for r in live)
-        done = comp.flush(dev, live_rows=live if known and comp.pending() else None)
+    def known_rows():
+        return [list(r) for r in live] if any(r[0] > 0 or r[1] < dev.n for r in live) else None
+
+    def settle():
+        """Before anything reads whole fields: rows that stand for zeros become zeros."""
+        if stale[0]:
+            dev.zero_outside_rows(live)
+            stale[0] = False
+
+    def flush(final_intensity=False):
+        if dead[0]:
+            comp.program()  # drop what was queued behind the PSF store
+            return 0
+        rows = known_rows()
+        if not comp.pending():
+            return 0
+        if final_intensity:
+            done, ticket = comp.flush(dev, live_rows=rows, rows_stale=stale[0] and rows is not None, final_intensity=True)
+            lean.psf_ticket = ticket
+            dead[0] = True
+        else:
+            done = comp.flush(dev, live_rows=rows, rows_stale=stale[0] and rows is not None)
         if done:
+            stale[0] = False
             for r in live:
                 r[0], r[1] = 0, dev.n
         return done
@@ -361,12 +401,22 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None):
 
         if fresh is not None:
             value, fresh = fresh, None
-            if _start_field(dev, plans, value):
+            rows0 = None
+            if lean is not None and hasattr(dev, "zero_outside_rows"):
+                trial = [[0, dev.n] for _ in states]
+                _live_rows_after(plans, trial, dev.n)
+                # worth it only when every item's aperture leaves whole rows dark
+                if all(r[0] > 0 or r[1] < dev.n for r in trial) and all(r[0] < r[1] for r in trial):
+                    rows0 = trial
+            if _start_field(dev, plans, value, write_rows=rows0):
                 _live_rows_after(plans, live, dev.n)
+                stale[0] = rows0 is not None
                 want_wfe = len(plans) == 1 and bool(items[0]["save"])
                 wfe = _launch_zernike(dev, plans, want_wfe=want_wfe)
                 wfe = _launch_phase_maps(dev, plans, wfe)
                 if saved:
+                    if lean is not None:
+                        lean.rows = known_rows()
                     on_saved(key, items, plans, wfe)
                 _queue_steps(comp, lens, stw, ptp, wts, inv_stw, inv_wts)
                 continue
@@ -386,22 +436,37 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None):
         breaker = saved or any(p["stop"] or p["zernike"] is not None or p["phase_map"] is not None or
                                (p["aperture"] is not None and not fuse_ap) for p in plans)
         if breaker:
-            npass += flush()  # the field must be current before a non-fusable operator
+            # the field must be current before a non-fusable operator -- unless all this surface wants of it is the
+            # PSF of every item (a lean walk's last, saved surface with nothing else on it): then the last pass
+            # stores |u|^2 instead
+            only_saved = saved and all(it["save"] for it in items) and not any(
+                p["stop"] or p["zernike"] is not None or p["phase_map"] is not None or
+                (p["aperture"] is not None and not fuse_ap) for p in plans)
+            npass += flush(final_intensity=(lean is not None and psf_at is not None and key == psf_at and only_saved
+                                            and comp.pending() and not dead[0]))
         if not fuse_ap:
             _launch_apertures(dev, plans)
             if not comp.pending():
                 _live_rows_after(plans, live, dev.n)
         if any(p["stop"] for p in plans):
+            settle()
             dev.make_stop([1.0 if p["stop"] else 0.0 for p in plans])
         want_wfe = len(plans) == 1 and bool(items[0]["save"])
         wfe = _launch_zernike(dev, plans, want_wfe=want_wfe)
         wfe = _launch_phase_maps(dev, plans, wfe)
         if saved:
+            if lean is not None:
+                lean.rows = known_rows() if not comp.pending() else None
+            else:
+                settle()
             on_saved(key, items, plans, wfe)
+            if lean is not None:
+                lean.rows, lean.psf_ticket = None, None
         _queue_steps(comp, lens, stw, ptp, wts, inv_stw, inv_wts)
     if fresh is not None:  # an empty chain still yields the initial wavefront
         dev.fill(fresh)
     npass += flush()
+    settle()
     if stats is not None:
         stats["fused_passes"] = npass
 
@@ -525,6 +590,9 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
             "phase": _lib.WHAT_PHASE}
 
     last_key = list(opt_chains[0].keys())[-1] if len(opt_chains[0]) else None
+    # nobody reads an array at a saved surface: the walk may skip writing dead rows at the start and store the PSF
+    # straight from the last pass (csrc/frugal_pass.h: STORE)
+    lean = _WalkState() if (not outputs and metrics_radii_px is None) else None
     tickets = []  # (ticket, [(item index, record)]): powers are fetched after the walk, so the
     # host keeps planning while the GPU works (no mid-chain synchronisation) -- except when a chain
     # saves more surfaces than the library has ticket slots: then the oldest are fetched early
@@ -554,16 +622,26 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
             for i, rec in pending:
                 rec["metrics"] = met[i]
         keep = keep_psf and key == last_key
+        fused = lean.psf_ticket if lean is not None else None  # the last pass has stored |u|^2 and enqueued its sum
+        rows = lean.rows if lean is not None else None
         if power:
-            if len(tickets) - drained[0] >= _lib.NORM_SLOTS - 1:
+            if len(tickets) - drained[0] >= _lib.NORM_SLOTS - 1 and fused is None:
                 drain()  # the ticket ring of the library is about to fill: fetch what is pending
             # the saved last surface of a run that keeps its PSFs: |u|^2 written and summed in one sweep
-            tickets.append((dev.psf_keep_power() if keep else dev.norm2_enqueue(), pending))
+            if fused is not None:
+                tickets.append((fused, pending))
+            elif keep:
+                tickets.append((dev.psf_keep_power(), pending))
+            else:
+                tickets.append((dev.norm2_enqueue(rows) if rows is not None else dev.norm2_enqueue(), pending))
+        elif fused is not None:
+            dev.norm2_release(fused)
         elif keep:
             dev.psf_keep()
 
     try:
-        _walk(dev, states, list(opt_chains), on_saved, stats=stats, fresh=1.0 + 0.0j)
+        _walk(dev, states, list(opt_chains), on_saved, stats=stats, fresh=1.0 + 0.0j, lean=lean,
+              psf_at=last_key if (keep_psf and lean is not None) else None)
         if sync or own:
             drain()
         else:  # caller synchronises later: hand out the tickets still outstanding

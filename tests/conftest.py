@@ -13,6 +13,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    if os.path.exists("/dev/kfd"):
+        # On a GPU box: tests that need helper processes fork them from a server that is started HERE, while this
+        # process has not touched the GPU yet (a process that holds a GPU context must not exec another program).
+        try:
+            from multiprocessing import forkserver
+
+            forkserver.ensure_running()
+        except Exception:  # noqa: BLE001 -- the test that needs it will say so
+            pass
 
 
 def load_golden(name):

@@ -61,10 +61,22 @@ class ModelDevice:
                         "encircled": np.array([I[d2 <= r * r].sum() for r in radii_px])})
         return out
 
-    def norm2_enqueue(self):
+    def norm2_enqueue(self, live_rows=None):
         self._tickets = getattr(self, "_tickets", [])
-        self._tickets.append(self.norm2())
+        if live_rows is None:
+            self._tickets.append(self.norm2())
+        else:  # rows outside [lo, hi) are not read (they may hold stale data: NaN in this model)
+            self._tickets.append(np.array([np.sum(np.abs(u[int(lo):int(hi)]) ** 2) for u, (lo, hi) in zip(self.u, live_rows)]))
         return len(self._tickets) - 1
+
+    def norm2_release(self, ticket):
+        pass
+
+    def zero_outside_rows(self, live_rows):
+        self.log.append(("zero_outside_rows", None))
+        for u, (lo, hi) in zip(self.u, live_rows):
+            u[:int(lo)] = 0.0
+            u[int(hi):] = 0.0
 
     def norm2_fetch(self, ticket):
         return self._tickets[ticket]
@@ -86,8 +98,9 @@ class ModelDevice:
     def psf_fetch(self, item=0):
         return self.psf[item].copy()
 
-    def start(self, value, shape, blocks, stop=None):
-        """paos_start: fill -> aperture -> make_stop on the flagged items."""
+    def start(self, value, shape, blocks, stop=None, write_rows=None):
+        """paos_start: fill -> aperture -> make_stop on the flagged items.  ``write_rows``: the rows outside
+        are NOT written and merely stand for zeros -- the model poisons them so that any read shows."""
         self.log.append(("start", shape))
         self.u[:] = value
         n0 = len(self.log)
@@ -95,6 +108,12 @@ class ModelDevice:
         if stop is not None and any(stop):
             self.make_stop(stop)
         del self.log[n0:]
+        if write_rows is not None:
+            for u, (lo, hi) in zip(self.u, write_rows):
+                lo, hi = (int(lo) // 4) * 4, min(self.n, -(-int(hi) // 4) * 4)
+                assert not u[:lo].any() and not u[hi:].any(), "write_rows must contain every non-zero row"
+                u[:lo] = np.nan
+                u[hi:] = np.nan
 
     def aperture(self, shape, blocks):
         self.log.append(("aperture", shape))
@@ -225,10 +244,22 @@ class ModelDevice:
             q = 6.283185307179586 * q
         return u * (np.cos(q) + 1j * p[4] * np.sin(q))
 
-    def run_passes(self, passes, blocks, live_rows=None):  # live_rows: a traffic hint, results are the same
+    def run_passes(self, passes, blocks, live_rows=None, rows_stale=False, final_intensity=False):
+        # live_rows: a traffic hint, results are the same -- unless rows_stale: then the rows outside hold garbage
+        # that stands for zeros and the program must behave as if they were zeros
         blocks = np.asarray(blocks, dtype=np.float64)
         assert blocks.ndim == 3 and blocks.shape[1:] == (self.batch, 5)
         n_ = self.n
+        if live_rows is not None:
+            for u, (lo, hi) in zip(self.u, live_rows):
+                lo, hi = (int(lo) // 4) * 4, min(self.n, -(-int(hi) // 4) * 4)
+                if rows_stale:
+                    u[:lo] = 0.0
+                    u[hi:] = 0.0
+                else:
+                    assert not u[:lo].any() and not u[hi:].any(), "live_rows promised zeros"
+        else:
+            assert not rows_stale
         for ps in passes:
             self.pass_count += 1
             self.log.append(("pass", ps["axis"]))
@@ -251,6 +282,14 @@ class ModelDevice:
                         ax = 1 if ps["axis"] == 0 else 0  # "along rows" = NumPy axis 1
                         u = np.fft.ifft(u, axis=ax) * self.n if blocks[ctl, i, 1] else np.fft.fft(u, axis=ax)
                 self.u[i] = u
+        if final_intensity:  # the PSF and its sum instead of the field, which is given up
+            self.log.append(("psf_store", None))
+            self.psf = self.u.real**2 + self.u.imag**2
+            self._tickets = getattr(self, "_tickets", [])
+            self._tickets.append(self.psf.sum(axis=(1, 2)))
+            self.u[:] = np.nan
+            return len(self._tickets) - 1
+        return None
 
     # one-operator programs, as csrc/paos_hip.hip builds them
     def _single(self, blocks, inverse, kind):

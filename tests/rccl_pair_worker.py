@@ -1,0 +1,26 @@
+"""Worker of tests/test_gpu_r3.py::test_two_ranks_asking_for_rccl_on_one_gpu_agree (a module of its own so that the
+fork server's children can import it without pytest)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(rank, key, out):
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    import numpy as np
+
+    from paos_amd.comm import Comm, CommError
+
+    try:
+        comm = Comm(2, rank, 0, "rccl", key=key, timeout=45)  # both ranks on device 0: the box has one GPU
+    except CommError as exc:
+        out.put((rank, "error", str(exc), None, None))
+        return
+    try:
+        text = comm.bcast_blob(b"two ranks, one GPU" if rank == 0 else None, root=0)
+        parts = comm.allgather_scalars(np.arange(rank + 2, dtype=float))
+        out.put((rank, comm.transport, text, comm.max(float(rank)), [list(p) for p in parts]))
+    finally:
+        comm.close()

@@ -1,0 +1,300 @@
+"""GPU tests added in round 3.
+
+* The oracle at the sizes BASELINE.json quotes where round 2 stopped short: Excite_TEL fp64 AND fp32 at
+  4096^2 (the first oracle check of frugal_pass_kernel<float, 4096, ...>), Ariel_FGS-FGS1 Monte-Carlo draws at
+  2048^2 with the on-device metrics, a 32-item heterogeneous batch (the benchmark's gridDim.y) with items
+  0 / 15 / 31 against the oracle, the dead-line pruning at 4096^2 with several wavelengths, and SYN20-4096 for
+  the last item of the benchmark's sweep.
+* The lean walk of run_batch (outputs=()): rows left unwritten at the start, the power of the first surface
+  over the live rows, the last pass storing |u|^2 (csrc/frugal_pass.h: STORE) -- against the ordinary walk.
+* paos_start_rows / paos_norm2_enqueue_rows / paos_zero_outside_rows / paos_run_program through the C ABI.
+* Two ranks asking for RCCL on the ONE GPU of this box: whatever RCCL makes of that, both ranks come out of
+  the bring-up on the same transport within the watchdog's time and the collectives work.
+
+Oracle cost on the GPU box's host: ~2.5 s per wavefront at 1024^2, ~11 s at 2048^2, ~50 s at 4096^2.
+Aperture-mask VALUES are parity-unpinned (photutils is absent): every end-to-end figure here is
+"the reference's arithmetic given the builder's masks".
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+FIELD_TOL = 1e-11
+PSF_TOL = 1e-10
+FP32_PSF_TOL = 2e-5
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LENS = os.path.join(ROOT, "data", "lens")
+WFE = os.path.join(ROOT, "data", "wfe", "wfe_realization_SN20210914.csv")
+ON_AXIS = {"us": 0.0, "ut": 0.0}
+
+
+def _oracle(*args):
+    from oracle.run_np import run as oracle_run
+
+    return oracle_run(*args, light=True)
+
+
+def _check(got, ref, where, psf_tol=PSF_TOL, field_tol=FIELD_TOL):
+    assert sorted(got) == sorted(ref), where
+    worst = 0.0
+    for k in ref:
+        if "wfo" in got[k]:
+            e = rel_err(got[k]["wfo"], ref[k]["wfo"])
+            assert e < field_tol, (where, k, "field", e)
+        e = rel_err(got[k]["psf"], ref[k]["amplitude"] ** 2)
+        worst = max(worst, e)
+        assert e < psf_tol, (where, k, "psf", e)
+        for key in ("dx", "dy", "wl", "fratio", "wz", "distancetofocus", "propagator"):
+            assert got[k][key] == ref[k][key], (where, k, key)
+    return worst
+
+
+def test_excite_fp64_and_fp32_at_4096_vs_oracle():
+    """BASELINE configs[4] at its quoted size: two wavelengths of the Excite_TEL sweep, complex128 and complex64
+    fields, every saved surface against the oracle.  fp32 bound 2e-5 of the PSF peak (SURVEY 8d predicted 3e-6)."""
+    from paos_amd.chains import parse_config_variant
+    from paos_amd.run import run_batch
+
+    n = 4096
+    pup, par, wls, fields, chains = parse_config_variant(os.path.join(LENS, "Excite_TEL.ini"), [1.0, 3.4])
+    w = [1.0e-6 * x for x in wls]
+    r64 = run_batch(pup, w, n, par["zoom"], fields[0], chains, outputs=("psf",))
+    r32 = run_batch(pup, w, n, par["zoom"], fields[0], chains, outputs=("psf",), precision="fp32")
+    report = []
+    for i in range(len(w)):
+        ref = _oracle(pup, w[i], n, par["zoom"], fields[0], chains[i])
+        e64 = _check(r64[i], ref, ("Excite fp64 4096", i))
+        e32 = _check(r32[i], ref, ("Excite fp32 4096", i), psf_tol=FP32_PSF_TOL)
+        assert e32 > 1e-9, "fp32 mode is expected to differ measurably from fp64"
+        last = max(ref)
+        assert rel_err(r32[i][last]["psf"], r64[i][last]["psf"]) < FP32_PSF_TOL
+        report.append((w[i], e64, e32))
+        del ref
+    print("Excite_TEL 4096^2 PSF error vs oracle (wavelength, fp64, fp32):", report)
+
+
+def test_fgs1_monte_carlo_at_2048_vs_oracle():
+    """BASELINE configs[3] at its quoted size: Ariel_FGS-FGS1 with the WFE surface un-ignored, two draws of the
+    realisation table as ONE batch at 2048^2, against the oracle, with the on-device PSF metrics."""
+    from paos_amd.chains import inject_wfe, parse_config_variant, read_wfe_table
+    from paos_amd.run import run_batch
+
+    n = 2048
+    pup, par, wls, fields, chains = parse_config_variant(os.path.join(LENS, "Ariel_FGS-FGS1.ini"), unignore=("Z1",))
+    _, _, _, table = read_wfe_table(WFE)
+    wl = 1.0e-6 * wls[0]
+    mc = [inject_wfe(chains[0], table[:, c]) for c in (5, 17)]
+    radii = np.geomspace(2.0, 256.0, 8)
+    got = run_batch(pup, [wl] * 2, n, par["zoom"], fields[0], mc, outputs=("psf",), metrics_radii_px=radii)
+    yy, xx = np.mgrid[0:n, 0:n]
+    d2 = (xx - n / 2) ** 2 + (yy - n / 2) ** 2
+    for c in range(2):
+        ref = _oracle(pup, wl, n, par["zoom"], fields[0], mc[c])
+        _check(got[c], ref, ("FGS1 2048 draw", c))
+        last = max(ref)
+        psf = ref[last]["amplitude"] ** 2
+        m = got[c][last]["metrics"]
+        assert abs(m["power"] - psf.sum()) < 1e-11 * psf.sum()
+        for r, ee in zip(radii, m["encircled"]):
+            assert abs(ee - psf[d2 <= r * r].sum()) < 1e-10 * psf.sum(), (c, r)
+    last = max(got[0])
+    assert rel_err(got[0][last]["psf"], got[1][last]["psf"]) > 1e-6  # two different draws
+
+
+def test_batch_of_32_wavelengths_vs_oracle():
+    """The benchmark launches with gridDim.y = 32; so does this: 32 Ariel_AIRS-CH0 wavelengths across the channel
+    (each its own chain: glass indices, prism magnification) at 1024^2 in ONE run_batch, items 0, 15 and 31 against
+    the oracle, and all 32 distinct."""
+    from paos_amd.chains import parse_config_variant
+    from paos_amd.run import run_batch
+
+    n = 1024
+    sweep = np.linspace(1.95, 3.9, 32)
+    pup, par, wls, fields, chains = parse_config_variant(os.path.join(LENS, "Ariel_AIRS-CH0.ini"), sweep)
+    w = [1.0e-6 * x for x in wls]
+    got = run_batch(pup, w, n, par["zoom"], fields[0], chains, outputs=("psf",))
+    assert len(got) == 32
+    for i in (0, 15, 31):
+        ref = _oracle(pup, w[i], n, par["zoom"], fields[0], chains[i])
+        _check(got[i], ref, ("AIRS x32", i))
+        last = max(ref)
+        assert abs(got[i][last]["power"] - float(np.sum(ref[last]["amplitude"] ** 2))) < 1e-11
+    last = max(got[0])
+    peaks = {float(g[last]["psf"].max()) for g in got}
+    assert len(peaks) == 32
+
+
+def test_dead_line_pruning_changes_nothing_at_4096():
+    """The 4096^2 shapes of the pruning (512-thread workgroups, 2-row tiles): four wavelengths of the SYN20 sweep,
+    pruning on and off, bit-equal saved fields and powers."""
+    import paos_amd.run as prun
+    from paos_amd import _lib
+    from paos_amd.chains import syn20_chain, syn20_wavelength
+
+    n = 4096
+    wls = [syn20_wavelength(k) for k in (0, 150, 333, 511)]
+    chains = [syn20_chain() for _ in wls]
+    out = []
+    for on in (True, False):
+        dev = _lib.DeviceFields(n, len(chains))
+        dev.set_pruning(on)
+        res = prun.run_batch(1.0, wls, n, 4, ON_AXIS, chains, outputs=("wfo",), dev=dev)
+        out.append([(r[20]["wfo"], r[20]["power"], r[1]["power"]) for r in res])
+        dev.close()
+    for (a, pa, qa), (b, pb, qb) in zip(*out):
+        assert np.array_equal(a, b)
+        assert pa == pb and qa == qb
+
+
+def test_syn20_4096_last_item_of_the_sweep_vs_oracle():
+    """SYN20 at 4096^2 for k = 31, the last wavelength of the benchmark's 32-wavefront step (round 2 checked
+    k = 0), run as item 1 of a two-item batch next to k = 0."""
+    from paos_amd.chains import syn20_chain, syn20_wavelength
+    from paos_amd.run import run_batch
+
+    n = 4096
+    wls = [syn20_wavelength(0), syn20_wavelength(31)]
+    got = run_batch(1.0, wls, n, 4, ON_AXIS, [syn20_chain(), syn20_chain()], outputs=("psf",))
+    ref = _oracle(1.0, wls[1], n, 4, ON_AXIS, syn20_chain())
+    e = _check(got[1], ref, ("SYN20 4096 k=31",))
+    print("SYN20 4096^2 k=31 PSF error vs oracle:", e)
+
+
+@pytest.mark.parametrize("n,precision", [(1024, "fp64"), (4096, "fp64"), (2048, "fp32")])
+def test_lean_walk_equals_the_ordinary_walk(n, precision):
+    """run_batch(outputs=(), keep_psf=True) -- the benchmark's mode -- leaves the dark rows of the first surface
+    unwritten, sums the first power over the live rows and has the last pass store |u|^2: PSFs bit-equal to the
+    ones the ordinary walk downloads, powers equal to rounding (another order of summation)."""
+    from paos_amd import _lib
+    from paos_amd.chains import syn20_chain, syn20_wavelength
+    from paos_amd.run import run_batch
+
+    wls = [syn20_wavelength(k) for k in (0, 31, 300)]
+    chains = [syn20_chain() for _ in wls]
+    plain = run_batch(1.0, wls, n, 4, ON_AXIS, chains, outputs=("psf",), precision=precision)
+    dev = _lib.DeviceFields(n, len(wls), precision)
+    try:
+        # poison the buffer: rows the lean start does not write must never be read as values
+        for i in range(len(wls)):
+            dev.upload(i, np.full((n, n), complex(np.nan, np.nan)))
+        stats = {}
+        lean = run_batch(1.0, wls, n, 4, ON_AXIS, chains, outputs=(), dev=dev, keep_psf=True, precision=precision,
+                         stats=stats)
+        for i in range(len(wls)):
+            psf = dev.psf_fetch(i)
+            assert np.array_equal(psf, plain[i][20]["psf"]), i
+            for k in (1, 20):
+                assert abs(lean[i][k]["power"] - plain[i][k]["power"]) <= 1e-13 * plain[i][k]["power"], (i, k)
+                for key in ("dx", "dy", "fratio", "wz", "propagator"):
+                    assert lean[i][k][key] == plain[i][k][key]
+        # and again on the same context: the second run starts from the first run's leftovers
+        lean2 = run_batch(1.0, wls, n, 4, ON_AXIS, chains, outputs=(), dev=dev, keep_psf=True, precision=precision)
+        for i in range(len(wls)):
+            assert np.array_equal(dev.psf_fetch(i), plain[i][20]["psf"])
+            assert lean2[i][20]["power"] == lean[i][20]["power"] and lean2[i][1]["power"] == lean[i][1]["power"]
+    finally:
+        dev.close()
+
+
+def test_row_window_entry_points():
+    """paos_start_rows + paos_norm2_enqueue_rows + paos_zero_outside_rows + paos_run_program(rows_stale) against
+    paos_start + paos_norm2_enqueue + paos_run_passes_live on the same inputs; argument checks."""
+    from paos_amd import _lib
+    from paos_amd.aperture import make_aperture
+    from paos_amd.passes import PassCompiler
+    from paos_amd.planner import PilotBeam
+
+    n, nb = 1024, 2
+    dev = _lib.DeviceFields(n, nb)
+    ref = _lib.DeviceFields(n, nb)
+    try:
+        beam = PilotBeam(1.0, 1.0e-6, n, 4)
+        handles = [make_aperture(n, beam.dx, beam.dy, 0.0, 0.0, hx=0.5, hy=0.5, shape="elliptical"),
+                   make_aperture(n, beam.dx, beam.dy, 0.01, -0.02, hx=0.4, hy=0.3, shape="elliptical")]
+        blocks = [h.block(obscuration=False) for h in handles]
+        rows = []
+        for h in handles:
+            yc, ext = float(h.positions[1]), h.b
+            rows.append([max(0, int(np.floor(yc - ext + 0.5)) - 1), min(n, int(np.ceil(yc + ext + 0.5)) + 1)])
+        for d in (dev, ref):
+            for i in range(nb):
+                d.upload(i, np.full((n, n), 7.0 - 3.0j))  # leftovers
+        ref.start(1.0 + 0j, _lib.SHAPE_ELLIPSE, blocks, [1.0, 1.0])
+        dev.start(1.0 + 0j, _lib.SHAPE_ELLIPSE, blocks, [1.0, 1.0], write_rows=rows)
+        for i in range(nb):
+            a, b = dev.download(i), ref.download(i)
+            lo, hi = (rows[i][0] // 4) * 4, -(-rows[i][1] // 4) * 4
+            assert np.array_equal(a[lo:hi], b[lo:hi])
+            assert np.all(a[:lo] == 7.0 - 3.0j) and np.all(a[hi:] == 7.0 - 3.0j)  # untouched
+            assert not b[:lo].any() and not b[hi:].any()
+        # the power over the live rows is the power of the zero-filled field, to the last bit
+        assert np.array_equal(dev.norm2_fetch(dev.norm2_enqueue(rows)), ref.norm2_fetch(ref.norm2_enqueue()))
+        assert np.array_equal(ref.norm2_fetch(ref.norm2_enqueue(rows)), ref.norm2_fetch(ref.norm2_enqueue()))
+        # a program that consumes the stale rows == the same program on real zeros
+        comp = PassCompiler(nb, n)
+        comp.ptp([beam.ptp(3.0)] * nb)
+        passes, pblocks = comp.program()
+        dev.run_passes(passes, pblocks, live_rows=rows, rows_stale=True)
+        ref.run_passes(passes, pblocks, live_rows=rows)
+        for i in range(nb):
+            assert np.array_equal(dev.download(i), ref.download(i))
+        # zero_outside_rows
+        dev.start(1.0 + 0j, _lib.SHAPE_ELLIPSE, blocks, [1.0, 0.0], write_rows=rows)
+        dev.zero_outside_rows(rows)
+        ref.start(1.0 + 0j, _lib.SHAPE_ELLIPSE, blocks, [1.0, 0.0])
+        for i in range(nb):
+            assert np.array_equal(dev.download(i), ref.download(i))
+        # the PSF instead of the field: same PSF, same power to rounding
+        ticket = dev.run_passes(passes, pblocks, final_intensity=True)
+        ref.run_passes(passes, pblocks)
+        want = ref.norm2_fetch(ref.psf_keep_power())
+        got = dev.norm2_fetch(ticket)
+        assert np.allclose(got, want, rtol=1e-13, atol=0)
+        for i in range(nb):
+            assert np.array_equal(dev.psf_fetch(i), ref.psf_fetch(i))
+        with pytest.raises(_lib.PaosHipError, match="row range"):
+            dev.norm2_enqueue([[0, n + 4], [0, n]])
+        with pytest.raises(_lib.PaosHipError, match="row range"):
+            dev.start(1.0 + 0j, _lib.SHAPE_ELLIPSE, blocks, [1.0, 1.0], write_rows=[[600, 400], [0, n]])
+        with pytest.raises(ValueError):
+            dev.zero_outside_rows([[0, n]])
+    finally:
+        dev.close()
+        ref.close()
+
+
+def test_two_ranks_asking_for_rccl_on_one_gpu_agree():
+    """ncclCommInitRank with nranks = 2 actually runs (under the watchdog): RCCL may refuse two ranks on one
+    device -- then both ranks must agree on the TCP transport -- or accept them, or never come back -- then the
+    watchdog ends both with an error; in no case does a rank hang or the two disagree.  The ranks are forked from
+    the fork server conftest.py started before this process touched the GPU (no exec from a process that holds
+    a GPU context)."""
+    import multiprocessing as mp
+    import uuid
+
+    import rccl_pair_worker
+
+    ctx = mp.get_context("forkserver")
+    out = ctx.Queue()
+    key = "pytest_" + uuid.uuid4().hex
+    procs = [ctx.Process(target=rccl_pair_worker.run, args=(r, key, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted(out.get(timeout=150) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    kinds = [r[1] for r in results]
+    print("two ranks on one GPU:", kinds, [r[2] for r in results if r[1] == "error"])
+    assert kinds[0] == kinds[1] and kinds[0] in ("rccl", "socket", "error")
+    if kinds[0] == "error":
+        assert all("ncclCommInitRank did not return" in r[2] for r in results)
+        return
+    for rank, transport, text, slowest, parts in results:
+        assert text == b"two ranks, one GPU" and slowest == 1.0
+        assert parts == [[0.0, 1.0], [0.0, 1.0, 2.0]]

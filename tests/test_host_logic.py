@@ -298,3 +298,55 @@ def test_package_exports_resolve_lazily():
     assert callable(importlib.import_module("paos_amd.run").run)
     with pytest.raises(AttributeError):
         paos_amd.no_such_thing
+
+
+def test_lean_walk_skips_dead_rows_and_ends_on_the_psf():
+    """run_batch that hands back no arrays (outputs=(), the benchmark's mode): the first field write leaves the
+    rows outside the aperture's box unwritten (the model device fills them with NaN, so any read would show), the
+    power of the first surface is summed over the live rows, and the last pass stores |u|^2 instead of the field.
+    Powers and PSFs equal those of the ordinary walk and of the oracle."""
+    from fakes import ModelDevice
+    from oracle.run_np import run as oracle_run
+    from paos_amd.chains import syn20_chain, syn20_wavelength
+    import paos_amd.run as prun
+    from paos_amd.run import run_batch
+
+    wls = [syn20_wavelength(0), syn20_wavelength(300)]
+    chains = [syn20_chain(), syn20_chain()]
+    field = {"us": 0.0, "ut": 0.0}
+    prun.FUSE_APERTURES = True  # as at the production sizes: the field stop rides on the last pass
+    try:
+        _lean_walk_checks(ModelDevice, oracle_run, run_batch, syn20_chain, wls, chains, field)
+    finally:
+        prun.FUSE_APERTURES = "auto"
+
+
+def _lean_walk_checks(ModelDevice, oracle_run, run_batch, syn20_chain, wls, chains, field):
+    plain_dev = ModelDevice(128, 2)
+    plain = run_batch(1.0, wls, 128, 4, field, chains, outputs=("psf",), dev=plain_dev, keep_psf=True)
+    dev = ModelDevice(128, 2)
+    lean = run_batch(1.0, wls, 128, 4, field, chains, outputs=(), dev=dev, keep_psf=True)
+    kinds = [name for name, _ in dev.log]
+    assert kinds.count("psf_store") == 1 and kinds.count("psf_keep") == 0
+    assert "zero_outside_rows" not in kinds  # the first pass program consumed the rows that stood for zeros
+    assert np.isnan(dev.u).all()  # the field was given up for its PSF
+    for i in range(2):
+        for k in (1, 20):
+            assert np.isfinite(lean[i][k]["power"])
+            assert abs(lean[i][k]["power"] - plain[i][k]["power"]) <= 1e-13 * plain[i][k]["power"]
+        assert np.allclose(dev.psf_fetch(i), plain[i][20]["psf"], rtol=0, atol=1e-13 * plain[i][20]["psf"].max())
+    ref = oracle_run(1.0, wls[1], 128, 4, field, syn20_chain(), light=True)
+    psf = ref[20]["amplitude"] ** 2
+    assert np.max(np.abs(dev.psf_fetch(1) - psf)) < 1e-11 * psf.max()
+    # power=False: the fused store's ticket is handed back, nothing else changes
+    dev2 = ModelDevice(128, 2)
+    run_batch(1.0, wls, 128, 4, field, chains, outputs=(), dev=dev2, keep_psf=True, power=False)
+    assert np.array_equal(dev2.psf_fetch(0), dev.psf_fetch(0))
+    # a chain whose second surface is a stop: the rows that stand for zeros are cleared before the sum reads them
+    chain = syn20_chain()
+    chain[2] = dict(chain[2], is_stop=True)
+    dev3 = ModelDevice(128, 1)
+    got = run_batch(1.0, wls[:1], 128, 4, field, [chain], outputs=(), dev=dev3, keep_psf=True)
+    assert [name for name, _ in dev3.log].count("zero_outside_rows") == 1
+    want = run_batch(1.0, wls[:1], 128, 4, field, [chain], outputs=("psf",), dev=ModelDevice(128, 1), keep_psf=True)
+    assert abs(got[0][20]["power"] - want[0][20]["power"]) <= 1e-13 * want[0][20]["power"]
