@@ -100,6 +100,10 @@ int paos_profile_end(paos_ctx* ctx, int* launches, double* total_ms);
 /* the same, also telling apart the launches that skipped dead tiles or loads (pruned passes move fewer
  * bytes, so a bandwidth figure must be taken over the others) */
 int paos_profile_end_split(paos_ctx* ctx, int* launches, double* total_ms, int* pruned_launches, double* pruned_ms);
+/* the same launch by launch, in launch order: ms_out[i], tag_out[i] (bit 0: the launch skipped whole tiles of dead
+ * lines, bit 1: loads of dead positions, bit 2: stores nobody reads, bit 3: it stored the PSF instead of the
+ * field; 0 = a full pass); *count launches, at most `capacity` */
+int paos_profile_end_launches(paos_ctx* ctx, int capacity, double* ms_out, int* tag_out, int* count);
 
 /* ---- field I/O ---------------------------------------------------------------------- */
 /* u[:] = re + i im for every batch item -- np.ones(..., complex128), wfo.py:118 */

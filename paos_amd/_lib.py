@@ -60,6 +60,8 @@ SYMBOLS = {
     "paos_profile_begin": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int]),
     "paos_profile_end": (ctypes.c_int, [_c_ctx, ctypes.POINTER(ctypes.c_int), _dbl_p]),
     "paos_profile_end_split": (ctypes.c_int, [_c_ctx, ctypes.POINTER(ctypes.c_int), _dbl_p, ctypes.POINTER(ctypes.c_int), _dbl_p]),
+    "paos_profile_end_launches": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p, ctypes.POINTER(ctypes.c_int),
+                                                 ctypes.POINTER(ctypes.c_int)]),
     "paos_fill": (ctypes.c_int, [_c_ctx, ctypes.c_double, ctypes.c_double]),
     "paos_import": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_void_p]),
     "paos_export": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
@@ -277,6 +279,17 @@ class DeviceFields:
         self._check(self._lib.paos_profile_end_split(self._ctx, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(pn),
                                                      ctypes.byref(pms)), "paos_profile_end_split")
         return n.value, ms.value, pn.value, pms.value
+
+    def profile_end_launches(self, capacity=1 << 16):
+        """(ms[i], tag[i]) of every timed launch, in launch order; tag bits: 1 skipped tiles, 2 skipped loads,
+        4 skipped stores, 8 stored the PSF instead of the field."""
+        ms = np.empty(capacity, dtype=np.float64)
+        tags = np.empty(capacity, dtype=np.int32)
+        n = ctypes.c_int(0)
+        self._check(self._lib.paos_profile_end_launches(self._ctx, int(capacity), _dptr(ms),
+                                                        tags.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), ctypes.byref(n)),
+                    "paos_profile_end_launches")
+        return ms[:n.value].copy(), tags[:n.value].copy()
 
     # -- field I/O ----------------------------------------------------------------
     def fill(self, value=1.0 + 0.0j):

@@ -678,11 +678,15 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const
   FrugalArgs a{c->field, c->tw, reinterpret_cast<const FrugalItem*>(ditems), c->pitch, c->item_stride, nullptr, nullptr};
   if (store_psf) { a.psf = c->psf; a.psf_partial = c->psf_partial; }
   const int nfft = lp.nfft;
-  c->prof_next_tag = 0;  // for the launch timer: does this launch skip anything?
-  for (const FrugalItem& fi : lp.items)
-    if (fi.active != 0.0 && (fi.line_lo > 0.0 || fi.line_hi < (double)c->n || fi.pos_lo > 0.0 || fi.pos_hi < (double)c->n ||
-                              fi.spos_lo > 0.0 || fi.spos_hi < (double)c->n))
-      c->prof_next_tag = 1;
+  // for the launch timer: what does this launch skip?  bit 0: whole tiles of dead lines, bit 1: loads of dead
+  // positions, bit 2: stores nobody reads, bit 3: it stores the PSF instead of the field
+  c->prof_next_tag = store_psf ? 8 : 0;
+  for (const FrugalItem& fi : lp.items) {
+    if (fi.active == 0.0) continue;
+    if (fi.line_lo > 0.0 || fi.line_hi < (double)c->n) c->prof_next_tag |= 1;
+    if (fi.pos_lo > 0.0 || fi.pos_hi < (double)c->n) c->prof_next_tag |= 2;
+    if (fi.spos_lo > 0.0 || fi.spos_hi < (double)c->n) c->prof_next_tag |= 4;
+  }
   if (c->precision == PAOS_F64) {
     switch (c->n) {
       case 1024: return paos_frugal_d1024(c, a, p.axis, lp.kpre, lp.kmid, nfft);
@@ -1073,6 +1077,24 @@ static int profile_end(paos_ctx* c, int* launches, double* total_ms, int* pruned
   *total_ms = sum;
   if (pruned_launches) *pruned_launches = pcount;
   if (pruned_ms) *pruned_ms = psum;
+  c->prof_kind = -1;
+  c->prof_used = 0;
+  return PAOS_OK;
+}
+
+int paos_profile_end_launches(paos_ctx* c, int capacity, double* ms_out, int* tag_out, int* count) {
+  if (c) (void)hipSetDevice(c->device);
+  if (!c || !ms_out || !tag_out || !count || capacity < 0) return fail(c, PAOS_EINVAL, "null argument");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int n = (int)(c->prof_used / 2);
+  if (n > capacity) return fail(c, PAOS_EINVAL, "more launches were timed than the caller's arrays hold");
+  for (int i = 0; i < n; ++i) {
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->prof_events[2 * i], c->prof_events[2 * i + 1]));
+    ms_out[i] = ms;
+    tag_out[i] = (size_t)i < c->prof_tags.size() ? c->prof_tags[i] : 0;
+  }
+  *count = n;
   c->prof_kind = -1;
   c->prof_used = 0;
   return PAOS_OK;
