@@ -164,20 +164,23 @@ def measure(dev, n, nb, precision, wavelengths, chains, steps, warmup, comm=None
         res = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    launches, kern_ms, pruned, pruned_ms = dev.profile_end_split()
+    ms, tags = dev.profile_end_launches()
     if comm is not None:
         elapsed = comm.max(elapsed)
-    return {"elapsed": elapsed, "launches": launches, "kern_ms": kern_ms, "pruned": pruned, "pruned_ms": pruned_ms,
+    full = tags == 0
+    return {"elapsed": elapsed, "launches": int(ms.size), "kern_ms": float(ms.sum()), "pruned": int((~full).sum()),
+            "pruned_ms": float(ms[~full].sum()), "launch_ms": ms, "launch_tags": tags,
             "fused_passes": stats.get("fused_passes"), "res": res}
 
 
-def measure_traffic(grid, batch, precision, alg_bytes):
-    """HBM bytes per full pass launch from the PMC counters, collected the way MI355X_MICROARCH.md prescribes: this
-    script once under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and once under `... --pmc WRITE_SIZE` (separate
-    passes, one chain step each, as child processes), FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE doubled (gfx950
-    reports half of the bytes of wide coalesced reads).  Launches are matched by dispatch order; "full" launches are
-    those that read AND write at least 90 % of the algorithmic bytes ``alg_bytes`` / 2 each (the ones next to an
-    aperture skip loads or stores and stay far below).  Returns (bytes or None, note)."""
+def measure_traffic(grid, batch, precision):
+    """HBM bytes of every kernel of ONE chain step from the PMC counters, collected the way MI355X_MICROARCH.md
+    prescribes: this script once under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and once under `... --pmc WRITE_SIZE`
+    (separate passes, as child processes running exactly one step and nothing else: --traffic-child), FETCH_SIZE /
+    WRITE_SIZE in KiB, FETCH_SIZE doubled (gfx950 reports half of the bytes of wide coalesced reads; the factor is
+    calibrated for 16 B per lane, which is what the pass kernels issue -- for the 8-byte accesses of the reduction and
+    PSF kernels it is an assumption).  Dispatches are matched between the two runs by dispatch order.
+    Returns ({"pass": [(read, written)] in launch order, "other": {kernel: {calls, read, written, ms}}} or None, note)."""
     import csv
     import glob
     import shutil
@@ -187,14 +190,14 @@ def measure_traffic(grid, batch, precision, alg_bytes):
     exe = shutil.which("rocprofv3")
     if exe is None:
         return None, "rocprofv3 not found"
-    series = {}
+    series, trace_ms = {}, {}
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         tmp = tempfile.mkdtemp(prefix="paos_pmc_", dir="/tmp")
         try:
             cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", tmp, "-o", "pmc", "--output-format", "csv", "--",
                    sys.executable, os.path.abspath(__file__), "--grid", str(grid), "--batch", str(batch),
                    "--precision", precision, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras",
-                   "--no-traffic"]
+                   "--no-traffic", "--traffic-child"]
             run = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
                                  stderr=subprocess.PIPE, timeout=600)
             files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
@@ -203,51 +206,121 @@ def measure_traffic(grid, batch, precision, alg_bytes):
             per_dispatch = {}
             with open(files[0]) as fh:
                 for row in csv.DictReader(fh):
-                    if "_pass_kernel" in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                        k = int(row["Dispatch_Id"])
-                        per_dispatch[k] = per_dispatch.get(k, 0.0) + float(row["Counter_Value"])
+                    if row["Counter_Name"] != counter or row["Kernel_Name"].startswith("__amd_rocclr"):
+                        continue  # the runtime's own fill / copy kernels (context creation, parameter uploads)
+                    k = int(row["Dispatch_Id"])
+                    name, val = per_dispatch.get(k, (row["Kernel_Name"], 0.0))
+                    per_dispatch[k] = (name, val + float(row["Counter_Value"]))
             series[counter] = [per_dispatch[k] for k in sorted(per_dispatch)]
+            if counter == "FETCH_SIZE":  # durations of the non-pass kernels (under the profiler: indicative)
+                for path in glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True):
+                    with open(path) as fh:
+                        for row in csv.DictReader(fh):
+                            name = row.get("Kernel_Name", "")
+                            try:
+                                dt = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6
+                            except (KeyError, ValueError):
+                                continue
+                            trace_ms[name] = trace_ms.get(name, 0.0) + dt
         except Exception as exc:  # noqa: BLE001 -- the bench line must come out whatever the profiler does
             return None, f"rocprofv3 --pmc {counter}: {type(exc).__name__}: {exc}"
         finally:
             shutil.rmtree(tmp, ignore_errors=True)
     f, w = series["FETCH_SIZE"], series["WRITE_SIZE"]
-    if not f or len(f) != len(w):
-        return None, f"pass launches seen: {len(f)} (FETCH_SIZE run) vs {len(w)} (WRITE_SIZE run)"
-    half = 0.9 * alg_bytes / 2.0
-    pairs = [(2.0 * a * 1024.0, b * 1024.0) for a, b in zip(f, w)]
-    full = [r + wr for r, wr in pairs if r >= half and wr >= half]
-    reads = [r for r, wr in pairs if r >= half and wr >= half]
-    if not full:
-        return None, "no pass launch moved the algorithmic bytes (unexpected counter values)"
-    note = (f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE on one chain step of this workload (two child runs, "
-            f"counters in KiB, FETCH_SIZE x2 per MI355X_MICROARCH.md): mean over the {len(full)} of {len(f)} pass launches "
-            f"that skip nothing; read {sum(reads) / len(reads) / 1e9:.3f} GB + written "
-            f"{(sum(full) - sum(reads)) / len(full) / 1e9:.3f} GB per launch")
-    return sum(full) / len(full), note
+    if not f or len(f) != len(w) or any(a[0] != b[0] for a, b in zip(f, w)):
+        return None, f"dispatches seen: {len(f)} (FETCH_SIZE run) vs {len(w)} (WRITE_SIZE run), or in another order"
+    out = {"pass": [], "other": {}}
+    for (name, fetch), (_, write) in zip(f, w):
+        rd, wr = 2.0 * fetch * 1024.0, write * 1024.0
+        if "_pass_kernel" in name:
+            out["pass"].append((rd, wr))
+        else:
+            short = name.split("<")[0].split("(")[0]
+            rec = out["other"].setdefault(short, {"calls": 0, "read": 0.0, "written": 0.0, "ms": 0.0})
+            rec["calls"] += 1
+            rec["read"] += rd
+            rec["written"] += wr
+    for name, ms in trace_ms.items():
+        short = name.split("<")[0].split("(")[0]
+        if short in out["other"]:
+            out["other"][short]["ms"] += ms
+    note = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE on exactly one chain step of this workload (two child "
+            "runs, counters in KiB, FETCH_SIZE x2 per MI355X_MICROARCH.md), every dispatch kept")
+    return out, note
 
 
-def roofline_block(m, n, nb, esz, dev, kernel_name):
+CLASS_NAMES = {0: "full", 1: "skips tiles of dead lines", 2: "skips loads of dead positions", 4: "skips stores nobody reads",
+               8: "stores the PSF instead of the field"}
+
+
+def class_name(tag):
+    return " + ".join(CLASS_NAMES[b] for b in (1, 2, 4, 8) if tag & b) if tag else CLASS_NAMES[0]
+
+
+def roofline_block(m, n, nb, esz, dev, kernel_name, steps, traffic=None):
+    """`achieved` = algorithmic bytes of one pass over the batch / mean HIP-event time of the launches that skip nothing.
+    With ``traffic`` (measure_traffic): per class of launch and for all pass launches of a step the bytes the counters
+    saw, next to the event times of the same launches -- no estimate anywhere."""
     pass_bytes = 2 * esz * n * n * nb  # one pass over the batch: every element read + written once
-    full = m["launches"] - m["pruned"]
-    full_ms = (m["kern_ms"] - m["pruned_ms"]) / max(full, 1)
-    achieved = pass_bytes / (full_ms * 1e-3) / 1e9 if full else 0.0
+    ms, tags = m["launch_ms"], m["launch_tags"]
+    full = tags == 0
+    full_ms = float(ms[full].mean()) if full.any() else 0.0
+    achieved = pass_bytes / (full_ms * 1e-3) / 1e9 if full.any() else 0.0
     y_ms, y_bytes = dev.copy_yardstick(10)
-    return {
+    per_step = ms.size // max(steps, 1)
+    folded = ms[:per_step * steps].reshape(steps, per_step).mean(axis=0) if per_step and ms.size == per_step * steps else None
+    step_tags = tags[:per_step] if folded is not None else None
+    block = {
         "bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
         "traffic_note": "not measured in this run (--no-traffic, an `extra` entry, or N > 1); per-kernel FETCH_SIZE / WRITE_SIZE "
-                        "of the default command under rocprofv3: profiles/r02_pmc_hbm_traffic_bench.txt",
-        "launches": full, "avg_launch_ms": full_ms, "algorithmic_bytes_per_launch": pass_bytes,
-        "pruned": {"launches": m["pruned"], "avg_launch_ms": m["pruned_ms"] / max(m["pruned"], 1),
+                        "of the default command under rocprofv3: profiles/r03_pmc_hbm_traffic_bench.txt",
+        "launches": int(full.sum()), "avg_launch_ms": full_ms, "algorithmic_bytes_per_launch": pass_bytes,
+        "pruned": {"launches": int((~full).sum()), "avg_launch_ms": float(ms[~full].mean()) if (~full).any() else 0.0,
                    "what": "pass launches next to an aperture that skip the tiles / loads of rows or columns it has zeroed, "
-                           "or the stores of rows it is about to zero (they move fewer bytes and are kept out of `achieved`)"},
-        "all_pass_launches_avg_ms": m["kern_ms"] / max(m["launches"], 1),
+                           "or the stores of rows it is about to zero, and the last pass that stores the PSF (they move "
+                           "fewer bytes and are kept out of `achieved`)"},
+        "all_pass_launches_avg_ms": float(ms.mean()) if ms.size else 0.0,
         "fused_passes_per_wavefront": m["fused_passes"],
         "copy_yardstick": {"ms_per_launch": y_ms, "GBps": y_bytes / (y_ms * 1e-3) / 1e9,
                            "what": "measured in this run (paos_copy_yardstick): in-place copy of the same batch buffer, "
                                    "16 B per lane, unit stride, no transform"},
     }
+    if folded is not None:
+        classes = {}
+        for i in range(per_step):
+            rec = classes.setdefault(class_name(int(step_tags[i])), {"launches_per_step": 0, "ms": 0.0, "bytes_measured": None})
+            rec["launches_per_step"] += 1
+            rec["ms"] += float(folded[i])
+        measured = traffic is not None and len(traffic["pass"]) == per_step
+        if measured:
+            for i in range(per_step):
+                rec = classes[class_name(int(step_tags[i]))]
+                rec["bytes_measured"] = (rec["bytes_measured"] or 0.0) + sum(traffic["pass"][i])
+        for rec in classes.values():
+            k = rec["launches_per_step"]
+            rec["avg_launch_ms"] = rec.pop("ms") / k
+            if rec["bytes_measured"] is not None:
+                rec["bytes_measured"] /= k
+                rec["GBps_measured"] = rec["bytes_measured"] / (rec["avg_launch_ms"] * 1e-3) / 1e9
+                rec["frac_measured"] = rec["GBps_measured"] / HBM_PEAK_GBS
+        block["classes"] = classes
+        block["all_launches"] = {"launches_per_step": per_step, "ms": float(folded.sum()), "bytes_measured": None, "frac": None,
+                                 "what": "every pass launch of one step: HIP-event time (mean over the timed steps) and, when "
+                                         "the counters were collected, the HBM bytes they saw for the same launches"}
+        if measured:
+            total = sum(r + w for r, w in traffic["pass"])
+            block["all_launches"]["bytes_measured"] = total
+            block["all_launches"]["frac"] = total / (float(folded.sum()) * 1e-3) / 1e9 / HBM_PEAK_GBS
+            fulls = [sum(traffic["pass"][i]) for i in range(per_step) if step_tags[i] == 0]
+            reads = [traffic["pass"][i][0] for i in range(per_step) if step_tags[i] == 0]
+            if fulls:
+                block["traffic"] = sum(fulls) / len(fulls)
+                block["traffic_over_algorithmic"] = block["traffic"] / pass_bytes
+                block["traffic_note"] = (f"mean over the {len(fulls)} of {per_step} pass launches of a step that skip nothing: read "
+                                         f"{sum(reads) / len(reads) / 1e9:.3f} GB + written "
+                                         f"{(sum(fulls) - sum(reads)) / len(fulls) / 1e9:.3f} GB per launch")
+    return block
 
 
 def main():
@@ -261,6 +334,9 @@ def main():
     ap.add_argument("--precision", default="fp64", choices=["fp64", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the 2048^2 / 1024^2 entries")
+    ap.add_argument("--allow-tcp", action="store_true",
+                    help="with --gpus N > 1: accept the TCP transport when RCCL does not come up on every rank (default: exit 3)")
+    ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)  # one chain step and nothing else (measure_traffic)
     args = ap.parse_args()
     if args.batch <= 0:
         # 8 -> 32 wavefronts per step is +3 % (launch tails and host work amortised; 64: +0.3 % more): 217 -> 224 at 4096^2
@@ -275,14 +351,16 @@ def main():
         args.gpus = world
 
     # forked CPU workers: before anything initialises the GPU in this process
-    cpu_parallel = None
+    cpu_parallel = cpu_single = None
     if world == 1 and not args.no_cpu_baseline:
         cpu_parallel = cpu_baseline_parallel(args.grid, args.batch)
+    if world > 1 and rank == 0 and not args.no_cpu_baseline:
+        # N > 1: the one-core baseline on rank 0 before any GPU call (the other ranks wait at the rendezvous)
+        cpu_single = cpu_baseline(args.grid)
     # the PMC child runs too: no process is started from one that holds a GPU context
     traffic_result = None
     if world == 1 and not args.no_traffic:
-        esz0 = 16 if args.precision == "fp64" else 8
-        traffic_result = measure_traffic(args.grid, args.batch, args.precision, 2 * esz0 * args.grid * args.grid * args.batch)
+        traffic_result = measure_traffic(args.grid, args.batch, args.precision)
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     from paos_amd import _lib
@@ -299,7 +377,14 @@ def main():
             local_rank = 0
             comm = Comm.from_env(transport="socket")
         else:
-            comm = Comm.from_env(transport="rccl")  # one process per GPU, RCCL over xGMI
+            comm = Comm.from_env(transport="rccl", timeout=900.0)  # one process per GPU, RCCL over xGMI
+            if comm.transport != "rccl" and world > 1 and not args.allow_tcp:
+                # the agreement is collective (paos_comm_init_rank): every rank sees the same transport and leaves here
+                if rank == 0:
+                    print("bench.py: --gpus %d was asked for but RCCL did not come up on every rank (the ranks agreed on the "
+                          "TCP transport); pass --allow-tcp to measure anyway" % world, file=sys.stderr)
+                comm.close()
+                sys.exit(3)
 
     n, nb = args.grid, args.batch
     total = nb * world
@@ -311,6 +396,11 @@ def main():
 
     dev = _lib.DeviceFields(n, nb, args.precision, device=local_rank)
     m = measure(dev, n, nb, args.precision, wavelengths, chains, args.steps, args.warmup, comm)
+    if args.traffic_child:  # measure_traffic's child: one step, every dispatch of which is counted
+        dev.close()
+        return
+    # who took part, as the communicator saw it: rank r's device ordinal, gathered over the data plane
+    ranks_seen = [int(p[0]) for p in comm.allgather_scalars([float(local_rank)])] if comm is not None else [local_rank]
     esz = 16 if args.precision == "fp64" else 8
     frugal = n >= (1024 if args.precision == "fp64" else 2048)
     kernel_name = ("frugal_pass_kernel" if frugal else "fused_pass_kernel") + " (every FFT pass launch, rows and columns)"
@@ -333,12 +423,12 @@ def main():
         n_ptp, n_stw, n_wts = chain_fft_counts(wavelengths[0], n)
         ffts = 2 * n_ptp + n_stw + n_wts
         survey_bytes = (ffts * 4 * esz + 8) * n * n  # 2 passes x (read + write) per 2-D FFT + the 8 B/px PSF write
-        # bytes the fused path moves: full passes at 32 B/px (c128), pruned passes at about half of that (PMC:
-        # profiles/r02_pmc_hbm_traffic_bench.txt -- a row pass behind an aperture moves ~0.3 of a full pass, the
-        # column pass after it ~0.75), plus ~85 B/px of start / Zernike / reductions / PSF write
-        per_step = max(args.steps, 1) * nb
-        full_p, pruned_p = (m["launches"] - m["pruned"]) / per_step * nb, m["pruned"] / per_step * nb
-        moved_bytes = ((full_p + 0.5 * pruned_p) * 2 * esz + 85) * n * n
+        # bytes the fused path really moves: every dispatch of one step under the FETCH_SIZE / WRITE_SIZE counters
+        traffic = traffic_result[0] if traffic_result is not None else None
+        moved_bytes = None
+        if traffic is not None:
+            moved_bytes = (sum(r + w for r, w in traffic["pass"]) +
+                           sum(k["read"] + k["written"] for k in traffic["other"].values())) / nb
         per_gpu = value / world
         dtype = "c128 (f64)" if args.precision == "fp64" else "c64 (f32, f64 phase arguments)"
         out = {
@@ -359,15 +449,20 @@ def main():
                                    f"{n_wts} wts); the final |u|^2 of every wavefront is written to HBM (8 B/px) and stays "
                                    f"there, powers of the saved surfaces are reduced on the GPU",
                        "grid": n, "batch_per_gpu": nb, "parallelism": f"wavefront-sharded x{world}",
-                       "transport": comm.transport if comm is not None else "none (single process)"},
-            "roofline": roofline_block(m, n, nb, esz, dev, kernel_name),
+                       "transport": comm.transport if comm is not None else "none (single process)",
+                       "ranks_seen": len(ranks_seen), "devices_seen": ranks_seen},
+            "roofline": roofline_block(m, n, nb, esz, dev, kernel_name, args.steps, traffic),
             "chain_vs_survey_model": {
                 "survey_model_bytes_per_wavefront": survey_bytes,
                 "frac_of_hbm_peak_vs_survey_model": survey_bytes * per_gpu / 1e9 / HBM_PEAK_GBS,
                 "bytes_moved_per_wavefront": moved_bytes,
-                "frac_bytes_moved": moved_bytes * per_gpu / 1e9 / HBM_PEAK_GBS,
+                "frac_bytes_moved": moved_bytes * per_gpu / 1e9 / HBM_PEAK_GBS if moved_bytes is not None else None,
+                "other_kernels": traffic["other"] if traffic is not None else None,
                 "note": "SURVEY 8d prices the chain UNFUSED (two HBM passes per 2-D FFT); the fused path moves fewer "
-                        "bytes, so the first figure is a speed-up in model units, not a roofline fraction"},
+                        "bytes, so the first figure is a speed-up in model units, not a roofline fraction.  "
+                        "bytes_moved_per_wavefront = every dispatch of one step under the FETCH_SIZE (x2) / WRITE_SIZE counters "
+                        "(pass kernels and the start / Zernike / aperture-record / reduction kernels in `other_kernels`, whose "
+                        "ms are rocprofv3 kernel-trace durations), null when the counters were not collected"},
             "ptp_step": {"what": "one ptp over the batch: 2 2-D FFTs + H, 3 fused passes",
                          "ms_per_wavefront": ptp_ms / nb,
                          "frac_of_hbm_peak_vs_survey_model": 8 * esz * n * n * nb / (ptp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -389,18 +484,17 @@ def main():
                     "value": nb2 * max(args.steps, 5) / m2["elapsed"], "unit": "wavefronts/s", "batch": nb2,
                     "ms_per_step": 1e3 * m2["elapsed"] / max(args.steps, 5),
                     "roofline": roofline_block(m2, n2, nb2, esz, dev2,
-                                               ("frugal_pass_kernel" if fr2 else "fused_pass_kernel") + " (every FFT pass launch)")}
+                                               ("frugal_pass_kernel" if fr2 else "fused_pass_kernel") + " (every FFT pass launch)",
+                                               max(args.steps, 5))}
                 dev2.close()
             out["extra"] = extra
         if traffic_result is not None:
-            traffic, note = traffic_result
-            out["roofline"]["traffic"] = traffic
-            out["roofline"]["traffic_note"] = note
-            if traffic is not None:
-                out["roofline"]["traffic_over_algorithmic"] = traffic / out["roofline"]["algorithmic_bytes_per_launch"]
+            out["roofline"]["counters_note"] = traffic_result[1]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(n)
             out["cpu_baseline_parallel"] = cpu_parallel
+        elif cpu_single is not None:
+            out["cpu_baseline"] = cpu_single
         print(json.dumps(out), flush=True)
     else:
         dev.close()

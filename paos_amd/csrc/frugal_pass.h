@@ -336,6 +336,9 @@ constexpr size_t frugal_lds_bytes() {
 #ifndef PAOS_NT_FULL_LINES
 #define PAOS_NT_FULL_LINES 1
 #endif
+#ifndef PAOS_SHARED_NT_LOADS
+#define PAOS_SHARED_NT_LOADS 0
+#endif
 #ifndef PAOS_MINW_SMALL
 #define PAOS_MINW_SMALL 3
 #endif
@@ -399,6 +402,9 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   // tiles that own whole 128-byte lines (c128 column tiles; row tiles that span a full block row) stream
   // around the caches; tiles that share lines with a sibling need the L2 to merge the halves
   constexpr bool NT = kBlockIsLine && (PAOS_NT_FULL_LINES ? (AXIS == 1 || LINES == BR) : (AXIS == 1));
+  // experiment knob (tools/build_variant.sh): nontemporal LOADS for tiles that share their lines with a sibling
+  // (stores stay ordinary so that the L2 can merge the halves)
+  constexpr bool NTL = NT || (PAOS_SHARED_NT_LOADS != 0);
   {  // a workgroup of dead lines only: nothing to transform (its tiles are consecutive lines)
     const int l0 = TILES == 1 ? (AXIS == 0 ? m.row0 : m.col0) : (int)blockIdx.x * (TILES * LINES);
     if (l0 + TILES * LINES <= (int)h_line_lo || l0 >= (int)h_line_hi) {
@@ -466,13 +472,13 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   const int plo = (int)h_pos_lo, phi = (int)h_pos_hi;
   if (plo <= 0 && phi >= N) {  // wave-uniform: the whole line is live
 #pragma unroll
-    for (int k = 0; k < E; ++k) v[k] = stream_load<NT>(at(k));
+    for (int k = 0; k < E; ++k) v[k] = stream_load<NTL>(at(k));
   } else {
 #pragma unroll
     for (int k = 0; k < E; ++k) {
       const int pos = m.t + k * (N / E);
       v[k] = cx<T>{(T)0, (T)0};
-      if (pos >= plo && pos < phi) v[k] = stream_load<NT>(at(k));
+      if (pos >= plo && pos < phi) v[k] = stream_load<NTL>(at(k));
     }
   }
   __builtin_amdgcn_sched_barrier(0);

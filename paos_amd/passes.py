@@ -25,6 +25,7 @@ import numpy as np
 from . import _lib
 
 _OFF = [0.0, 0.0, 0.0, 0.0, 0.0]
+MAX_MERGED_PTP = 3  # transfer functions one middle pass can carry (kFrugalMaxMid of csrc/frugal_pass.h)
 
 
 def _rows(rows, batch):
@@ -49,6 +50,7 @@ class PassCompiler:
         self.passes = []    # emitted, in order
         self.open = None    # last pass, if its second transform slot is still free
         self.tail = []      # pointwise operators not yet attached to a pass
+        self.last_ptp = None  # the ptp just emitted, while another one may still merge with it (see ptp)
 
     # ---- helpers -------------------------------------------------------------------
     def _block(self, rows):
@@ -150,15 +152,38 @@ class PassCompiler:
         arr = _rows(rows, self.batch)
         if not arr[:, 0].any():
             return
+        # Two ptp in a row (OI then IO, or II then II: wfo.py:560-570) with nothing between them:
+        #   F^-1 H2 F . F^-1 H1 F  =  F^-1 (H2 H1) F        since fft2(ifft2(X)) = X,
+        # so the second one only adds its transfer function to the first one's middle pass -- two passes per
+        # junction less, and the same numbers up to the rounding noise of the transform pair that is not run
+        # (~1e-16 relative; each phase keeps its own, separately rounded argument).  Items that take only one of
+        # the two have the other phase switched off (factor 1); the transforms run for the union.
+        lp = self.last_ptp
+        if (lp is not None and self.open is lp["tail"] and not self.tail and lp["tail"]["mid"] == lp["tail_mid"] and
+                sum(op[0] == _lib.PW_QPHASE_NATURAL for op in lp["middle"]["mid"]) < MAX_MERGED_PTP):
+            par = self._block(arr)
+            on = arr[:, 0] != 0.0
+            for blk, col, val in ((lp["fwd"], 1, 0.0), (lp["inv"], 1, 1.0), (lp["scl"], 3, 1.0 / self.n)):
+                b = self.blocks[blk]
+                new = on & (b[:, 0] == 0.0)
+                b[new, :] = 0.0
+                b[new, 0] = 1.0
+                b[new, col] = val
+            mid = lp["middle"]["mid"]
+            mid.insert(len(mid) - 1, (_lib.PW_QPHASE_NATURAL, 0, par))  # in front of the 1/N
+            return
         par = self._block(arr)
         fwd = self._derived(arr, v1=0.0)
         inv = self._derived(arr, v1=1.0)
         scl = self._derived(arr, v3=1.0 / self.n)
         axis = self._first_pass([], fwd)
-        self.passes.append({"axis": 1 - axis, "fft1": fwd, "fft2": inv, "pre": [], "post": [],
-                            "mid": [(_lib.PW_QPHASE_NATURAL, 0, par), (_lib.PW_SCALE, 0, scl)]})
+        middle = {"axis": 1 - axis, "fft1": fwd, "fft2": inv, "pre": [], "post": [],
+                  "mid": [(_lib.PW_QPHASE_NATURAL, 0, par), (_lib.PW_SCALE, 0, scl)]}
+        self.passes.append(middle)
         self.open = None
         self._open_pass(axis, inv, [(_lib.PW_SCALE, 0, scl)])
+        self.last_ptp = {"middle": middle, "tail": self.open, "tail_mid": list(self.open["mid"]), "fwd": fwd, "inv": inv,
+                         "scl": scl}
 
     def open_takes_mask(self):
         """True when a pass is still open whose operator slot after its transform can take an

@@ -122,9 +122,11 @@ def test_fused_pass_programs_reproduce_reference(name):
 
 
 def test_syn20_pass_budget():
-    """SURVEY 8d counts 43 2-D FFTs for SYN20 (16 ptp, 6 stw, 5 wts); fused they take 49 HBM
+    """SURVEY 8d counts 43 2-D FFTs for SYN20 (16 ptp, 6 stw, 5 wts); fused they take 39 HBM
     passes + 7 stand-alone aperture passes (unfused: 70 transform + 11 lens + 7 aperture), or
-    45 passes in all when the apertures ride on passes too (PAOS_FUSE_APERTURES=1)."""
+    34 passes in all when the apertures ride on passes too (PAOS_FUSE_APERTURES=1).  Round 3: each of the five
+    relays has two ptp in a row (OI then IO); the second one's transfer function joins the first one's middle
+    pass (fft2(ifft2(X)) = X), two passes less per relay: 49 -> 39 and 44 -> 34."""
     import paos_amd.run as prun
 
     prun.FUSE_APERTURES = False
@@ -132,7 +134,7 @@ def test_syn20_pass_budget():
         _, dev, stats = _model_run(_spec("SYN20"), 64)
     finally:
         prun.FUSE_APERTURES = "auto"
-    assert stats["fused_passes"] == dev.pass_count == 49
+    assert stats["fused_passes"] == dev.pass_count == 39
     kinds = [name for name, _ in dev.log]
     # the first surface (ones -> aperture -> stop) is one "start" launch
     assert kinds.count("start") == 1 and kinds.count("aperture") == 6 and kinds.count("make_stop") == 0
@@ -144,7 +146,7 @@ def test_syn20_pass_budget():
     finally:
         prun.FUSE_APERTURES = "auto"
     kinds = [name for name, _ in dev.log]
-    assert kinds.count("aperture") == 0 and kinds.count("start") == 1 and stats["fused_passes"] == 44
+    assert kinds.count("aperture") == 0 and kinds.count("start") == 1 and stats["fused_passes"] == 34
     gr = load_golden("run_SYN20.npz")
     saved, _, _ = _model_run(_spec("SYN20"), 128)
     prun.FUSE_APERTURES = True
@@ -350,3 +352,49 @@ def _lean_walk_checks(ModelDevice, oracle_run, run_batch, syn20_chain, wls, chai
     assert [name for name, _ in dev3.log].count("zero_outside_rows") == 1
     want = run_batch(1.0, wls[:1], 128, 4, field, [chain], outputs=("psf",), dev=ModelDevice(128, 1), keep_psf=True)
     assert abs(got[0][20]["power"] - want[0][20]["power"]) <= 1e-13 * want[0][20]["power"]
+
+
+def test_consecutive_ptp_merge_into_one_middle_pass():
+    """ptp . ptp = F^-1 (H2 H1) F: the pass compiler drops the inverse / forward transform pair between two
+    ptp that follow each other directly.  Against the oracle's two separate ptp (wfo.py:445-472) on a random
+    field, with items that take both, only the first, only the second, or neither; a lens or an aperture in
+    between keeps them apart; a fourth ptp in a row starts a new group (three phases per pass at most)."""
+    from fakes import ModelDevice
+    from oracle.pop_numpy import RefWFO
+    from paos_amd import _lib
+    from paos_amd.passes import PassCompiler
+    from paos_amd.planner import PilotBeam
+
+    n, nb = 64, 4
+    rng = np.random.default_rng(11)
+    u0 = rng.standard_normal((nb, n, n)) + 1j * rng.standard_normal((nb, n, n))
+    takes = [(True, True), (True, False), (False, True), (False, False)]
+    dz = (0.7, 1.9)
+    beams = [PilotBeam(1.0, 1.0e-6 * (1 + 0.1 * i), n, 4) for i in range(nb)]
+    dev = ModelDevice(n, nb)
+    dev.u[:] = u0
+    comp = PassCompiler(nb, n)
+    for k in range(2):
+        comp.ptp([beams[i].ptp(dz[k]) if takes[i][k] else None for i in range(nb)])
+    assert len(comp.passes) == 3 and sum(op[0] == _lib.PW_QPHASE_NATURAL for op in comp.passes[1]["mid"]) == 2
+    comp.flush(dev)
+    for i in range(nb):
+        w = RefWFO(1.0, 1.0e-6 * (1 + 0.1 * i), n, 4)
+        w._wfo = u0[i].copy()
+        for k in range(2):
+            if takes[i][k]:
+                w.ptp(dz[k])
+        assert rel_err(dev.u[i], w._wfo) < 1e-13, i
+    # something between two ptp: no merge
+    comp = PassCompiler(1, n)
+    comp.ptp([beams[0].ptp(1.0)])
+    comp.lens([[1.0, beams[0].dx, beams[0].dy, 0.5 / 1.0e-6 * 0.1, -1.0]])
+    comp.ptp([beams[0].ptp(1.0)])
+    assert len(comp.program()[0]) == 5
+    # four in a row: 3 + 1
+    comp = PassCompiler(1, n)
+    for _ in range(4):
+        comp.ptp([beams[0].ptp(0.5)])
+    prog = comp.program()[0]
+    assert len(prog) == 5
+    assert [sum(op[0] == _lib.PW_QPHASE_NATURAL for op in p["mid"]) for p in prog] == [0, 3, 0, 1, 0]
