@@ -151,9 +151,23 @@ __device__ __forceinline__ T flip_sign(T x, unsigned mask_hi) {
 #ifndef PAOS_COL_PRE
 #define PAOS_COL_PRE 1
 #endif
-template <typename T, int N, int E, int K, typename Map, int PLAIN = 0>
+// SHARE (round 3): a quadratic phase is even along the line -- position p and its mirror N - p (mod N; both in the
+// centred and in the natural-order coordinates) have the SAME rounded argument, hence the same factor bit for bit.
+// Element k of thread t sits at p = t + k TL; its mirror belongs to thread TL - t, element E - 1 - k (thread 0:
+// itself, element E - k).  So every thread evaluates the factors of its first E / 2 elements only, leaves them in
+// the line's exchange area (idle between the transforms) and fetches the other half from its mirror thread:
+// per phase slot 8 x (argument + sincos) = 184 fp64 instructions less per thread for 8 ds_write_b128 + 8
+// ds_read_b128 and two workgroup barriers (`area_busy`: the area may still be read by the transform in front).
+// The self-mirrored position N / 2 (thread 0, element E / 2) is evaluated by its owner.
+#ifndef PAOS_SHARE_PHASES
+#define PAOS_SHARE_PHASES 1
+#endif
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <typename T, int N, int E, int K, typename Map, int PLAIN = 0, bool SHARE = false>
 __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, const FrugalPhase* ph,
-                                            const Map& m, const cx<double>* circle, bool conj_in, bool conj_out, int tpos) {
+                                            const Map& m, const cx<double>* circle, bool conj_in, bool conj_out, int tpos,
+                                            void* area = nullptr, bool area_busy = false) {
   if constexpr (PLAIN == 1) {  // column passes: the conjugation, nothing else
     static_assert(K == 0, "a plain slot has no phases");
     const unsigned mask = (conj_out != conj_in) ? 0x80000000u : 0u;
@@ -233,6 +247,8 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
     g_lo[j] = (double)(nat ? tpos : tpos - N / 2);
     g_hi[j] = (double)(nat ? tpos - N : tpos - N / 2);
   }
+  const int mt = tpos == 0 ? 0 : TL - tpos;             // the thread that holds the mirror positions
+  const int mbase = (tpos == 0 ? TL : 0) + mt;          // + (E - 1 - k) TL: where element k's factor was left
   if constexpr (sizeof(T) == 4) {
     // fp32 mode: the field carries ~1e-7, so the phase needs no more than that -- but its ARGUMENT
     // reaches 1e6 rad and is still formed in fp64: in turns, s * (m2 coef / 2 pi), one fraction
@@ -243,6 +259,41 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
 #pragma unroll
     for (int j = 0; j < K; ++j) turn_coef[j] = ph[j].m2 * coefq[j] * 0.15915494309189535;  // / 2 pi; coef carries the sign
     const float ff = (float)f, ffy = (float)fy;
+    auto factor32 = [&](int k) __attribute__((always_inline)) {
+      cx<float> p = {1.0f, 0.0f};
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        const double x = ((k < E / 2 ? g_lo[j] : g_hi[j]) + (double)(k * TL)) * step[j];
+        const double turns = fma(x, x, across2[j]) * turn_coef[j];
+        const float frac = (float)(turns - floor(turns));
+        const float snf = __builtin_amdgcn_sinf(frac), csf = __builtin_amdgcn_cosf(frac);
+        p = j == 0 ? cx<float>{csf, snf} : cmul_after_trans(p, cx<float>{csf, snf});
+      }
+      return p;
+    };
+    if constexpr (SHARE && K > 0) {
+      cx<float>* fac = reinterpret_cast<cx<float>*>(area);
+      if (area_busy) lds_barrier();
+#pragma unroll
+      for (int k = 0; k < E / 2; ++k) {
+        const cx<float> p = factor32(k);
+        fac[k * TL + tpos] = p;
+        const cx<float> zs = scale2(K == 1 ? cmul_after_trans(cx<float>{(float)v[k].x, (float)v[k].y}, p)
+                                           : cmul(cx<float>{(float)v[k].x, (float)v[k].y}, p), ff, ffy);
+        v[k] = {(T)zs.x, (T)zs.y};
+        if ((k + 1) % PAOS_FENCE_EVERY == 0) __builtin_amdgcn_sched_barrier(0);
+      }
+      if (tpos == 0) fac[(E / 2) * TL] = factor32(E / 2);
+      lds_barrier();
+#pragma unroll
+      for (int k = E / 2; k < E; ++k) {
+        const cx<float> p = fac[(E - 1 - k) * TL + mbase];
+        const cx<float> zs = scale2(cmul(cx<float>{(float)v[k].x, (float)v[k].y}, p), ff, ffy);
+        v[k] = {(T)zs.x, (T)zs.y};
+      }
+      lds_barrier();  // the transform behind the slot writes the area next
+      return;
+    }
 #pragma unroll
     for (int k = 0; k < E; ++k) {
       cx<float> z = {(float)v[k].x, (float)v[k].y};
@@ -260,9 +311,9 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
     }
     return;
   }
-#pragma unroll
-  for (int k = 0; k < E; ++k) {
-    cx<double> vd = {(double)v[k].x, (double)v[k].y};
+  // the factor prod_j exp(i q_j) of element k: each argument rounded like the reference's
+  auto factor = [&](int k) __attribute__((always_inline)) {
+    cx<double> p = {1.0, 0.0};
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       const double x = __dmul_rn((k < E / 2 ? g_lo[j] : g_hi[j]) + (double)(k * TL), step[j]);
@@ -273,10 +324,39 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
       const double q = __dmul_rn(ph[j].m2, __dmul_rn(coefq[j], s));
       double sn, cs;
       sincos_tab(q, circle, &sn, &cs);
-      // only the phase ARGUMENT is rounded like the reference's; the product itself may use FMA
-      vd = {fma(vd.x, cs, -(vd.y * sn)), fma(vd.x, sn, vd.y * cs)};
+      // only the phase ARGUMENT is rounded like the reference's; the products themselves may use FMA
+      p = j == 0 ? cx<double>{cs, sn} : cx<double>{fma(p.x, cs, -(p.y * sn)), fma(p.x, sn, p.y * cs)};
     }
-    v[k] = {(T)(vd.x * f), (T)(vd.y * fy)};
+    return p;
+  };
+  auto apply = [&](int k, cx<double> p) __attribute__((always_inline)) {
+    const cx<double> vd = {(double)v[k].x, (double)v[k].y};
+    v[k] = {(T)(fma(vd.x, p.x, -(vd.y * p.y)) * f), (T)(fma(vd.x, p.y, vd.y * p.x) * fy)};
+  };
+  if constexpr (SHARE && K > 0) {
+    cx<double>* fac = reinterpret_cast<cx<double>*>(area);
+    if (area_busy) lds_barrier();
+#pragma unroll
+    for (int k = 0; k < E / 2; ++k) {
+      const cx<double> p = factor(k);
+      fac[k * TL + tpos] = p;
+      apply(k, p);
+      if ((k + 1) % PAOS_FENCE_EVERY == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    if (tpos == 0) fac[(E / 2) * TL] = factor(E / 2);
+    lds_barrier();
+#pragma unroll
+    for (int k = E / 2; k < E; ++k) {
+      apply(k, fac[(E - 1 - k) * TL + mbase]);
+      if ((k + 1) % PAOS_FENCE_EVERY == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    lds_barrier();  // the transform behind the slot writes the area next
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < E; ++k) {
+    if constexpr (K > 0) apply(k, factor(k));
+    else v[k] = {(T)((double)v[k].x * f), (T)((double)v[k].y * fy)};
     if ((k + 1) % PAOS_FENCE_EVERY == 0) __builtin_amdgcn_sched_barrier(0);
   }
 }
@@ -550,15 +630,19 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   const bool ran1 = it.fft1_on != 0.0;
   const bool ran2 = NFFT == 2 && it.fft2_on != 0.0;
   const bool inv1 = ran1 && it.fft1_inv != 0.0;
-  frugal_slot<T, N, E, KPRE, decltype(m), kPlainPre>(v, it.pre, it.pre_ph, m, circle, false, inv1, m.t);
+  constexpr bool kShare = PAOS_SHARE_PHASES != 0;
+  // (with phases in BOTH slots the second sharing loop costs the shape its spill-free register allocation: there
+  // only the slot between the transforms shares)
+  frugal_slot<T, N, E, KPRE, decltype(m), kPlainPre, kShare && KMID == 0>(v, it.pre, it.pre_ph, m, circle, false, inv1, m.t, lds, false);
   PAOS_STAMP(2);
   if (ran1) frugal_fft<T, N, E, SPLIT, false>(v, lds, m.t, tw, circle, it.fft1_inv);
   PAOS_STAMP(3);
-  frugal_slot<T, N, E, KMID>(v, it.mid, it.mid_ph, m, circle, inv1, ran2 && it.fft2_inv != 0.0, m.t);
+  constexpr bool kShareMid = kShare && KPRE == 0 && KMID < 3;
+  frugal_slot<T, N, E, KMID, decltype(m), 0, kShareMid>(v, it.mid, it.mid_ph, m, circle, inv1, ran2 && it.fft2_inv != 0.0, m.t, lds, ran1);
   PAOS_STAMP(4);
   if constexpr (NFFT == 2) {
     if (ran2) {
-      if (ran1) __syncthreads();
+      if (ran1 && !(kShareMid && KMID > 0)) __syncthreads();  // (a sharing slot ends on a barrier of its own)
       frugal_fft<T, N, E, SPLIT>(v, lds, m.t, tw, circle, it.fft2_inv);
     }
   }
