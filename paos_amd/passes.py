@@ -161,8 +161,18 @@ class PassCompiler:
         lp = self.last_ptp
         if (lp is not None and self.open is lp["tail"] and not self.tail and lp["tail"]["mid"] == lp["tail_mid"] and
                 sum(op[0] == _lib.PW_QPHASE_NATURAL for op in lp["middle"]["mid"]) < MAX_MERGED_PTP):
-            par = self._block(arr)
+            first = self.blocks[lp["par"]]
             on = arr[:, 0] != 0.0
+            # ... and when the second one undoes the first (a surface a hair past a waist: OI steps stw, ptp(+d) and the
+            # next IO step starts with ptp(-d); SYN20 does this at every focus with d = 1.6 nm): H(-d) H(d) = 1 for
+            # every item, so both go -- and the stw in front and the wts behind meet in ONE pass.  (Items that take
+            # neither ptp are covered: the pair is the identity for them too.)
+            if (lp["single"] and np.array_equal(first[:, 0] != 0.0, on) and
+                    np.array_equal(first[on, 1:3], arr[on, 1:3]) and np.array_equal(first[on, 3], -arr[on, 3]) and
+                    np.array_equal(first[on, 4], arr[on, 4])):
+                self._restore(lp["undo"])
+                return
+            par = self._block(arr)
             for blk, col, val in ((lp["fwd"], 1, 0.0), (lp["inv"], 1, 1.0), (lp["scl"], 3, 1.0 / self.n)):
                 b = self.blocks[blk]
                 new = on & (b[:, 0] == 0.0)
@@ -171,7 +181,9 @@ class PassCompiler:
                 b[new, col] = val
             mid = lp["middle"]["mid"]
             mid.insert(len(mid) - 1, (_lib.PW_QPHASE_NATURAL, 0, par))  # in front of the 1/N
+            lp["single"] = False
             return
+        undo = self._snapshot()
         par = self._block(arr)
         fwd = self._derived(arr, v1=0.0)
         inv = self._derived(arr, v1=1.0)
@@ -183,7 +195,20 @@ class PassCompiler:
         self.open = None
         self._open_pass(axis, inv, [(_lib.PW_SCALE, 0, scl)])
         self.last_ptp = {"middle": middle, "tail": self.open, "tail_mid": list(self.open["mid"]), "fwd": fwd, "inv": inv,
-                         "scl": scl}
+                         "scl": scl, "par": par, "single": True, "undo": undo}
+
+    def _snapshot(self):
+        """What ``_restore`` needs to take the compiler back to this point (before an operator was queued)."""
+        o = self.open
+        return {"n_blocks": len(self.blocks), "n_passes": len(self.passes), "open": o, "tail": list(self.tail),
+                "open_state": None if o is None else (list(o["mid"]), o.get("fft2", -1)), "last_ptp": self.last_ptp}
+
+    def _restore(self, snap):
+        del self.blocks[snap["n_blocks"]:]
+        del self.passes[snap["n_passes"]:]
+        self.open, self.tail, self.last_ptp = snap["open"], list(snap["tail"]), snap["last_ptp"]
+        if self.open is not None:
+            self.open["mid"], self.open["fft2"] = list(snap["open_state"][0]), snap["open_state"][1]
 
     def open_takes_mask(self):
         """True when a pass is still open whose operator slot after its transform can take an

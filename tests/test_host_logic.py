@@ -122,11 +122,12 @@ def test_fused_pass_programs_reproduce_reference(name):
 
 
 def test_syn20_pass_budget():
-    """SURVEY 8d counts 43 2-D FFTs for SYN20 (16 ptp, 6 stw, 5 wts); fused they take 39 HBM
+    """SURVEY 8d counts 43 2-D FFTs for SYN20 (16 ptp, 6 stw, 5 wts); fused they take 29 HBM
     passes + 7 stand-alone aperture passes (unfused: 70 transform + 11 lens + 7 aperture), or
-    34 passes in all when the apertures ride on passes too (PAOS_FUSE_APERTURES=1).  Round 3: each of the five
-    relays has two ptp in a row (OI then IO); the second one's transfer function joins the first one's middle
-    pass (fft2(ifft2(X)) = X), two passes less per relay: 49 -> 39 and 44 -> 34."""
+    24 passes in all when the apertures ride on passes too (PAOS_FUSE_APERTURES=1).  Round 3: each of the five
+    relays has two ptp in a row at its focus (OI then IO: ptp(+1.6 nm), ptp(-1.6 nm)); since fft2(ifft2(X)) = X
+    the second joins the first one's middle pass, and since H(-d) H(d) = 1 the pair goes altogether and the stw in
+    front meets the wts behind in one pass: four passes less per relay, 49 -> 29 and 44 -> 24."""
     import paos_amd.run as prun
 
     prun.FUSE_APERTURES = False
@@ -134,7 +135,7 @@ def test_syn20_pass_budget():
         _, dev, stats = _model_run(_spec("SYN20"), 64)
     finally:
         prun.FUSE_APERTURES = "auto"
-    assert stats["fused_passes"] == dev.pass_count == 39
+    assert stats["fused_passes"] == dev.pass_count == 29
     kinds = [name for name, _ in dev.log]
     # the first surface (ones -> aperture -> stop) is one "start" launch
     assert kinds.count("start") == 1 and kinds.count("aperture") == 6 and kinds.count("make_stop") == 0
@@ -146,7 +147,7 @@ def test_syn20_pass_budget():
     finally:
         prun.FUSE_APERTURES = "auto"
     kinds = [name for name, _ in dev.log]
-    assert kinds.count("aperture") == 0 and kinds.count("start") == 1 and stats["fused_passes"] == 34
+    assert kinds.count("aperture") == 0 and kinds.count("start") == 1 and stats["fused_passes"] == 24
     gr = load_golden("run_SYN20.npz")
     saved, _, _ = _model_run(_spec("SYN20"), 128)
     prun.FUSE_APERTURES = True
@@ -385,6 +386,29 @@ def test_consecutive_ptp_merge_into_one_middle_pass():
             if takes[i][k]:
                 w.ptp(dz[k])
         assert rel_err(dev.u[i], w._wfo) < 1e-13, i
+    # ptp(+d) then ptp(-d): the pair is the identity and leaves no pass behind -- for every item or not at all
+    comp = PassCompiler(nb, n)
+    comp.stw([beams[i].ptp(0.3) for i in range(nb)], [False] * nb)  # (any block will do for the structure)
+    before = len(comp.passes)
+    fwd = [beams[i].ptp(2.0e-9 * (i + 1)) if i != 3 else None for i in range(nb)]
+    back = [beams[i].ptp(-2.0e-9 * (i + 1)) if i != 3 else None for i in range(nb)]
+    assert all(b is None or b[3] == -f[3] for f, b in zip(fwd, back))
+    comp.ptp(fwd)
+    assert len(comp.passes) == before + 2
+    comp.ptp(back)
+    assert len(comp.passes) == before and comp.open is comp.passes[-1] and comp.open["fft2"] == -1
+    comp.ptp(fwd)
+    odd = [list(b) if b is not None else None for b in back]
+    odd[1][3] *= 1.0000001  # one item whose second step is not the exact inverse: the pair stays, merged
+    comp.ptp(odd)
+    assert len(comp.passes) == before + 2
+    assert sum(op[0] == _lib.PW_QPHASE_NATURAL for op in comp.passes[-2]["mid"]) == 2
+    dev = ModelDevice(n, nb)
+    dev.u[:] = u0
+    comp = PassCompiler(nb, n)
+    comp.ptp(fwd)
+    comp.ptp(back)
+    assert not comp.pending() or not comp.program()[0]
     # something between two ptp: no merge
     comp = PassCompiler(1, n)
     comp.ptp([beams[0].ptp(1.0)])
