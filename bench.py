@@ -9,17 +9,21 @@ A "step" propagates one batch of ``--batch`` wavefronts (wavelength sweep lambda
 through all 20 surfaces on the HIP path; fields are created and stay in HBM.  With N GPUs every rank gets its own
 contiguous block of the sweep (weak scaling) after ONE broadcast of the packed work description from rank 0
 (paos_comm_bcast_blob: RCCL over xGMI, driven from libpaoship.so -- torch is only the launcher, it is never
-imported here).  Rank 0 prints one JSON line (contract in the task statement) with these extra objects:
+imported here).  With N > 1 the run FAILS (exit 3) when the ranks could not agree on RCCL, unless --allow-tcp is
+given; `config.ranks_seen` / `devices_seen` come from the communicator.  Rank 0 prints one JSON line (contract in the task statement) with these extra objects:
 
   roofline           the dominant kernel (the fused FFT pass): every pass launch of the timed region is
-                     bracketed by HIP events on the context's stream; `achieved` = 32 B/px x N^2 x batch (one read
-                     and one write of every element) / mean duration of the launches that process every tile
-                     (launches that skip dead tiles behind an aperture move fewer bytes and are listed apart under
-                     `pruned`); `copy_yardstick` is measured in this run (paos_copy_yardstick); `traffic` = HBM bytes
-                     per full launch from FETCH_SIZE / WRITE_SIZE, collected by two child runs of this script under
+                     bracketed by HIP events on the context's stream (paos_profile_end_launches: time and class of
+                     each launch); `achieved` = 32 B/px x N^2 x batch (one read and one write of every element) / mean
+                     duration of the launches that skip nothing; `classes` lists every class of launch (full, skipping
+                     tiles of dead lines / loads of dead positions / stores nobody reads, storing the PSF) with its mean
+                     time and -- from the counters -- the bytes it really moved; `all_launches` sums both over one
+                     step; `copy_yardstick` is measured in this run (paos_copy_yardstick); `traffic` = HBM bytes per
+                     full launch from FETCH_SIZE / WRITE_SIZE, collected by two child runs of this script under
                      rocprofv3 --pmc (measure_traffic; N = 1 only, --no-traffic skips it).
   chain_vs_survey_model / ptp_step   the whole chain and one ptp priced with SURVEY 8d's UNFUSED byte model (2 passes
-                     per 2-D FFT) next to the bytes the fused passes really move (`frac_bytes_moved`).
+                     per 2-D FFT) next to the bytes the launches of one step really moved under the counters
+                     (`bytes_moved_per_wavefront`, every kernel of the step; `other_kernels` lists the non-pass ones).
   extra              the same chain at 2048^2 and 1024^2 (the north star's sweep), value + roofline each.
   cpu_baseline       the NumPy oracle ("port") on the host: one wavefront of the workload at the benchmark grid
                      on one core, and `cpu_baseline_parallel`: min(batch, cores, memory, 8) worker processes over

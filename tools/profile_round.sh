@@ -10,7 +10,7 @@ rm -rf "$OUT" && mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 BENCH="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --no-traffic"
 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o stats --output-format csv -- $BENCH > "$OUT/bench_under_rocprof.log" 2>&1
-python3 "$ROOT/tools/kernel_stats_summary.py" "$OUT/stats" "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras (4096^2 c128, batch 32; 6 chain steps + ptp probe + copy yardstick)" > "$OUT/kernel_stats.txt"
+python3 "$ROOT/tools/kernel_stats_summary.py" "$OUT/stats" "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras --no-traffic (4096^2 c128, batch 32; 6 chain steps of 24 passes + ptp probe + copy yardstick)" > "$OUT/kernel_stats.txt"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/fetch" -o fetch --output-format csv -- python3 "$ROOT/bench.py" --steps 2 --warmup 0 --no-cpu-baseline --no-extras --no-traffic > "$OUT/bench_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/write" -o write --output-format csv -- python3 "$ROOT/bench.py" --steps 2 --warmup 0 --no-cpu-baseline --no-extras --no-traffic > "$OUT/bench_write.log" 2>&1
 python3 "$ROOT/tools/pmc_summary.py" $(find "$OUT/fetch" -name "*counter_collection.csv" | head -1) > "$OUT/pmc_fetch.txt"

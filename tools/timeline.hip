@@ -144,9 +144,10 @@ void timeline(const char* name, int batch, int pad_blocks) {
 
 int main() {
   const int b = 8, pad = 3;
+  // One-transform shapes only: the stamped build of a two-transform pass runs 1.8x slower than the real kernel (the
+  // stamps' s_waitcnt / s_memtime pairs serialise the second transform: round 2 measured 1.98 ms against 1.10), so its
+  // phase split says nothing about the real kernel.  These two run within 4 % of their un-instrumented time.
   timeline<double, 4096, 0, 0, 0, 1>("rows single", b, pad);
   timeline<double, 4096, 1, 0, 0, 1>("cols single", b, pad);
-  timeline<double, 4096, 0, 0, 1, 2>("rows double + 1 phase", b, pad);
-  timeline<double, 4096, 1, 0, 1, 2>("cols double + 1 phase", b, pad);
   return 0;
 }
