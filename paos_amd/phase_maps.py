@@ -43,95 +43,97 @@ def _unit_factor(units):
     raise ValueError(f"cannot interpret units {units!r}")
 
 
+def _as_masked(sag):
+    """Samples that are not finite or exactly zero carry no information (wfo.py:745-752)."""
+    if isinstance(sag, np.ma.MaskedArray):
+        return sag
+    return np.ma.MaskedArray(sag, mask=~np.isfinite(sag) | (sag == 0))
+
+
+def _recentre(image, xdec, ydec):
+    """Sub-pixel decentre through the Fourier shift theorem (wfo.py:765-770; the shift tuple is the reference's)."""
+    from scipy.ndimage import fourier_shift
+
+    return np.fft.ifft2(fourier_shift(np.fft.fft2(image), shift=(-xdec, -ydec))).real
+
+
+def _fit_extent(planes, fills, axis, excess):
+    """Bring every plane to the grid's extent along ``axis``: ``excess`` samples too many are cropped (split
+    left/right like wfo.py:812-821, 832-841), ``-excess`` too few are padded with the plane's fill value
+    (wfo.py:804-810, 824-830: the sag with 0, its mask with 1)."""
+    if excess == 0:
+        return planes
+    if excess < 0:
+        lack = -excess
+        before = lack // 2
+        width = [(0, 0), (0, 0)]
+        width[axis] = (before, lack - before)
+        return [np.pad(p, width, mode="constant", constant_values=f) for p, f in zip(planes, fills)]
+    first = excess // 2
+    last = planes[0].shape[axis] - (excess - first)
+    window = [slice(None), slice(None)]
+    window[axis] = slice(first, last)
+    return [p[tuple(window)] for p in planes]
+
+
 def grid_sag_map(sag, nx, ny, delx, dely, xdec, ydec, shape, dx, dy):
     """The masked WFE map ``WFO.grid_sag`` applies and returns (wfo.py:745-867)."""
     assert sag.ndim == 2, "sag shall be a 2D array"
     assert sag.shape == (ny, nx)
-    if not isinstance(sag, np.ma.MaskedArray):
-        mask = ~np.isfinite(sag) | (sag == 0)
-        sag = np.ma.MaskedArray(sag, mask=mask)
-    mask = sag.mask.astype(float)
-    sag = sag.filled(0.0)
+    sag = _as_masked(sag)
+    planes = [sag.filled(0.0), sag.mask.astype(float)]  # heights (masked samples count as 0) and the mask as 0 / 1
+    if (xdec != 0) or (ydec != 0):
+        planes = [_recentre(p, xdec, ydec) for p in planes]
 
-    if (xdec != 0) or (ydec != 0):  # wfo.py:765-770
-        from scipy.ndimage import fourier_shift
-
-        sag = fourier_shift(np.fft.fft2(sag), shift=(-xdec, -ydec))
-        sag = np.fft.ifft2(sag).real
-        mask = fourier_shift(np.fft.fft2(mask), shift=(-xdec, -ydec))
-        mask = np.fft.ifft2(mask).real
-
-    target_width = shape[1] * dx
-    target_height = shape[0] * dy
-    current_width = sag.shape[1] * delx
-    current_height = sag.shape[0] * dely
-    width_diff = int(np.floor((current_width - target_width) / delx))
-    height_diff = int(np.floor((current_height - target_height) / dely))
-    if width_diff % 2 == 1 or height_diff % 2 == 1:
+    # how many samples the map overhangs the grid by, per axis (wfo.py:773-783)
+    rows, cols = planes[0].shape
+    excess_x = int(np.floor((cols * delx - shape[1] * dx) / delx))
+    excess_y = int(np.floor((rows * dely - shape[0] * dy) / dely))
+    if excess_x % 2 == 1 or excess_y % 2 == 1:
         raise NotImplementedError("grid_sag: an odd size difference needs skimage.transform.rescale "
                                   "(wfo.py:786-800), which is not restated")
-
-    def pad_map(s, m, padding):
-        return (np.pad(s, padding, mode="constant", constant_values=0),
-                np.pad(m, padding, mode="constant", constant_values=1))
-
-    if width_diff < 0.0:
-        pad_width = abs(width_diff)
-        pad_left = pad_width // 2
-        sag, mask = pad_map(sag, mask, ((0, 0), (pad_left, pad_width - pad_left)))
-    elif width_diff > 0.0:
-        crop_left = width_diff // 2
-        crop_right = sag.shape[1] - (width_diff - crop_left)
-        sag = sag[:, crop_left:crop_right]
-        mask = mask[:, crop_left:crop_right]
-    if height_diff < 0.0:
-        pad_height = abs(height_diff)
-        pad_top = pad_height // 2
-        sag, mask = pad_map(sag, mask, ((pad_top, pad_height - pad_top), (0, 0)))
-    elif height_diff > 0.0:
-        crop_top = height_diff // 2
-        crop_bottom = sag.shape[0] - (height_diff - crop_top)
-        sag = sag[crop_top:crop_bottom, :]
-        mask = mask[crop_top:crop_bottom, :]
+    planes = _fit_extent(planes, (0, 1), 1, excess_x)
+    planes = _fit_extent(planes, (0, 1), 0, excess_y)
 
     if (delx / dx != 1) or (dely / dy != 1):
         raise NotImplementedError("grid_sag: a map at another pixel scale needs skimage.transform.rescale "
                                   "(wfo.py:845-849), which is not restated: resample the sag to the "
                                   "wavefront's dx, dy first")
-    if sag.shape != tuple(shape):
+    heights, coverage = planes
+    if heights.shape != tuple(shape):
         raise NotImplementedError("grid_sag: a residual shape mismatch needs skimage.transform.resize "
                                   "(wfo.py:855-859), which is not restated")
-    mask = mask > 0.1
-    return np.ma.MaskedArray(sag, mask=mask)
+    return np.ma.MaskedArray(heights, mask=coverage > 0.1)
+
+
+def _radial_frequency(shape, dx, dy):
+    """|f| on the FFT grid of the pupil, with the origin nudged off zero (wfo.py:908-913)."""
+    gx, gy = np.meshgrid(np.fft.fftfreq(shape[1], dx), np.fft.fftfreq(shape[0], dy))
+    rho = np.sqrt(gx**2 + gy**2)
+    rho[rho == 0] = 1e-100
+    return rho
 
 
 def psd_map(shape, dx, dy, A=10.0, B=0.0, C=0.0, fknee=1.0, fmin=None, fmax=None, SR=0.0, units="m"):
-    """The WFE map ``WFO.psd`` applies and returns (wfo.py:908-943 + psd.py:100-160)."""
-    fx = np.fft.fftfreq(shape[1], dx)
-    fy = np.fft.fftfreq(shape[0], dy)
-    fxx, fyy = np.meshgrid(fx, fy)
-    f = np.sqrt(fxx**2 + fyy**2)
-    f[f == 0] = 1e-100
-    f_nyq = 0.5 * np.sqrt(dx**-2 + dy**-2)
+    """The WFE map ``WFO.psd`` applies and returns (wfo.py:908-943 + psd.py:100-160).  The two draws come from
+    NumPy's legacy global generator in the reference's order (screen first, roughness second)."""
+    rho = _radial_frequency(shape, dx, dy)
+    nyquist = 0.5 * np.sqrt(dx**-2 + dy**-2)
     if fmax is None:
-        fmax = f_nyq
+        fmax = nyquist
     else:
-        assert fmax <= f_nyq, f"fmax must be less than or equal to f_Nyq ({f_nyq})"
+        assert fmax <= nyquist, f"fmax must be less than or equal to f_Nyq ({nyquist})"
     if fmin is None:
         fmin = 1 / (shape[0] * np.max([dx, dy]))
 
-    nx_, ny_ = shape  # psd.py:103 names them Nx, Ny = pupil.shape
-    wfe = np.random.randn(nx_, ny_)
-    ft_wfe = np.fft.fft2(wfe)
-    dfx = f[0, 2] - f[0, 1]
-    dfy = f[2, 0] - f[1, 0]
-    psd2d = A / (B + (f / fknee) ** C) / (2 * np.pi * f) * (dfx * dfy)
-    ft_wfe *= np.sqrt(psd2d) * np.sqrt(nx_ * ny_)
-    idx = np.logical_or(f < fmin, f > fmax)
-    ft_wfe[idx] = 0.0
-    wfe = np.fft.ifft2(ft_wfe).real
-    wfe = np.ma.masked_array(wfe, mask=np.zeros((nx_, ny_)).astype(bool))
-    wfe += SR * np.random.randn(nx_, ny_)
-    wfe *= 2
-    wfe *= _unit_factor(units)
-    return wfe
+    n0, n1 = shape  # the reference draws an array of the pupil's shape, whatever it calls the two numbers (psd.py:103)
+    spectrum = np.fft.fft2(np.random.randn(n0, n1))
+    cell = (rho[0, 2] - rho[0, 1]) * (rho[2, 0] - rho[1, 0])  # frequency-bin area
+    density = A / (B + (rho / fknee) ** C) / (2 * np.pi * rho) * cell
+    spectrum *= np.sqrt(density) * np.sqrt(n0 * n1)
+    spectrum[np.logical_or(rho < fmin, rho > fmax)] = 0.0
+    screen = np.ma.masked_array(np.fft.ifft2(spectrum).real, mask=np.zeros((n0, n1)).astype(bool))
+    screen += SR * np.random.randn(n0, n1)
+    screen *= 2
+    screen *= _unit_factor(units)
+    return screen
