@@ -430,6 +430,7 @@ constexpr size_t frugal_lds_bytes() {
 #endif
 template <typename T, int N, int THREADS>
 constexpr int frugal_min_waves() {
+  if (sizeof(T) == 4 && THREADS >= 1024) return 8;  // 4-row tiles of complex64: two 1024-thread workgroups per CU
   if (sizeof(T) == 4 && THREADS >= 512) return PAOS_F32_MINW;
   return THREADS >= 512 ? 4 : PAOS_MINW_SMALL;
 }

@@ -43,7 +43,21 @@ using namespace paos;
 #ifndef PAOS_PAD_BLOCKS
 #define PAOS_PAD_BLOCKS 3
 #endif
-static constexpr int BR = PAOS_BR;
+static constexpr int BR = PAOS_BR;  // complex128 and the base case of complex64
+// complex64 at N >= 2048 (where the frugal kernels serve it): blocks of 8 rows x 2 columns = 128 B like a complex128
+// block, so that column tiles own whole lines (round 3; profiles/r02_fftbench_c64_8row_blocks_experiment.txt).  Below
+// 2048 the generic kernels keep 4 x 2 (a column tile needs N / 16 >= block height threads per line).
+#ifndef PAOS_F32_BR
+#define PAOS_F32_BR 8
+#endif
+template <typename T, int N>
+constexpr int block_rows() { return (sizeof(T) == 4 && N >= 2048) ? PAOS_F32_BR : PAOS_BR; }
+// one float launch for either block height: FBR is the compile-time block height inside the statement
+#define F32_BR_SWITCH(c, ...)                                                            \
+  do {                                                                                   \
+    if ((c)->br == PAOS_F32_BR) { constexpr int FBR = PAOS_F32_BR; __VA_ARGS__; }        \
+    else { constexpr int FBR = PAOS_BR; __VA_ARGS__; }                                   \
+  } while (0)
 [[maybe_unused]] static constexpr int kNormSlots = PAOS_NORM_SLOTS;  // outstanding paos_norm2_enqueue results
 template <typename T>
 struct Lay {
@@ -67,6 +81,7 @@ struct Arena {
 
 struct paos_ctx {
   int device = 0, n = 0, batch = 0, precision = 0;
+  int br = PAOS_BR;  // block height of this context's layout (block_rows<T, N>())
   unsigned pitch = 0, item_stride = 0;
   hipStream_t stream = nullptr;
   double* psf = nullptr;  // batch x item_stride intensities kept on the device, blocked like the field (paos_psf_keep)
@@ -213,12 +228,16 @@ int pw_blocks(const paos_ctx* c) {
 template <typename T, int N>
 struct FftCfg {
   static constexpr int BC = Lay<T>::BC;
+  static constexpr int BR = block_rows<T, N>();
   // 16 points per thread.  (32 points of complex64 fill the same 64 data VGPRs, but the
   // radix-32 butterflies spill: 256 VGPRs + 60-70 AGPRs measured, so E stays 16 for both types.)
   static constexpr int E = 16;
   // rows of a block row handled by one row tile: all four, except at N = 4096 where four
   // lines of 4096 points do not fit the register file of a spill-free workgroup
-  static constexpr int ROW_LINES = (N >= 2048) ? BR / 2 : BR;  // 256-thread tiles at 2048 measured +29 %
+  static constexpr int ROW_LINES = (N >= 2048) ? PAOS_BR / 2 : PAOS_BR;  // 256-thread tiles at 2048 measured +29 %
+  // the frugal kernels' row tile: half a block row -- 2 rows of complex128, 4 rows of complex64 at N >= 2048 (1024
+  // threads at <= 64 VGPRs at 4096: two workgroups per CU either way)
+  static constexpr int FR_ROW_LINES = (N >= 2048) ? BR / 2 : BR;
   static constexpr int COL_LINES = BC;
   static constexpr int ROW_THREADS = ROW_LINES * N / E, COL_THREADS = COL_LINES * N / E;
   static constexpr int ROW_TILES = (ROW_THREADS >= 128) ? 1 : 128 / ROW_THREADS;
@@ -273,7 +292,7 @@ int pass_launch(paos_ctx* c, const PassArgs& a) {
   constexpr bool SPLIT = AXIS == 0 ? C::ROW_SPLIT : C::COL_SPLIT;
   const dim3 grid(N / LINES / TILES, c->batch), block(TILES * LINES * N / C::E);
   const size_t lds = (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT>();
-  return launch_pass(c, fused_pass_kernel<T, N, C::E, LINES, TILES, AXIS, BR, BC, SPLIT, C::MINW, 1, 0, FEAT>,
+  return launch_pass(c, fused_pass_kernel<T, N, C::E, LINES, TILES, AXIS, C::BR, BC, SPLIT, C::MINW, 1, 0, FEAT>,
                      grid, block, lds, a, AXIS == 0 ? PAOS_KERNEL_PASS_ROWS : PAOS_KERNEL_PASS_COLS);
 }
 
@@ -449,10 +468,11 @@ bool mask_live_range(const paos_ctx* c, const double* q, const double* q2, int a
   const double a = std::floor(centre - ext + 0.5) - 1.0, b = std::ceil(centre + ext + 0.5) + 1.0;
   const int n = c->n;
   int l = a < 0.0 ? 0 : (a > n ? n : (int)a), h = b < 0.0 ? 0 : (b > n ? n : (int)b);
-  l = (l / BR) * BR;
-  h = ((h + BR - 1) / BR) * BR;
+  const int br = c->br;
+  l = (l / br) * br;
+  h = ((h + br - 1) / br) * br;
   if (h > n) h = n;
-  if (l >= h) { l = 0; h = BR; }  // aperture off the grid along this axis: keep one block row live
+  if (l >= h) { l = 0; h = br; }  // aperture off the grid along this axis: keep one block row live
   *lo = l; *hi = h;
   return true;
 }
@@ -472,8 +492,8 @@ void plan_pruning(const paos_ctx* c, const paos_pass* passes, int n_passes, cons
     int axis = 0, lo = 0, hi = n, last_skip = -1;
     if (entry_rows) {
       int l = (int)entry_rows[2 * it], h = (int)entry_rows[2 * it + 1];
-      l = l < 0 ? 0 : (l / BR) * BR;
-      h = h > n ? n : ((h + BR - 1) / BR) * BR;
+      l = l < 0 ? 0 : (l / c->br) * c->br;
+      h = h > n ? n : ((h + c->br - 1) / c->br) * c->br;
       if (h > n) h = n;
       // entry_stale: the rows outside hold old data that STANDS for zeros (paos_start_rows): virtual from the start
       if (l < h && (l > 0 || h < n)) { zl = true; axis = 0; lo = l; hi = h; virt = entry_stale; }
@@ -498,7 +518,7 @@ void plan_pruning(const paos_ctx* c, const paos_pass* passes, int n_passes, cons
           const int l2 = lo > mlo ? lo : mlo, h2 = hi < mhi ? hi : mhi;
           if (l2 != lo || h2 != hi) virt = true;  // newly dead lines still hold data
           lo = l2; hi = h2;
-          if (lo >= hi) { lo = 0; hi = BR; virt = true; }
+          if (lo >= hi) { lo = 0; hi = c->br; virt = true; }
         }
       } else if (masked && (mlo > 0 || mhi < n)) {
         zl = true; virt = true; axis = ax; lo = mlo; hi = mhi;
@@ -525,14 +545,14 @@ void plan_pruning(const paos_ctx* c, const paos_pass* passes, int n_passes, cons
 template <typename T, int N, int AXIS, int KPRE, int KMID, int NFFT, int STORE = 0>
 int frugal_launch(paos_ctx* c, const FrugalArgs& a) {
   using C = FftCfg<T, N>;
-  constexpr int LINES = AXIS == 0 ? C::ROW_LINES : C::COL_LINES;
+  constexpr int LINES = AXIS == 0 ? C::FR_ROW_LINES : C::COL_LINES;
   constexpr int TILES = AXIS == 0 ? C::ROW_TILES : C::COL_TILES;
   // several workgroups share the 160 KiB of LDS: c128 exchanges re and im in turn; a c64 line
-  // fits whole (the same 35 KiB) and so needs half the barriers
-  constexpr bool SPLIT = sizeof(T) == 8;
+  // fits whole (the same 35 KiB) and so needs half the barriers -- except in the 4-line row tiles
+  constexpr bool SPLIT = sizeof(T) == 8 || LINES > 2;
   const dim3 grid(N / LINES / TILES, c->batch), block(TILES * LINES * N / C::E);
   const size_t lds = frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, C::E, STORE>();
-  auto kern = frugal_pass_kernel<T, N, C::E, LINES, TILES, AXIS, BR, C::BC, SPLIT, KPRE, KMID, NFFT, STORE>;
+  auto kern = frugal_pass_kernel<T, N, C::E, LINES, TILES, AXIS, C::BR, C::BC, SPLIT, KPRE, KMID, NFFT, STORE>;
   {
     int rc = opt_in_lds(c, (const void*)kern, lds);
     if (rc) return rc;
@@ -723,8 +743,8 @@ int launch_one_pass(paos_ctx* c, const paos_pass& p, const double* dblocks, int 
             hipLaunchKernelGGL((aperture_kernel<double, BR, Lay<double>::BC, 0>), grid, block, 0, c->stream, (cx<double>*)nullptr, ap, ap2, FP_STRIDE, c->n, c->pitch, c->item_stride, c->mask, 1);
             hipLaunchKernelGGL((aperture_kernel<double, BR, Lay<double>::BC, 1>), grid, block, 0, c->stream, (cx<double>*)nullptr, ap, ap2, FP_STRIDE, c->n, c->pitch, c->item_stride, c->mask, 1);
           } else {
-            hipLaunchKernelGGL((aperture_kernel<float, BR, Lay<float>::BC, 0>), grid, block, 0, c->stream, (cx<float>*)nullptr, ap, ap2, FP_STRIDE, c->n, c->pitch, c->item_stride, c->mask, 1);
-            hipLaunchKernelGGL((aperture_kernel<float, BR, Lay<float>::BC, 1>), grid, block, 0, c->stream, (cx<float>*)nullptr, ap, ap2, FP_STRIDE, c->n, c->pitch, c->item_stride, c->mask, 1);
+            F32_BR_SWITCH(c, hipLaunchKernelGGL((aperture_kernel<float, FBR, Lay<float>::BC, 0>), grid, block, 0, c->stream, (cx<float>*)nullptr, ap, ap2, FP_STRIDE, c->n, c->pitch, c->item_stride, c->mask, 1));
+            F32_BR_SWITCH(c, hipLaunchKernelGGL((aperture_kernel<float, FBR, Lay<float>::BC, 1>), grid, block, 0, c->stream, (cx<float>*)nullptr, ap, ap2, FP_STRIDE, c->n, c->pitch, c->item_stride, c->mask, 1));
           }
           HIPCHK(c, hipGetLastError());
         }
@@ -756,7 +776,7 @@ int launch_one_pass(paos_ctx* c, const paos_pass& p, const double* dblocks, int 
   if (c->precision == PAOS_F64)
     hipLaunchKernelGGL((pointwise_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream, a, c->n);
   else
-    hipLaunchKernelGGL((pointwise_kernel<float, BR, Lay<float>::BC>), grid, block, 0, c->stream, a, c->n);
+    F32_BR_SWITCH(c, hipLaunchKernelGGL((pointwise_kernel<float, FBR, Lay<float>::BC>), grid, block, 0, c->stream, a, c->n));
   HIPCHK(c, hipGetLastError());
   return PAOS_OK;
 }
@@ -845,7 +865,7 @@ int run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double*
     if (fused_store)
       for (const FrugalItem& fi : low[n_passes - 1].items) fused_store = fused_store && fi.active != 0.0;
     if (fused_store) {
-      const int lines = passes[n_passes - 1].axis == 0 ? (c->n >= 2048 ? BR / 2 : BR) : 2;  // FftCfg: ROW_LINES / COL_LINES
+      const int lines = passes[n_passes - 1].axis == 0 ? (c->n >= 2048 ? c->br / 2 : c->br) : 2;  // FftCfg: FR_ROW_LINES / COL_LINES
       const int groups = c->n / lines;
       if (c->psf_nparts < groups) {
         if (c->psf_partial) (void)hipFree(c->psf_partial);
@@ -907,7 +927,7 @@ int run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double*
   }
   if (final_ticket) {
     if (fused_store) {
-      const int lines = passes[n_passes - 1].axis == 0 ? (c->n >= 2048 ? BR / 2 : BR) : 2;
+      const int lines = passes[n_passes - 1].axis == 0 ? (c->n >= 2048 ? c->br / 2 : c->br) : 2;
       return psf_power_ticket(c, c->psf_partial, c->n / lines, final_ticket);
     }
     return psf_keep_power_impl(c, final_ticket);
@@ -990,7 +1010,7 @@ extern "C" {
 const char* paos_last_error(const paos_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
 const char* paos_build_info(void) {
-  static const std::string info = std::string("libpaoship gfx950 layout=") + std::to_string(BR) + "x(" +
+  static const std::string info = std::string("libpaoship gfx950 layout=") + std::to_string(BR) + "(c64 at N>=2048: " + std::to_string(PAOS_F32_BR) + ")x(" +
                                   std::to_string(Lay<double>::BC) + "|" + std::to_string(Lay<float>::BC) +
                                   ") pad_blocks=" + std::to_string(PAOS_PAD_BLOCKS);
   return info.c_str();
@@ -1011,8 +1031,9 @@ int paos_ctx_create(int device, int n, int batch, int precision, paos_ctx** out)
   paos_ctx* c = new paos_ctx();
   c->device = device; c->n = n; c->batch = batch; c->precision = precision;
   const int bc = precision == PAOS_F64 ? Lay<double>::BC : Lay<float>::BC;
-  c->pitch = (unsigned)n * BR + (unsigned)PAOS_PAD_BLOCKS * BR * bc;
-  c->item_stride = c->pitch * (unsigned)(n / BR);
+  c->br = (precision == PAOS_F32 && n >= 2048) ? PAOS_F32_BR : PAOS_BR;  // block_rows<T, N>()
+  c->pitch = (unsigned)n * c->br + (unsigned)PAOS_PAD_BLOCKS * c->br * bc;
+  c->item_stride = c->pitch * (unsigned)(n / c->br);
   const size_t eb = elem_bytes(c);
   auto bail = [&](hipError_t e, const char* what) {
     std::string msg = std::string(what) + ": " + hipGetErrorString(e);
@@ -1213,22 +1234,22 @@ static int start_impl(paos_ctx* c, double re, double im, int shape, const double
     if ((rc = arena_push(c, write_rows, (size_t)2 * c->batch, &drows))) return rc;
   }
   const dim3 block(kPwThreads);
-#define START_LAUNCH(T, S)                                                                              \
+#define START_LAUNCH(T, BRV, S)                                                                         \
   do {                                                                                                  \
     if (any_stop) {                                                                                     \
-      hipLaunchKernelGGL((start_power_kernel<T, BR, Lay<T>::BC, S>), dim3(c->nparts, c->batch), block, 0, \
+      hipLaunchKernelGGL((start_power_kernel<T, BRV, Lay<T>::BC, S>), dim3(c->nparts, c->batch), block, 0, \
                          c->stream, dp, c->n, c->pitch, c->item_stride, re, im, c->partial, dcompute);  \
       hipLaunchKernelGGL(norm2_final_kernel, dim3(c->batch), block, 0, c->stream, c->partial, c->norm2,   \
                          c->nparts, ds, 1, dpower_of);                                                  \
     }                                                                                                   \
-    hipLaunchKernelGGL((start_write_kernel<T, BR, Lay<T>::BC, S>), dim3(pw_blocks(c), c->batch), block, 0, \
+    hipLaunchKernelGGL((start_write_kernel<T, BRV, Lay<T>::BC, S>), dim3(pw_blocks(c), c->batch), block, 0, \
                        c->stream, (cx<T>*)c->field, dp, c->n, c->pitch, c->item_stride, re, im,          \
                        (const double*)c->norm2, ds, drows);                                             \
   } while (0)
   if (c->precision == PAOS_F64) {
-    if (shape == PAOS_SHAPE_ELLIPSE) START_LAUNCH(double, 0); else START_LAUNCH(double, 1);
+    if (shape == PAOS_SHAPE_ELLIPSE) START_LAUNCH(double, BR, 0); else START_LAUNCH(double, BR, 1);
   } else {
-    if (shape == PAOS_SHAPE_ELLIPSE) START_LAUNCH(float, 0); else START_LAUNCH(float, 1);
+    if (shape == PAOS_SHAPE_ELLIPSE) F32_BR_SWITCH(c, START_LAUNCH(float, FBR, 0)); else F32_BR_SWITCH(c, START_LAUNCH(float, FBR, 1));
   }
 #undef START_LAUNCH
   HIPCHK(c, hipGetLastError());
@@ -1262,9 +1283,9 @@ int paos_import(paos_ctx* c, int item, const void* host) {
                        (cx<double>*)c->field + (size_t)item * c->item_stride, (const cx<double>*)c->staging,
                        c->n, c->pitch);
   else
-    hipLaunchKernelGGL((import_kernel<float, BR, Lay<float>::BC>), dim3(pw_blocks(c)), dim3(kPwThreads), 0, c->stream,
+    F32_BR_SWITCH(c, hipLaunchKernelGGL((import_kernel<float, FBR, Lay<float>::BC>), dim3(pw_blocks(c)), dim3(kPwThreads), 0, c->stream,
                        (cx<float>*)c->field + (size_t)item * c->item_stride, (const cx<double>*)c->staging,
-                       c->n, c->pitch);
+                       c->n, c->pitch));
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));  // the host buffer is only borrowed
   return PAOS_OK;
@@ -1278,9 +1299,9 @@ static int export_impl(paos_ctx* c, int item, int what, void* host_out, bool pin
                        (const cx<double>*)c->field + (size_t)item * c->item_stride, (double*)c->staging,
                        c->n, c->pitch, what);
   else
-    hipLaunchKernelGGL((export_kernel<float, BR, Lay<float>::BC>), dim3(pw_blocks(c)), dim3(kPwThreads), 0, c->stream,
+    F32_BR_SWITCH(c, hipLaunchKernelGGL((export_kernel<float, FBR, Lay<float>::BC>), dim3(pw_blocks(c)), dim3(kPwThreads), 0, c->stream,
                        (const cx<float>*)c->field + (size_t)item * c->item_stride, (double*)c->staging,
-                       c->n, c->pitch, what);
+                       c->n, c->pitch, what));
   HIPCHK(c, hipGetLastError());
   const size_t bytes = (size_t)c->n * c->n * (what == PAOS_WHAT_FIELD ? 16 : 8);
   if (pinned) {  // one DMA into page-locked memory
@@ -1312,8 +1333,8 @@ int paos_psf_keep(paos_ctx* c) {
     hipLaunchKernelGGL((intensity_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream,
                        (const cx<double>*)c->field, c->psf, c->n, c->pitch, c->item_stride);
   else
-    hipLaunchKernelGGL((intensity_kernel<float, BR, Lay<float>::BC>), grid, block, 0, c->stream,
-                       (const cx<float>*)c->field, c->psf, c->n, c->pitch, c->item_stride);
+    F32_BR_SWITCH(c, hipLaunchKernelGGL((intensity_kernel<float, FBR, Lay<float>::BC>), grid, block, 0, c->stream,
+                       (const cx<float>*)c->field, c->psf, c->n, c->pitch, c->item_stride));
   HIPCHK(c, hipGetLastError());
   return PAOS_OK;
 }
@@ -1327,8 +1348,8 @@ int paos_psf_fetch(paos_ctx* c, int item, double* host_out) {
     hipLaunchKernelGGL((psf_unblock_kernel<BR, Lay<double>::BC>), dim3(pw_blocks(c)), dim3(kPwThreads), 0, c->stream,
                        (const double*)c->psf + (size_t)item * c->item_stride, (double*)c->staging, c->n, c->pitch);
   else
-    hipLaunchKernelGGL((psf_unblock_kernel<BR, Lay<float>::BC>), dim3(pw_blocks(c)), dim3(kPwThreads), 0, c->stream,
-                       (const double*)c->psf + (size_t)item * c->item_stride, (double*)c->staging, c->n, c->pitch);
+    F32_BR_SWITCH(c, hipLaunchKernelGGL((psf_unblock_kernel<FBR, Lay<float>::BC>), dim3(pw_blocks(c)), dim3(kPwThreads), 0, c->stream,
+                       (const double*)c->psf + (size_t)item * c->item_stride, (double*)c->staging, c->n, c->pitch));
   HIPCHK(c, hipGetLastError());
   return copy_to_host(c, host_out, c->staging, (size_t)c->n * c->n * sizeof(double));
 }
@@ -1353,14 +1374,14 @@ int paos_host_free(void* p) {
 
 static int aperture_launch(paos_ctx* c, int shape, const double* dp, int nitems, double* mask_out) {
   const dim3 grid(pw_blocks(c), nitems), block(kPwThreads);
-#define AP_LAUNCH(T, S)                                                                          \
-  hipLaunchKernelGGL((aperture_kernel<T, BR, Lay<T>::BC, S>), grid, block, 0, c->stream,                 \
+#define AP_LAUNCH(T, BRV, S)                                                                     \
+  hipLaunchKernelGGL((aperture_kernel<T, BRV, Lay<T>::BC, S>), grid, block, 0, c->stream,                \
                      mask_out ? (cx<T>*)nullptr : (cx<T>*)c->field, dp, (const double*)nullptr,    \
                      AP_STRIDE, c->n, c->pitch, c->item_stride, mask_out, 0)
   if (c->precision == PAOS_F64) {
-    if (shape == PAOS_SHAPE_ELLIPSE) AP_LAUNCH(double, 0); else AP_LAUNCH(double, 1);
+    if (shape == PAOS_SHAPE_ELLIPSE) AP_LAUNCH(double, BR, 0); else AP_LAUNCH(double, BR, 1);
   } else {
-    if (shape == PAOS_SHAPE_ELLIPSE) AP_LAUNCH(float, 0); else AP_LAUNCH(float, 1);
+    if (shape == PAOS_SHAPE_ELLIPSE) F32_BR_SWITCH(c, AP_LAUNCH(float, FBR, 0)); else F32_BR_SWITCH(c, AP_LAUNCH(float, FBR, 1));
   }
 #undef AP_LAUNCH
   HIPCHK(c, hipGetLastError());
@@ -1395,8 +1416,8 @@ static int norm2_launch(paos_ctx* c, const double* den) {
     hipLaunchKernelGGL((norm2_partial_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream,
                        (const cx<double>*)c->field, c->partial, c->n, c->pitch, c->item_stride, den, 1);
   else
-    hipLaunchKernelGGL((norm2_partial_kernel<float, BR, Lay<float>::BC>), grid, block, 0, c->stream,
-                       (const cx<float>*)c->field, c->partial, c->n, c->pitch, c->item_stride, den, 1);
+    F32_BR_SWITCH(c, hipLaunchKernelGGL((norm2_partial_kernel<float, FBR, Lay<float>::BC>), grid, block, 0, c->stream,
+                       (const cx<float>*)c->field, c->partial, c->n, c->pitch, c->item_stride, den, 1));
   HIPCHK(c, hipGetLastError());
   hipLaunchKernelGGL(norm2_final_kernel, dim3(c->batch), block, 0, c->stream, c->partial, c->norm2,
                      c->nparts, den, 1);
@@ -1440,7 +1461,7 @@ int paos_psf_metrics(paos_ctx* c, int nr, const double* radii_px, double cx_px, 
   for (int k = 0; k < nr; ++k) a.r2[k] = radii_px[k] * radii_px[k];
   const dim3 grid(nblocks, c->batch), block(kPwThreads);
   if (c->precision == PAOS_F64) hipLaunchKernelGGL((psf_metrics_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream, a);
-  else hipLaunchKernelGGL((psf_metrics_kernel<float, BR, Lay<float>::BC>), grid, block, 0, c->stream, a);
+  else F32_BR_SWITCH(c, hipLaunchKernelGGL((psf_metrics_kernel<float, FBR, Lay<float>::BC>), grid, block, 0, c->stream, a));
   HIPCHK(c, hipGetLastError());
   hipLaunchKernelGGL(psf_metrics_final_kernel, dim3(c->batch), dim3(64), 0, c->stream, c->metric_partial, c->metric_out, nblocks, nvals);
   HIPCHK(c, hipGetLastError());
@@ -1495,8 +1516,8 @@ int psf_keep_power_impl(paos_ctx* c, int* ticket) {
     hipLaunchKernelGGL((intensity_power_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream,
                        (const cx<double>*)c->field, c->psf, c->partial, c->n, c->pitch, c->item_stride);
   else
-    hipLaunchKernelGGL((intensity_power_kernel<float, BR, Lay<float>::BC>), grid, block, 0, c->stream,
-                       (const cx<float>*)c->field, c->psf, c->partial, c->n, c->pitch, c->item_stride);
+    F32_BR_SWITCH(c, hipLaunchKernelGGL((intensity_power_kernel<float, FBR, Lay<float>::BC>), grid, block, 0, c->stream,
+                       (const cx<float>*)c->field, c->psf, c->partial, c->n, c->pitch, c->item_stride));
   HIPCHK(c, hipGetLastError());
   return psf_power_ticket(c, c->partial, c->nparts, ticket);
 }
@@ -1505,11 +1526,12 @@ int psf_keep_power_impl(paos_ctx* c, int* ticket) {
 int zero_outside_rows(paos_ctx* c, const double* live_rows) {
   const size_t eb = elem_bytes(c);
   for (int i = 0; i < c->batch; ++i) {
-    int lo = ((int)live_rows[2 * i] / BR) * BR, hi = (((int)live_rows[2 * i + 1] + BR - 1) / BR) * BR;
+    const int br = c->br;
+    int lo = ((int)live_rows[2 * i] / br) * br, hi = (((int)live_rows[2 * i + 1] + br - 1) / br) * br;
     if (hi > c->n) hi = c->n;
     if (lo >= hi) { lo = 0; hi = 0; }
     char* base = (char*)c->field + (size_t)i * c->item_stride * eb;
-    const size_t row_bytes = (size_t)c->pitch / BR * eb;  // one row's share of a block row
+    const size_t row_bytes = (size_t)c->pitch / br * eb;  // one row's share of a block row
     if (lo > 0) HIPCHK(c, hipMemsetAsync(base, 0, (size_t)lo * row_bytes, c->stream));
     if (hi < c->n) HIPCHK(c, hipMemsetAsync(base + (size_t)hi * row_bytes, 0, (size_t)(c->n - hi) * row_bytes, c->stream));
   }
@@ -1554,8 +1576,8 @@ int paos_norm2_enqueue_rows(paos_ctx* c, const double* live_rows, int* ticket) {
     hipLaunchKernelGGL((norm2_partial_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream,
                        (const cx<double>*)c->field, c->partial, c->n, c->pitch, c->item_stride, (const double*)nullptr, 1, drows);
   else
-    hipLaunchKernelGGL((norm2_partial_kernel<float, BR, Lay<float>::BC>), grid, block, 0, c->stream,
-                       (const cx<float>*)c->field, c->partial, c->n, c->pitch, c->item_stride, (const double*)nullptr, 1, drows);
+    F32_BR_SWITCH(c, hipLaunchKernelGGL((norm2_partial_kernel<float, FBR, Lay<float>::BC>), grid, block, 0, c->stream,
+                       (const cx<float>*)c->field, c->partial, c->n, c->pitch, c->item_stride, (const double*)nullptr, 1, drows));
   HIPCHK(c, hipGetLastError());
   return psf_power_ticket(c, c->partial, c->nparts, ticket);
 }
@@ -1609,8 +1631,8 @@ int paos_phase_map(paos_ctx* c, int item, const double* host_wfe, double wl) {
     hipLaunchKernelGGL((phase_map_kernel<double, BR, Lay<double>::BC>), dim3(pw_blocks(c)), dim3(kPwThreads), 0, c->stream,
                        (cx<double>*)c->field + (size_t)item * c->item_stride, (const double*)c->staging, c->n, c->pitch, wl);
   else
-    hipLaunchKernelGGL((phase_map_kernel<float, BR, Lay<float>::BC>), dim3(pw_blocks(c)), dim3(kPwThreads), 0, c->stream,
-                       (cx<float>*)c->field + (size_t)item * c->item_stride, (const double*)c->staging, c->n, c->pitch, wl);
+    F32_BR_SWITCH(c, hipLaunchKernelGGL((phase_map_kernel<float, FBR, Lay<float>::BC>), dim3(pw_blocks(c)), dim3(kPwThreads), 0, c->stream,
+                       (cx<float>*)c->field + (size_t)item * c->item_stride, (const double*)c->staging, c->n, c->pitch, wl));
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));  // the host buffer is only borrowed
   return PAOS_OK;
@@ -1708,19 +1730,19 @@ static int zernike_apply(paos_ctx* c, int nmax, int kdim, const double* table, c
     }
     if (known && half >= 0.0 && half < (double)c->n) {
       int lo = (int)std::floor((double)(c->n / 2) - half) - 2, hi = (int)std::ceil((double)(c->n / 2) + half) + 3;
-      lo = lo < 0 ? 0 : (lo / BR) * BR;
-      hi = hi > c->n ? c->n : ((hi + BR - 1) / BR) * BR;
+      lo = lo < 0 ? 0 : (lo / c->br) * c->br;
+      hi = hi > c->n ? c->n : ((hi + c->br - 1) / c->br) * c->br;
       if (hi > c->n) hi = c->n;
-      m_first = (unsigned)(lo / BR) * c->pitch;
-      m_end = (unsigned)(hi / BR) * c->pitch;
+      m_first = (unsigned)(lo / c->br) * c->pitch;
+      m_end = (unsigned)(hi / c->br) * c->pitch;
     }
   }
   if (c->precision == PAOS_F64)
     hipLaunchKernelGGL((zernike_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream, (cx<double>*)c->field,
                        dt, dp, param_stride, c->n, c->pitch, c->item_stride, nmax, kdim, wfe, pupil, m_first, m_end);
   else
-    hipLaunchKernelGGL((zernike_kernel<float, BR, Lay<float>::BC>), grid, block, 0, c->stream, (cx<float>*)c->field, dt,
-                       dp, param_stride, c->n, c->pitch, c->item_stride, nmax, kdim, wfe, pupil, m_first, m_end);
+    F32_BR_SWITCH(c, hipLaunchKernelGGL((zernike_kernel<float, FBR, Lay<float>::BC>), grid, block, 0, c->stream, (cx<float>*)c->field, dt,
+                       dp, param_stride, c->n, c->pitch, c->item_stride, nmax, kdim, wfe, pupil, m_first, m_end));
   HIPCHK(c, hipGetLastError());
   if (host_wfe) return copy_to_host(c, host_wfe, c->staging, (size_t)c->n * c->n * 8);
   return PAOS_OK;
@@ -1754,12 +1776,13 @@ int paos_pupil_aperture(paos_ctx* c, int shape, const double* params) {
   if (rc) return rc;
   const dim3 grid(pw_blocks(c), c->batch), block(kPwThreads);
   // the mask values of the aperture OBJECT, whatever its obscuration flag says (run.py:136-141)
+  // (the element type is irrelevant without a field; the block height is the context's)
   if (shape == PAOS_SHAPE_ELLIPSE)
-    hipLaunchKernelGGL((aperture_kernel<double, BR, Lay<double>::BC, 0>), grid, block, 0, c->stream, (cx<double>*)nullptr,
-                       dp, (const double*)nullptr, AP_STRIDE, c->n, c->pitch, c->item_stride, c->mask, 2);
+    F32_BR_SWITCH(c, hipLaunchKernelGGL((aperture_kernel<double, FBR, Lay<double>::BC, 0>), grid, block, 0, c->stream, (cx<double>*)nullptr,
+                       dp, (const double*)nullptr, AP_STRIDE, c->n, c->pitch, c->item_stride, c->mask, 2));
   else
-    hipLaunchKernelGGL((aperture_kernel<double, BR, Lay<double>::BC, 1>), grid, block, 0, c->stream, (cx<double>*)nullptr,
-                       dp, (const double*)nullptr, AP_STRIDE, c->n, c->pitch, c->item_stride, c->mask, 2);
+    F32_BR_SWITCH(c, hipLaunchKernelGGL((aperture_kernel<double, FBR, Lay<double>::BC, 1>), grid, block, 0, c->stream, (cx<double>*)nullptr,
+                       dp, (const double*)nullptr, AP_STRIDE, c->n, c->pitch, c->item_stride, c->mask, 2));
   HIPCHK(c, hipGetLastError());
   return PAOS_OK;
 }
@@ -1771,8 +1794,8 @@ int paos_pupil_upload(paos_ctx* c, int item, const double* host_weights) {
   int rc = ensure_pupil(c);
   if (rc) return rc;
   HIPCHK(c, hipMemcpyAsync(c->staging, host_weights, (size_t)c->n * c->n * 8, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL((import_weights_kernel<BR, Lay<double>::BC>), dim3(pw_blocks(c)), dim3(kPwThreads), 0, c->stream,
-                     (const double*)c->staging, c->mask + (size_t)item * c->item_stride, c->n, c->pitch, c->item_stride);
+  F32_BR_SWITCH(c, hipLaunchKernelGGL((import_weights_kernel<FBR, Lay<double>::BC>), dim3(pw_blocks(c)), dim3(kPwThreads), 0, c->stream,
+                     (const double*)c->staging, c->mask + (size_t)item * c->item_stride, c->n, c->pitch, c->item_stride));
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));  // host_weights is borrowed
   return PAOS_OK;
@@ -1814,7 +1837,7 @@ int paos_zernike_gram(paos_ctx* c, int nmax, int kdim, const double* table, cons
     return fail(c, PAOS_EHIP, "hipMalloc(gram sums)");
   }
   const size_t lds = (size_t)K * kGramRow * sizeof(double);
-  auto kern = zernike_gram_kernel<BR, Lay<double>::BC>;
+  auto kern = c->br == PAOS_F32_BR ? zernike_gram_kernel<PAOS_F32_BR, Lay<double>::BC> : zernike_gram_kernel<BR, Lay<double>::BC>;
   hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(kern, dim3(nblocks, c->batch), dim3(kGramThreads), lds, c->stream, dt, dp, param_stride, c->n,
