@@ -165,11 +165,13 @@ def test_syn20_4096_last_item_of_the_sweep_vs_oracle():
     print("SYN20 4096^2 k=31 PSF error vs oracle:", e)
 
 
-@pytest.mark.parametrize("n,precision", [(1024, "fp64"), (4096, "fp64"), (2048, "fp32")])
+@pytest.mark.parametrize("n,precision", [(256, "fp64"), (512, "fp32"), (1024, "fp64"), (4096, "fp64"), (2048, "fp32")])
 def test_lean_walk_equals_the_ordinary_walk(n, precision):
     """run_batch(outputs=(), keep_psf=True) -- the benchmark's mode -- leaves the dark rows of the first surface
     unwritten, sums the first power over the live rows and has the last pass store |u|^2: PSFs bit-equal to the
-    ones the ordinary walk downloads, powers equal to rounding (another order of summation)."""
+    ones the ordinary walk downloads, powers equal to rounding (another order of summation).  At 256^2 / 512^2 the
+    generic kernels run: the rows that stand for zeros are cleared before the first program and the PSF comes from
+    the intensity sweep -- the same answers through the fall-back paths."""
     from paos_amd import _lib
     from paos_amd.chains import syn20_chain, syn20_wavelength
     from paos_amd.run import run_batch
