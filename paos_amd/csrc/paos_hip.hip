@@ -97,8 +97,20 @@ struct paos_ctx {
   double* metric_partial = nullptr;  // psf metrics scratch
   double* metric_out = nullptr;
   double* metric_host = nullptr;     // pinned
-  MaskLine* mask_lines = nullptr;  // batch x n line records of the aperture riding on a frugal pass
-  double* mask_vals = nullptr;     // batch x n x 2 kMaskW partial weights
+  // Line records of apertures riding on frugal passes: a few rendered sets are kept, keyed by everything the
+  // renderer reads (the aperture's two parameter block sets, the pass axis, which items share records), so that a
+  // chain whose relays repeat one aperture -- and the next wavefront batch through the same optics (a Monte-Carlo
+  // study, a benchmark step) -- find their records instead of rendering them again (round 3: 6 renderings of
+  // 0.3 ms per SYN20 step -> 0 in steady state).
+  struct MaskSet {
+    MaskLine* lines = nullptr;  // batch x n
+    double* vals = nullptr;     // batch x n x 2 kMaskW partial weights
+    std::vector<double> key;    // empty: holds nothing valid
+    unsigned long long used = 0;
+  };
+  static constexpr int kMaskSets = 4;
+  MaskSet mask_sets[kMaskSets];
+  unsigned long long mask_clock = 0;
   int* mask_overflow = nullptr;    // device counter: partial runs that did not fit (must stay 0)
   double* partial = nullptr;
   double* norm2 = nullptr;
@@ -345,7 +357,8 @@ bool use_frugal() {
 
 // Express pass p as   load | sign*scale*K phases | FFT | sign*scale*K phases | [FFT] | store.
 bool lower_frugal(const paos_ctx* c, const paos_pass& p, const double* blocks /*host*/, std::vector<FrugalItem>& items,
-                  int& kpre, int& kmid, int& nfft, int& mask_block, int& mask_slot, std::vector<double>& mask_shared) {
+                  int& kpre, int& kmid, int& nfft, int& mask_block, int& mask_slot, std::vector<double>& mask_shared,
+                  std::vector<int>& mask_rep) {
   if (p.axis != 0 && p.axis != 1) return false;
   if (p.fft1 < 0 || p.n_post != 0) return false;
   const paos_pw_op* lists[2] = {p.pre, p.mid};
@@ -388,6 +401,7 @@ bool lower_frugal(const paos_ctx* c, const paos_pass& p, const double* blocks /*
   kpre = k[0]; kmid = k[1]; nfft = p.fft2 >= 0 ? 2 : 1;
   items.assign(c->batch, FrugalItem{});
   mask_shared.assign(c->batch, 0.0);
+  mask_rep.assign(c->batch, -1);
   auto blk = [&](int b, int it) { return blocks + ((size_t)b * c->batch + it) * FP_STRIDE; };
   for (int it = 0; it < c->batch; ++it) {
     FrugalItem& fi = items[it];
@@ -419,8 +433,7 @@ bool lower_frugal(const paos_ctx* c, const paos_pass& p, const double* blocks /*
             if (!std::memcmp(blk(op.block, j), q, FP_STRIDE * sizeof(double)) &&
                 !std::memcmp(blk(op.block + 1, j), q2, FP_STRIDE * sizeof(double))) { rep = j; break; }
           mask_shared[it] = rep != it ? 1.0 : 0.0;
-          slots[l]->lines = c->mask_lines + (size_t)rep * c->n;
-          slots[l]->vals = c->mask_vals + (size_t)rep * c->n * 2 * kMaskW;
+          mask_rep[it] = rep;  // the record set is chosen later (assign_mask_set): pointers are filled in there
         } else if (op.kind == PAOS_PW_SIGN) { if (on) slots[l]->sign_on = slots[l]->sign_on != 0.0 ? 0.0 : 1.0; }
         else if (op.kind == PAOS_PW_SCALE) { if (on) slots[l]->scale *= q[FP_COEF]; }
         else {
@@ -453,6 +466,9 @@ struct LoweredPass {
   std::vector<FrugalItem> items;
   int kpre = 0, kmid = 0, nfft = 1, mask_block = -1, mask_slot = -1;
   std::vector<double> mask_shared;  // [batch] 1: the item reads the line records of an earlier, identical item
+  std::vector<int> mask_rep;        // [batch] item whose records this item reads (-1: none)
+  int mask_set = -1;                // which of the context's record sets this pass reads
+  bool mask_render = false;         // ... and whether it has to be rendered first
 };
 
 // Lines (rows for a row pass, columns for a column pass) outside the returned range get weight
@@ -657,13 +673,51 @@ bool frugal_sizes(const paos_ctx* c) {
 }
 
 int ensure_mask_store(paos_ctx* c) {
-  if (!c->mask_lines) {  // line-record store of an aperture riding on a pass (lazily)
-    HIPCHK(c, hipMalloc(&c->mask_lines, (size_t)c->batch * c->n * sizeof(MaskLine)));
-    HIPCHK(c, hipMalloc(&c->mask_vals, (size_t)c->batch * c->n * 2 * kMaskW * sizeof(double)));
+  if (!c->mask_overflow) {
     HIPCHK(c, hipMalloc(&c->mask_overflow, sizeof(int)));
     HIPCHK(c, hipMemsetAsync(c->mask_overflow, 0, sizeof(int), c->stream));
   }
   return PAOS_OK;
+}
+
+// Pick the record set pass `lp` reads -- one that already holds its aperture, or the least recently used one, to
+// be rendered -- and point the items' slots at it.  Called for the passes of a program in order, before anything is
+// launched: launches follow in the same order on one stream, so a set re-used further down the program is
+// overwritten only after the pass that read it.
+int assign_mask_set(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const double* blocks) {
+  std::vector<double> key;
+  key.reserve((size_t)2 * c->batch * FP_STRIDE + c->batch + 2);
+  key.push_back((double)p.axis);
+  const double* ap = blocks + (size_t)lp.mask_block * c->batch * FP_STRIDE;
+  key.insert(key.end(), ap, ap + (size_t)2 * c->batch * FP_STRIDE);  // the two consecutive block sets
+  key.insert(key.end(), lp.mask_shared.begin(), lp.mask_shared.end());
+  int hit = -1, victim = 0;
+  for (int k = 0; k < paos_ctx::kMaskSets; ++k) {
+    const paos_ctx::MaskSet& ms = c->mask_sets[k];
+    if (!ms.key.empty() && ms.key.size() == key.size() && !std::memcmp(ms.key.data(), key.data(), key.size() * sizeof(double))) hit = k;
+    if (ms.used < c->mask_sets[victim].used) victim = k;
+  }
+  const int k = hit >= 0 ? hit : victim;
+  paos_ctx::MaskSet& ms = c->mask_sets[k];
+  if (!ms.lines) {
+    HIPCHK(c, hipMalloc(&ms.lines, (size_t)c->batch * c->n * sizeof(MaskLine)));
+    HIPCHK(c, hipMalloc(&ms.vals, (size_t)c->batch * c->n * 2 * kMaskW * sizeof(double)));
+  }
+  ms.used = ++c->mask_clock;
+  lp.mask_set = k;
+  lp.mask_render = hit < 0;
+  if (hit < 0) ms.key = std::move(key);
+  for (int it = 0; it < c->batch; ++it) {
+    if (lp.mask_rep[it] < 0) continue;
+    FrugalSlot& sl = lp.mask_slot == 0 ? lp.items[it].pre : lp.items[it].mid;
+    sl.lines = ms.lines + (size_t)lp.mask_rep[it] * c->n;
+    sl.vals = ms.vals + (size_t)lp.mask_rep[it] * c->n * 2 * kMaskW;
+  }
+  return PAOS_OK;
+}
+
+void forget_mask_sets(paos_ctx* c) {  // after a failed program: what the sets hold is no longer known
+  for (auto& ms : c->mask_sets) ms.key.clear();
 }
 
 // launch a pass that lower_frugal accepted
@@ -677,17 +731,18 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const
                  f.pre.scale, f.pre.mask_on, f.fft1_on, f.fft1_inv, f.mid.sign_on, f.mid.scale, f.mid.mask_on, f.fft2_on, f.fft2_inv,
                  f.line_lo, f.line_hi, f.line_fill, f.pos_lo, f.pos_hi, f.spos_lo, f.spos_hi);
   }
-  if (lp.mask_block >= 0) {  // render the records along the pass axis, right before the pass
+  if (lp.mask_block >= 0 && lp.mask_render) {  // render the records along the pass axis, right before the pass
     const double* ap = dblocks + (size_t)lp.mask_block * c->batch * FP_STRIDE;
     const double* ap2 = ap + (size_t)c->batch * FP_STRIDE;
     const dim3 grid((c->n + 3) / 4, c->batch), block(256);
     const double* dshared = nullptr;
     int rcs = arena_push(c, lp.mask_shared.data(), lp.mask_shared.size(), &dshared);
     if (rcs) return rcs;
+    const paos_ctx::MaskSet& ms = c->mask_sets[lp.mask_set];
     hipLaunchKernelGGL(mask_lines_kernel<0>, grid, block, 0, c->stream, ap, ap2, (int)FP_STRIDE, c->n, p.axis,
-                       c->mask_lines, c->mask_vals, c->mask_overflow, dshared);
+                       ms.lines, ms.vals, c->mask_overflow, dshared);
     hipLaunchKernelGGL(mask_lines_kernel<1>, grid, block, 0, c->stream, ap, ap2, (int)FP_STRIDE, c->n, p.axis,
-                       c->mask_lines, c->mask_vals, c->mask_overflow, dshared);
+                       ms.lines, ms.vals, c->mask_overflow, dshared);
     HIPCHK(c, hipGetLastError());
   }
   const double* ditems = nullptr;
@@ -793,8 +848,18 @@ int psf_keep_power_impl(paos_ctx* c, int* ticket);
 
 // entry_rows / entry_stale: see paos_program_opts.  final_ticket != nullptr: the caller wants |u|^2 and its sum of
 // the field the program ends with, not the field.
+int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks, int n_blocks,
+                    const double* entry_rows, bool entry_stale, int* final_ticket);
+
 int run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks, int n_blocks,
                const double* entry_rows = nullptr, bool entry_stale = false, int* final_ticket = nullptr) {
+  const int rc = run_passes_impl(c, passes, n_passes, blocks, n_blocks, entry_rows, entry_stale, final_ticket);
+  if (rc != PAOS_OK && c) forget_mask_sets(c);  // a program that stopped half way: which records were rendered is moot
+  return rc;
+}
+
+int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks, int n_blocks,
+                    const double* entry_rows, bool entry_stale, int* final_ticket) {
   if (!c || !passes || !blocks || n_passes < 0 || n_blocks < 1) return fail(c, PAOS_EINVAL, "bad pass program");
   // The device sincos has no huge-argument path: bound every enabled phase operator here.
   for (int i = 0; i < n_passes; ++i) {
@@ -834,7 +899,9 @@ int run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double*
     if ((rc = ensure_mask_store(c))) return rc;
     for (int q = 0; q < n_passes; ++q) {
       LoweredPass& lp = low[q];
-      lp.ok = lower_frugal(c, passes[q], blocks, lp.items, lp.kpre, lp.kmid, lp.nfft, lp.mask_block, lp.mask_slot, lp.mask_shared);
+      lp.ok = lower_frugal(c, passes[q], blocks, lp.items, lp.kpre, lp.kmid, lp.nfft, lp.mask_block, lp.mask_slot, lp.mask_shared,
+                           lp.mask_rep);
+      if (lp.ok && lp.mask_block >= 0 && (rc = assign_mask_set(c, passes[q], lp, blocks))) return rc;
       all_frugal = all_frugal && lp.ok;
     }
   }
@@ -1143,8 +1210,10 @@ int paos_ctx_destroy(paos_ctx* c) {
   if (c->metric_partial) (void)hipFree(c->metric_partial);
   if (c->metric_out) (void)hipFree(c->metric_out);
   if (c->metric_host) (void)hipHostFree(c->metric_host);
-  if (c->mask_lines) (void)hipFree(c->mask_lines);
-  if (c->mask_vals) (void)hipFree(c->mask_vals);
+  for (auto& ms : c->mask_sets) {
+    if (ms.lines) (void)hipFree(ms.lines);
+    if (ms.vals) (void)hipFree(ms.vals);
+  }
   if (c->mask_overflow) (void)hipFree(c->mask_overflow);
   if (c->partial) (void)hipFree(c->partial);
   if (c->norm2) (void)hipFree(c->norm2);
@@ -1169,6 +1238,7 @@ static int check_mask_overflow(paos_ctx* c) {
   HIPCHK(c, hipMemcpy(&n, c->mask_overflow, sizeof(int), hipMemcpyDeviceToHost));
   if (n != 0) {
     (void)hipMemset(c->mask_overflow, 0, sizeof(int));
+    for (auto& ms : c->mask_sets) ms.key.clear();
     return fail(c, PAOS_EUNSUPPORTED, "aperture line records overflowed (partial run longer than kMaskW): results are invalid");
   }
   return PAOS_OK;

@@ -300,3 +300,53 @@ def test_two_ranks_asking_for_rccl_on_one_gpu_agree():
     for rank, transport, text, slowest, parts in results:
         assert text == b"two ranks, one GPU" and slowest == 1.0
         assert parts == [[0.0, 1.0], [0.0, 1.0, 2.0]]
+
+
+def test_record_sets_are_reused_and_evicted_correctly():
+    """The context keeps a few rendered sets of aperture line records (csrc/paos_hip.hip: MaskSet): a chain whose
+    relays repeat one aperture renders it once, a second batch through the same optics renders nothing, and a
+    chain with more distinct apertures than there are sets evicts.  Whatever the cache does, the fields equal those
+    of a fresh context bit for bit, and those of the stand-alone aperture kernel to rounding."""
+    import paos_amd.run as prun
+    from paos_amd import _lib
+    from paos_amd.chains import syn20_chain, syn20_wavelength
+
+    n = 1024
+    wls = [syn20_wavelength(0), syn20_wavelength(40)]
+
+    def chain(radii):
+        c = syn20_chain()
+        relays = [k for k, it in c.items() if it["name"].endswith("c")]
+        for k, r in zip(relays, radii):
+            c[k] = dict(c[k], aperture=dict(c[k]["aperture"], xrad=r, yrad=0.9 * r), save=True)
+        return c
+
+    same = [chain([0.5] * 5) for _ in wls]
+    many = [chain([0.5, 0.45, 0.4, 0.35, 0.3]) for _ in wls]  # five relay apertures + the field stop > 4 sets
+
+    def fields(res):
+        return [(k, r[k]["wfo"]) for r in res for k in sorted(r)]
+
+    dev = _lib.DeviceFields(n, len(wls))
+    try:
+        a1 = fields(prun.run_batch(1.0, wls, n, 4, ON_AXIS, same, outputs=("wfo",), dev=dev))
+        b1 = fields(prun.run_batch(1.0, wls, n, 4, ON_AXIS, many, outputs=("wfo",), dev=dev))
+        a2 = fields(prun.run_batch(1.0, wls, n, 4, ON_AXIS, same, outputs=("wfo",), dev=dev))   # after evictions
+        b2 = fields(prun.run_batch(1.0, wls, n, 4, ON_AXIS, many, outputs=("wfo",), dev=dev))
+    finally:
+        dev.close()
+    fresh_a = fields(prun.run_batch(1.0, wls, n, 4, ON_AXIS, same, outputs=("wfo",)))
+    fresh_b = fields(prun.run_batch(1.0, wls, n, 4, ON_AXIS, many, outputs=("wfo",)))
+    for got in (a1, a2):
+        assert all(k == kk and np.array_equal(x, y) for (k, x), (kk, y) in zip(got, fresh_a))
+    for got in (b1, b2):
+        assert all(k == kk and np.array_equal(x, y) for (k, x), (kk, y) in zip(got, fresh_b))
+    old = prun.FUSE_APERTURES
+    prun.FUSE_APERTURES = False
+    try:
+        alone = fields(prun.run_batch(1.0, wls, n, 4, ON_AXIS, many, outputs=("wfo",)))
+    finally:
+        prun.FUSE_APERTURES = old
+    for (k, x), (kk, y) in zip(b1, alone):
+        assert k == kk and rel_err(x, y) < 1e-12, k
+    assert rel_err(b1[-1][1], a1[-1][1]) > 1e-6  # the two chains really differ
