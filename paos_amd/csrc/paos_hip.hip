@@ -108,7 +108,7 @@ struct paos_ctx {
     std::vector<double> key;    // empty: holds nothing valid
     unsigned long long used = 0;
   };
-  static constexpr int kMaskSets = 4;
+  static constexpr int kMaskSets = 8;  // (SYN20: five relay apertures whose pixel radii differ in the last digits + the field stop)
   MaskSet mask_sets[kMaskSets];
   unsigned long long mask_clock = 0;
   int* mask_overflow = nullptr;    // device counter: partial runs that did not fit (must stay 0)

@@ -322,7 +322,7 @@ def test_record_sets_are_reused_and_evicted_correctly():
         return c
 
     same = [chain([0.5] * 5) for _ in wls]
-    many = [chain([0.5, 0.45, 0.4, 0.35, 0.3]) for _ in wls]  # five relay apertures + the field stop > 4 sets
+    many = [chain([0.5, 0.45, 0.4, 0.35, 0.3]) for _ in wls]  # with `same` before and after: 11 distinct record sets > the 8 kept
 
     def fields(res):
         return [(k, r[k]["wfo"]) for r in res for k in sorted(r)]
