@@ -1807,12 +1807,16 @@ static int zernike_apply(paos_ctx* c, int nmax, int kdim, const double* table, c
       m_end = (unsigned)(hi / c->br) * c->pitch;
     }
   }
-  if (c->precision == PAOS_F64)
-    hipLaunchKernelGGL((zernike_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream, (cx<double>*)c->field,
-                       dt, dp, param_stride, c->n, c->pitch, c->item_stride, nmax, kdim, wfe, pupil, m_first, m_end);
-  else
-    F32_BR_SWITCH(c, hipLaunchKernelGGL((zernike_kernel<float, FBR, Lay<float>::BC>), grid, block, 0, c->stream, (cx<float>*)c->field, dt,
-                       dp, param_stride, c->n, c->pitch, c->item_stride, nmax, kdim, wfe, pupil, m_first, m_end));
+  // orders up to 8 (45 polynomials) run on the unrolled build
+#define ZK_LAUNCH(T, BRV, NC)                                                                                          \
+  hipLaunchKernelGGL((zernike_kernel<T, BRV, Lay<T>::BC, NC>), grid, block, 0, c->stream, (cx<T>*)c->field, dt, dp,   \
+                     param_stride, c->n, c->pitch, c->item_stride, nmax, kdim, wfe, pupil, m_first, m_end)
+  if (c->precision == PAOS_F64) {
+    if (nmax <= 8) ZK_LAUNCH(double, BR, 8); else ZK_LAUNCH(double, BR, 0);
+  } else {
+    if (nmax <= 8) F32_BR_SWITCH(c, ZK_LAUNCH(float, FBR, 8)); else F32_BR_SWITCH(c, ZK_LAUNCH(float, FBR, 0));
+  }
+#undef ZK_LAUNCH
   HIPCHK(c, hipGetLastError());
   if (host_wfe) return copy_to_host(c, host_wfe, c->staging, (size_t)c->n * c->n * 8);
   return PAOS_OK;

@@ -737,7 +737,11 @@ __global__ void __launch_bounds__(kMaskWaves * 64) mask_lines_kernel(const doubl
 //                  then coefC[am][k], coefS[am][k]] with the (-1)^k norm Z product folded in.
 enum : int { ZP_ENABLE = 0, ZP_DX, ZP_DY, ZP_RADIUS, ZP_ORIGIN_Y, ZP_COS_OFF, ZP_SIN_OFF, ZP_INV_WL, ZP_HEAD };
 
-template <typename T, int BR, int BC>
+// NMAXC > 0: the loops over the azimuthal order and the radial index are unrolled for orders up to NMAXC (the host
+// picks this build when nmax <= NMAXC): the recurrence constants and coefficients of a whole order are then fetched
+// in one go instead of five dependent scalar loads per term (round 3: the kernel waited four times as long as it
+// computed, profiles/r03_sq_counters.txt).  NMAXC = 0: any order, rolled loops.
+template <typename T, int BR, int BC, int NMAXC = 0>
 __global__ void zernike_kernel(cx<T>* field, const double* table, const double* params,
                                int param_stride, int n, unsigned pitch, unsigned item_stride,
                                int nmax, int kdim, double* wfe_out, const double* pupil,
@@ -773,10 +777,9 @@ __global__ void zernike_kernel(cx<T>* field, const double* table, const double* 
       const double cr = c1 * co - s1 * so, sr = s1 * co + c1 * so;
       const double xj = 1.0 - 2.0 * rho * rho;
       double rho_pow = 1.0, cm = 1.0, sm = 0.0;
-      for (int am = 0; am <= nmax; ++am) {
-        const int kmax = (nmax - am) / 2;
+      auto order = [&](int am, int k_end) __attribute__((always_inline)) {
         double pkm1 = 0.0, pk = 1.0;
-        for (int k = 0; k <= kmax; ++k) {
+        for (int k = 0; k <= k_end; ++k) {
           if (k > 0) {
             const double* abc = table + ((size_t)am * kdim + k) * 3;
             const double pn = (abc[0] * xj + abc[1]) * pk - abc[2] * pkm1;
@@ -790,6 +793,32 @@ __global__ void zernike_kernel(cx<T>* field, const double* table, const double* 
         const double cn = cm * cr - sm * sr;
         sm = sm * cr + cm * sr;
         cm = cn;
+      };
+      if constexpr (NMAXC > 0) {  // same operations in the same order, loops unrolled
+#pragma unroll
+        for (int am = 0; am <= NMAXC; ++am) {
+          if (am > nmax) break;
+          const int kmax = (nmax - am) / 2;
+          double pkm1 = 0.0, pk = 1.0;
+#pragma unroll
+          for (int k = 0; k <= (NMAXC - am) / 2; ++k) {
+            if (k > kmax) break;
+            if (k > 0) {
+              const double* abc = table + ((size_t)am * kdim + k) * 3;
+              const double pn = (abc[0] * xj + abc[1]) * pk - abc[2] * pkm1;
+              pkm1 = pk;
+              pk = pn;
+            }
+            const size_t ci = (size_t)am * kdim + k;
+            wfe += (rho_pow * pk) * (coef_c[ci] * cm + coef_s[ci] * sm);
+          }
+          rho_pow *= rho;
+          const double cn = cm * cr - sm * sr;
+          sm = sm * cr + cm * sr;
+          cm = cn;
+        }
+      } else {
+        for (int am = 0; am <= nmax; ++am) order(am, (nmax - am) / 2);
       }
       const double arg = __dmul_rn(__dmul_rn(6.283185307179586, wfe), inv_wl);
       double sn, cs;
