@@ -149,7 +149,7 @@ __device__ __forceinline__ T flip_sign(T x, unsigned mask_hi) {
 #define PAOS_ROW_PRE 2
 #endif
 #ifndef PAOS_COL_PRE
-#define PAOS_COL_PRE 1
+#define PAOS_COL_PRE 2  // round 3 (24-pass chain, shared phase factors): the paced form is +0.8 % in column passes too (profiles/r03_ab_variants_bench.txt)
 #endif
 // SHARE (round 3): a quadratic phase is even along the line -- position p and its mirror N - p (mod N; both in the
 // centred and in the natural-order coordinates) have the SAME rounded argument, hence the same factor bit for bit.
