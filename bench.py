@@ -424,6 +424,19 @@ def main():
         ptp_ms = tot / 5.0
 
         value = total * args.steps / m["elapsed"]
+        # the same steps with the compiler's ptp identities switched off (every ptp of the reference as three passes)
+        plain = None
+        if world == 1:
+            import paos_amd.passes as ppasses
+
+            ppasses.PTP_ALGEBRA = False
+            try:
+                mp = measure(dev, n, nb, args.precision, wavelengths, chains, min(args.steps, 3), 1, None)
+                plain = {"value": nb * min(args.steps, 3) / mp["elapsed"], "unit": "wavefronts/s",
+                         "fused_passes_per_wavefront": mp["fused_passes"],
+                         "what": "PAOS_PTP_ALGEBRA=0: consecutive ptp neither share a middle pass nor cancel"}
+            finally:
+                ppasses.PTP_ALGEBRA = True
         n_ptp, n_stw, n_wts = chain_fft_counts(wavelengths[0], n)
         ffts = 2 * n_ptp + n_stw + n_wts
         survey_bytes = (ffts * 4 * esz + 8) * n * n  # 2 passes x (read + write) per 2-D FFT + the 8 B/px PSF write
@@ -450,8 +463,13 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"SYN20 20-surface chain, {n}x{n} {args.precision}, wavelength sweep 1um*(1+k/512), "
                                    f"{nb} wavefronts/GPU/step, {ffts} 2-D FFTs per wavefront ({n_ptp} ptp, {n_stw} stw, "
-                                   f"{n_wts} wts); the final |u|^2 of every wavefront is written to HBM (8 B/px) and stays "
-                                   f"there, powers of the saved surfaces are reduced on the GPU",
+                                   f"{n_wts} wts as the reference executes them; the pass compiler runs them as "
+                                   f"{m['fused_passes']} fused passes: at each of the chain's five foci the reference steps "
+                                   f"ptp(+d), ptp(-d) with d = 1.6 nm, which cancel algebraically (H(-d) H(d) = 1, "
+                                   f"fft2(ifft2(X)) = X; same results to 1e-15, `without_ptp_algebra` gives the rate with every "
+                                   f"ptp run on its own); the final |u|^2 of every wavefront is written to HBM (8 B/px) and stays "
+                                   f"there, powers of the saved surfaces are reduced on the GPU; aperture line records are "
+                                   f"kept per context and found again by later steps (same optics)",
                        "grid": n, "batch_per_gpu": nb, "parallelism": f"wavefront-sharded x{world}",
                        "transport": comm.transport if comm is not None else "none (single process)",
                        "ranks_seen": len(ranks_seen), "devices_seen": ranks_seen},
@@ -472,6 +490,7 @@ def main():
                          "frac_of_hbm_peak_vs_survey_model": 8 * esz * n * n * nb / (ptp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "frac_bytes_moved": 6 * esz * n * n * nb / (ptp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "note": "SURVEY 8d prices a ptp at 128 B/px (4 passes); the fused path moves 96 B/px"},
+            "without_ptp_algebra": plain,
             "power_check": float(dev.norm2_fetch(m["res"][0][20]["power_ticket"])[0]),
             "build": dev.build_info(),
         }

@@ -24,8 +24,15 @@ import numpy as np
 
 from . import _lib
 
+import os
+
 _OFF = [0.0, 0.0, 0.0, 0.0, 0.0]
 MAX_MERGED_PTP = 3  # transfer functions one middle pass can carry (kFrugalMaxMid of csrc/frugal_pass.h)
+# The two identities the compiler uses on consecutive ptp (see PassCompiler.ptp): fft2(ifft2(X)) = X and
+# H(-d) H(d) = 1.  PAOS_PTP_ALGEBRA=0 (or setting this to False) runs every ptp of the reference as its own three
+# passes again -- same results to rounding, 44 instead of 24 passes for SYN20; bench.py reports that rate beside the
+# headline one.
+PTP_ALGEBRA = os.environ.get("PAOS_PTP_ALGEBRA", "1") != "0"
 
 
 def _rows(rows, batch):
@@ -158,7 +165,7 @@ class PassCompiler:
         # junction less, and the same numbers up to the rounding noise of the transform pair that is not run
         # (~1e-16 relative; each phase keeps its own, separately rounded argument).  Items that take only one of
         # the two have the other phase switched off (factor 1); the transforms run for the union.
-        lp = self.last_ptp
+        lp = self.last_ptp if PTP_ALGEBRA else None
         if (lp is not None and self.open is lp["tail"] and not self.tail and lp["tail"]["mid"] == lp["tail_mid"] and
                 sum(op[0] == _lib.PW_QPHASE_NATURAL for op in lp["middle"]["mid"]) < MAX_MERGED_PTP):
             first = self.blocks[lp["par"]]

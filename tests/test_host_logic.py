@@ -422,3 +422,24 @@ def test_consecutive_ptp_merge_into_one_middle_pass():
     prog = comp.program()[0]
     assert len(prog) == 5
     assert [sum(op[0] == _lib.PW_QPHASE_NATURAL for op in p["mid"]) for p in prog] == [0, 3, 0, 1, 0]
+
+
+def test_ptp_algebra_switch():
+    """PAOS_PTP_ALGEBRA=0 / passes.PTP_ALGEBRA = False: every ptp of the reference runs as its own three passes
+    (SYN20: 44 with the apertures riding) -- same fields to rounding as the 24-pass program."""
+    import paos_amd.passes as ppasses
+    import paos_amd.run as prun
+
+    prun.FUSE_APERTURES = True
+    try:
+        fast, _, stats_fast = _model_run(_spec("SYN20"), 128)
+        ppasses.PTP_ALGEBRA = False
+        try:
+            plain, _, stats_plain = _model_run(_spec("SYN20"), 128)
+        finally:
+            ppasses.PTP_ALGEBRA = True
+    finally:
+        prun.FUSE_APERTURES = "auto"
+    assert stats_fast["fused_passes"] == 24 and stats_plain["fused_passes"] == 44
+    for k in fast[0]:
+        assert rel_err(fast[0][k]["wfo"], plain[0][k]["wfo"]) < 1e-13
