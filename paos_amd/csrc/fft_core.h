@@ -408,6 +408,9 @@ __device__ __forceinline__ void apply_twiddle_chain(cx<T>* v, cx<T> w1) {
 // which keeps a 4096-point c128 pass at ~118 VGPRs -- four waves per SIMD, i.e. two 512-thread
 // workgroups per CU whose load / compute / store phases overlap (profiles/r01_vgpr_experiments.txt).
 #define PAOS_FENCE() do { if constexpr (FR != 0) __builtin_amdgcn_sched_barrier(0); } while (0)
+#ifndef PAOS_TAIL_FENCE
+#define PAOS_TAIL_FENCE 1
+#endif
 #ifndef PAOS_TABLE_TWIDDLES
 #define PAOS_TABLE_TWIDDLES 1
 #endif
@@ -449,7 +452,9 @@ __device__ __forceinline__ void fft_stages(cx<T>* v, void* lds, int t,
       PAOS_FENCE();
     }
     dft<R, DIR>(v + s * R);
-    PAOS_FENCE();
+    // (PAOS_TAIL_FENCE = 0, experiment: no fence behind the LAST stage's butterflies, so that the scheduler may start
+    // the tile's stores while the remaining outputs are still being computed)
+    if constexpr (!(S::LAST && PAOS_TAIL_FENCE == 0)) PAOS_FENCE();
   }
 
   if constexpr (!S::LAST) {

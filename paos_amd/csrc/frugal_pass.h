@@ -89,6 +89,12 @@ struct FrugalArgs {
   // `psf_partial[item * gridDim.x + blockIdx.x]`; the field itself is not written
   double* psf;
   double* psf_partial;
+  // Row tiles that share their 128-byte lines with a sibling workgroup (half a block row each): one counter per
+  // (item, block row), zeroed before the launch.  The siblings meet here before they store (bounded wait), so that
+  // their half-line stores reach the L2 together and leave it as whole lines (round 3, tools/membench2.hip: with the
+  // arithmetic of a two-transform pass between loads and stores the half-line pattern runs at 0.97 ms per 4.29 GB
+  // free-running and 0.86 ms with the rendezvous; column tiles: 0.85).  nullptr: no rendezvous.
+  unsigned* meet;
 #if PAOS_STAMPS
   unsigned long long* stamps;  // [gridDim.y][gridDim.x][kStampSlots]
 #endif
@@ -161,6 +167,9 @@ __device__ __forceinline__ T flip_sign(T x, unsigned mask_hi) {
 // The self-mirrored position N / 2 (thread 0, element E / 2) is evaluated by its owner.
 #ifndef PAOS_SHARE_PHASES
 #define PAOS_SHARE_PHASES 1
+#endif
+#ifndef PAOS_MEET_POLLS
+#define PAOS_MEET_POLLS 64  // polls of ~0.3 us a workgroup waits for its sibling at most before it stores anyway (0: never waits)
 #endif
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -398,7 +407,7 @@ __device__ __forceinline__ void frugal_fft(cx<T>* v, void* lds, int t, const cx<
 #pragma unroll
     for (int k = 0; k < E; ++k) v[k].y = flip_sign(v[k].y, mask);
   }
-  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (!(FLIP && PAOS_TAIL_FENCE == 0)) __builtin_amdgcn_sched_barrier(0);
 }
 
 // dynamic LDS of one workgroup: exchange areas | stage twiddles | (c128 with phases) circle table
@@ -663,6 +672,19 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
     double* scratch = reinterpret_cast<double*>(smem + frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, E, 0>());
     tile_power_out<TILES * LINES * N / E>(acc, scratch, a.psf_partial + (size_t)item * gridDim.x + blockIdx.x);
     return;
+  }
+  if constexpr (AXIS == 0 && BR > 1 && LINES < BR && PAOS_MEET_POLLS > 0) {
+    if (a.meet) {  // wave-uniform.  Timing only: whatever the counter says, the stores below are the same
+      if (threadIdx.x == 0) {
+        unsigned* flag = a.meet + ((size_t)item * (N / BR) + (unsigned)m.row0 / BR);
+        __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int tries = 0; tries < PAOS_MEET_POLLS; ++tries) {
+          if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(BR / LINES)) break;
+          __builtin_amdgcn_s_sleep(8);
+        }
+      }
+      __syncthreads();
+    }
   }
   const int slo = (int)h_spos_lo, shi = (int)h_spos_hi;
   if (slo <= 0 && shi >= N) {  // wave-uniform: everything is stored

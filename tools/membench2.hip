@@ -25,6 +25,8 @@ struct Args {
   int mode;       // 0 read + write, 1 read only, 2 write only
   double fa, fb;
   double* sink;
+  unsigned* meet;  // != nullptr (row tiles): sibling workgroups (the two halves of a block row) meet before they store
+  int meet_spins;  // give up after this many polls
 };
 
 // PAT 0: row tile (2 of the 4 rows of a block row, sibling 8 workgroups away), 1: column tile (one block column),
@@ -80,6 +82,23 @@ __global__ void __launch_bounds__(THREADS) tile_copy(Args a) {
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = v[k] * a.fa + a.fb;
   }
+  if (PAT == 0 && a.meet) {
+    // the two workgroups that share every line of a block row wait for each other (bounded) so that their half-line
+    // stores reach the L2 together
+    __shared__ int dummy;
+    if (tid == 0) {
+      const int grp = tile / 16, in = tile % 16;
+      unsigned* flag = a.meet + ((size_t)item * 1024 + (grp * 8 + in % 8));
+      __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int tries = 0;
+      while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < 2u && tries < a.meet_spins) {
+        __builtin_amdgcn_s_sleep(8);
+        ++tries;
+      }
+      dummy = tries;
+    }
+    __syncthreads();
+  }
   if (a.mode == 1) {
     double acc = 0;
 #pragma unroll
@@ -96,6 +115,8 @@ __global__ void __launch_bounds__(THREADS) tile_copy(Args a) {
 
 static v2d *gp, *gq;
 static double* gsink;
+static unsigned* gmeet;
+static int gmeet_spins = 0;
 static int greps = 10;
 constexpr int kBatch = 8;
 
@@ -126,6 +147,8 @@ static void run(const char* name, int pad, int ntl, int nts, int out, int mode, 
     a.dst = out ? (flip ? gp : gq) : gp;
     flip ^= 1;
     a.pad = pad; a.spin = spin; a.ntl = ntl; a.nts = nts; a.mode = mode; a.fa = 1.0000001; a.fb = 1e-9; a.sink = gsink;
+    a.meet = gmeet_spins > 0 ? gmeet : nullptr; a.meet_spins = gmeet_spins;
+    if (a.meet) CK(hipMemsetAsync(gmeet, 0, (size_t)kBatch * 1024 * sizeof(unsigned), 0));
     hipLaunchKernelGGL(k, dim3(tiles, kBatch), dim3(THREADS), lds_kib * 1024, 0, a);
   });
   const double bytes = (mode == 0 ? 2.0 : 1.0) * kBatch * (double)kN * kN * 16;
@@ -139,6 +162,21 @@ int main(int argc, char** argv) {
   const size_t n = (size_t)kBatch * kBlockRows * (kBlocksPerRow + 72) * 8;
   CK(hipMalloc(&gp, n * 16)); CK(hipMalloc(&gq, n * 16)); CK(hipMalloc(&gsink, 8));
   CK(hipMemset(gp, 0, n * 16)); CK(hipMemset(gq, 0, n * 16));
+  CK(hipMalloc(&gmeet, (size_t)kBatch * 1024 * sizeof(unsigned)));
+  if (argc > 2 && atoi(argv[2]) == 1) {  // only the sibling-rendezvous experiment
+    printf("## row tiles whose sibling workgroups meet before storing (bounded spin), against free-running ones\n");
+    for (int sp : {0, 20, 40, 60}) {
+      for (int spins : {0, 50, 200, 1000}) {
+        gmeet_spins = spins;
+        char name[64];
+        snprintf(name, sizeof(name), "rows half-lines, meet<=%d polls", spins);
+        run<0, 1, 512>(name, 3, 0, 0, 0, 0, sp, 70);
+      }
+      gmeet_spins = 0;
+      run<1, 1, 512>("cols lines nt (reference)", 3, 1, 1, 0, 0, sp, 70);
+    }
+    return 0;
+  }
 
   printf("## yardstick: contiguous chunks\n");
   for (int out = 0; out < 2; ++out)
