@@ -8,10 +8,11 @@ same NumPy build:
 
 * :func:`grid_sag_map` -- wfo.py:745-867: masking of non-finite / zero samples, the optional
   sub-pixel recentring (``scipy.ndimage.fourier_shift``), zero padding or cropping to the extent of
-  the grid.  The two steps that call scikit-image (``rescale`` for an odd size difference or a
-  different pixel scale, ``resize`` for a final shape mismatch; wfo.py:702-716, 739-750) are NOT
-  restated -- scikit-image is not in this image, so there is nothing to pin them against -- and raise
-  ``NotImplementedError``: maps must come at the pixel scale of the wavefront.
+  the grid: bit-exact against vectors of the reference.  The steps that call scikit-image (``rescale`` for an
+  odd size difference or a different pixel scale, ``resize`` for a final shape mismatch; wfo.py:702-716, 739-750,
+  786-800, 845-859) run on :func:`_ski_resize`, a restatement of ``skimage.transform.resize`` 0.24.0
+  (poetry.lock:3268; the package is neither under /root/reference nor in this image) from its published
+  algorithm on ``scipy.ndimage`` -- **parity unpinned**: nothing here can be compared with scikit-image itself.
 * :func:`psd_map` -- paos/classes/psd.py:100-160: a white-noise field from NumPy's legacy global
   generator (``np.random.randn`` exactly like the reference, so ``np.random.seed`` makes a run
   reproducible -- and comparable with the reference), filtered by the power-law PSD, plus surface
@@ -41,6 +42,31 @@ def _unit_factor(units):
 
         return float(units.to(u.m))
     raise ValueError(f"cannot interpret units {units!r}")
+
+
+def _ski_resize(image, output_shape, anti_aliasing):
+    """``skimage.transform.resize(image, output_shape, order=3, anti_aliasing=...)`` of scikit-image 0.24.0 with its
+    defaults (``mode="reflect"``, ``cval=0``, ``clip=True``, float input), restated: when shrinking and asked to, a
+    Gaussian pre-filter of sigma = (input / output - 1) / 2 per axis; cubic-spline ``ndimage.zoom`` by output / input
+    with ``grid_mode=True`` in ndimage's "mirror" boundary mode (what scikit-image maps its "reflect" to); the
+    result clipped to the input's value range.  PARITY UNPINNED (no scikit-image to run against)."""
+    from scipy import ndimage as ndi
+
+    image = np.asarray(image, dtype=np.float64)
+    shape = tuple(int(v) for v in output_shape)
+    factors = np.divide(image.shape, shape)
+    filtered = image
+    if anti_aliasing:
+        filtered = ndi.gaussian_filter(image, np.maximum(0, (factors - 1) / 2), cval=0, mode="mirror")
+    out = ndi.zoom(filtered, [1 / f for f in factors], order=3, mode="mirror", cval=0, grid_mode=True)
+    return np.clip(out, np.nanmin(image), np.nanmax(image))
+
+
+def _ski_rescale(image, scale_x, scale_y):
+    """``skimage.transform.rescale(image, scale=(scale_y, scale_x), anti_aliasing=shrinking, order=3)`` as
+    ``rescale_map`` of wfo.py:697-716 calls it: output shape = round(scale * shape), at least 1."""
+    shape = np.maximum(np.round(np.array([scale_y, scale_x]) * np.asarray(image.shape)), 1)
+    return _ski_resize(image, shape, anti_aliasing=(scale_x < 1.0 or scale_y < 1.0))
 
 
 def _as_masked(sag):
@@ -89,20 +115,22 @@ def grid_sag_map(sag, nx, ny, delx, dely, xdec, ydec, shape, dx, dy):
     rows, cols = planes[0].shape
     excess_x = int(np.floor((cols * delx - shape[1] * dx) / delx))
     excess_y = int(np.floor((rows * dely - shape[0] * dy) / dely))
-    if excess_x % 2 == 1 or excess_y % 2 == 1:
-        raise NotImplementedError("grid_sag: an odd size difference needs skimage.transform.rescale "
-                                  "(wfo.py:786-800), which is not restated")
+    # an odd overhang cannot be split evenly: sample that axis twice as finely first (wfo.py:785-800)
+    up_x, up_y = (2 if excess_x % 2 == 1 else 1), (2 if excess_y % 2 == 1 else 1)
+    if up_x != 1 or up_y != 1:
+        planes = [_ski_rescale(p, up_x, up_y) for p in planes]
+        delx, dely = delx / up_x, dely / up_y
+        excess_x, excess_y = excess_x * up_x, excess_y * up_y
     planes = _fit_extent(planes, (0, 1), 1, excess_x)
     planes = _fit_extent(planes, (0, 1), 0, excess_y)
 
+    # the map's pixel scale -> the wavefront's (wfo.py:843-849), then a last nudge to the exact shape (:851-859)
     if (delx / dx != 1) or (dely / dy != 1):
-        raise NotImplementedError("grid_sag: a map at another pixel scale needs skimage.transform.rescale "
-                                  "(wfo.py:845-849), which is not restated: resample the sag to the "
-                                  "wavefront's dx, dy first")
+        planes = [_ski_rescale(p, delx / dx, dely / dy) for p in planes]
+    if planes[0].shape != tuple(shape):
+        shrink = shape[1] / planes[0].shape[1] < 1.0 or shape[0] / planes[0].shape[0] < 1.0
+        planes = [_ski_resize(p, shape, anti_aliasing=shrink) for p in planes]
     heights, coverage = planes
-    if heights.shape != tuple(shape):
-        raise NotImplementedError("grid_sag: a residual shape mismatch needs skimage.transform.resize "
-                                  "(wfo.py:855-859), which is not restated")
     return np.ma.MaskedArray(heights, mask=coverage > 0.1)
 
 

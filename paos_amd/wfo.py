@@ -5,8 +5,8 @@ Same constructor, read-only properties and methods as ``paos.classes.wfo.WFO``
 (``_lib.DeviceFields``); every method below runs the scalar pilot-beam part on
 the host (``planner.PilotBeam``) and the field part as HIP kernels.  ``grid_sag``
 and ``psd`` (wfo.py:656-949) build their WFE map on the host (``phase_maps``: the reference's own
-NumPy / SciPy steps; the scikit-image resampling of a sag at another pixel scale is not restated and
-raises) and apply it with the ``paos_phase_map`` kernel.
+NumPy / SciPy steps; the scikit-image resampling of a sag at another pixel scale is a parity-unpinned
+restatement on scipy.ndimage) and apply it with the ``paos_phase_map`` kernel.
 """
 import numpy as np
 

@@ -120,12 +120,47 @@ def test_grid_sag_maps_match_reference():
         assert np.array_equal(np.ma.getmaskarray(got), g[f"gs_{tag}_mask"]), tag
         assert np.array_equal(got.filled(0.0), g[f"gs_{tag}_wfe"]), tag
     b = _beam(False)
-    with pytest.raises(NotImplementedError, match="rescale"):
-        grid_sag_map(np.ones((64, 64)), 64, 64, 2 * b.dx, 2 * b.dy, 0.0, 0.0, (64, 64), b.dx, b.dy)
-    with pytest.raises(NotImplementedError):
-        grid_sag_map(np.ones((64, 63)), 63, 64, b.dx, b.dy, 0.0, 0.0, (64, 64), b.dx, b.dy)
     with pytest.raises(AssertionError):
         grid_sag_map(np.ones((64, 64)), 32, 64, b.dx, b.dy, 0.0, 0.0, (64, 64), b.dx, b.dy)
+
+
+def test_grid_sag_resampling_is_sane_but_unpinned():
+    """The branches of WFO.grid_sag that call scikit-image (wfo.py:786-800, 845-859): a sag at another pixel scale, an
+    odd size difference, a final shape nudge.  scikit-image 0.24.0 is not available, so `_ski_resize` restates its
+    published algorithm on scipy.ndimage and NOTHING here pins it to the real package: the checks are about sanity
+    (shapes, masks, a smooth surface reproduced to the accuracy of cubic interpolation, value range kept)."""
+    from paos_amd.phase_maps import _ski_rescale, _ski_resize, grid_sag_map
+
+    n, dx = 64, 1.0 / 16
+    surface = lambda x, y: 1.0e-7 * np.cos(2 * np.pi * x / 40.0) * np.sin(2 * np.pi * y / 56.0) + 2.0e-7  # noqa: E731
+    yy, xx = np.mgrid[0:n, 0:n]
+    # twice as finely sampled over the same extent: output pixel k covers input pixels 2k, 2k + 1
+    y2, x2 = np.mgrid[0:2 * n, 0:2 * n]
+    got = grid_sag_map(surface(x2, y2), 2 * n, 2 * n, dx / 2, dx / 2, 0.0, 0.0, (n, n), dx, dx)
+    want = surface(2 * xx + 0.5, 2 * yy + 0.5)
+    assert got.shape == (n, n) and not got.mask.any()
+    assert np.max(np.abs(got.filled(0.0) - want)) < 1e-2 * np.ptp(want)
+    # half as finely sampled: cubic upsampling
+    y3, x3 = np.mgrid[0:n // 2, 0:n // 2]
+    got = grid_sag_map(surface(4 * x3, 4 * y3), n // 2, n // 2, 2 * dx, 2 * dx, 0.0, 0.0, (n, n), dx, dx)
+    want = surface(2 * xx - 1.0, 2 * yy - 1.0)  # output pixel k sits at input coordinate (k + 0.5) / 2 - 0.5
+    assert got.shape == (n, n)
+    assert np.max(np.abs(got.filled(0.0)[4:-4, 4:-4] - want[4:-4, 4:-4])) < 2e-2 * np.ptp(want)
+    # an odd overhang (67 samples at the wavefront's scale) and anamorphic sampling end on the grid's shape
+    y4, x4 = np.mgrid[0:67, 0:67]
+    assert grid_sag_map(surface(x4, y4), 67, 67, dx, dx, 0.0, 0.0, (n, n), dx, dx).shape == (n, n)
+    assert grid_sag_map(surface(x4, y4), 67, 67, 1.03 * dx, 0.97 * dx, 0.0, 0.0, (n, n), dx, dx).shape == (n, n)
+    # masked samples (zeros) stay masked after resampling, valid ones stay valid away from the edge of the hole
+    holed = surface(x2, y2)
+    holed[40:60, 50:90] = 0.0
+    got = grid_sag_map(holed, 2 * n, 2 * n, dx / 2, dx / 2, 0.0, 0.0, (n, n), dx, dx)
+    assert got.mask[22:28, 27:43].all() and not got.mask[:15].any()
+    # the building blocks: identity at scale 1, value range kept, shapes by rounding
+    img = np.random.default_rng(0).standard_normal((20, 30))
+    assert np.allclose(_ski_resize(img, (20, 30), False), img, atol=1e-12)
+    big = _ski_rescale(img, 2, 2)
+    assert big.shape == (40, 60) and big.min() >= img.min() and big.max() <= img.max()
+    assert _ski_rescale(img, 0.5, 0.33).shape == (7, 15)
 
 
 def test_psd_maps_match_reference():
