@@ -89,12 +89,6 @@ struct FrugalArgs {
   // `psf_partial[item * gridDim.x + blockIdx.x]`; the field itself is not written
   double* psf;
   double* psf_partial;
-  // Row tiles that share their 128-byte lines with a sibling workgroup (half a block row each): one counter per
-  // (item, block row), zeroed before the launch.  The siblings meet here before they store (bounded wait), so that
-  // their half-line stores reach the L2 together and leave it as whole lines (round 3, tools/membench2.hip: with the
-  // arithmetic of a two-transform pass between loads and stores the half-line pattern runs at 0.97 ms per 4.29 GB
-  // free-running and 0.86 ms with the rendezvous; column tiles: 0.85).  nullptr: no rendezvous.
-  unsigned* meet;
 #if PAOS_STAMPS
   unsigned long long* stamps;  // [gridDim.y][gridDim.x][kStampSlots]
 #endif
@@ -168,9 +162,10 @@ __device__ __forceinline__ T flip_sign(T x, unsigned mask_hi) {
 #ifndef PAOS_SHARE_PHASES
 #define PAOS_SHARE_PHASES 1
 #endif
-#ifndef PAOS_MEET_POLLS
-#define PAOS_MEET_POLLS 64  // polls of ~0.3 us a workgroup waits for its sibling at most before it stores anyway (0: never waits)
+#ifndef PAOS_MERGE_PHASES
+#define PAOS_MERGE_PHASES 1  // two phases of one slot through one sincos of their exactly summed arguments
 #endif
+
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <typename T, int N, int E, int K, typename Map, int PLAIN = 0, bool SHARE = false>
@@ -323,6 +318,22 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
   // the factor prod_j exp(i q_j) of element k: each argument rounded like the reference's
   auto factor = [&](int k) __attribute__((always_inline)) {
     cx<double> p = {1.0, 0.0};
+    if constexpr (K == 2 && PAOS_MERGE_PHASES != 0) {
+      // Two phases of one slot through ONE sincos: exp(i q0) exp(i q1) = exp(i (q0 + q1)).  The sum of the two rounded
+      // arguments is taken exactly (TwoSum: a = fl(q0 + q1), e = q0 + q1 - a, |e| <= ulp(a) / 2 ~ 1e-10 at 1e6 rad)
+      // and the tail applied to first order, exp(i (a + e)) = exp(i a) (1 + i e) + O(e^2 ~ 1e-20): 12 + 6 + 17 + 2
+      // instructions instead of 2 x 23 + 4.  (Each argument is still the reference's rounded one.)
+      const double x0 = __dmul_rn((k < E / 2 ? g_lo[0] : g_hi[0]) + (double)(k * TL), step[0]);
+      const double q0 = __dmul_rn(ph[0].m2, __dmul_rn(coefq[0], __dadd_rn(__dmul_rn(x0, x0), across2[0])));
+      const double x1 = __dmul_rn((k < E / 2 ? g_lo[KK - 1] : g_hi[KK - 1]) + (double)(k * TL), step[KK - 1]);
+      const double q1 = __dmul_rn(ph[KK - 1].m2, __dmul_rn(coefq[KK - 1], __dadd_rn(__dmul_rn(x1, x1), across2[KK - 1])));
+      const double a = __dadd_rn(q0, q1);
+      const double bb = __dsub_rn(a, q0);
+      const double e = __dadd_rn(__dsub_rn(q0, __dsub_rn(a, bb)), __dsub_rn(q1, bb));
+      double sn, cs;
+      sincos_tab(a, circle, &sn, &cs);
+      return cx<double>{fma(-e, sn, cs), fma(e, cs, sn)};
+    }
 #pragma unroll
     for (int j = 0; j < K; ++j) {
       const double x = __dmul_rn((k < E / 2 ? g_lo[j] : g_hi[j]) + (double)(k * TL), step[j]);
@@ -672,19 +683,6 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
     double* scratch = reinterpret_cast<double*>(smem + frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, E, 0>());
     tile_power_out<TILES * LINES * N / E>(acc, scratch, a.psf_partial + (size_t)item * gridDim.x + blockIdx.x);
     return;
-  }
-  if constexpr (AXIS == 0 && BR > 1 && LINES < BR && PAOS_MEET_POLLS > 0) {
-    if (a.meet) {  // wave-uniform.  Timing only: whatever the counter says, the stores below are the same
-      if (threadIdx.x == 0) {
-        unsigned* flag = a.meet + ((size_t)item * (N / BR) + (unsigned)m.row0 / BR);
-        __hip_atomic_fetch_add(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int tries = 0; tries < PAOS_MEET_POLLS; ++tries) {
-          if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)(BR / LINES)) break;
-          __builtin_amdgcn_s_sleep(8);
-        }
-      }
-      __syncthreads();
-    }
   }
   const int slo = (int)h_spos_lo, shi = (int)h_spos_hi;
   if (slo <= 0 && shi >= N) {  // wave-uniform: everything is stored

@@ -87,7 +87,6 @@ struct paos_ctx {
   double* psf = nullptr;  // batch x item_stride intensities kept on the device, blocked like the field (paos_psf_keep)
   double* psf_partial = nullptr;  // per-workgroup sums of a pass that stores the PSF (paos_run_program: final_intensity)
   int psf_nparts = 0;
-  unsigned* meet = nullptr;  // batch x n / br rendezvous counters of sibling row tiles (frugal_pass.h: FrugalArgs::meet)
   void* bounce[2] = {nullptr, nullptr};  // pinned host buffers for device -> pageable host copies
   hipEvent_t bounce_ev[2] = {nullptr, nullptr};
   void* field = nullptr;
@@ -721,14 +720,6 @@ void forget_mask_sets(paos_ctx* c) {  // after a failed program: what the sets h
   for (auto& ms : c->mask_sets) ms.key.clear();
 }
 
-// PAOS_MEET=1: sibling row tiles wait for each other (bounded) before storing.  Off by default: in the access-pattern
-// model (tools/membench2.hip) the rendezvous takes the half-line pattern with arithmetic from 0.97 to 0.86 ms, in the
-// real pass kernel it changes nothing (-0.3 %, profiles/r03_ab_variants_bench.txt) -- kept as a switch for A/B runs.
-bool use_meet() {
-  static const bool on = [] { const char* e = getenv("PAOS_MEET"); return e && e[0] == '1'; }();
-  return on;
-}
-
 // launch a pass that lower_frugal accepted
 int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const double* dblocks, bool store_psf = false) {
   // PAOS_DUMP_PASSES=1: one line per pass launch on stderr (shape and what item 0's two slots carry)
@@ -759,14 +750,8 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const
   int rc = arena_push(c, reinterpret_cast<const double*>(lp.items.data()),
                       lp.items.size() * sizeof(FrugalItem) / sizeof(double), &ditems);
   if (rc) return rc;
-  FrugalArgs a{c->field, c->tw, reinterpret_cast<const FrugalItem*>(ditems), c->pitch, c->item_stride, nullptr, nullptr, nullptr};
+  FrugalArgs a{c->field, c->tw, reinterpret_cast<const FrugalItem*>(ditems), c->pitch, c->item_stride, nullptr, nullptr};
   if (store_psf) { a.psf = c->psf; a.psf_partial = c->psf_partial; }
-  if (p.axis == 0 && c->n >= 2048 && !store_psf && use_meet()) {  // row tiles of half a block row: siblings meet before storing
-    const size_t bytes = (size_t)c->batch * (c->n / c->br) * sizeof(unsigned);
-    if (!c->meet) HIPCHK(c, hipMalloc(&c->meet, bytes));
-    HIPCHK(c, hipMemsetAsync(c->meet, 0, bytes, c->stream));
-    a.meet = c->meet;
-  }
   const int nfft = lp.nfft;
   // for the launch timer: what does this launch skip?  bit 0: whole tiles of dead lines, bit 1: loads of dead
   // positions, bit 2: stores nobody reads, bit 3: it stores the PSF instead of the field
@@ -951,7 +936,6 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
       const int groups = c->n / lines;
       if (c->psf_nparts < groups) {
         if (c->psf_partial) (void)hipFree(c->psf_partial);
-  if (c->meet) (void)hipFree(c->meet);
         c->psf_partial = nullptr; c->psf_nparts = 0;
         HIPCHK(c, hipMalloc(&c->psf_partial, (size_t)c->batch * groups * sizeof(double)));
         c->psf_nparts = groups;
@@ -1236,7 +1220,6 @@ int paos_ctx_destroy(paos_ctx* c) {
   if (c->norm2_host) (void)hipHostFree(c->norm2_host);
   if (c->psf) (void)hipFree(c->psf);
   if (c->psf_partial) (void)hipFree(c->psf_partial);
-  if (c->meet) (void)hipFree(c->meet);
   for (int i = 0; i < 2; ++i) {
     if (c->bounce[i]) (void)hipHostFree(c->bounce[i]);
     if (c->bounce_ev[i]) (void)hipEventDestroy(c->bounce_ev[i]);
