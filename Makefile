@@ -37,5 +37,12 @@ build/fftbench: tools/fftbench.hip $(CSRC)/fft_core.h $(CSRC)/fft_kernels.h $(CS
 	mkdir -p build
 	$(HIPCC) -O3 --offload-arch=$(ARCH) -ffp-contract=off -I$(CSRC) tools/fftbench.hip -o build/fftbench
 
+# every pass-kernel shape should fit its register budget without scratch: rebuild with the compiler's resource remarks
+# and list the shapes that spill (a change that costs a shape its allocation shows here, not only in the bench)
+spillcheck:
+	touch $(CSRC)/paos_hip.hip
+	$(MAKE) -j6 EXTRA=-Rpass-analysis=kernel-resource-usage > build/make.log 2>&1
+	python3 tools/spill_report.py build/make.log
+
 clean:
 	rm -f $(LIB) $(OBJS) build/fftbench
