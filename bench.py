@@ -24,6 +24,8 @@ given; `config.ranks_seen` / `devices_seen` come from the communicator.  Rank 0 
   chain_vs_survey_model / ptp_step   the whole chain and one ptp priced with SURVEY 8d's UNFUSED byte model (2 passes
                      per 2-D FFT) next to the bytes the launches of one step really moved under the counters
                      (`bytes_moved_per_wavefront`, every kernel of the step; `other_kernels` lists the non-pass ones).
+  without_ptp_algebra  the rate (3 steps) with the pass compiler's two ptp identities switched off (PAOS_PTP_ALGEBRA=0:
+                     44 passes per wavefront instead of 24), so that the headline value can be read without them.
   extra              the same chain at 2048^2 and 1024^2 (the north star's sweep), value + roofline each.
   cpu_baseline       the NumPy oracle ("port") on the host: one wavefront of the workload at the benchmark grid
                      on one core, and `cpu_baseline_parallel`: min(batch, cores, memory, 8) worker processes over
