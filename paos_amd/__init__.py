@@ -16,7 +16,9 @@ from .coordinate_break import coordinate_break
 from .parse_config import parse_config
 from .zernike import Zernike
 
-__all__ = ["ABCD", "WFO", "Zernike", "coordinate_break", "parse_config", "run_batch", "run_sharded"]
+from .raytrace import raytrace
+
+__all__ = ["ABCD", "WFO", "Zernike", "coordinate_break", "parse_config", "raytrace", "run_batch", "run_sharded"]
 __version__ = "0.1.0"
 
 
