@@ -147,6 +147,7 @@ void bench_frugal(const char* name, int batch, int reps, int pad_blocks) {
 #define PAOS_BENCH_BR 4
 #endif
   constexpr int BR = PAOS_BENCH_BR;
+  if (getenv("PAOS_BENCH_BATCH")) batch = atoi(getenv("PAOS_BENCH_BATCH"));
   const unsigned pitch = (unsigned)N * BR + (unsigned)pad_blocks * BR * BC;
   const unsigned item_stride = pitch * (N / BR);
   cx<T>* d;
@@ -155,6 +156,24 @@ void bench_frugal(const char* name, int batch, int reps, int pad_blocks) {
   std::vector<std::complex<T>> h((size_t)N * N);
   srand(1);
   for (auto& z : h) z = std::complex<T>((T)(rand() / (double)RAND_MAX - 0.5), (T)(rand() / (double)RAND_MAX - 0.5));
+  // PAOS_BENCH_FIELD: what the field holds (default: uniform random everywhere).  "beam": a smooth Gaussian beam with a
+  // smooth phase, nonzero everywhere; "pupil": random inside the central N/4 x N/4 box, exact zeros outside (a pupil plane
+  // of the chain at zoom 4); "zeros".  Same bytes, same instructions: what differs is what the lanes toggle.
+  if (const char* fld = getenv("PAOS_BENCH_FIELD")) {
+    for (int r = 0; r < N; ++r)
+      for (int c = 0; c < N; ++c) {
+        std::complex<T>& z = h[(size_t)r * N + c];
+        const double y = (r - N / 2) / (double)N, x = (c - N / 2) / (double)N;
+        if (!strcmp(fld, "beam")) {
+          const double amp = exp(-(x * x + y * y) * 64.0), ph = 40.0 * (x * x + y * y) + 3.0 * x;
+          z = std::complex<T>((T)(amp * cos(ph)), (T)(amp * sin(ph)));
+        } else if (!strcmp(fld, "pupil")) {
+          if (fabs(x) > 0.125 || fabs(y) > 0.125) z = std::complex<T>(0, 0);
+        } else if (!strcmp(fld, "zeros")) {
+          z = std::complex<T>(0, 0);
+        }
+      }
+  }
   for (int b = 0; b < batch; ++b)
     for (int r = 0; r < N / BR; ++r)
       CK(hipMemcpy(d + (size_t)b * item_stride + (size_t)r * pitch, h.data() + (size_t)r * N * BR,
