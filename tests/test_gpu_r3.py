@@ -165,6 +165,37 @@ def test_syn20_4096_last_item_of_the_sweep_vs_oracle():
     print("SYN20 4096^2 k=31 PSF error vs oracle:", e)
 
 
+def test_syn20_without_the_ptp_identities_vs_oracle_and_vs_the_fused_chain():
+    """The pass compiler's two ptp identities (consecutive ptp share a middle pass; a ptp and its exact inverse
+    cancel: 24 passes per SYN20 wavefront instead of 44) switched off -- the configuration bench.py reports as
+    ``without_ptp_algebra`` -- against the oracle, and the default chain against it: the identities move the PSF by
+    rounding only."""
+    import paos_amd.passes as ppasses
+    from paos_amd.chains import syn20_chain, syn20_wavelength
+    from paos_amd.run import run_batch
+
+    n = 2048
+    wls = [syn20_wavelength(0), syn20_wavelength(17)]
+    chains = [syn20_chain(), syn20_chain()]
+    fused_stats, plain_stats = {}, {}
+    fused = run_batch(1.0, wls, n, 4, ON_AXIS, chains, outputs=("psf",), stats=fused_stats)
+    assert ppasses.PTP_ALGEBRA is True
+    ppasses.PTP_ALGEBRA = False
+    try:
+        plain = run_batch(1.0, wls, n, 4, ON_AXIS, chains, outputs=("psf",), stats=plain_stats)
+    finally:
+        ppasses.PTP_ALGEBRA = True
+    assert plain_stats["fused_passes"] > fused_stats["fused_passes"] + 15
+    ref = _oracle(1.0, wls[1], n, 4, ON_AXIS, syn20_chain())
+    e_plain = _check(plain[1], ref, ("SYN20 2048 k=17, no ptp identities",))
+    e_fused = _check(fused[1], ref, ("SYN20 2048 k=17",))
+    for a, b in zip(fused, plain):
+        for k in a:
+            assert rel_err(a[k]["psf"], b[k]["psf"]) < 1e-12, k
+            assert abs(a[k]["power"] / b[k]["power"] - 1.0) < 1e-12
+    print("SYN20 2048^2 k=17 PSF error vs oracle: %.2e without the identities, %.2e with" % (e_plain, e_fused))
+
+
 @pytest.mark.parametrize("n,precision", [(256, "fp64"), (512, "fp32"), (1024, "fp64"), (4096, "fp64"), (2048, "fp32")])
 def test_lean_walk_equals_the_ordinary_walk(n, precision):
     """run_batch(outputs=(), keep_psf=True) -- the benchmark's mode -- leaves the dark rows of the first surface
