@@ -1303,6 +1303,31 @@ static int start_impl(paos_ctx* c, double re, double im, int shape, const double
     if ((rc = check_rows(c, write_rows))) return rc;
     if ((rc = arena_push(c, write_rows, (size_t)2 * c->batch, &drows))) return rc;
   }
+  // groups of items that start from the same field (start_write_kernel)
+  static const bool share_start = [] { const char* e = getenv("PAOS_SHARE_START"); return !(e && e[0] == '0'); }();
+  std::vector<double> goff(c->batch, 0.0), glen(c->batch, 0.0), members;
+  {
+    std::vector<int> lead(c->batch);
+    for (int i = 0; i < c->batch; ++i) {
+      lead[i] = i;
+      if (!share_start) continue;
+      for (int j = 0; j < i; ++j)
+        if (lead[j] == j && flags[j] == flags[i] &&
+            !std::memcmp(aperture + (size_t)j * AP_STRIDE, aperture + (size_t)i * AP_STRIDE, AP_STRIDE * sizeof(double)) &&
+            (!write_rows || !std::memcmp(write_rows + 2 * j, write_rows + 2 * i, 2 * sizeof(double)))) { lead[i] = j; break; }
+    }
+    for (int i = 0; i < c->batch; ++i) {
+      if (lead[i] != i) continue;
+      goff[i] = (double)members.size();
+      for (int j = i; j < c->batch; ++j)
+        if (lead[j] == i) members.push_back((double)j);
+      glen[i] = (double)members.size() - goff[i];
+    }
+  }
+  const double *dgoff = nullptr, *dglen = nullptr, *dmembers = nullptr;
+  if ((rc = arena_push(c, goff.data(), goff.size(), &dgoff))) return rc;
+  if ((rc = arena_push(c, glen.data(), glen.size(), &dglen))) return rc;
+  if ((rc = arena_push(c, members.data(), members.size(), &dmembers))) return rc;
   const dim3 block(kPwThreads);
 #define START_LAUNCH(T, BRV, S)                                                                         \
   do {                                                                                                  \
@@ -1314,7 +1339,7 @@ static int start_impl(paos_ctx* c, double re, double im, int shape, const double
     }                                                                                                   \
     hipLaunchKernelGGL((start_write_kernel<T, BRV, Lay<T>::BC, S>), dim3(pw_blocks(c), c->batch), block, 0, \
                        c->stream, (cx<T>*)c->field, dp, c->n, c->pitch, c->item_stride, re, im,          \
-                       (const double*)c->norm2, ds, drows);                                             \
+                       (const double*)c->norm2, ds, drows, dgoff, dglen, dmembers);                     \
   } while (0)
   if (c->precision == PAOS_F64) {
     if (shape == PAOS_SHAPE_ELLIPSE) START_LAUNCH(double, BR, 0); else START_LAUNCH(double, BR, 1);
@@ -1781,6 +1806,37 @@ static int zernike_apply(paos_ctx* c, int nmax, int kdim, const double* table, c
   if (rc) return rc;
   rc = arena_push(c, params, (size_t)c->batch * param_stride, &dp);
   if (rc) return rc;
+  // groups of items with one wfe map: records equal in everything but the wavelength (and no per-item pupil)
+  static const bool share_wfe = [] { const char* e = getenv("PAOS_SHARE_WFE"); return !(e && e[0] == '0'); }();
+  std::vector<double> goff(c->batch, 0.0), glen(c->batch, 0.0), members;
+  {
+    std::vector<int> lead(c->batch, -1);
+    auto same_map = [&](int a, int b) {
+      const double *qa = params + (size_t)a * param_stride, *qb = params + (size_t)b * param_stride;
+      for (int k = 0; k < param_stride; ++k)
+        if (k != ZP_INV_WL && std::memcmp(qa + k, qb + k, sizeof(double))) return false;
+      return true;
+    };
+    for (int i = 0; i < c->batch; ++i) {
+      if (params[(size_t)i * param_stride + ZP_ENABLE] == 0.0) continue;
+      lead[i] = i;
+      if (share_wfe && !use_pupil)
+        for (int j = 0; j < i; ++j)
+          if (lead[j] == j && same_map(j, i)) { lead[i] = j; break; }
+    }
+    for (int i = 0; i < c->batch; ++i) {
+      if (lead[i] != i) continue;
+      goff[i] = (double)members.size();
+      for (int j = i; j < c->batch; ++j)
+        if (lead[j] == i) members.push_back((double)j);
+      glen[i] = (double)members.size() - goff[i];
+    }
+    if (members.empty()) members.push_back(0.0);
+  }
+  const double *dgoff = nullptr, *dglen = nullptr, *dmembers = nullptr;
+  if ((rc = arena_push(c, goff.data(), goff.size(), &dgoff))) return rc;
+  if ((rc = arena_push(c, glen.data(), glen.size(), &dglen))) return rc;
+  if ((rc = arena_push(c, members.data(), members.size(), &dmembers))) return rc;
   const dim3 grid(pw_blocks(c), c->batch), block(kPwThreads);
   double* wfe = host_wfe ? (double*)c->staging : nullptr;
   const double* pupil = use_pupil ? c->mask : nullptr;
@@ -1810,7 +1866,8 @@ static int zernike_apply(paos_ctx* c, int nmax, int kdim, const double* table, c
   // orders up to 8 (45 polynomials) run on the unrolled build
 #define ZK_LAUNCH(T, BRV, NC)                                                                                          \
   hipLaunchKernelGGL((zernike_kernel<T, BRV, Lay<T>::BC, NC>), grid, block, 0, c->stream, (cx<T>*)c->field, dt, dp,   \
-                     param_stride, c->n, c->pitch, c->item_stride, nmax, kdim, wfe, pupil, m_first, m_end)
+                     param_stride, c->n, c->pitch, c->item_stride, nmax, kdim, wfe, pupil, m_first, m_end, dgoff, dglen, \
+                     dmembers)
   if (c->precision == PAOS_F64) {
     if (nmax <= 8) ZK_LAUNCH(double, BR, 8); else ZK_LAUNCH(double, BR, 0);
   } else {

@@ -560,8 +560,15 @@ __global__ void start_power_kernel(const double* params, int n, unsigned pitch, 
 template <typename T, int BR, int BC, int SHAPE>
 __global__ void start_write_kernel(cx<T>* field, const double* params, int n, unsigned pitch,
                                    unsigned item_stride, double vre, double vim, const double* norm2,
-                                   const double* stop, const double* rows = nullptr) {
+                                   const double* stop, const double* rows, const double* grp_off,
+                                   const double* grp_len, const double* grp_members) {
+  // Items with the same aperture record, stop flag and row window (a wavelength sweep at the entrance pupil, a
+  // Monte-Carlo batch) start from the same field: the first of them evaluates the weights once per pixel and writes
+  // every member of its group (grp_members[grp_off[item] ...], grp_len[item] of them; 0 = somebody else's member).
   const int item = blockIdx.y;
+  const int glen = (int)grp_len[item];
+  if (glen == 0) return;
+  const double* members = grp_members + (int)grp_off[item];
   const double* p = params + (size_t)item * AP_STRIDE;
   ApertureEval<SHAPE> ap;
   ap.init(p, p + AP_THETA);
@@ -569,7 +576,6 @@ __global__ void start_write_kernel(cx<T>* field, const double* params, int n, un
   const bool scaled = stop[item] != 0.0;
   const double s = scaled ? 1.0 / sqrt(norm2[item]) : 1.0;
   const double v0re = (double)(T)vre, v0im = (double)(T)vim;
-  cx<T>* f = field + (size_t)item * item_stride;
   // ``rows`` ([batch][2], optional): only the rows [lo, hi) are written; the others are left as they are and stand
   // for zeros (paos_start_rows: the caller promises that nobody reads them before a pass program consumes them)
   size_t total = item_stride, first = 0;
@@ -589,7 +595,7 @@ __global__ void start_write_kernel(cx<T>* field, const double* params, int n, un
       y = w == 1.0 ? v0im : (w == 0.0 ? 0.0 : (double)(T)__dmul_rn(v0im, w));
       if (scaled) { x = __dmul_rn(x, s); y = __dmul_rn(y, s); }
     }
-    f[m] = {(T)x, (T)y};
+    for (int g = 0; g < glen; ++g) field[(size_t)(int)members[g] * item_stride + m] = {(T)x, (T)y};
   }
 }
 
@@ -745,16 +751,22 @@ template <typename T, int BR, int BC, int NMAXC = 0>
 __global__ void zernike_kernel(cx<T>* field, const double* table, const double* params,
                                int param_stride, int n, unsigned pitch, unsigned item_stride,
                                int nmax, int kdim, double* wfe_out, const double* pupil,
-                               unsigned m_first = 0, unsigned m_end = 0xffffffffu) {
+                               unsigned m_first, unsigned m_end, const double* grp_off, const double* grp_len,
+                               const double* grp_members) {
+  // Items whose records differ in the wavelength only (a wavelength sweep through one lens file: same sampling,
+  // same coefficients) have the same wfe map: the first of them evaluates the polynomials once per pixel and applies
+  // the phase to every member of its group (grp_members[grp_off[item] ...], grp_len[item] of them; 0 = this item is
+  // somebody else's member, or switched off).  The arithmetic per item is unchanged.
   const int item = blockIdx.y;
+  const int glen = (int)grp_len[item];
+  if (glen == 0) return;
+  const double* members = grp_members + (int)grp_off[item];
   const double* p = params + (size_t)item * param_stride;
-  if (p[ZP_ENABLE] == 0.0) return;
-  const double dx = p[ZP_DX], dy = p[ZP_DY], radius = p[ZP_RADIUS], inv_wl = p[ZP_INV_WL];
+  const double dx = p[ZP_DX], dy = p[ZP_DY], radius = p[ZP_RADIUS];
   const bool origin_y = p[ZP_ORIGIN_Y] != 0.0;
   const double co = p[ZP_COS_OFF], so = p[ZP_SIN_OFF];
   const double* coef_c = p + ZP_HEAD;
   const double* coef_s = coef_c + (size_t)(nmax + 1) * kdim;
-  cx<T>* f = field + (size_t)item * item_stride;
   // [m_first, m_end): the block rows that meet the unit disk of some item (the host bounds them); outside, the
   // kernel changes nothing
   const size_t total = m_end < item_stride ? m_end : item_stride;
@@ -820,12 +832,17 @@ __global__ void zernike_kernel(cx<T>* field, const double* table, const double* 
       } else {
         for (int am = 0; am <= nmax; ++am) order(am, (nmax - am) / 2);
       }
-      const double arg = __dmul_rn(__dmul_rn(6.283185307179586, wfe), inv_wl);
-      double sn, cs;
-      sincos_fast(arg, &sn, &cs);
-      const cx<double> v = {(double)f[m].x, (double)f[m].y};
-      f[m] = {(T)__dsub_rn(__dmul_rn(v.x, cs), __dmul_rn(v.y, sn)),
-              (T)__dadd_rn(__dmul_rn(v.x, sn), __dmul_rn(v.y, cs))};
+      const double turns = __dmul_rn(6.283185307179586, wfe);
+      for (int g = 0; g < glen; ++g) {
+        const int it = (int)members[g];
+        const double arg = __dmul_rn(turns, params[(size_t)it * param_stride + ZP_INV_WL]);
+        double sn, cs;
+        sincos_fast(arg, &sn, &cs);
+        cx<T>* f = field + (size_t)it * item_stride;
+        const cx<double> v = {(double)f[m].x, (double)f[m].y};
+        f[m] = {(T)__dsub_rn(__dmul_rn(v.x, cs), __dmul_rn(v.y, sn)),
+                (T)__dadd_rn(__dmul_rn(v.x, sn), __dmul_rn(v.y, cs))};
+      }
     }
     if (wfe_out && item == 0) wfe_out[(size_t)r * n + c] = masked ? __longlong_as_double(0x7ff8000000000000LL) : wfe;
   }

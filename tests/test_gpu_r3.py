@@ -301,6 +301,68 @@ def test_row_window_entry_points():
         ref.close()
 
 
+@pytest.mark.parametrize("precision", ["fp64", "fp32"])
+def test_items_sharing_a_start_field_or_a_wfe_map_equal_their_solo_runs(precision):
+    """Items of a batch with the same aperture record / the same Zernike record up to the wavelength are written by
+    the first of them (start_write_kernel, zernike_kernel: one evaluation of the weights / polynomials per pixel for
+    the whole group).  A batch that mixes two groups, a loner and a switched-off item, against one-item contexts:
+    bit for bit."""
+    from paos_amd import _lib
+    from paos_amd.aperture import make_aperture
+    from paos_amd.planner import jacobi_recurrence, zernike_block
+    from paos_amd.zernike import Zernike
+
+    n, nb = 512, 6
+    dx = 4.0 / n
+    # apertures: items 0, 2, 5 equal; 1, 3 equal (another radius); 4 alone (and not a stop)
+    radius = [0.5, 0.42, 0.5, 0.42, 0.37, 0.5]
+    stops = [1.0, 1.0, 1.0, 1.0, 0.0, 1.0]
+    handles = [make_aperture(n, dx, dx, 0.0, 0.0, hx=r, hy=r, shape="elliptical") for r in radius]
+    blocks = [h.block(obscuration=False) for h in handles]
+    rows = [[96, 416], [112, 400], [96, 416], [112, 400], [0, n], [96, 416]]
+    # Zernike records: items 0, 2, 5 one draw at three wavelengths; 1, 3 another draw; item 4 switched off
+    rng = np.random.default_rng(11)
+    draws = [rng.normal(0.0, 30e-9, 15), rng.normal(0.0, 30e-9, 15)]
+    which = [0, 1, 0, 1, None, 0]
+    wls = [1.0e-6, 1.3e-6, 1.7e-6, 2.1e-6, 1.0e-6, 0.8e-6]
+    m, nn = Zernike.j2mn(15, "standard")
+    norm = np.sqrt(nn + 1.0) * np.where(m == 0, 1.0, np.sqrt(2.0))
+    nmax = int(nn.max())
+    zb = []
+    for i in range(nb):
+        if which[i] is None:
+            blk = np.zeros(_lib.ZERNIKE_HEAD + 2 * (nmax + 1) * (nmax // 2 + 1))
+        else:
+            blk, _, kdim = zernike_block(m, nn, norm, draws[which[i]], dx, dx, 0.5, wls[i], nmax=nmax)
+        zb.append(blk)
+    table = jacobi_recurrence(nmax)
+    value = 1.0 + 0.0j
+
+    def run(dev, items, windowed):
+        sel = lambda seq: [seq[i] for i in items]  # noqa: E731
+        if windowed:
+            dev.start(value, _lib.SHAPE_ELLIPSE, sel(blocks), sel(stops), write_rows=sel(rows))
+            dev.zero_outside_rows(sel(rows))
+        else:
+            dev.start(value, _lib.SHAPE_ELLIPSE, sel(blocks), sel(stops))
+        dev.zernike(nmax, nmax // 2 + 1, table, np.array(sel(zb)))
+        return [dev.download(k) for k in range(len(items))]
+
+    many = _lib.DeviceFields(n, nb, precision)
+    one = _lib.DeviceFields(n, 1, precision)
+    try:
+        for windowed in (False, True):
+            got = run(many, list(range(nb)), windowed)
+            for i in range(nb):
+                (solo,) = run(one, [i], windowed)
+                assert np.array_equal(got[i], solo), (windowed, i)
+            assert not np.array_equal(got[0], got[2]) and not np.array_equal(got[1], got[3])  # the wavelengths differ
+            assert np.abs(got[4]).max() == 1.0  # not a stop, no Zernike: the bare aperture
+    finally:
+        many.close()
+        one.close()
+
+
 def test_two_ranks_asking_for_rccl_on_one_gpu_agree():
     """ncclCommInitRank with nranks = 2 actually runs (under the watchdog): RCCL may refuse two ranks on one
     device -- then both ranks must agree on the TCP transport -- or accept them, or never come back -- then the
