@@ -33,6 +33,9 @@ MAX_MERGED_PTP = 3  # transfer functions one middle pass can carry (kFrugalMaxMi
 # passes again -- same results to rounding, 44 instead of 24 passes for SYN20; bench.py reports that rate beside the
 # headline one.
 PTP_ALGEBRA = os.environ.get("PAOS_PTP_ALGEBRA", "1") != "0"
+# The axis of a pass that has no open pass to glue onto (the first pass of a program).  Every later pass alternates
+# from there, so this decides which of the chain's passes run along rows and which along columns.
+FIRST_AXIS = 1 if os.environ.get("PAOS_FIRST_AXIS", "0") == "1" else 0
 
 
 def _rows(rows, batch):
@@ -106,8 +109,8 @@ class PassCompiler:
             self.tail = []
         else:
             self._close_open()
-        self.passes.append({"axis": 0, "fft1": ctl, "pre": pre, "mid": [], "post": []})
-        return 0
+        self.passes.append({"axis": FIRST_AXIS, "fft1": ctl, "pre": pre, "mid": [], "post": []})
+        return FIRST_AXIS
 
     def _open_pass(self, axis, ctl, mid_ops):
         p = {"axis": axis, "fft1": ctl, "fft2": -1, "pre": [], "mid": list(mid_ops), "post": []}
