@@ -61,6 +61,7 @@ class PassCompiler:
         self.open = None    # last pass, if its second transform slot is still free
         self.tail = []      # pointwise operators not yet attached to a pass
         self.last_ptp = None  # the ptp just emitted, while another one may still merge with it (see ptp)
+        self.last_single = None  # the stw / wts just emitted, while the next operator may still undo it (see _single)
 
     # ---- helpers -------------------------------------------------------------------
     def _block(self, rows):
@@ -142,8 +143,23 @@ class PassCompiler:
         arr = _rows(rows, self.batch)
         if not arr[:, 0].any():
             return
+        inv = np.where(np.asarray(inverse, dtype=bool), 1.0, 0.0) * np.ones(self.batch)
+        # A wts straight into an stw that undoes it (wfo.py:566-570: two outside-to-outside hops in a row, the second
+        # starting where the first ended, with no power, aperture or saved surface between them -- the flat windows
+        # and fold mirrors of a real prescription): the first ends with q_w = exp(i pi r^2 / (lambda dz)), FFT2 towards
+        # z; the second starts with FFT2^-1 back to the waist and q_s = exp(-i pi lambda dz f^2), which on the same
+        # pixels is 1 / q_w.  fft2(ifft2(X)) = X, the four checkerboards and the two 1/N with the N^2 of the
+        # transform pair are exactly 1, and the two phases multiply to 1 up to the rounding noise of their separately
+        # rounded arguments (~1e-12 rad at 1e4 rad, which the reference carries and this does not): both operators
+        # go, and the stw in front meets the wts behind -- the two hops become the one hop they are.
+        ls = self.last_single if PTP_ALGEBRA else None
+        if (ls is not None and kind == "stw" and ls["kind"] == "wts" and self.open is ls["open"] and not self.tail and
+                self.open["mid"] == ls["open_mid"] and self._undoes(ls["arr"], ls["inv"], arr, inv)):
+            self._restore(ls["undo"])
+            return
+        undo = self._snapshot()
         par = self._block(arr)
-        ctl = self._derived(arr, v1=np.where(np.asarray(inverse, dtype=bool), 1.0, 0.0))
+        ctl = self._derived(arr, v1=inv)
         scl = self._derived(arr, v3=1.0 / self.n)
         sign = (_lib.PW_SIGN, 0, par)
         phase = (_lib.PW_QPHASE_CENTRED, 0, par)
@@ -151,6 +167,26 @@ class PassCompiler:
         post = [sign, phase] if kind == "stw" else [sign]
         axis = self._first_pass(pre, ctl)
         self._open_pass(1 - axis, ctl, post + [(_lib.PW_SCALE, 0, scl)])
+        self.last_single = {"kind": kind, "arr": arr.copy(), "inv": inv.copy(), "open": self.open,
+                            "open_mid": list(self.open["mid"]), "undo": undo}
+
+    def _undoes(self, first, first_inv, second, second_inv, max_residual=1.0e-9):
+        """Does the stw ``second`` undo the wts ``first`` for every item?  Same items, opposite transform directions,
+        and phases exp(i c (sx^2 x^2 + sy^2 y^2)) (x, y in pixels from the centre) whose coefficients cancel: the
+        residual phase at the corner of the grid stays below ``max_residual`` rad (rounding noise is ~1e-12; anything
+        physical -- a different distance, a magnification between the two -- is many radians)."""
+        on = second[:, 0] != 0.0
+        if not np.array_equal(first[:, 0] != 0.0, on) or not np.array_equal(first_inv[on], 1.0 - second_inv[on]):
+            return False
+        half = (self.n / 2.0) ** 2
+        for a, b in ((first[on], second[on]),):
+            rx = a[:, 3] * a[:, 4] * a[:, 1] ** 2 + b[:, 3] * b[:, 4] * b[:, 1] ** 2
+            ry = a[:, 3] * a[:, 4] * a[:, 2] ** 2 + b[:, 3] * b[:, 4] * b[:, 2] ** 2
+            if not np.all(np.isfinite(rx)) or not np.all(np.isfinite(ry)):
+                return False
+            if np.any((np.abs(rx) + np.abs(ry)) * half >= max_residual):
+                return False
+        return True
 
     def stw(self, rows, inverse):
         self._single(rows, inverse, "stw")
@@ -211,12 +247,14 @@ class PassCompiler:
         """What ``_restore`` needs to take the compiler back to this point (before an operator was queued)."""
         o = self.open
         return {"n_blocks": len(self.blocks), "n_passes": len(self.passes), "open": o, "tail": list(self.tail),
-                "open_state": None if o is None else (list(o["mid"]), o.get("fft2", -1)), "last_ptp": self.last_ptp}
+                "open_state": None if o is None else (list(o["mid"]), o.get("fft2", -1)), "last_ptp": self.last_ptp,
+                "last_single": self.last_single}
 
     def _restore(self, snap):
         del self.blocks[snap["n_blocks"]:]
         del self.passes[snap["n_passes"]:]
         self.open, self.tail, self.last_ptp = snap["open"], list(snap["tail"]), snap["last_ptp"]
+        self.last_single = snap["last_single"]
         if self.open is not None:
             self.open["mid"], self.open["fft2"] = list(snap["open_state"][0]), snap["open_state"][1]
 

@@ -87,6 +87,10 @@ class _Lib:
             fn.restype, fn.argtypes = res, args
         if lib.H5open() < 0:
             raise RuntimeError("H5open failed")
+        # failures come back as exceptions with the name of the call (_ok); the library's own stack dump on stderr
+        # adds nothing (h5py switches it off as well)
+        lib.H5Eset_auto2.restype, lib.H5Eset_auto2.argtypes = ctypes.c_int, [_HID, ctypes.c_void_p, ctypes.c_void_p]
+        lib.H5Eset_auto2(0, None, None)
         self.NATIVE_DOUBLE = _HID.in_dll(lib, "H5T_NATIVE_DOUBLE_g").value
         self.NATIVE_INT64 = _HID.in_dll(lib, "H5T_NATIVE_INT64_g").value
         self.C_S1 = _HID.in_dll(lib, "H5T_C_S1_g").value

@@ -101,6 +101,26 @@ def main():
           f"PSF metrics; image-plane power {min(powers):.6f}..{max(powers):.6f}; rEE90 {1e6 * min(ree90):.2f}..{1e6 * max(ree90):.2f} um "
           f"(median {1e6 * float(np.median(ree90)):.2f}); draw 0 @512^2 PSF err vs oracle {rel(got[k]['amplitude'] ** 2, ref[k]['amplitude'] ** 2):.1e}")
 
+    # 4b. the same study the way the reference's CLI runs it (--light_output: only the image plane is saved): no
+    # saved surface interrupts the pass program, so consecutive operators fuse and the compiler's identities apply
+    light = {key: dict(item, save=item["name"] == "IMAGE_PLANE") for key, item in base.items()}
+    stats = {}
+    t0 = time.perf_counter()
+    ree90b = []
+    dev = _lib.DeviceFields(2048, 32)
+    for lo in range(0, 256, 32):
+        mc = [inject_wfe(light, table[:, k]) for k in range(lo, lo + 32)]
+        res = run_batch(pup, [wl] * 32, 2048, par["zoom"], fields[0], mc, outputs=(), dev=dev, sync=True,
+                        metrics_radii_px=radii, stats=stats)
+        for r in res:
+            rec = r[max(r)]
+            ee = rec["metrics"]["encircled"] / rec["metrics"]["power"]
+            ree90b.append(float(np.interp(0.9, ee, radii)) * rec["dx"])
+    dtb = time.perf_counter() - t0
+    dev.close()
+    print(f"4b same, light_output (image plane only): {dtb:.2f} s = {256 / dtb:.1f} wavefronts/s, {stats['fused_passes']} fused passes "
+          f"per wavefront; rEE90 agrees with 4 to {max(abs(a - b) for a, b in zip(ree90, ree90b)) / max(ree90):.1e}")
+
     # 5. Excite_TEL, wavelength sweep, 4096^2, fp32 vs fp64 (one GPU: 8 of the 512 wavelengths)
     sweep = np.linspace(1.0, 4.0, 512)[::64]
     pup, par, wls, fields, chains = parse_config_variant(os.path.join(LENS, "Excite_TEL.ini"), sweep)

@@ -363,6 +363,32 @@ def test_items_sharing_a_start_field_or_a_wfe_map_equal_their_solo_runs(precisio
         one.close()
 
 
+@pytest.mark.parametrize("name,n", [("Ariel_FGS-FGS1", 2048), ("Ariel_FGS-FGS2", 1024), ("Excite_TEL", 1024)])
+def test_light_output_chains_with_cancelled_hops_vs_oracle(name, n):
+    """Only the image plane saved (pipeline.py:111-114): the stretches between saved surfaces are long enough for the
+    pass compiler to find a wts and the stw that undoes it (flat windows: two outside-to-outside hops become one;
+    FGS1 35 -> 17 passes with all identities).  Two wavelengths / WFE draws per batch, both against the oracle."""
+    from paos_amd.chains import inject_wfe, parse_config_variant, read_wfe_table
+    from paos_amd.run import run_batch
+
+    pup, par, wls, fields, chains = parse_config_variant(os.path.join(LENS, name + ".ini"), unignore=("Z1",))
+    table = read_wfe_table(WFE)[3]
+    batch = []
+    for k in (0, 1):
+        chain = chains[min(k, len(chains) - 1)]
+        if any(it["name"] == "Z1" for it in chain.values()):
+            chain = inject_wfe(chain, table[:, 3 + k])
+        chain = {key: dict(item, save=item["name"] == "IMAGE_PLANE") for key, item in chain.items()}
+        batch.append((1.0e-6 * wls[min(k, len(wls) - 1)], chain))
+    stats = {}
+    got = run_batch(pup, [b[0] for b in batch], n, par["zoom"], fields[0], [b[1] for b in batch], outputs=("psf", "wfo"),
+                    stats=stats)
+    for i, (wl, chain) in enumerate(batch):
+        ref = _oracle(pup, wl, n, par["zoom"], fields[0], chain)
+        e = _check(got[i], ref, (name, n, i))
+        print(f"{name} {n}^2 item {i}: {stats['fused_passes']} passes, PSF error vs oracle {e:.2e}")
+
+
 def test_two_ranks_asking_for_rccl_on_one_gpu_agree():
     """ncclCommInitRank with nranks = 2 actually runs (under the watchdog): RCCL may refuse two ranks on one
     device -- then both ranks must agree on the TCP transport -- or accept them, or never come back -- then the

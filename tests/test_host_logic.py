@@ -443,3 +443,65 @@ def test_ptp_algebra_switch():
     assert stats_fast["fused_passes"] == 24 and stats_plain["fused_passes"] == 44
     for k in fast[0]:
         assert rel_err(fast[0][k]["wfo"], plain[0][k]["wfo"]) < 1e-13
+
+
+@pytest.mark.parametrize("name,fewer", [("Ariel_FGS-FGS1", 8), ("Ariel_FGS-FGS2", None), ("Ariel_AIRS-CH0", 0),
+                                        ("Excite_TEL", None), ("Hubble_simple", None)])
+def test_a_wts_and_the_stw_that_undoes_it_cancel(name, fewer):
+    """Two outside-to-outside hops in a row with nothing between them (the flat windows of the Ariel FGS channels):
+    the wts that ends the first and the stw that starts the second are each other's inverse and go (passes.py:
+    _single / _undoes).  Needs a stretch without saved surfaces, i.e. ``light_output``: the image plane of the
+    fused program against the chain with the identities off, and -- through the other tests of this file, which
+    pin that configuration to the reference -- against the reference."""
+    import paos_amd.passes as ppasses
+    import paos_amd.run as prun
+
+    spec = _spec(name)
+    chain = copy.deepcopy(spec["chain"])
+    for item in chain.values():
+        item["save"] = item["name"] == "IMAGE_PLANE"
+    spec = dict(spec, chain=chain)
+    prun.FUSE_APERTURES = True
+    try:
+        fast, _, stats_fast = _model_run(spec, 128)
+        ppasses.PTP_ALGEBRA = False
+        try:
+            plain, _, stats_plain = _model_run(spec, 128)
+        finally:
+            ppasses.PTP_ALGEBRA = True
+    finally:
+        prun.FUSE_APERTURES = "auto"
+    (k,) = fast[0]
+    assert rel_err(fast[0][k]["wfo"], plain[0][k]["wfo"]) < 1e-11, name
+    if fewer is not None:
+        assert stats_plain["fused_passes"] - stats_fast["fused_passes"] >= fewer, (stats_plain, stats_fast)
+    print(name, stats_plain["fused_passes"], "->", stats_fast["fused_passes"],
+          "image-plane difference", rel_err(fast[0][k]["wfo"], plain[0][k]["wfo"]))
+
+
+def test_undoes_needs_opposite_directions_equal_items_and_cancelling_phases():
+    from paos_amd.passes import PassCompiler
+
+    comp = PassCompiler(2, 256)
+    wts = np.array([[1.0, 1e-3, 1e-3, np.pi / (0.5 * 1e-6), 1.0]] * 2)  # dx = 1 mm, dz = 0.5 m, lambda = 1 um
+    dxn = 1e-6 * 0.5 / (256 * 1e-3)
+    fs = 1.0 / (256 * dxn)
+    stw = np.array([[1.0, fs, fs, np.pi * 1e-6 * -0.5, 1.0]] * 2)
+    fwd, inv = np.zeros(2), np.ones(2)
+    assert comp._undoes(wts, fwd, stw, inv)
+    assert not comp._undoes(wts, fwd, stw, fwd)                      # same direction: a coordinate flip, not the identity
+    assert not comp._undoes(wts, np.array([0.0, 1.0]), stw, inv)     # one item disagrees
+    off = stw.copy(); off[1, 0] = 0.0
+    assert not comp._undoes(wts, fwd, off, inv)                      # not the same items
+    far = stw.copy(); far[:, 3] *= 1.001
+    assert not comp._undoes(wts, fwd, far, inv)                      # another distance: radians of residual phase
+    # through the operator interface: wts then stw cancel, a lens between them keeps both
+    comp.stw(stw * [1, 1, 1, -1, 1], fwd)
+    n0 = len(comp.passes)
+    comp.wts(wts, fwd)
+    comp.stw(stw, inv)
+    assert len(comp.passes) == n0 and comp.open is comp.passes[-1]
+    comp.wts(wts, fwd)
+    comp.lens(np.array([[1.0, 1e-3, 1e-3, 0.25, 1.0]] * 2))
+    comp.stw(stw, inv)
+    assert len(comp.passes) == n0 + 2
