@@ -74,6 +74,11 @@ def main():
     print(f"3 Ariel_AIRS-CH0 2048^2 fp64 64 wl batch: {dt * 1e3:.1f} ms per batch = {64 / dt:.1f} wavefronts/s, "
           f"{stats.get('fused_passes')} fused passes per wavefront")
 
+    light = [{key: dict(item, save=item["name"] == "IMAGE_PLANE") for key, item in c.items()} for c in chains]
+    dtl, _, statsl = timed_batch(pup, [1e-6 * w for w in wls], 2048, par["zoom"], fields[0], light)
+    print(f"3b same, light_output (image plane only): {dtl * 1e3:.1f} ms per batch = {64 / dtl:.1f} wavefronts/s, "
+          f"{statsl.get('fused_passes')} fused passes per wavefront")
+
     # 4. Ariel_FGS-FGS1 + WFE table, 256 Monte-Carlo draws, 2048^2 (one GPU: 8 batches of 32)
     _, _, _, table = read_wfe_table(WFE)
     pup, par, wls, fields, chains = parse_config_variant(os.path.join(LENS, "Ariel_FGS-FGS1.ini"), unignore=("Z1",))
