@@ -135,6 +135,15 @@ def main():
     errs = [rel(a[max(a)]["psf"], b[max(b)]["psf"]) for a, b in zip(r32, r64)]
     print(f"5 Excite_TEL 4096^2, 8 of 512 wavelengths: fp64 {8 / dt64:.1f} wavefronts/s, fp32 {8 / dt32:.1f} wavefronts/s "
           f"(both incl. PSF download); fp32-vs-fp64 PSF max-norm error {min(errs):.1e}..{max(errs):.1e}")
+    # 5b. the same sweep with the PSFs left in HBM (32 of the 512 wavelengths per batch): what the two precisions cost
+    # on the GPU -- 5 is bound by 128 MiB of PSF crossing PCIe per wavefront in either mode
+    sweep = np.linspace(1.0, 4.0, 512)[::16]
+    pup, par, wls, fields, chains = parse_config_variant(os.path.join(LENS, "Excite_TEL.ini"), sweep)
+    w = [1e-6 * x for x in wls]
+    d64, _, st64 = timed_batch(pup, w, 4096, par["zoom"], fields[0], chains, "fp64", reps=3)
+    d32, _, _ = timed_batch(pup, w, 4096, par["zoom"], fields[0], chains, "fp32", reps=3)
+    print(f"5b same chain, 32 wavelengths per batch, PSFs stay on the GPU: fp64 {32 / d64:.1f} wavefronts/s, fp32 {32 / d32:.1f} "
+          f"wavefronts/s ({d64 / d32:.2f}x), {st64.get('fused_passes')} fused passes per wavefront")
 
 
 if __name__ == "__main__":
