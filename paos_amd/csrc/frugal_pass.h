@@ -265,6 +265,15 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
     const float ff = (float)f, ffy = (float)fy;
     auto factor32 = [&](int k) __attribute__((always_inline)) {
       cx<float> p = {1.0f, 0.0f};
+      if constexpr (K == 2 && PAOS_MERGE_PHASES != 0) {
+        // two phases of one slot: their turns add in fp64 (1e5 turns to 1e-11, the field carries 1e-7), then ONE
+        // fraction and ONE hardware sin / cos instead of two of each and a rotation
+        const double x0 = ((k < E / 2 ? g_lo[0] : g_hi[0]) + (double)(k * TL)) * step[0];
+        const double x1 = ((k < E / 2 ? g_lo[KK - 1] : g_hi[KK - 1]) + (double)(k * TL)) * step[KK - 1];
+        const double turns = fma(fma(x0, x0, across2[0]), turn_coef[0], fma(x1, x1, across2[KK - 1]) * turn_coef[KK - 1]);
+        const float frac = (float)(turns - floor(turns));
+        return cx<float>{__builtin_amdgcn_cosf(frac), __builtin_amdgcn_sinf(frac)};
+      }
 #pragma unroll
       for (int j = 0; j < K; ++j) {
         const double x = ((k < E / 2 ? g_lo[j] : g_hi[j]) + (double)(k * TL)) * step[j];
@@ -282,7 +291,8 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
       for (int k = 0; k < E / 2; ++k) {
         const cx<float> p = factor32(k);
         fac[k * TL + tpos] = p;
-        const cx<float> zs = scale2(K == 1 ? cmul_after_trans(cx<float>{(float)v[k].x, (float)v[k].y}, p)
+        constexpr bool kFresh = K == 1 || (K == 2 && PAOS_MERGE_PHASES != 0);  // p comes straight from the transcendental unit
+        const cx<float> zs = scale2(kFresh ? cmul_after_trans(cx<float>{(float)v[k].x, (float)v[k].y}, p)
                                            : cmul(cx<float>{(float)v[k].x, (float)v[k].y}, p), ff, ffy);
         v[k] = {(T)zs.x, (T)zs.y};
         if ((k + 1) % PAOS_FENCE_EVERY == 0) __builtin_amdgcn_sched_barrier(0);
