@@ -216,7 +216,14 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
       if (pos >= ml.p0 && pos < ml.p1) w = val(pos - ml.p0);
       if (pos >= ml.p2 && pos < ml.p3) w = val(kMaskW + pos - ml.p2);
       w *= ml.lm;
-      v[k] = {(T)__dmul_rn((double)v[k].x, w), (T)__dmul_rn((double)v[k].y, w)};
+      if constexpr (sizeof(T) == 4) {
+        // fp32 mode: the weight rounded to the field's type and two fp32 products (the fp64 round trip -- two
+        // conversions up, two products, two conversions down at the fp64 rate -- bought nothing at 1e-7)
+        const float wf = (float)w;
+        v[k] = {(T)(v[k].x * wf), (T)(v[k].y * wf)};
+      } else {
+        v[k] = {(T)__dmul_rn((double)v[k].x, w), (T)__dmul_rn((double)v[k].y, w)};
+      }
       // a few elements at a time: unfenced, the scheduler issues all sixteen weight loads first and
       // this rarely taken branch sets the register allocation of the whole kernel
       if ((k + 1) % PAOS_FENCE_EVERY == 0) __builtin_amdgcn_sched_barrier(0);
