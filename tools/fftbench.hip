@@ -189,6 +189,12 @@ void bench_frugal(const char* name, int batch, int reps, int pad_blocks) {
     if (getenv("PAOS_BENCH_NOFFT")) it.fft1_on = it.fft2_on = 0;  // tile yardstick: the pass's loads and stores, no transform
     it.pre.scale = 1.0; it.mid.scale = 1.0 / N; it.mid.sign_on = 0;
     it.line_lo = 0; it.line_hi = N; it.pos_lo = 0; it.pos_hi = N; it.spos_lo = 0; it.spos_hi = N;  // no pruning
+    // PAOS_BENCH_LIVE=mid|low: only a quarter of the lines is live (a tile-skipping launch without an aperture on it;
+    // the GB/s column still counts the whole field)
+    if (const char* lv = getenv("PAOS_BENCH_LIVE")) {  // "mid": the central quarter, "low": the first quarter
+      if (!strcmp(lv, "mid")) { it.line_lo = N * 3 / 8; it.line_hi = N * 5 / 8; }
+      if (!strcmp(lv, "low")) { it.line_lo = 0; it.line_hi = N / 4; }
+    }
     for (int j = 0; j < kFrugalMaxPre; ++j) it.pre_ph[j] = {0.01, 0.01, 0.21, 1.0, 1.0, 0.0};
     for (int j = 0; j < kFrugalMaxMid; ++j) it.mid_ph[j] = {0.01, 0.01, 0.37, -1.0, 1.0, 1.0};
   }
