@@ -168,10 +168,13 @@ __device__ __forceinline__ T flip_sign(T x, unsigned mask_hi) {
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <typename T, int N, int E, int K, typename Map, int PLAIN = 0, bool SHARE = false>
+// RECS > 0: the aperture line records of the workgroup's RECS lines (first line ``lbase``) were fetched by the kernel
+// before the tile's loads (wave-uniform: scalar registers); RECS = 0: the slot loads its line's record itself.
+template <typename T, int N, int E, int K, typename Map, int PLAIN = 0, bool SHARE = false, int RECS = 0>
 __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, const FrugalPhase* ph,
                                             const Map& m, const cx<double>* circle, bool conj_in, bool conj_out, int tpos,
-                                            void* area = nullptr, bool area_busy = false) {
+                                            void* area = nullptr, bool area_busy = false, const MaskLine* recs = nullptr,
+                                            int lbase = 0) {
   if constexpr (PLAIN == 1) {  // column passes: the conjugation, nothing else
     static_assert(K == 0, "a plain slot has no phases");
     const unsigned mask = (conj_out != conj_in) ? 0x80000000u : 0u;
@@ -204,18 +207,51 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
   const double sc = sl.scale;
   const int line = Map::kAxis == 0 ? m.row(0) : m.col(0);  // this thread's row (column): constant
   if (sl.mask_on != 0.0) {  // wave-uniform: an aperture rides on this slot
-    const MaskLine ml = sl.lines[line];
-    // weights by a wave-uniform base and a 32-bit byte offset (one VGPR per load instead of a pointer pair)
+    MaskLine ml;
+    if constexpr (RECS > 0) {
+      ml = recs[0];
+#pragma unroll
+      for (int j = 1; j < RECS; ++j)
+        if (line - lbase == j) ml = recs[j];
+    } else {
+      ml = sl.lines[line];
+    }
+    // The two partial runs [p0, p1) and [p2, p3) are at most kMaskW positions long, so a thread (positions
+    // tpos + k TL) meets each of them at most R = ceil(kMaskW / TL) times, at consecutive k: which k, and which
+    // recorded weights, is known before the loop.  The weights are fetched up front, unconditionally (a clamped
+    // index where the thread misses the run) -- as conditional loads inside the loop they cost every wave that met a
+    // run a full memory latency in the middle of the tile's life, and the pass 40 % of its time
+    // (tools/per_launch.py with PAOS_NO_PRUNE=1: 4.9 against 3.5 ms).
+    constexpr int R = (kMaskW + TL - 1) / TL;
     const char* vb = reinterpret_cast<const char*>(sl.vals);
     const unsigned vlo = (unsigned)line * (unsigned)(2 * kMaskW * sizeof(double));
     auto val = [&](int idx) { return *reinterpret_cast<const double*>(vb + (vlo + (unsigned)idx * (unsigned)sizeof(double))); };
+    // first k at or behind the start of each run: ceil((p - tpos) / TL), the numerator + TL - 1 is never negative
+    const int ka = (int)((unsigned)(ml.p0 - tpos + TL - 1) / (unsigned)TL);
+    const int kb = (int)((unsigned)(ml.p2 - tpos + TL - 1) / (unsigned)TL);
+    double wa[R], wb[R];
+    int sel_a[R], sel_b[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int pa = tpos + (ka + j) * TL, pb = tpos + (kb + j) * TL;
+      const bool hit_a = ka + j < E && pa < ml.p1, hit_b = kb + j < E && pb < ml.p3;
+      wa[j] = val(hit_a ? pa - ml.p0 : 0);
+      wb[j] = val(hit_b ? kMaskW + pb - ml.p2 : kMaskW);
+      sel_a[j] = hit_a ? ka + j : -1;
+      sel_b[j] = hit_b ? kb + j : -1;
+    }
+    const double w_in = __dmul_rn(sl.w_in, ml.lm), w_out = __dmul_rn(sl.w_out, ml.lm);
+#pragma unroll
+    for (int j = 0; j < R; ++j) { wa[j] = __dmul_rn(wa[j], ml.lm); wb[j] = __dmul_rn(wb[j], ml.lm); }
 #pragma unroll
     for (int k = 0; k < E; ++k) {
       const int pos = tpos + k * TL;
-      double w = (pos >= ml.p1 && pos < ml.p2) ? sl.w_in : sl.w_out;
-      if (pos >= ml.p0 && pos < ml.p1) w = val(pos - ml.p0);
-      if (pos >= ml.p2 && pos < ml.p3) w = val(kMaskW + pos - ml.p2);
-      w *= ml.lm;
+      double w = (pos >= ml.p1 && pos < ml.p2) ? w_in : w_out;
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        w = (k == sel_a[j]) ? wa[j] : w;
+        w = (k == sel_b[j]) ? wb[j] : w;
+      }
       if constexpr (sizeof(T) == 4) {
         // fp32 mode: the weight rounded to the field's type and two fp32 products (the fp64 round trip -- two
         // conversions up, two products, two conversions down at the fp64 rate -- bought nothing at 1e-7)
@@ -224,8 +260,6 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
       } else {
         v[k] = {(T)__dmul_rn((double)v[k].x, w), (T)__dmul_rn((double)v[k].y, w)};
       }
-      // a few elements at a time: unfenced, the scheduler issues all sixteen weight loads first and
-      // this rarely taken branch sets the register allocation of the whole kernel
       if ((k + 1) % PAOS_FENCE_EVERY == 0) __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -487,6 +521,9 @@ __device__ __forceinline__ void tile_power_out(double acc, double* scratch, doub
   }
 }
 
+#ifndef PAOS_HOIST_RECORDS
+#define PAOS_HOIST_RECORDS 1  // experiment knob: 0 = the slot between the transforms loads its aperture record itself
+#endif
 template <typename T, int N, int E, int LINES, int TILES, int AXIS, int BR, int BC, bool SPLIT,
           int KPRE, int KMID, int NFFT, int STORE = 0>
 __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, TILES * LINES * N / E>()))
@@ -583,6 +620,20 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
     asm volatile("" : "+v"(bo));
     return (cx<T>*)((GlobalBytes)(((unsigned long long)hi << 32) | lo) + bo);
   };
+  // The records of an aperture riding BETWEEN the transforms are wanted in the middle of the tile's life; fetched
+  // there they are a dependent global load (and the recorded weights a second one) with nothing to hide behind.
+  // The lines of a workgroup are consecutive, so their records are read here, wave-uniformly, in front of the tile.
+  // (two-line workgroups without phases in front of the first transform: with four records, or with a busy first
+  // slot, the early fetch costs the shape its spill-free register allocation)
+  constexpr int kRecs = (PAOS_HOIST_RECORDS != 0 && TILES * LINES == 2 && KPRE == 0) ? 2 : 0;
+  MaskLine mrec[kRecs > 0 ? kRecs : 1] = {};
+  const int lbase = __builtin_amdgcn_readfirstlane(TILES == 1 ? (AXIS == 0 ? m.row0 : m.col0) : (int)blockIdx.x * (TILES * LINES));
+  if constexpr (kRecs > 0) {
+    if (it.mid.mask_on != 0.0) {
+#pragma unroll
+      for (int j = 0; j < kRecs; ++j) mrec[j] = it.mid.lines[lbase + j];
+    }
+  }
   // The empty slot in front of the first transform without its 32 multiplications by +-1 (frugal_slot: PLAIN):
   // 16 sign flips in column passes, a paced variant in row passes.
   constexpr int kPlainPre = KPRE != 0 ? 0 : (AXIS == 1 ? PAOS_COL_PRE : PAOS_ROW_PRE);
@@ -676,7 +727,8 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   if (ran1) frugal_fft<T, N, E, SPLIT, false>(v, lds, m.t, tw, circle, it.fft1_inv);
   PAOS_STAMP(3);
   constexpr bool kShareMid = kShare && KPRE == 0 && KMID < 3;
-  frugal_slot<T, N, E, KMID, decltype(m), 0, kShareMid>(v, it.mid, it.mid_ph, m, circle, inv1, ran2 && it.fft2_inv != 0.0, m.t, lds, ran1);
+  frugal_slot<T, N, E, KMID, decltype(m), 0, kShareMid, kRecs>(v, it.mid, it.mid_ph, m, circle, inv1, ran2 && it.fft2_inv != 0.0, m.t, lds, ran1,
+                                                              mrec, lbase);
   PAOS_STAMP(4);
   if constexpr (NFFT == 2) {
     if (ran2) {

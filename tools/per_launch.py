@@ -1,0 +1,21 @@
+"""Mean duration of every pass launch of one SYN20 step (4096^2 c128, batch 32), in launch order, with the class tag
+(bit 0 tiles skipped, 1 loads skipped, 2 stores skipped, 3 PSF stored): python tools/per_launch.py [PAOS_NO_PRUNE=1 ...]"""
+import os, sys
+sys.path.insert(0, os.getcwd())
+import numpy as np
+import bench
+from paos_amd import _lib
+from paos_amd.chains import syn20_chain, syn20_wavelength
+n, nb = 4096, 32
+wls = [syn20_wavelength(k) for k in range(nb)]
+chains = [syn20_chain() for _ in range(nb)]
+dev = _lib.DeviceFields(n, nb, "fp64")
+m = bench.measure(dev, n, nb, "fp64", wls, chains, 4, 1)
+ms, tags = m["launch_ms"], m["launch_tags"]
+per = len(ms) // 4
+ms = ms.reshape(4, per).mean(axis=0); tags = tags[:per]
+os.environ["PAOS_DUMP_PASSES"] = "0"
+print("launches per step", per)
+for i, (t, g) in enumerate(zip(ms, tags)):
+    print(f"  pass {i:2d}  tag {int(g):2d}  {t:.3f} ms")
+dev.close()
