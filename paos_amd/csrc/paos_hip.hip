@@ -87,6 +87,11 @@ struct paos_ctx {
   double* psf = nullptr;  // batch x item_stride intensities kept on the device, blocked like the field (paos_psf_keep)
   double* psf_partial = nullptr;  // per-workgroup sums of a pass that stores the PSF (paos_run_program: final_intensity)
   int psf_nparts = 0;
+  // What the PSF buffer (and psf_partial) is known to hold after a pass stored it: for item i the lines along
+  // psf_zero_axis outside [psf_zero_lo[i], psf_zero_hi[i]) are zero (their per-workgroup sums too).  The next
+  // PSF-storing pass with the same live lines need not write those zeros again; -1 = nothing known.
+  int psf_zero_axis = -1;
+  std::vector<double> psf_zero_lo, psf_zero_hi;
   void* bounce[2] = {nullptr, nullptr};  // pinned host buffers for device -> pageable host copies
   hipEvent_t bounce_ev[2] = {nullptr, nullptr};
   void* field = nullptr;
@@ -937,9 +942,24 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
       if (c->psf_nparts < groups) {
         if (c->psf_partial) (void)hipFree(c->psf_partial);
         c->psf_partial = nullptr; c->psf_nparts = 0;
+        c->psf_zero_axis = -1;
         HIPCHK(c, hipMalloc(&c->psf_partial, (size_t)c->batch * groups * sizeof(double)));
         c->psf_nparts = groups;
       }
+      // dead tiles of the storing pass write PSF zeros (line_fill) -- unless the buffer already holds zeros there:
+      // the previous storing pass had the same live lines (the next batch of a sweep, the next Monte-Carlo batch)
+      static const bool reuse = [] { const char* e = getenv("PAOS_PSF_ZERO_REUSE"); return !(e && e[0] == '0'); }();
+      const int axis = passes[n_passes - 1].axis;
+      std::vector<FrugalItem>& last = low[n_passes - 1].items;
+      bool same = reuse && c->psf_zero_axis == axis && (int)c->psf_zero_lo.size() == c->batch;
+      for (int it = 0; it < c->batch && same; ++it)
+        same = c->psf_zero_lo[it] == last[it].line_lo && c->psf_zero_hi[it] == last[it].line_hi;
+      c->psf_zero_lo.resize(c->batch); c->psf_zero_hi.resize(c->batch);
+      for (int it = 0; it < c->batch; ++it) {
+        last[it].line_fill = same ? 0.0 : 1.0;
+        c->psf_zero_lo[it] = last[it].line_lo; c->psf_zero_hi[it] = last[it].line_hi;
+      }
+      c->psf_zero_axis = -1;  // set again below once the pass is on the stream
     }
   }
   // Walk the program in chunks whose phase operators fit the table store: fill the tables of
@@ -994,6 +1014,7 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
   }
   if (final_ticket) {
     if (fused_store) {
+      c->psf_zero_axis = passes[n_passes - 1].axis;  // every launch of the program went through
       const int lines = passes[n_passes - 1].axis == 0 ? (c->n >= 2048 ? c->br / 2 : c->br) : 2;
       return psf_power_ticket(c, c->psf_partial, c->n / lines, final_ticket);
     }
@@ -1423,6 +1444,7 @@ int paos_psf_keep(paos_ctx* c) {
   if (c) (void)hipSetDevice(c->device);
   if (!c) return fail(c, PAOS_EINVAL, "null context");
   if (!c->psf) HIPCHK(c, hipMalloc(&c->psf, (size_t)c->batch * c->item_stride * sizeof(double)));
+  c->psf_zero_axis = -1;  // the whole buffer is rewritten
   const dim3 grid(pw_blocks(c), c->batch), block(kPwThreads);
   if (c->precision == PAOS_F64)
     hipLaunchKernelGGL((intensity_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream,
@@ -1606,6 +1628,7 @@ int psf_keep_power_impl(paos_ctx* c, int* ticket) {
   if (c->norm_busy[c->norm_slot])
     return fail(c, PAOS_EINVAL, "64 power reductions outstanding: fetch earlier tickets (paos_norm2_fetch) first");
   if (!c->psf) HIPCHK(c, hipMalloc(&c->psf, (size_t)c->batch * c->item_stride * sizeof(double)));
+  c->psf_zero_axis = -1;  // the whole buffer is rewritten
   const dim3 grid(c->nparts, c->batch), block(kPwThreads);
   if (c->precision == PAOS_F64)
     hipLaunchKernelGGL((intensity_power_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream,

@@ -234,6 +234,46 @@ def test_lean_walk_equals_the_ordinary_walk(n, precision):
         dev.close()
 
 
+def test_psf_zeros_are_reused_only_while_they_are_there():
+    """The pass that stores the PSF does not write the zeros of its dead tiles again when the buffer is known to hold
+    them (the previous storing pass had the same live lines: paos_hip.hip, psf_zero_*).  A sequence that keeps and
+    breaks that knowledge -- the same chain twice, a chain with a wider field stop (other live columns), back, an
+    intensity sweep over junk in between -- must give the ordinary walk's PSFs bit for bit every time."""
+    from paos_amd import _lib
+    from paos_amd.chains import syn20_chain, syn20_wavelength
+    from paos_amd.run import run_batch
+
+    n = 1024
+    wls = [syn20_wavelength(k) for k in (0, 200)]
+
+    def chains(stop_mm):
+        out = []
+        for _ in wls:
+            c = syn20_chain()
+            c[19]["aperture"]["xrad"] = c[19]["aperture"]["yrad"] = stop_mm * 1.0e-3
+            out.append(c)
+        return out
+
+    plain = {mm: run_batch(1.0, wls, n, 4, ON_AXIS, chains(mm), outputs=("psf",)) for mm in (1.0, 2.5)}
+    assert not np.array_equal(plain[1.0][0][20]["psf"], plain[2.5][0][20]["psf"])
+    assert (plain[2.5][0][20]["psf"] > 0).sum() > 2 * (plain[1.0][0][20]["psf"] > 0).sum()  # more live columns
+    dev = _lib.DeviceFields(n, len(wls))
+    rng = np.random.default_rng(3)
+    try:
+        for step, mm in enumerate((1.0, 1.0, 2.5, 2.5, 1.0, "junk", 1.0, "junk", 2.5, 1.0)):
+            if mm == "junk":  # the whole PSF buffer rewritten by the intensity sweep of an unrelated field
+                for i in range(len(wls)):
+                    dev.upload(i, rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n)))
+                dev.psf_keep()
+                assert dev.psf_fetch(0).min() > 0.0
+                continue
+            run_batch(1.0, wls, n, 4, ON_AXIS, chains(mm), outputs=(), dev=dev, keep_psf=True)
+            for i in range(len(wls)):
+                assert np.array_equal(dev.psf_fetch(i), plain[mm][i][20]["psf"]), (step, mm, i)
+    finally:
+        dev.close()
+
+
 def test_row_window_entry_points():
     """paos_start_rows + paos_norm2_enqueue_rows + paos_zero_outside_rows + paos_run_program(rows_stale) against
     paos_start + paos_norm2_enqueue + paos_run_passes_live on the same inputs; argument checks."""
