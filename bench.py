@@ -182,7 +182,7 @@ def measure(dev, n, nb, precision, wavelengths, chains, steps, warmup, comm=None
 def measure_traffic(grid, batch, precision):
     """HBM bytes of every kernel of ONE chain step from the PMC counters, collected the way MI355X_MICROARCH.md
     prescribes: this script once under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and once under `... --pmc WRITE_SIZE`
-    (separate passes, as child processes running exactly one step and nothing else: --traffic-child), FETCH_SIZE /
+    (separate passes, as child processes running one warm-up step and one counted step and nothing else: --traffic-child), FETCH_SIZE /
     WRITE_SIZE in KiB, FETCH_SIZE doubled (gfx950 reports half of the bytes of wide coalesced reads; the factor is
     calibrated for 16 B per lane, which is what the pass kernels issue -- for the 8-byte accesses of the reduction and
     PSF kernels it is an assumption).  Dispatches are matched between the two runs by dispatch order.
@@ -202,7 +202,7 @@ def measure_traffic(grid, batch, precision):
         try:
             cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", tmp, "-o", "pmc", "--output-format", "csv", "--",
                    sys.executable, os.path.abspath(__file__), "--grid", str(grid), "--batch", str(batch),
-                   "--precision", precision, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--no-extras",
+                   "--precision", precision, "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-extras",
                    "--no-traffic", "--traffic-child"]
             run = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
                                  stderr=subprocess.PIPE, timeout=600)
@@ -217,17 +217,26 @@ def measure_traffic(grid, batch, precision):
                     k = int(row["Dispatch_Id"])
                     name, val = per_dispatch.get(k, (row["Kernel_Name"], 0.0))
                     per_dispatch[k] = (name, val + float(row["Counter_Value"]))
-            series[counter] = [per_dispatch[k] for k in sorted(per_dispatch)]
+            seq = [per_dispatch[k] for k in sorted(per_dispatch)]
+            # the child runs a warm-up step first: the counted step is the steady state the timed region measures
+            # (aperture records found in the context's sets, PSF zeros already in the buffer).  A step opens with the
+            # start-of-chain power kernel: keep what follows the last one.
+            starts = [i for i, (name, _) in enumerate(seq) if "start_power_kernel" in name]
+            series[counter] = seq[starts[-1]:] if starts else seq
             if counter == "FETCH_SIZE":  # durations of the non-pass kernels (under the profiler: indicative)
+                rows = []
                 for path in glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True):
                     with open(path) as fh:
                         for row in csv.DictReader(fh):
-                            name = row.get("Kernel_Name", "")
                             try:
-                                dt = (int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) * 1e-6
+                                t0, t1 = int(row["Start_Timestamp"]), int(row["End_Timestamp"])
                             except (KeyError, ValueError):
                                 continue
-                            trace_ms[name] = trace_ms.get(name, 0.0) + dt
+                            rows.append((t0, row.get("Kernel_Name", ""), (t1 - t0) * 1e-6))
+                rows.sort()
+                opens = [i for i, r in enumerate(rows) if "start_power_kernel" in r[1]]
+                for _, name, dt in (rows[opens[-1]:] if opens else rows):  # the counted step, like the counters
+                    trace_ms[name] = trace_ms.get(name, 0.0) + dt
         except Exception as exc:  # noqa: BLE001 -- the bench line must come out whatever the profiler does
             return None, f"rocprofv3 --pmc {counter}: {type(exc).__name__}: {exc}"
         finally:
@@ -250,8 +259,8 @@ def measure_traffic(grid, batch, precision):
         short = name.split("<")[0].split("(")[0]
         if short in out["other"]:
             out["other"][short]["ms"] += ms
-    note = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE on exactly one chain step of this workload (two child "
-            "runs, counters in KiB, FETCH_SIZE x2 per MI355X_MICROARCH.md), every dispatch kept")
+    note = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE on one chain step of this workload behind a warm-up step "
+            "(two child runs, counters in KiB, FETCH_SIZE x2 per MI355X_MICROARCH.md), every dispatch of that step kept")
     return out, note
 
 
