@@ -86,12 +86,17 @@ struct FrugalArgs {
   unsigned pitch, item_stride;
   // STORE = 1 (the last pass of a program whose caller wants the PSF, not the field -- plot.py:125-130): |u|^2 goes
   // to `psf` (doubles, the field's own blocked layout and item stride) and its sum over the workgroup's tile to
-  // `psf_partial[item * gridDim.x + blockIdx.x]`; the field itself is not written
+  // `psf_partial[item * (workgroups per item) + workgroup]`; the field itself is not written
   double* psf;
   double* psf_partial;
 #if PAOS_STAMPS
   unsigned long long* stamps;  // [gridDim.y][gridDim.x][kStampSlots]
 #endif
+  // Workgroups of dead lines that have nothing to write need not be launched: when every item's live lines lie in
+  // [live_lo, live_hi) and no item wants its dead tiles written (host: launch_lowered; 0, 0 = all lines), the grid
+  // covers the workgroups of these lines only and workgroup blockIdx.x stands for wg0 + blockIdx.x (frugal_launch
+  // sets wg0, a multiple of 16: TileMap renumbers the tiles inside aligned groups of 16 workgroups).
+  unsigned live_lo, live_hi, wg0;
 };
 #if PAOS_STAMPS
 #define PAOS_STAMP(i)                                                                              \
@@ -552,7 +557,8 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   // a block of BR x BC elements is a whole 128-byte line for complex128, half of one for complex64
   constexpr bool kBlockIsLine = BR * BC * sizeof(cx<T>) >= 128;
   constexpr int COLSIB = kBlockIsLine ? 1 : (int)(128 / (BR * BC * sizeof(cx<T>)));
-  const TileMap<N, E, LINES, TILES, AXIS, BR, BC, 1, COLSIB> m(blockIdx.x, threadIdx.x, a.pitch);
+  const unsigned wg = blockIdx.x + a.wg0;  // compact grids (FrugalArgs::wg0)
+  const TileMap<N, E, LINES, TILES, AXIS, BR, BC, 1, COLSIB> m(wg, threadIdx.x, a.pitch);
   cx<T>* f = reinterpret_cast<cx<T>*>(a.field) + (size_t)item * a.item_stride;
   // tiles that own whole 128-byte lines (c128 column tiles; row tiles that span a full block row) stream
   // around the caches; tiles that share lines with a sibling need the L2 to merge the halves
@@ -561,14 +567,14 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   // (stores stay ordinary so that the L2 can merge the halves)
   constexpr bool NTL = NT || (PAOS_SHARED_NT_LOADS != 0);
   {  // a workgroup of dead lines only: nothing to transform (its tiles are consecutive lines)
-    const int l0 = TILES == 1 ? (AXIS == 0 ? m.row0 : m.col0) : (int)blockIdx.x * (TILES * LINES);
+    const int l0 = TILES == 1 ? (AXIS == 0 ? m.row0 : m.col0) : (int)wg * (TILES * LINES);
     if (l0 + TILES * LINES <= (int)h_line_lo || l0 >= (int)h_line_hi) {
       if constexpr (STORE == 1) {  // the PSF of a dead tile is zero (and so is its share of the power)
         if (h_line_fill == 0.0) return;  // ... and the buffer is known to hold those zeros already (host: psf_zero_*)
         double* ps = a.psf + (size_t)item * a.item_stride;
 #pragma unroll
         for (int k = 0; k < E; ++k) ps[m.base + (unsigned)k * m.stride] = 0.0;
-        if (threadIdx.x == 0) a.psf_partial[(size_t)item * gridDim.x + blockIdx.x] = 0.0;
+        if (threadIdx.x == 0) a.psf_partial[(size_t)item * (N / LINES / TILES) + wg] = 0.0;
         return;
       }
       if (h_line_fill != 0.0) {
@@ -628,7 +634,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   // slot, the early fetch costs the shape its spill-free register allocation)
   constexpr int kRecs = (PAOS_HOIST_RECORDS != 0 && TILES * LINES == 2 && KPRE == 0) ? 2 : 0;
   MaskLine mrec[kRecs > 0 ? kRecs : 1] = {};
-  const int lbase = __builtin_amdgcn_readfirstlane(TILES == 1 ? (AXIS == 0 ? m.row0 : m.col0) : (int)blockIdx.x * (TILES * LINES));
+  const int lbase = __builtin_amdgcn_readfirstlane(TILES == 1 ? (AXIS == 0 ? m.row0 : m.col0) : (int)wg * (TILES * LINES));
   if constexpr (kRecs > 0) {
     if (it.mid.mask_on != 0.0) {
 #pragma unroll
@@ -751,7 +757,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
       acc += w;
     }
     double* scratch = reinterpret_cast<double*>(smem + frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, E, 0>());
-    tile_power_out<TILES * LINES * N / E>(acc, scratch, a.psf_partial + (size_t)item * gridDim.x + blockIdx.x);
+    tile_power_out<TILES * LINES * N / E>(acc, scratch, a.psf_partial + (size_t)item * (N / LINES / TILES) + wg);
     return;
   }
   const int slo = (int)h_spos_lo, shi = (int)h_spos_hi;

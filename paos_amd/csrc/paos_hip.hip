@@ -564,14 +564,25 @@ void plan_pruning(const paos_ctx* c, const paos_pass* passes, int n_passes, cons
 }
 
 template <typename T, int N, int AXIS, int KPRE, int KMID, int NFFT, int STORE = 0>
-int frugal_launch(paos_ctx* c, const FrugalArgs& a) {
+int frugal_launch(paos_ctx* c, const FrugalArgs& args) {
   using C = FftCfg<T, N>;
   constexpr int LINES = AXIS == 0 ? C::FR_ROW_LINES : C::COL_LINES;
   constexpr int TILES = AXIS == 0 ? C::ROW_TILES : C::COL_TILES;
   // several workgroups share the 160 KiB of LDS: c128 exchanges re and im in turn; a c64 line
   // fits whole (the same 35 KiB) and so needs half the barriers -- except in the 4-line row tiles
   constexpr bool SPLIT = sizeof(T) == 8 || LINES > 2;
-  const dim3 grid(N / LINES / TILES, c->batch), block(TILES * LINES * N / C::E);
+  FrugalArgs a = args;
+  unsigned groups = N / LINES / TILES;
+  a.wg0 = 0;
+  static_assert((N / LINES / TILES) % 16 == 0, "TileMap renumbers tiles inside aligned groups of 16 workgroups");
+  if (a.live_hi > a.live_lo) {  // launch the workgroups of live lines only, in whole groups of 16
+    const unsigned per = LINES * TILES;
+    a.wg0 = (a.live_lo / per) / 16 * 16;
+    unsigned end = ((a.live_hi + per - 1) / per + 15) / 16 * 16;
+    if (end > groups) end = groups;
+    groups = end - a.wg0;
+  }
+  const dim3 grid(groups, c->batch), block(TILES * LINES * N / C::E);
   const size_t lds = frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, C::E, STORE>();
   auto kern = frugal_pass_kernel<T, N, C::E, LINES, TILES, AXIS, C::BR, C::BC, SPLIT, KPRE, KMID, NFFT, STORE>;
   {
@@ -757,6 +768,23 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const
   if (rc) return rc;
   FrugalArgs a{c->field, c->tw, reinterpret_cast<const FrugalItem*>(ditems), c->pitch, c->item_stride, nullptr, nullptr};
   if (store_psf) { a.psf = c->psf; a.psf_partial = c->psf_partial; }
+  {  // the lines some item still works on: the grid need not cover the others when their tiles have nothing to write
+    // PAOS_COMPACT_GRID=0 launches the full grid (dead workgroups exit in their prologue)
+    static const bool want = [] { const char* e = getenv("PAOS_COMPACT_GRID"); return !(e && e[0] == '0'); }();
+    double lo = (double)c->n, hi = 0.0;
+    bool fill = false;
+    for (const FrugalItem& fi : lp.items) {
+      if (fi.active == 0.0) continue;
+      lo = fi.line_lo < lo ? fi.line_lo : lo;
+      hi = fi.line_hi > hi ? fi.line_hi : hi;
+      fill = fill || fi.line_fill != 0.0;
+    }
+    a.live_lo = a.live_hi = a.wg0 = 0;
+    if (want && !fill && hi > lo && (lo > 0.0 || hi < (double)c->n)) {
+      a.live_lo = (unsigned)lo;
+      a.live_hi = (unsigned)hi;
+    }
+  }
   const int nfft = lp.nfft;
   // for the launch timer: what does this launch skip?  bit 0: whole tiles of dead lines, bit 1: loads of dead
   // positions, bit 2: stores nobody reads, bit 3: it stores the PSF instead of the field

@@ -1,16 +1,18 @@
 """Mean duration of every pass launch of one SYN20 step (4096^2 c128, batch 32), in launch order, with the class tag
-(bit 0 tiles skipped, 1 loads skipped, 2 stores skipped, 3 PSF stored): python tools/per_launch.py [PAOS_NO_PRUNE=1 ...]"""
+(bit 0 tiles skipped, 1 loads skipped, 2 stores skipped, 3 PSF stored): [PAOS_NO_PRUNE=1 ...] python tools/per_launch.py [grid [fp64|fp32]]"""
 import os, sys
 sys.path.insert(0, os.getcwd())
 import numpy as np
 import bench
 from paos_amd import _lib
 from paos_amd.chains import syn20_chain, syn20_wavelength
-n, nb = 4096, 32
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+precision = sys.argv[2] if len(sys.argv) > 2 else "fp64"
+nb = max(32, 32 * (4096 // n) ** 2)
 wls = [syn20_wavelength(k) for k in range(nb)]
 chains = [syn20_chain() for _ in range(nb)]
-dev = _lib.DeviceFields(n, nb, "fp64")
-m = bench.measure(dev, n, nb, "fp64", wls, chains, 4, 1)
+dev = _lib.DeviceFields(n, nb, precision)
+m = bench.measure(dev, n, nb, precision, wls, chains, 4, 1)
 ms, tags = m["launch_ms"], m["launch_tags"]
 per = len(ms) // 4
 ms = ms.reshape(4, per).mean(axis=0); tags = tags[:per]
