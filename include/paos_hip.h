@@ -167,6 +167,11 @@ int paos_norm2_enqueue(paos_ctx* ctx, int* ticket);
 /* paos_norm2_enqueue that reads only the rows [lo, hi) of each item: the caller knows the others to be zero
  * (or to stand for zeros, paos_start_rows).  Bit-identical to the full sum of the zero-filled field. */
 int paos_norm2_enqueue_rows(paos_ctx* ctx, const double* live_rows, int* ticket);
+/* ... and that sums only once what the caller knows to be copies: same_as[i] (a double holding an index) names the
+ * item whose field equals item i's (itself for the first of a group; items of a group share their row window) --
+ * the wavelengths of a sweep right behind paos_start_rows, whose aperture records agree (wfo.py:195-201 at the
+ * entrance pupil does not depend on the wavelength).  Every item gets its leader's sum. */
+int paos_norm2_enqueue_rows_like(paos_ctx* ctx, const double* live_rows, const double* same_as, int* ticket);
 int paos_norm2_fetch(paos_ctx* ctx, int ticket, double* host_out);
 /* give a ticket back without reading it (no synchronisation) */
 int paos_norm2_release(paos_ctx* ctx, int ticket);

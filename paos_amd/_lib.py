@@ -98,6 +98,7 @@ SYMBOLS = {
     "paos_start_rows": (ctypes.c_int, [_c_ctx, ctypes.c_double, ctypes.c_double, ctypes.c_int, _dbl_p, _dbl_p, _dbl_p]),
     "paos_zero_outside_rows": (ctypes.c_int, [_c_ctx, _dbl_p]),
     "paos_norm2_enqueue_rows": (ctypes.c_int, [_c_ctx, _dbl_p, ctypes.POINTER(ctypes.c_int)]),
+    "paos_norm2_enqueue_rows_like": (ctypes.c_int, [_c_ctx, _dbl_p, _dbl_p, ctypes.POINTER(ctypes.c_int)]),
     "paos_run_program": (ctypes.c_int, [_c_ctx, ctypes.POINTER(Pass), ctypes.c_int, _dbl_p, ctypes.c_int,
                                         ctypes.POINTER(ProgramOpts)]),
 }
@@ -360,9 +361,17 @@ class DeviceFields:
             raise ValueError("row ranges must be [batch][2]")
         return lr
 
-    def norm2_enqueue(self, live_rows=None):
-        """``live_rows`` ([batch][2], optional): rows outside [lo, hi) are zero (or stand for zeros) and are not read."""
+    def norm2_enqueue(self, live_rows=None, same_as=None):
+        """``live_rows`` ([batch][2], optional): rows outside [lo, hi) are zero (or stand for zeros) and are not read.
+        ``same_as`` ([batch] indices, with ``live_rows``): item i's field is a copy of item same_as[i]'s -- summed once."""
         t = ctypes.c_int(-1)
+        if live_rows is not None and same_as is not None:
+            like = np.ascontiguousarray(same_as, dtype=np.float64)
+            if like.shape != (self.batch,):
+                raise ValueError("same_as must be [batch]")
+            self._check(self._lib.paos_norm2_enqueue_rows_like(self._ctx, _dptr(self._rows(live_rows)), _dptr(like),
+                                                               ctypes.byref(t)), "paos_norm2_enqueue_rows_like")
+            return t.value
         if live_rows is not None:
             self._check(self._lib.paos_norm2_enqueue_rows(self._ctx, _dptr(self._rows(live_rows)), ctypes.byref(t)),
                         "paos_norm2_enqueue_rows")

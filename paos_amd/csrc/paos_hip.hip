@@ -876,7 +876,7 @@ bool use_pruning() {
 }
 
 int zero_outside_rows(paos_ctx* c, const double* live_rows);
-int psf_power_ticket(paos_ctx* c, const double* partial, int nparts, int* ticket);
+int psf_power_ticket(paos_ctx* c, const double* partial, int nparts, int* ticket, const double* source = nullptr);
 int psf_keep_power_impl(paos_ctx* c, int* ticket);
 
 // entry_rows / entry_stale: see paos_program_opts.  final_ticket != nullptr: the caller wants |u|^2 and its sum of
@@ -1637,12 +1637,12 @@ int paos_norm2_enqueue(paos_ctx* c, int* ticket) {
 namespace {
 
 // partial sums -> norm2 -> a ticket of the power ring
-int psf_power_ticket(paos_ctx* c, const double* partial, int nparts, int* ticket) {
+int psf_power_ticket(paos_ctx* c, const double* partial, int nparts, int* ticket, const double* source) {
   const int slot = c->norm_slot;
   if (c->norm_busy[slot])
     return fail(c, PAOS_EINVAL, "64 power reductions outstanding: fetch earlier tickets (paos_norm2_fetch) first");
   hipLaunchKernelGGL(norm2_final_kernel, dim3(c->batch), dim3(kPwThreads), 0, c->stream, partial, c->norm2, nparts,
-                     (const double*)nullptr, 1);
+                     (const double*)nullptr, 1, source);
   HIPCHK(c, hipGetLastError());
   c->norm_busy[slot] = true;
   c->norm_slot = (slot + 1) % kNormSlots;
@@ -1707,7 +1707,7 @@ int paos_run_program(paos_ctx* c, const paos_pass* passes, int n_passes, const d
                     opts->final_intensity ? opts->power_ticket : nullptr);
 }
 
-int paos_norm2_enqueue_rows(paos_ctx* c, const double* live_rows, int* ticket) {
+static int norm2_enqueue_rows_impl(paos_ctx* c, const double* live_rows, const double* same_as, int* ticket) {
   if (c) (void)hipSetDevice(c->device);
   if (!c || !ticket || !live_rows) return fail(c, PAOS_EINVAL, "null argument");
   int rc = check_rows(c, live_rows);
@@ -1715,17 +1715,39 @@ int paos_norm2_enqueue_rows(paos_ctx* c, const double* live_rows, int* ticket) {
   const int slot = c->norm_slot;
   if (c->norm_busy[slot])
     return fail(c, PAOS_EINVAL, "64 power reductions outstanding: fetch earlier tickets (paos_norm2_fetch) first");
-  const double* drows = nullptr;
+  const double *drows = nullptr, *dlead = nullptr, *dsame = nullptr;
   if ((rc = arena_push(c, live_rows, (size_t)2 * c->batch, &drows))) return rc;
+  if (same_as) {  // items whose fields the caller knows to be copies of another item's: summed once
+    std::vector<double> lead(c->batch);
+    for (int i = 0; i < c->batch; ++i) {
+      const int j = (int)same_as[i];
+      if (!(same_as[i] >= 0.0) || j >= c->batch || (double)j != same_as[i] || (int)same_as[j] != j)
+        return fail(c, PAOS_EINVAL, "same_as must name an item that stands for itself");
+      if (live_rows[2 * i] != live_rows[2 * j] || live_rows[2 * i + 1] != live_rows[2 * j + 1])
+        return fail(c, PAOS_EINVAL, "items that share a sum must share their row window");
+      lead[i] = j == i ? 1.0 : 0.0;
+    }
+    if ((rc = arena_push(c, lead.data(), lead.size(), &dlead))) return rc;
+    if ((rc = arena_push(c, same_as, (size_t)c->batch, &dsame))) return rc;
+  }
   const dim3 grid(c->nparts, c->batch), block(kPwThreads);
   if (c->precision == PAOS_F64)
     hipLaunchKernelGGL((norm2_partial_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream,
-                       (const cx<double>*)c->field, c->partial, c->n, c->pitch, c->item_stride, (const double*)nullptr, 1, drows);
+                       (const cx<double>*)c->field, c->partial, c->n, c->pitch, c->item_stride, dlead, 1, drows);
   else
     F32_BR_SWITCH(c, hipLaunchKernelGGL((norm2_partial_kernel<float, FBR, Lay<float>::BC>), grid, block, 0, c->stream,
-                       (const cx<float>*)c->field, c->partial, c->n, c->pitch, c->item_stride, (const double*)nullptr, 1, drows));
+                       (const cx<float>*)c->field, c->partial, c->n, c->pitch, c->item_stride, dlead, 1, drows));
   HIPCHK(c, hipGetLastError());
-  return psf_power_ticket(c, c->partial, c->nparts, ticket);
+  return psf_power_ticket(c, c->partial, c->nparts, ticket, dsame);
+}
+
+int paos_norm2_enqueue_rows(paos_ctx* c, const double* live_rows, int* ticket) {
+  return norm2_enqueue_rows_impl(c, live_rows, nullptr, ticket);
+}
+
+int paos_norm2_enqueue_rows_like(paos_ctx* c, const double* live_rows, const double* same_as, int* ticket) {
+  if (!same_as) return fail(c, PAOS_EINVAL, "null argument");
+  return norm2_enqueue_rows_impl(c, live_rows, same_as, ticket);
 }
 
 int paos_norm2_fetch(paos_ctx* c, int ticket, double* host_out) {

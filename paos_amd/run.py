@@ -287,13 +287,13 @@ def _queue_steps(comp, lens, stw, ptp, wts, inv_stw, inv_wts):
 def _start_field(dev, plans, value, write_rows=None):
     """The wavefront is still the constant ``value`` (wfo.py:118).  When every item opens with a
     stand-alone aperture of one shape, ones -> aperture -> [make_stop] is a single write of the
-    field (paos_start); otherwise fill and let the surface run as usual.  Returns True when the
-    first surface's aperture and stop are done.  ``write_rows`` ([lo, hi) per item): only these rows are
+    field (paos_start); otherwise fill and let the surface run as usual.  Returns False, or -- when the
+    first surface's aperture and stop are done -- per item the index of the first item with the same field.  ``write_rows`` ([lo, hi) per item): only these rows are
     written, the others are left standing for zeros (paos_start_rows)."""
     aps = [p["aperture"] for p in plans]
     if any(a is None for a in aps) or len({isinstance(a[0], EllipticalAperture) for a in aps}) != 1:
         dev.fill(value)
-        return False
+        return None
     code = _lib.SHAPE_ELLIPSE if isinstance(aps[0][0], EllipticalAperture) else _lib.SHAPE_RECT
     blocks = [a[0].block(obscuration=a[1]) for a in aps]
     stops = [1.0 if p["stop"] else 0.0 for p in plans]
@@ -301,17 +301,24 @@ def _start_field(dev, plans, value, write_rows=None):
         dev.start(value, code, blocks, stops)
     else:
         dev.start(value, code, blocks, stops, write_rows=write_rows)
-    return True
+    # which items now hold the same field: same aperture record, stop flag and row window
+    seen, same_as = {}, []
+    for i, (b, st) in enumerate(zip(blocks, stops)):
+        key = (tuple(float(x) for x in b), st, tuple(write_rows[i]) if write_rows is not None else None)
+        same_as.append(seen.setdefault(key, i))
+    return same_as
 
 
 class _WalkState:
     """What ``on_saved`` may want to know about the field at a saved surface of a lean walk:
     ``rows`` -- per item [lo, hi) outside which the field is zero (or stands for zero), or None;
     ``psf_ticket`` -- set when the pass program that ended at this surface has already written |u|^2 to the
-    PSF buffer and enqueued its sum (the field itself is then undefined)."""
+    PSF buffer and enqueued its sum (the field itself is then undefined);
+    ``same_as`` -- per item the index of an item whose field is known to be identical (the first surface of a sweep:
+    the start field does not depend on the wavelength), or None."""
 
     def __init__(self):
-        self.rows, self.psf_ticket = None, None
+        self.rows, self.psf_ticket, self.same_as = None, None, None
 
 
 def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_at=None):
@@ -408,7 +415,8 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
                 # worth it only when every item's aperture leaves whole rows dark
                 if all(r[0] > 0 or r[1] < dev.n for r in trial) and all(r[0] < r[1] for r in trial):
                     rows0 = trial
-            if _start_field(dev, plans, value, write_rows=rows0):
+            same_as = _start_field(dev, plans, value, write_rows=rows0)
+            if same_as is not None:
                 _live_rows_after(plans, live, dev.n)
                 stale[0] = rows0 is not None
                 want_wfe = len(plans) == 1 and bool(items[0]["save"])
@@ -417,7 +425,12 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
                 if saved:
                     if lean is not None:
                         lean.rows = known_rows()
+                        # still copies of each other unless this surface put a wavefront error on them
+                        untouched = not any(p["zernike"] is not None or p["phase_map"] is not None for p in plans)
+                        lean.same_as = same_as if untouched and len(set(same_as)) < len(same_as) else None
                     on_saved(key, items, plans, wfe)
+                    if lean is not None:
+                        lean.same_as = None
                 _queue_steps(comp, lens, stw, ptp, wts, inv_stw, inv_wts)
                 continue
         fuse_ap = FUSE_APERTURES
@@ -633,7 +646,11 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
             elif keep:
                 tickets.append((dev.psf_keep_power(), pending))
             else:
-                tickets.append((dev.norm2_enqueue(rows) if rows is not None else dev.norm2_enqueue(), pending))
+                like = lean.same_as if lean is not None else None
+                if rows is not None and like is not None:
+                    tickets.append((dev.norm2_enqueue(rows, same_as=like), pending))
+                else:
+                    tickets.append((dev.norm2_enqueue(rows) if rows is not None else dev.norm2_enqueue(), pending))
         elif fused is not None:
             dev.norm2_release(fused)
         elif keep:

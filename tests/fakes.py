@@ -61,8 +61,12 @@ class ModelDevice:
                         "encircled": np.array([I[d2 <= r * r].sum() for r in radii_px])})
         return out
 
-    def norm2_enqueue(self, live_rows=None):
+    def norm2_enqueue(self, live_rows=None, same_as=None):
         self._tickets = getattr(self, "_tickets", [])
+        if same_as is not None:  # the caller claims copies: hold it to that
+            for i, j in enumerate(same_as):
+                lo, hi = (int(x) for x in live_rows[i])
+                assert int(same_as[int(j)]) == int(j) and np.array_equal(self.u[i][lo:hi], self.u[int(j)][lo:hi]), (i, j)
         if live_rows is None:
             self._tickets.append(self.norm2())
         else:  # rows outside [lo, hi) are not read (they may hold stale data: NaN in this model)

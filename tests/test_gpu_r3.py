@@ -308,6 +308,19 @@ def test_row_window_entry_points():
         # the power over the live rows is the power of the zero-filled field, to the last bit
         assert np.array_equal(dev.norm2_fetch(dev.norm2_enqueue(rows)), ref.norm2_fetch(ref.norm2_enqueue()))
         assert np.array_equal(ref.norm2_fetch(ref.norm2_enqueue(rows)), ref.norm2_fetch(ref.norm2_enqueue()))
+        # copies are summed once (paos_norm2_enqueue_rows_like): a context whose items start from the same field
+        twin = _lib.DeviceFields(n, 3)
+        try:
+            twin.start(1.0 + 0j, _lib.SHAPE_ELLIPSE, [blocks[0], blocks[1], blocks[0]], [1.0, 1.0, 1.0], write_rows=[rows[0], rows[1], rows[0]])
+            wr = [rows[0], rows[1], rows[0]]
+            plain = twin.norm2_fetch(twin.norm2_enqueue(wr))
+            assert np.array_equal(twin.norm2_fetch(twin.norm2_enqueue(wr, same_as=[0, 1, 0])), plain) and plain[0] == plain[2]
+            assert np.array_equal(twin.norm2_fetch(twin.norm2_enqueue(wr, same_as=[2, 1, 2])), plain)  # any member may lead
+            for bad in ([0, 1, 1], [1, 1, 0], [0, 1, 3], [0, 1, -1], [0, 1, 0.5]):  # other window / not its own leader / range
+                with pytest.raises(_lib.PaosHipError):
+                    twin.norm2_enqueue(wr, same_as=bad)
+        finally:
+            twin.close()
         # a program that consumes the stale rows == the same program on real zeros
         comp = PassCompiler(nb, n)
         comp.ptp([beam.ptp(3.0)] * nb)
