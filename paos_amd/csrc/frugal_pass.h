@@ -174,7 +174,8 @@ __device__ __forceinline__ T flip_sign(T x, unsigned mask_hi) {
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // RECS > 0: the aperture line records of the workgroup's RECS lines (first line ``lbase``) were fetched by the kernel
-// before the tile's loads (wave-uniform: scalar registers); RECS = 0: the slot loads its line's record itself.
+// before the tile's loads (wave-uniform: scalar registers); RECS < 0: the kernel staged them in LDS (``recs``);
+// RECS = 0: the slot loads its line's record itself.
 template <typename T, int N, int E, int K, typename Map, int PLAIN = 0, bool SHARE = false, int RECS = 0>
 __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, const FrugalPhase* ph,
                                             const Map& m, const cx<double>* circle, bool conj_in, bool conj_out, int tpos,
@@ -218,6 +219,8 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
 #pragma unroll
       for (int j = 1; j < RECS; ++j)
         if (line - lbase == j) ml = recs[j];
+    } else if constexpr (RECS < 0) {
+      ml = recs[line - lbase];  // staged in LDS by the kernel
     } else {
       ml = sl.lines[line];
     }
@@ -479,10 +482,22 @@ __device__ __forceinline__ void frugal_fft(cx<T>* v, void* lds, int t, const cx<
 
 // dynamic LDS of one workgroup: exchange areas | stage twiddles | (c128 with phases) circle table
 constexpr size_t kStoreScratch = 16 * sizeof(double);  // one partial sum per wave (<= 16 waves) of a STORE = 1 workgroup
+#ifndef PAOS_HOIST_RECORDS
+#define PAOS_HOIST_RECORDS 1  // experiment knob: 0 = the slot between the transforms loads its aperture record itself
+#endif
+// How the slot between the transforms gets the aperture line records of the workgroup's lines: 2 = fetched in front of
+// the tile's loads into scalar registers (two-line workgroups with an empty first slot), 1 = fetched behind the tile's
+// loads into a few bytes of LDS (the others: more lines, or a first slot whose register budget has no room),
+// 0 = loaded by the slot when it gets there.
+template <int LINES, int TILES, int KPRE>
+constexpr int frugal_record_mode() {
+  return PAOS_HOIST_RECORDS == 0 ? 0 : ((TILES * LINES == 2 && KPRE == 0) ? 2 : (TILES * LINES <= 16 ? 1 : 0));
+}
 template <typename T, int N, int LINES, int TILES, bool SPLIT, int KPRE, int KMID, int E = 16, int STORE = 0>
 constexpr size_t frugal_lds_bytes() {
   return (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT, LINES>() + twiddle_lds_entries<N, E>() * sizeof(cx<T>) +
-         (sizeof(T) == 8 ? kCircleLds * sizeof(cx<double>) : 0) + (STORE ? kStoreScratch : 0);
+         (sizeof(T) == 8 ? kCircleLds * sizeof(cx<double>) : 0) + kStoreScratch +
+         (frugal_record_mode<LINES, TILES, KPRE>() == 1 ? (size_t)TILES * LINES * sizeof(MaskLine) : 0);
 }
 
 // Waves per SIMD the kernel is compiled for.  N = 4096: 512-thread workgroups, two per CU (their
@@ -526,9 +541,6 @@ __device__ __forceinline__ void tile_power_out(double acc, double* scratch, doub
   }
 }
 
-#ifndef PAOS_HOIST_RECORDS
-#define PAOS_HOIST_RECORDS 1  // experiment knob: 0 = the slot between the transforms loads its aperture record itself
-#endif
 template <typename T, int N, int E, int LINES, int TILES, int AXIS, int BR, int BC, bool SPLIT,
           int KPRE, int KMID, int NFFT, int STORE = 0>
 __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, TILES * LINES * N / E>()))
@@ -632,7 +644,8 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   // The lines of a workgroup are consecutive, so their records are read here, wave-uniformly, in front of the tile.
   // (two-line workgroups without phases in front of the first transform: with four records, or with a busy first
   // slot, the early fetch costs the shape its spill-free register allocation)
-  constexpr int kRecs = (PAOS_HOIST_RECORDS != 0 && TILES * LINES == 2 && KPRE == 0) ? 2 : 0;
+  constexpr int kRecMode = frugal_record_mode<LINES, TILES, KPRE>();
+  constexpr int kRecs = kRecMode == 2 ? 2 : 0;
   MaskLine mrec[kRecs > 0 ? kRecs : 1] = {};
   const int lbase = __builtin_amdgcn_readfirstlane(TILES == 1 ? (AXIS == 0 ? m.row0 : m.col0) : (int)wg * (TILES * LINES));
   if constexpr (kRecs > 0) {
@@ -661,6 +674,14 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   // The LDS tables are fetched BEHIND the tile's loads (they are L2 hits and return in order right after the
   // tile) and written once everything has arrived: nothing stands between the prologue and the first tile load.
   cx<T> tw_fetch[kTwIt], cl_fetch[kClIt];
+  // (the aperture records of the workgroup's lines ride along: one dword per thread of the first wave)
+  constexpr int kRecDwords = kRecMode == 1 ? TILES * LINES * (int)(sizeof(MaskLine) / 4) : 0;
+  static_assert(kRecDwords <= 128, "the record area is filled by the first 128 threads");
+  const bool stage_recs = kRecMode == 1 && it.mid.mask_on != 0.0;
+  unsigned rec_fetch = 0;
+  if constexpr (kRecMode == 1) {
+    if (stage_recs && (int)threadIdx.x < kRecDwords) rec_fetch = reinterpret_cast<const unsigned*>(it.mid.lines + lbase)[threadIdx.x];
+  }
 #pragma unroll
   for (int j = 0; j < kTwIt; ++j) {
     const int i = (int)threadIdx.x + j * kThreads;
@@ -686,6 +707,11 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
       const int i = (int)threadIdx.x + j * kThreads;
       if (i < kCircleLds) cl[i] = {(double)cl_fetch[j].x, -(double)cl_fetch[j].y};
     }
+  }
+  MaskLine* rec_lds = reinterpret_cast<MaskLine*>(smem + frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, E, 0>() -
+                                                  (kRecMode == 1 ? (size_t)TILES * LINES * sizeof(MaskLine) : 0));
+  if constexpr (kRecMode == 1) {
+    if (stage_recs && (int)threadIdx.x < kRecDwords) reinterpret_cast<unsigned*>(rec_lds)[threadIdx.x] = rec_fetch;
   }
   // The LDS tables above are read before the first exchange barrier when a phase sits in front of the first
   // transform (sincos_tab in the pre slot), or when the first transform is switched off: publish them here,
@@ -734,8 +760,8 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   if (ran1) frugal_fft<T, N, E, SPLIT, false>(v, lds, m.t, tw, circle, it.fft1_inv);
   PAOS_STAMP(3);
   constexpr bool kShareMid = kShare && KPRE == 0 && KMID < 3;
-  frugal_slot<T, N, E, KMID, decltype(m), 0, kShareMid, kRecs>(v, it.mid, it.mid_ph, m, circle, inv1, ran2 && it.fft2_inv != 0.0, m.t, lds, ran1,
-                                                              mrec, lbase);
+  frugal_slot<T, N, E, KMID, decltype(m), 0, kShareMid, (kRecMode == 1 ? -1 : kRecs)>(
+      v, it.mid, it.mid_ph, m, circle, inv1, ran2 && it.fft2_inv != 0.0, m.t, lds, ran1, kRecMode == 1 ? rec_lds : mrec, lbase);
   PAOS_STAMP(4);
   if constexpr (NFFT == 2) {
     if (ran2) {
@@ -756,7 +782,8 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
       ps[m.base + (unsigned)k * m.stride] = w;
       acc += w;
     }
-    double* scratch = reinterpret_cast<double*>(smem + frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, E, 0>());
+    double* scratch = reinterpret_cast<double*>(smem + frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, E, 0>() - kStoreScratch -
+                                                (kRecMode == 1 ? (size_t)TILES * LINES * sizeof(MaskLine) : 0));
     tile_power_out<TILES * LINES * N / E>(acc, scratch, a.psf_partial + (size_t)item * (N / LINES / TILES) + wg);
     return;
   }
