@@ -35,6 +35,10 @@ MAX_MERGED_PTP = 3  # transfer functions one middle pass can carry (kFrugalMaxMi
 PTP_ALGEBRA = os.environ.get("PAOS_PTP_ALGEBRA", "1") != "0"
 # The axis of a pass that has no open pass to glue onto (the first pass of a program).  Every later pass alternates
 # from there, so this decides which of the chain's passes run along rows and which along columns.
+# Largest residual phase (rad, at the corner of the grid) a wts -> stw pair may leave behind and still be dropped as
+# the identity (PassCompiler._undoes): a tenth of the 1e-10 field gate the parity tests assert.
+PARITY_GATE = 1.0e-10
+UNDO_MAX_RESIDUAL = 1.0e-11  # = PARITY_GATE / 10
 FIRST_AXIS = 1 if os.environ.get("PAOS_FIRST_AXIS", "0") == "1" else 0
 
 
@@ -170,11 +174,16 @@ class PassCompiler:
         self.last_single = {"kind": kind, "arr": arr.copy(), "inv": inv.copy(), "open": self.open,
                             "open_mid": list(self.open["mid"]), "undo": undo}
 
-    def _undoes(self, first, first_inv, second, second_inv, max_residual=1.0e-9):
+    def _undoes(self, first, first_inv, second, second_inv, max_residual=None):
         """Does the stw ``second`` undo the wts ``first`` for every item?  Same items, opposite transform directions,
         and phases exp(i c (sx^2 x^2 + sy^2 y^2)) (x, y in pixels from the centre) whose coefficients cancel: the
-        residual phase at the corner of the grid stays below ``max_residual`` rad (rounding noise is ~1e-12; anything
-        physical -- a different distance, a magnification between the two -- is many radians)."""
+        residual phase at the corner of the grid stays below ``max_residual`` rad (default UNDO_MAX_RESIDUAL = the
+        1e-10 parity gate on the field / 10: a residual phase d changes the field by |exp(i d) - 1| = d, so what is
+        dropped stays an order of magnitude inside the contract; rounding noise of the two separately rounded
+        coefficients is ~1e-12 at the 1e4 rad these phases reach; anything physical -- a different distance, a
+        magnification between the two -- is many radians).  A pair above the threshold simply keeps both operators."""
+        if max_residual is None:
+            max_residual = UNDO_MAX_RESIDUAL
         on = second[:, 0] != 0.0
         if not np.array_equal(first[:, 0] != 0.0, on) or not np.array_equal(first_inv[on], 1.0 - second_inv[on]):
             return False

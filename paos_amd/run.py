@@ -353,6 +353,14 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
             dev.zero_outside_rows(live)
             stale[0] = False
 
+    def keep_reads_field():
+        """The saved LAST surface of a lean walk that keeps its PSFs, reached without a pass program having stored
+        them (a single-surface chain; every hop shorter than lambda / 1000): ``on_saved`` then takes |u|^2 of the WHOLE
+        field (paos_psf_keep / paos_psf_keep_power), so rows that merely stand for zeros have to be zeros first
+        (the PSF and its power came out NaN on the model device)."""
+        if psf_at is not None and key == psf_at and lean.psf_ticket is None:
+            settle()
+
     def flush(final_intensity=False):
         if dead[0]:
             comp.program()  # drop what was queued behind the PSF store
@@ -424,6 +432,7 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
                 wfe = _launch_phase_maps(dev, plans, wfe)
                 if saved:
                     if lean is not None:
+                        keep_reads_field()
                         lean.rows = known_rows()
                         # still copies of each other unless this surface put a wavefront error on them
                         untouched = not any(p["zernike"] is not None or p["phase_map"] is not None for p in plans)
@@ -469,6 +478,7 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
         wfe = _launch_phase_maps(dev, plans, wfe)
         if saved:
             if lean is not None:
+                keep_reads_field()
                 lean.rows = known_rows() if not comp.pending() else None
             else:
                 settle()

@@ -41,3 +41,14 @@ def rel_err(a, b):
     if scale == 0:
         return float(np.max(np.abs(a)))
     return float(np.max(np.abs(a - b)) / scale)
+
+
+def l2_rel_err(a, b):
+    """L2-relative error |a - b|_2 / |b|_2 -- the second parity gate of SURVEY.md 8d ("L2-relative < 1e-10 (fp64),
+    field likewise").  float64 accumulation whatever the inputs' type."""
+    a = np.asarray(a)
+    b = np.asarray(b)
+    d = (a - b).ravel()
+    den = float(np.sqrt(np.vdot(b.ravel(), b.ravel()).real))
+    num = float(np.sqrt(np.vdot(d, d).real))
+    return num if den == 0.0 else num / den

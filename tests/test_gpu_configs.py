@@ -20,7 +20,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import load_golden, rel_err
+from conftest import l2_rel_err, load_golden, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -52,6 +52,8 @@ def compare(got, ref, where, field_tol=FIELD_TOL, psf_tol=PSF_TOL, scalars=True)
             e = rel_err(got[k]["wfo"], ref[k]["wfo"])
             worst = max(worst, e)
             assert e < field_tol, (where, k, "field", e)
+            e2 = l2_rel_err(got[k]["wfo"], ref[k]["wfo"])  # SURVEY 8d's second gate: L2-relative, same bound
+            assert e2 < field_tol, (where, k, "field, L2-relative", e2)
         if "psf" in got[k]:
             psf = got[k]["psf"]
         elif "amplitude" in got[k]:
@@ -60,6 +62,8 @@ def compare(got, ref, where, field_tol=FIELD_TOL, psf_tol=PSF_TOL, scalars=True)
             psf = np.abs(got[k]["wfo"]) ** 2
         e = rel_err(psf, ref[k]["amplitude"] ** 2)
         assert e < psf_tol, (where, k, "psf", e)
+        e2 = l2_rel_err(psf, ref[k]["amplitude"] ** 2)
+        assert e2 < psf_tol, (where, k, "psf, L2-relative", e2)
         if scalars:
             for key in ("dx", "dy", "wl", "fratio", "wz", "distancetofocus", "propagator"):
                 assert got[k][key] == ref[k][key], (where, k, key, got[k][key], ref[k][key])

@@ -483,8 +483,12 @@ def test_undoes_needs_opposite_directions_equal_items_and_cancelling_phases():
     from paos_amd.passes import PassCompiler
 
     comp = PassCompiler(2, 256)
-    wts = np.array([[1.0, 1e-3, 1e-3, np.pi / (0.5 * 1e-6), 1.0]] * 2)  # dx = 1 mm, dz = 0.5 m, lambda = 1 um
-    dxn = 1e-6 * 0.5 / (256 * 1e-3)
+    # dz = 0.5 m, lambda = 1 um, dx at the critical sampling of the chirp (dx^2 = lambda dz / N: the corner phase is
+    # pi N / 2 = 402 rad, its coefficient's rounding noise ~1e-13 rad -- an undersampled 1 mm grid would carry 2e5 rad
+    # and 2e-11 rad of noise, above UNDO_MAX_RESIDUAL: such a pair keeps both operators, which is always correct)
+    dx = (1e-6 * 0.5 / 256) ** 0.5
+    wts = np.array([[1.0, dx, dx, np.pi / (0.5 * 1e-6), 1.0]] * 2)
+    dxn = 1e-6 * 0.5 / (256 * dx)
     fs = 1.0 / (256 * dxn)
     stw = np.array([[1.0, fs, fs, np.pi * 1e-6 * -0.5, 1.0]] * 2)
     fwd, inv = np.zeros(2), np.ones(2)
@@ -502,6 +506,99 @@ def test_undoes_needs_opposite_directions_equal_items_and_cancelling_phases():
     comp.stw(stw, inv)
     assert len(comp.passes) == n0 and comp.open is comp.passes[-1]
     comp.wts(wts, fwd)
-    comp.lens(np.array([[1.0, 1e-3, 1e-3, 0.25, 1.0]] * 2))
+    comp.lens(np.array([[1.0, dx, dx, 0.25, 1.0]] * 2))
     comp.stw(stw, inv)
     assert len(comp.passes) == n0 + 2
+
+
+def test_undoes_threshold_sits_a_decade_inside_the_parity_gate():
+    """VERDICT r03 "weak" 2: the residual phase a dropped wts -> stw pair may leave is bounded by the field gate the
+    parity tests assert (1e-10) / 10.  A pair whose corner residual is 1e-10 rad must NOT cancel, one at
+    1e-13 rad (rounding noise of separately rounded coefficients) must."""
+    import paos_amd.passes as ppasses
+    from paos_amd.passes import PassCompiler
+
+    assert ppasses.UNDO_MAX_RESIDUAL <= 1.0e-11 and ppasses.UNDO_MAX_RESIDUAL <= ppasses.PARITY_GATE / 10.0
+    n = 256
+    comp = PassCompiler(1, n)
+    wts = np.array([[1.0, 1e-3, 1e-3, np.pi / (0.5 * 1e-6), 1.0]])
+    dxn = 1e-6 * 0.5 / (n * 1e-3)
+    fs = 1.0 / (n * dxn)
+    fwd, inv = np.zeros(1), np.ones(1)
+    half = (n / 2.0) ** 2
+
+    def stw_with_residual(target):
+        """stw block whose coefficient leaves ``target`` rad at the corner against ``wts`` (x and y alike)."""
+        cw = wts[0, 3] * wts[0, 4] * wts[0, 1] ** 2          # per-pixel^2 coefficient of the wts phase
+        c = (target / (2.0 * half) - cw) / fs ** 2            # ... so that (cw + c fs^2) * 2 half = target
+        blk = np.array([[1.0, fs, fs, c, 1.0]])
+        got = 2.0 * abs(blk[0, 3] * blk[0, 4] * blk[0, 1] ** 2 + cw) * half
+        return blk, got
+
+    corner = abs(wts[0, 3] * wts[0, 1] ** 2) * 2.0 * half      # ~2e5 rad: ulp ~ 3e-11, so targets are met to ~1e-11
+    assert corner > 1e3
+    above, got_above = stw_with_residual(1.0e-10 * 4.0)        # well above the threshold whatever the rounding
+    assert got_above > ppasses.UNDO_MAX_RESIDUAL
+    assert not comp._undoes(wts, fwd, above, inv)
+    # exactly representable cancellation (residual 0) and an explicit 1e-13 through the max_residual argument's default
+    exact = np.array([[1.0, wts[0, 1], wts[0, 2], -wts[0, 3], 1.0]])
+    assert comp._undoes(wts, fwd, exact, inv)
+    # a small-phase pair, where 1e-13 and 1e-10 are far above the coefficient's ulp: both sides of the threshold
+    small = np.array([[1.0, 1e-3, 1e-3, 1.0, 1.0]])           # corner phase 2 * 128^2 * 1e-6 = 0.033 rad
+    cw = small[0, 3] * small[0, 1] ** 2
+    for target, cancels in ((1.0e-13, True), (5.0e-12, True), (1.0e-10, False), (1.0e-9 * 0.5, False)):
+        c = target / (2.0 * half) - cw
+        blk = np.array([[1.0, 1.0, 1.0, c, 1.0]])
+        resid = 2.0 * abs(c + cw) * half
+        assert abs(resid - target) < 1e-3 * target, (resid, target)
+        assert comp._undoes(small, fwd, blk, inv) is cancels, (target, resid)
+    # through the operator interface: the 1e-10 pair keeps both operators (two more passes), the 1e-13 pair leaves none
+    for target, extra in ((1.0e-10, 2), (1.0e-13, 0)):
+        comp = PassCompiler(1, n)
+        comp.stw(np.array([[1.0, 1.0, 1.0, -0.5, 1.0]]), fwd)
+        n0 = len(comp.passes)
+        comp.wts(small, fwd)
+        comp.stw(np.array([[1.0, 1.0, 1.0, target / (2.0 * half) - cw, 1.0]]), inv)
+        assert len(comp.passes) == n0 + extra, (target, len(comp.passes), n0)
+
+
+def _short_chain(surfaces):
+    """The first ``surfaces`` of a STOP | flat (thickness 0) ... | IMAGE_PLANE prescription: no hop ever exceeds
+    lambda / 1000, so no pass program runs between the start field and the saved last surface."""
+    from paos_amd.abcd import ABCD
+
+    chain = {1: {"num": 1, "type": "Standard", "name": "STOP", "is_stop": True, "save": True,
+                 "aperture": {"shape": "elliptical", "type": "aperture", "xrad": 0.5, "yrad": 0.5, "xc": 0.0, "yc": 0.0},
+                 "ABCDt": ABCD(thickness=0.0, curvature=0.0), "ABCDs": ABCD(thickness=0.0, curvature=0.0)}}
+    for num in range(2, surfaces + 1):
+        chain[num] = {"num": num, "type": "Standard", "name": "IMAGE_PLANE" if num == surfaces else f"FLAT{num}",
+                      "is_stop": False, "save": num == surfaces,
+                      "ABCDt": ABCD(thickness=0.0, curvature=0.0), "ABCDs": ABCD(thickness=0.0, curvature=0.0)}
+    return chain
+
+
+@pytest.mark.parametrize("surfaces", [1, 3])
+def test_lean_walk_that_keeps_the_psf_without_any_pass_program(surfaces):
+    """a lean walk (outputs=(), keep_psf=True) whose saved last surface is reached before any
+    pass program has consumed the rows that merely stand for zeros -- a single-surface chain, or a chain of hops
+    shorter than lambda / 1000 -- takes |u|^2 of the whole field (psf_keep / psf_keep_power).  The model device holds
+    NaN in those rows: power and PSF must be finite and equal to the ordinary walk's."""
+    from paos_amd.run import run_batch
+
+    n, wl, field = 128, 1.0e-6, {"us": 0.0, "ut": 0.0}
+    chain = _short_chain(surfaces)
+    last = surfaces
+    want_dev = ModelDevice(n, 1)
+    want = run_batch(1.0, [wl], n, 4, field, [chain], outputs=("psf",), dev=want_dev, keep_psf=True)
+    for power in (True, False):
+        dev = ModelDevice(n, 1)
+        got = run_batch(1.0, [wl], n, 4, field, [chain], outputs=(), dev=dev, keep_psf=True, power=power)
+        kinds = [name for name, _ in dev.log]
+        assert "zero_outside_rows" in kinds, kinds  # the rows were stale (lean start) and had to become zeros
+        psf = dev.psf_fetch(0)
+        assert np.isfinite(psf).all()
+        assert np.array_equal(psf, want[0][last]["psf"])
+        if power:
+            assert np.isfinite(got[0][last]["power"])
+            assert abs(got[0][last]["power"] - want[0][last]["power"]) <= 1e-13 * want[0][last]["power"]
+            assert abs(got[0][last]["power"] - 1.0) < 1e-12  # behind the stop the power is 1
