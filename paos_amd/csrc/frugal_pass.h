@@ -17,6 +17,24 @@
 #ifndef PAOS_FENCE_EVERY
 #define PAOS_FENCE_EVERY 2
 #endif
+// Round-4 scheduling experiments (tools/build_variant.sh; profiles/r04_ab_variants_bench.txt) -- all three measured
+// and left OFF: priority -2.0 / -2.5 % wavefronts/s, prefetch -9 % (full launches 3.43 -> 4.04 ms):
+//   PAOS_PRIO_LOAD  p > 0: the waves of a fresh workgroup run at priority p until their tile loads are issued (they
+//                   compete for the issue ports with the fp64 stream of the OLDER workgroup of the CU, and the
+//                   arbiter prefers the older wave)
+//   PAOS_PRIO_STORE p > 0: ... and again from their last butterflies to the end of their stores
+//   PAOS_PREFETCH   d > 0: a workgroup touches the tile of workgroup wg + d (one dword per 64 bytes), so that the
+//                   tile comes from the Infinity Cache when its own workgroup asks for it about one round later:
+//                   bytes in flight are otherwise bounded by the register files (2 x 128 KiB per CU)
+#ifndef PAOS_PRIO_LOAD
+#define PAOS_PRIO_LOAD 0
+#endif
+#ifndef PAOS_PRIO_STORE
+#define PAOS_PRIO_STORE 0
+#endif
+#ifndef PAOS_PREFETCH
+#define PAOS_PREFETCH 0
+#endif
 
 namespace paos {
 
@@ -541,10 +559,28 @@ __device__ __forceinline__ void tile_power_out(double acc, double* scratch, doub
   }
 }
 
+// The kernel takes the fields of FrugalArgs as separate scalar arguments, the ones the prologue needs first: built with
+// -mllvm -amdgpu-kernarg-preload-count=N (Makefile) they arrive in SGPRs with the wave, instead of by a scalar load
+// that every workgroup waits for before it can even ask for its item's record.  Launch with PAOS_FRUGAL_PASS(args).
+#if PAOS_STAMPS
+#define PAOS_FRUGAL_PARAMS const FrugalItem *k_items, void *k_field, unsigned k_pitch, unsigned k_item_stride, unsigned k_wg0, \
+                           const void *k_tw, double *k_psf, double *k_psf_partial, unsigned long long *k_stamps
+#define PAOS_FRUGAL_PASS(a) (a).items, (a).field, (a).pitch, (a).item_stride, (a).wg0, (a).tw, (a).psf, (a).psf_partial, (a).stamps
+#else
+#define PAOS_FRUGAL_PARAMS const FrugalItem *k_items, void *k_field, unsigned k_pitch, unsigned k_item_stride, unsigned k_wg0, \
+                           const void *k_tw, double *k_psf, double *k_psf_partial
+#define PAOS_FRUGAL_PASS(a) (a).items, (a).field, (a).pitch, (a).item_stride, (a).wg0, (a).tw, (a).psf, (a).psf_partial
+#endif
 template <typename T, int N, int E, int LINES, int TILES, int AXIS, int BR, int BC, bool SPLIT,
           int KPRE, int KMID, int NFFT, int STORE = 0>
 __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, TILES * LINES * N / E>()))
-    frugal_pass_kernel(FrugalArgs a) {
+    frugal_pass_kernel(PAOS_FRUGAL_PARAMS) {
+  FrugalArgs a;
+  a.items = k_items; a.field = k_field; a.pitch = k_pitch; a.item_stride = k_item_stride; a.wg0 = k_wg0;
+  a.tw = k_tw; a.psf = k_psf; a.psf_partial = k_psf_partial; a.live_lo = a.live_hi = 0;
+#if PAOS_STAMPS
+  a.stamps = k_stamps;
+#endif
   const int item = blockIdx.y;
   // constant address space: the per-item records are invariant during the kernel, so the scalar
   // loads of their fields may be kept or merged across the workgroup barriers instead of re-issued
@@ -562,9 +598,18 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   constexpr int kClIt = sizeof(T) == 8 ? (kCircleLds + kThreads - 1) / kThreads : 1;
   const double h_active = it.active, h_line_lo = it.line_lo, h_line_hi = it.line_hi, h_line_fill = it.line_fill,
                h_pos_lo = it.pos_lo, h_pos_hi = it.pos_hi, h_spos_lo = it.spos_lo, h_spos_hi = it.spos_hi;
-  asm volatile("" ::"s"(h_active), "s"(h_line_lo), "s"(h_line_hi), "s"(h_line_fill), "s"(h_pos_lo), "s"(h_pos_hi), "s"(h_spos_lo),
-               "s"(h_spos_hi));
+  // (shapes that fetch their aperture line records in front of the tile: the switch and the pointer ride along
+  // instead of costing two more dependent scalar loads behind the header)
+  const double h_mask_on = it.mid.mask_on;
+  const MaskLine* const h_lines = it.mid.lines;
+  if constexpr (frugal_record_mode<LINES, TILES, KPRE>() != 0)
+    asm volatile("" ::"s"(h_active), "s"(h_line_lo), "s"(h_line_hi), "s"(h_line_fill), "s"(h_pos_lo), "s"(h_pos_hi), "s"(h_spos_lo),
+                 "s"(h_spos_hi), "s"(h_mask_on), "s"(h_lines));
+  else
+    asm volatile("" ::"s"(h_active), "s"(h_line_lo), "s"(h_line_hi), "s"(h_line_fill), "s"(h_pos_lo), "s"(h_pos_hi), "s"(h_spos_lo),
+                 "s"(h_spos_hi));
   if (h_active == 0.0) return;
+  if constexpr (PAOS_PRIO_LOAD > 0) __builtin_amdgcn_s_setprio(PAOS_PRIO_LOAD);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // a block of BR x BC elements is a whole 128-byte line for complex128, half of one for complex64
   constexpr bool kBlockIsLine = BR * BC * sizeof(cx<T>) >= 128;
@@ -649,9 +694,9 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   MaskLine mrec[kRecs > 0 ? kRecs : 1] = {};
   const int lbase = __builtin_amdgcn_readfirstlane(TILES == 1 ? (AXIS == 0 ? m.row0 : m.col0) : (int)wg * (TILES * LINES));
   if constexpr (kRecs > 0) {
-    if (it.mid.mask_on != 0.0) {
+    if (h_mask_on != 0.0) {
 #pragma unroll
-      for (int j = 0; j < kRecs; ++j) mrec[j] = it.mid.lines[lbase + j];
+      for (int j = 0; j < kRecs; ++j) mrec[j] = h_lines[lbase + j];
     }
   }
   // The empty slot in front of the first transform without its 32 multiplications by +-1 (frugal_slot: PLAIN):
@@ -659,6 +704,25 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   constexpr int kPlainPre = KPRE != 0 ? 0 : (AXIS == 1 ? PAOS_COL_PRE : PAOS_ROW_PRE);
   cx<T> v[E];
   const int plo = (int)h_pos_lo, phi = (int)h_pos_hi;
+  // PAOS_PREFETCH: one dword out of every 64 bytes of the tile of workgroup wg + d, issued IN FRONT of the own tile's
+  // loads.  Loads return in order, so once any tile element has arrived these have too: their (single, never read)
+  // destination register stays reserved until the tile's stores (the empty asm in front of them).
+  unsigned pf_sink = 0;
+  if constexpr (PAOS_PREFETCH > 0) {
+    const unsigned wgp = wg + (unsigned)PAOS_PREFETCH;
+    if (wgp < a.wg0 + gridDim.x) {
+      const TileMap<N, E, LINES, TILES, AXIS, BR, BC, 1, COLSIB> mp(wgp, threadIdx.x & ~3u, a.pitch);
+      // threads 4 q .. 4 q + 3 own one 64-byte piece per element index k: lane (tid & 3) touches the pieces k = 4 j + (tid & 3)
+      typedef const __attribute__((address_space(1))) char* GlobalBytes;
+      const GlobalBytes pbase = (GlobalBytes)fb;
+#pragma unroll
+      for (int j = 0; j < E / 4; ++j) {
+        const unsigned off = (mp.base + (unsigned)(4 * j + (threadIdx.x & 3)) * mp.stride) * (unsigned)sizeof(cx<T>);
+        asm volatile("global_load_dword %0, %1, %2" : "+v"(pf_sink) : "v"(off), "s"(pbase) : "memory");
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
   if (plo <= 0 && phi >= N) {  // wave-uniform: the whole line is live
 #pragma unroll
     for (int k = 0; k < E; ++k) v[k] = stream_load<NTL>(at(k));
@@ -677,10 +741,10 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   // (the aperture records of the workgroup's lines ride along: one dword per thread of the first wave)
   constexpr int kRecDwords = kRecMode == 1 ? TILES * LINES * (int)(sizeof(MaskLine) / 4) : 0;
   static_assert(kRecDwords <= 128, "the record area is filled by the first 128 threads");
-  const bool stage_recs = kRecMode == 1 && it.mid.mask_on != 0.0;
+  const bool stage_recs = kRecMode == 1 && h_mask_on != 0.0;
   unsigned rec_fetch = 0;
   if constexpr (kRecMode == 1) {
-    if (stage_recs && (int)threadIdx.x < kRecDwords) rec_fetch = reinterpret_cast<const unsigned*>(it.mid.lines + lbase)[threadIdx.x];
+    if (stage_recs && (int)threadIdx.x < kRecDwords) rec_fetch = reinterpret_cast<const unsigned*>(h_lines + lbase)[threadIdx.x];
   }
 #pragma unroll
   for (int j = 0; j < kTwIt; ++j) {
@@ -717,6 +781,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   // transform (sincos_tab in the pre slot), or when the first transform is switched off: publish them here,
   // with the tile's loads already in flight.  LDS only -- a __syncthreads() would also wait for those loads.
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  if constexpr (PAOS_PRIO_LOAD > 0) __builtin_amdgcn_s_setprio(0);
   PAOS_STAMP_WAIT_VM();
   PAOS_STAMP(1);
 
@@ -788,6 +853,8 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
     return;
   }
   const int slo = (int)h_spos_lo, shi = (int)h_spos_hi;
+  if constexpr (PAOS_PREFETCH > 0) asm volatile("" ::"v"(pf_sink));
+  if constexpr (PAOS_PRIO_STORE > 0) __builtin_amdgcn_s_setprio(PAOS_PRIO_STORE);
   if (slo <= 0 && shi >= N) {  // wave-uniform: everything is stored
 #pragma unroll
     for (int k = 0; k < E; ++k) stream_store<NT>(at(k), v[k]);

@@ -593,7 +593,7 @@ int frugal_launch(paos_ctx* c, const FrugalArgs& args) {
   const bool timed = (c->prof_kind == kind || c->prof_kind == PAOS_KERNEL_PASS_ANY) &&
                      (c->prof_used + 2 <= c->prof_events.size());
   if (timed) HIPCHK(c, hipEventRecord(c->prof_events[c->prof_used], c->stream));
-  hipLaunchKernelGGL(kern, grid, block, lds, c->stream, a);
+  hipLaunchKernelGGL(kern, grid, block, lds, c->stream, PAOS_FRUGAL_PASS(a));
   HIPCHK(c, hipGetLastError());
   if (timed) {
     HIPCHK(c, hipEventRecord(c->prof_events[c->prof_used + 1], c->stream));

@@ -120,7 +120,7 @@ void bench_variant(const char* name, int batch, int reps, int pad_blocks = 0) {
 
   a.n_mid = 1; a.mid[0] = {PWK_SCALE, 0, 3};  // keep magnitudes bounded over repeated launches
   Timer tm;
-  float ms = tm.run([&] { hipLaunchKernelGGL(kf, grid, block, lds, 0, a); }, reps);
+  float ms = tm.run([&] { hipLaunchKernelGGL(kf, grid, block, lds, 0, PAOS_FRUGAL_PASS(a)); }, reps);
   const double bytes = 2.0 * elems * sizeof(cx<T>);
   int nb = 0;
   CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kf, block.x, lds));
@@ -211,7 +211,7 @@ void bench_frugal(const char* name, int batch, int reps, int pad_blocks) {
   auto kf = frugal_pass_kernel<T, N, E, LINES, TILES, AXIS, BR, BC, SPLIT, KPRE, KMID, NFFT>;
   CK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   Timer tm;
-  float ms = tm.run([&] { hipLaunchKernelGGL(kf, grid, block, lds, 0, a); }, reps);
+  float ms = tm.run([&] { hipLaunchKernelGGL(kf, grid, block, lds, 0, PAOS_FRUGAL_PASS(a)); }, reps);
   int nb = 0;
   CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kf, block.x, lds));
   const double bytes = 2.0 * (double)N * N * batch * sizeof(cx<T>);

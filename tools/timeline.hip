@@ -73,10 +73,10 @@ void timeline(const char* name, int batch, int pad_blocks) {
   CK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kf, grid, block, lds, 0, a);  // warm, clocks up
+  for (int w = 0; w < 3; ++w) hipLaunchKernelGGL(kf, grid, block, lds, 0, PAOS_FRUGAL_PASS(a));  // warm, clocks up
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  hipLaunchKernelGGL(kf, grid, block, lds, 0, a);
+  hipLaunchKernelGGL(kf, grid, block, lds, 0, PAOS_FRUGAL_PASS(a));
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   float ms;
