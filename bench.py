@@ -2,31 +2,39 @@
 """Headline benchmark: wavefronts/s through the 20-surface SYN20 chain.
 
     python bench.py --gpus 1 --steps 5 --warmup 1            # 4096^2 complex128 (default)
+    python bench.py --gpus N --steps K --warmup W            # starts its own N ranks (one process per GPU, no torch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W   # ... or joins the ranks a launcher started
 
-A "step" propagates one batch of ``--batch`` wavefronts (wavelength sweep lambda_k = 1 um (1 + k/512)) per GPU
-through all 20 surfaces on the HIP path; fields are created and stay in HBM.  With N GPUs every rank gets its own
-contiguous block of the sweep (weak scaling) after ONE broadcast of the packed work description from rank 0
-(paos_comm_bcast_blob: RCCL over xGMI, driven from libpaoship.so -- torch is only the launcher, it is never
-imported here).  With N > 1 the run FAILS (exit 3) when the ranks could not agree on RCCL, unless --allow-tcp is
-given; `config.ranks_seen` / `devices_seen` come from the communicator.  Rank 0 prints one JSON line (contract in the task statement) with these extra objects:
+A "step" propagates one batch of ``--batch`` wavefronts per GPU through all 20 surfaces on the HIP path; fields are
+created and stay in HBM.  The sweep is WALKED: step g (warm-up steps count) runs the wavelengths
+lambda_k = 1 um (1 + k/512), k = g * batch * N ... (g + 1) * batch * N - 1 (mod 512), so what the library keeps
+between batches (aperture line records, the shared start field) sees what a real 512-wavelength sweep gives it;
+`sweep` in the line reports the records found / rendered per step.  With N GPUs every rank gets its own contiguous
+block of each step's wavelengths (weak scaling) after ONE broadcast of the packed work description from rank 0
+(paos_comm_bcast_blob: RCCL over xGMI, driven from libpaoship.so -- torch is never imported).  Without a launcher's
+WORLD_SIZE in the environment `--gpus N` starts the N ranks itself, BEFORE anything touches a GPU in the parent, which
+only relays rank 0's line and the exit codes.  With N > 1 the run FAILS (exit 3) when the ranks could not agree on
+RCCL, unless --allow-tcp is given -- and still prints a JSON line then (`"value": null`, the transport, the ranks
+seen and every rank's bring-up note).  Rank 0 prints one JSON line (contract in the task statement) with these extras:
 
-  roofline           the dominant kernel (the fused FFT pass): every pass launch of the timed region is
-                     bracketed by HIP events on the context's stream (paos_profile_end_launches: time and class of
-                     each launch); `achieved` = 32 B/px x N^2 x batch (one read and one write of every element) / mean
-                     duration of the launches that skip nothing; `classes` lists every class of launch (full, skipping
-                     tiles of dead lines / loads of dead positions / stores nobody reads, storing the PSF) with its mean
-                     time and -- from the counters -- the bytes it really moved; `all_launches` sums both over one
-                     step; `copy_yardstick` is measured in this run (paos_copy_yardstick); `traffic` = HBM bytes per
-                     full launch from FETCH_SIZE / WRITE_SIZE, collected by two child runs of this script under
+  roofline           the dominant kernel (the fused FFT pass): every pass launch of the timed region is bracketed by
+                     HIP events on the context's stream (paos_profile_end_launches: time and class of each launch);
+                     `achieved` = 32 B/px x N^2 x batch (one read and one write of every element) / mean duration of
+                     the launches that skip nothing; `classes` lists every class of launch (full, skipping tiles of
+                     dead lines / loads of dead positions / stores nobody reads, storing the PSF) with its mean time
+                     and -- from the counters -- the bytes it really moved; `all_launches` sums both over one step;
+                     `copy_yardstick` is measured in this run (paos_copy_yardstick); `traffic` = HBM bytes per full
+                     launch from FETCH_SIZE / WRITE_SIZE, collected by two child runs of this script under
                      rocprofv3 --pmc (measure_traffic; N = 1 only, --no-traffic skips it).
-  chain_vs_survey_model / ptp_step   the whole chain and one ptp priced with SURVEY 8d's UNFUSED byte model (2 passes
-                     per 2-D FFT) next to the bytes the launches of one step really moved under the counters
-                     (`bytes_moved_per_wavefront`, every kernel of the step; `other_kernels` lists the non-pass ones).
-  without_ptp_algebra  the rate (3 steps) with the pass compiler's two ptp identities switched off (PAOS_PTP_ALGEBRA=0:
-                     44 passes per wavefront instead of 24), so that the headline value can be read without them.
-  extra              the same chain at 2048^2 and 1024^2 (the north star's sweep), value + roofline each.
+  chain_vs_survey_model / ptp_step   the whole chain and one ptp priced with SURVEY 8d's UNFUSED byte model next to
+                     the bytes the launches of one step really moved under the counters.
+  without_ptp_algebra  the rate over the SAME number of steps with the pass compiler's ptp identities switched off
+                     (PAOS_PTP_ALGEBRA=0: 44 passes per wavefront instead of 24).
+  extra              2048^2 / 1024^2 (the north star's sweep); fp32_4096 (SYN20 in fp32 mode with its roofline);
+                     dense (SYN20 behind a white-noise grid-sag screen: rough fields everywhere, per-class times);
+                     configs (BASELINE.json configs 3-5 on one GPU: AIRS-CH0 64 wavelengths @2048^2, FGS1 256
+                     Monte-Carlo draws @2048^2 with on-device rEE90, Excite_TEL @4096^2 fp64 and fp32).
   cpu_baseline       the NumPy oracle ("port") on the host: one wavefront of the workload at the benchmark grid
                      on one core, and `cpu_baseline_parallel`: min(batch, cores, memory, 8) worker processes over
                      wavelengths at the benchmark grid -- the reference's own joblib scheme (pipeline.py:140).
@@ -43,6 +51,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 ON_AXIS = {"us": 0.0, "ut": 0.0}
+SWEEP = 512            # wavelengths of the sweep the steps walk through
 
 
 def chain_fft_counts(wavelength, gridsize):
@@ -61,6 +70,7 @@ def chain_fft_counts(wavelength, gridsize):
     return n_ptp, n_stw, n_wts
 
 
+# ---- CPU baseline (the ONLY place this script touches oracle/) ---------------------------------------------------
 def _oracle_seconds(task):
     """One SYN20 wavefront of the sweep through the NumPy oracle; returns its wall time."""
     k, n = task
@@ -136,16 +146,23 @@ def cpu_baseline_parallel(gridsize, batch):
     }
 
 
-def measure(dev, n, nb, precision, wavelengths, chains, steps, warmup, comm=None):
-    """Timed region of the contract: W untimed steps, then exactly K steps between barriers; every pass launch
-    is event-timed.  Returns a dict of raw numbers."""
+# ---- the timed region ---------------------------------------------------------------------------------------------
+def sweep_block(step, per_step, lo, hi):
+    """Sweep indices k of this rank's wavefronts in global step ``step`` (``per_step`` wavefronts over all ranks)."""
+    return [(step * per_step + i) % SWEEP for i in range(lo, hi)]
+
+
+def measure(dev, n, precision, wavelengths_of, chains, steps, warmup, comm=None, first_step=0, timer=True):
+    """Timed region of the contract: W untimed steps, then exactly K steps between barriers; every pass launch is
+    event-timed.  ``wavelengths_of(g)`` lists this rank's wavelengths of global step g (warm-up steps are
+    g = first_step ... first_step + W - 1).  Returns a dict of raw numbers."""
     from paos_amd import _lib
     from paos_amd.run import run_batch
 
     stats = {}
 
-    def step():
-        return run_batch(1.0, wavelengths, n, 4, ON_AXIS, chains, precision=precision, outputs=(), dev=dev,
+    def step(g):
+        return run_batch(1.0, wavelengths_of(g), n, 4, ON_AXIS, chains, precision=precision, outputs=(), dev=dev,
                          sync=False, stats=stats, keep_psf=True)
 
     def barrier():
@@ -158,34 +175,53 @@ def measure(dev, n, nb, precision, wavelengths, chains, steps, warmup, comm=None
             for t in {rec["power_ticket"] for r in results for rec in r.values() if "power_ticket" in rec}:
                 dev.norm2_release(t)
 
+    has_sets = hasattr(dev, "record_set_stats")
     res = None
+    g = first_step
     for _ in range(warmup):
         release(res)
-        res = step()
+        res = step(g)
+        g += 1
     barrier()
-    dev.profile_begin(_lib.KERNEL_PASS_ANY, max_launches=64 * 1024)
+    if timer:
+        dev.profile_begin(_lib.KERNEL_PASS_ANY, max_launches=64 * 1024)
+    per_step_passes, per_step_sets = [], []
+    seen = dev.record_set_stats() if has_sets else (0, 0)
     t0 = time.perf_counter()
     for _ in range(steps):
         release(res)
-        res = step()
+        res = step(g)
+        g += 1
+        per_step_passes.append(stats.get("fused_passes"))
+        if has_sets:
+            now = dev.record_set_stats()
+            per_step_sets.append((now[0] - seen[0], now[1] - seen[1]))
+            seen = now
     barrier()
     elapsed = time.perf_counter() - t0
-    ms, tags = dev.profile_end_launches()
+    if timer:
+        ms, tags = dev.profile_end_launches()
+    else:
+        import numpy as np
+
+        ms, tags = np.zeros(0), np.zeros(0, dtype=np.int32)
     if comm is not None:
         elapsed = comm.max(elapsed)
     full = tags == 0
     return {"elapsed": elapsed, "launches": int(ms.size), "kern_ms": float(ms.sum()), "pruned": int((~full).sum()),
             "pruned_ms": float(ms[~full].sum()), "launch_ms": ms, "launch_tags": tags,
-            "fused_passes": stats.get("fused_passes"), "res": res}
+            "fused_passes": stats.get("fused_passes"), "per_step_passes": per_step_passes,
+            "per_step_sets": per_step_sets, "first_timed_step": first_step + warmup, "res": res}
 
 
 def measure_traffic(grid, batch, precision):
     """HBM bytes of every kernel of ONE chain step from the PMC counters, collected the way MI355X_MICROARCH.md
     prescribes: this script once under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and once under `... --pmc WRITE_SIZE`
-    (separate passes, as child processes running one warm-up step and one counted step and nothing else: --traffic-child), FETCH_SIZE /
-    WRITE_SIZE in KiB, FETCH_SIZE doubled (gfx950 reports half of the bytes of wide coalesced reads; the factor is
-    calibrated for 16 B per lane, which is what the pass kernels issue -- for the 8-byte accesses of the reduction and
-    PSF kernels it is an assumption).  Dispatches are matched between the two runs by dispatch order.
+    (separate passes, as child processes running one warm-up step (g = 0) and one counted step (g = 1) and nothing
+    else: --traffic-child), FETCH_SIZE / WRITE_SIZE in KiB, FETCH_SIZE doubled (gfx950 reports half of the bytes of
+    wide coalesced reads; the factor is calibrated for 16 B per lane, which is what the pass kernels issue -- for the
+    8-byte accesses of the reduction and PSF kernels it is an assumption).  Dispatches are matched between the two
+    runs by dispatch order.
     Returns ({"pass": [(read, written)] in launch order, "other": {kernel: {calls, read, written, ms}}} or None, note)."""
     import csv
     import glob
@@ -218,9 +254,8 @@ def measure_traffic(grid, batch, precision):
                     name, val = per_dispatch.get(k, (row["Kernel_Name"], 0.0))
                     per_dispatch[k] = (name, val + float(row["Counter_Value"]))
             seq = [per_dispatch[k] for k in sorted(per_dispatch)]
-            # the child runs a warm-up step first: the counted step is the steady state the timed region measures
-            # (aperture records found in the context's sets, PSF zeros already in the buffer).  A step opens with the
-            # start-of-chain power kernel: keep what follows the last one.
+            # the child runs a warm-up step first: the counted step is the steady state the timed region measures.
+            # A step opens with the start-of-chain power kernel: keep what follows the last one.
             starts = [i for i, (name, _) in enumerate(seq) if "start_power_kernel" in name]
             series[counter] = seq[starts[-1]:] if starts else seq
             if counter == "FETCH_SIZE":  # durations of the non-pass kernels (under the profiler: indicative)
@@ -259,8 +294,9 @@ def measure_traffic(grid, batch, precision):
         short = name.split("<")[0].split("(")[0]
         if short in out["other"]:
             out["other"][short]["ms"] += ms
-    note = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE on one chain step of this workload behind a warm-up step "
-            "(two child runs, counters in KiB, FETCH_SIZE x2 per MI355X_MICROARCH.md), every dispatch of that step kept")
+    note = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE on one chain step of this workload (global step 1 of the "
+            "walked sweep) behind a warm-up step (two child runs, counters in KiB, FETCH_SIZE x2 per MI355X_MICROARCH.md), "
+            "every dispatch of that step kept")
     return out, note
 
 
@@ -272,24 +308,24 @@ def class_name(tag):
     return " + ".join(CLASS_NAMES[b] for b in (1, 2, 4, 8) if tag & b) if tag else CLASS_NAMES[0]
 
 
-def roofline_block(m, n, nb, esz, dev, kernel_name, steps, traffic=None):
+def roofline_block(m, n, nb, esz, dev, kernel_name, steps, traffic=None, traffic_step=1):
     """`achieved` = algorithmic bytes of one pass over the batch / mean HIP-event time of the launches that skip nothing.
-    With ``traffic`` (measure_traffic): per class of launch and for all pass launches of a step the bytes the counters
-    saw, next to the event times of the same launches -- no estimate anywhere."""
+    `classes`: per class of launch the mean event time over every timed launch of that class and -- with ``traffic``
+    (measure_traffic: the launches of global step ``traffic_step``) -- the bytes the counters saw for the launches of
+    that class: no estimate anywhere."""
+    import numpy as np
+
     pass_bytes = 2 * esz * n * n * nb  # one pass over the batch: every element read + written once
     ms, tags = m["launch_ms"], m["launch_tags"]
     full = tags == 0
     full_ms = float(ms[full].mean()) if full.any() else 0.0
     achieved = pass_bytes / (full_ms * 1e-3) / 1e9 if full.any() else 0.0
     y_ms, y_bytes = dev.copy_yardstick(10)
-    per_step = ms.size // max(steps, 1)
-    folded = ms[:per_step * steps].reshape(steps, per_step).mean(axis=0) if per_step and ms.size == per_step * steps else None
-    step_tags = tags[:per_step] if folded is not None else None
     block = {
         "bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
         "traffic_note": "not measured in this run (--no-traffic, an `extra` entry, or N > 1); per-kernel FETCH_SIZE / WRITE_SIZE "
-                        "of the default command under rocprofv3: profiles/r03_pmc_hbm_traffic_bench.txt",
+                        "of the default command under rocprofv3: profiles/r04_pmc_hbm_traffic_bench.txt",
         "launches": int(full.sum()), "avg_launch_ms": full_ms, "algorithmic_bytes_per_launch": pass_bytes,
         "pruned": {"launches": int((~full).sum()), "avg_launch_ms": float(ms[~full].mean()) if (~full).any() else 0.0,
                    "what": "pass launches next to an aperture that skip the tiles / loads of rows or columns it has zeroed, "
@@ -301,44 +337,139 @@ def roofline_block(m, n, nb, esz, dev, kernel_name, steps, traffic=None):
                            "what": "measured in this run (paos_copy_yardstick): in-place copy of the same batch buffer, "
                                    "16 B per lane, unit stride, no transform"},
     }
-    if folded is not None:
-        classes = {}
-        for i in range(per_step):
-            rec = classes.setdefault(class_name(int(step_tags[i])), {"launches_per_step": 0, "ms": 0.0, "bytes_measured": None})
-            rec["launches_per_step"] += 1
-            rec["ms"] += float(folded[i])
-        measured = traffic is not None and len(traffic["pass"]) == per_step
-        if measured:
-            for i in range(per_step):
-                rec = classes[class_name(int(step_tags[i]))]
-                rec["bytes_measured"] = (rec["bytes_measured"] or 0.0) + sum(traffic["pass"][i])
-        for rec in classes.values():
-            k = rec["launches_per_step"]
-            rec["avg_launch_ms"] = rec.pop("ms") / k
-            if rec["bytes_measured"] is not None:
-                rec["bytes_measured"] /= k
-                rec["GBps_measured"] = rec["bytes_measured"] / (rec["avg_launch_ms"] * 1e-3) / 1e9
-                rec["frac_measured"] = rec["GBps_measured"] / HBM_PEAK_GBS
-        block["classes"] = classes
-        block["all_launches"] = {"launches_per_step": per_step, "ms": float(folded.sum()), "bytes_measured": None, "frac": None,
-                                 "what": "every pass launch of one step: HIP-event time (mean over the timed steps) and, when "
-                                         "the counters were collected, the HBM bytes they saw for the same launches"}
-        if measured:
-            total = sum(r + w for r, w in traffic["pass"])
-            block["all_launches"]["bytes_measured"] = total
-            block["all_launches"]["frac"] = total / (float(folded.sum()) * 1e-3) / 1e9 / HBM_PEAK_GBS
-            fulls = [sum(traffic["pass"][i]) for i in range(per_step) if step_tags[i] == 0]
-            reads = [traffic["pass"][i][0] for i in range(per_step) if step_tags[i] == 0]
-            if fulls:
-                block["traffic"] = sum(fulls) / len(fulls)
-                block["traffic_over_algorithmic"] = block["traffic"] / pass_bytes
-                block["traffic_note"] = (f"mean over the {len(fulls)} of {per_step} pass launches of a step that skip nothing: read "
-                                         f"{sum(reads) / len(reads) / 1e9:.3f} GB + written "
-                                         f"{(sum(fulls) - sum(reads)) / len(fulls) / 1e9:.3f} GB per launch")
+    counts = [c for c in m["per_step_passes"] if c is not None]
+    if not ms.size or len(counts) != steps or sum(counts) != ms.size:
+        return block  # (a generic-kernel pass that is not timed: the launches cannot be cut into steps)
+    bounds = np.concatenate([[0], np.cumsum(counts)])
+    classes = {}
+    for t in sorted(set(int(x) for x in tags)):
+        sel = tags == t
+        classes[class_name(t)] = {"launches_per_step": float(sel.sum()) / steps, "avg_launch_ms": float(ms[sel].mean()),
+                                  "bytes_measured": None}
+    block["classes"] = classes
+    block["all_launches"] = {"launches_per_step": float(ms.size) / steps, "ms": float(ms.sum()) / steps, "bytes_measured": None,
+                             "frac": None,
+                             "what": "every pass launch of one step: HIP-event time (mean over the timed steps) and, when "
+                                     "the counters were collected, the HBM bytes they saw for the launches of one step"}
+    # the counted step of the traffic children is global step `traffic_step`: its launches carry the tags of the same
+    # step of this run when it lies in the timed region, of the first timed step otherwise (same chain, other wavelengths)
+    s = traffic_step - m["first_timed_step"]
+    s = s if 0 <= s < steps else 0
+    step_tags = tags[bounds[s]:bounds[s + 1]]
+    if traffic is not None and len(traffic["pass"]) == len(step_tags):
+        per_class = {}
+        for tag, (rd, wr) in zip(step_tags, traffic["pass"]):
+            per_class.setdefault(class_name(int(tag)), []).append(rd + wr)
+        for name, vals in per_class.items():
+            rec = classes[name]
+            rec["bytes_measured"] = sum(vals) / len(vals)
+            rec["GBps_measured"] = rec["bytes_measured"] / (rec["avg_launch_ms"] * 1e-3) / 1e9
+            rec["frac_measured"] = rec["GBps_measured"] / HBM_PEAK_GBS
+        total = sum(r + w for r, w in traffic["pass"])
+        block["all_launches"]["bytes_measured"] = total
+        block["all_launches"]["frac"] = total / (block["all_launches"]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        fulls = [r + w for t, (r, w) in zip(step_tags, traffic["pass"]) if t == 0]
+        reads = [r for t, (r, w) in zip(step_tags, traffic["pass"]) if t == 0]
+        if fulls:
+            block["traffic"] = sum(fulls) / len(fulls)
+            block["traffic_over_algorithmic"] = block["traffic"] / pass_bytes
+            block["traffic_note"] = (f"mean over the {len(fulls)} of {len(step_tags)} pass launches of a step that skip nothing: read "
+                                     f"{sum(reads) / len(reads) / 1e9:.3f} GB + written "
+                                     f"{(sum(fulls) - sum(reads)) / len(fulls) / 1e9:.3f} GB per launch")
     return block
 
 
-def main():
+def sweep_report(m):
+    """What the walked sweep did to the context's kept aperture line records, per timed step."""
+    sets = m["per_step_sets"]
+    return {"walked": True, "wavelengths_in_sweep": SWEEP,
+            "record_sets_found_per_step": [a for a, _ in sets], "record_sets_rendered_per_step": [b for _, b in sets],
+            "what": "step g runs the next block of the 512-wavelength sweep (mod 512), so what the context keeps between "
+                    "batches is hit or missed as in a real sweep: aperture line records found in / rendered into its kept "
+                    "sets, per timed step (paos_record_set_stats)"}
+
+
+# ---- self-launch: `bench.py --gpus N` with no launcher ------------------------------------------------------------
+def self_launch(n_ranks, argv, child=None, timeout=3000.0, env_extra=None, grace=30.0):
+    """Start ``n_ranks`` copies of this script (``child``: another command, for tests) as one job and relay rank 0's
+    stdout.  The parent never touches a GPU -- no HIP call, no library load -- so its children are ordinary fresh
+    processes (nothing is exec'ed from a process that holds a GPU context).  Every rank gets RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT and a job key of its own (PAOS_COMM_KEY), like a launcher would set them.
+    Returns the exit code: 0 when every rank returned 0, else the first non-zero one; when a rank fails the others are
+    given ``grace`` seconds to finish and are then terminated (by PID)."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    key = f"bench_{os.getpid()}_{time.time_ns()}"
+    one_gpu = os.environ.get("PAOS_BENCH_REHEARSAL") == "1"
+    cmd = list(child) if child else [sys.executable, os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(0 if one_gpu else r), WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PAOS_COMM_KEY=key, PAOS_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.update(env_extra or {})
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    deadline = time.monotonic() + timeout
+    first_bad, grace_until = None, None
+    import threading
+
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    while any(p.poll() is None for p in procs):
+        now = time.monotonic()
+        for r, p in enumerate(procs):
+            if p.poll() not in (None, 0) and first_bad is None:
+                first_bad, grace_until = (r, p.returncode), now + grace
+        if now > deadline or (grace_until is not None and now > grace_until):
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            time.sleep(2.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            if first_bad is None:
+                first_bad = (-1, 124)
+                print(f"bench.py: the ranks did not finish within {timeout:.0f} s", file=sys.stderr)
+            break
+        time.sleep(0.05)
+    reader.join(timeout=10.0)
+    if out0 and out0[0]:
+        sys.stdout.write(out0[0].decode(errors="replace"))
+        sys.stdout.flush()
+    codes = [p.returncode for p in procs]
+    if first_bad is None:
+        bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+        first_bad = bad[0] if bad else None
+    if first_bad is not None:
+        print(f"bench.py: rank exit codes {codes}", file=sys.stderr)
+        return first_bad[1] if first_bad[1] not in (None, 0) else 1
+    return 0
+
+
+def no_rccl_line(args, comm, world, local_rank):
+    """The record of a scaling run that could not use RCCL (exit 3): how far the bring-up got, per rank."""
+    notes = comm.gather_text(comm.bringup_note or "")
+    seen = [int(p[0]) for p in comm.allgather_scalars([float(local_rank)])]
+    if comm.rank != 0:
+        return
+    print(json.dumps({
+        "metric": f"wavefronts/sec ({args.grid}^2 {'c128' if args.precision == 'fp64' else 'c64'}, 20-surface chain) + achieved HBM GB/s",
+        "value": None, "unit": "wavefronts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+        "error": "RCCL did not come up on every rank: the ranks agreed on the TCP transport and --allow-tcp was not given "
+                 "(exit 3, nothing was measured)",
+        "config": {"workload": "not run", "grid": args.grid, "transport": comm.transport, "transport_requested": "rccl",
+                   "ranks_seen": len(seen), "devices_seen": seen,
+                   "bringup_notes": {str(r): t for r, t in enumerate(notes)}}}), flush=True)
+
+
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC child runs that measure roofline.traffic")
@@ -348,21 +479,24 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="wavefronts per GPU per step (default: 32 at 4096^2 = 8 GiB of fields + 4 GiB of PSFs of the 288 GB)")
     ap.add_argument("--precision", default="fp64", choices=["fp64", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the 2048^2 / 1024^2 entries")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra entries (other grids, fp32, dense, BASELINE configs)")
     ap.add_argument("--allow-tcp", action="store_true",
                     help="with --gpus N > 1: accept the TCP transport when RCCL does not come up on every rank (default: exit 3)")
+    ap.add_argument("--launch-timeout", type=float, default=3000.0, help="self-launch: seconds the ranks may take")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)  # one chain step and nothing else (measure_traffic)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     if args.batch <= 0:
         # 8 -> 32 wavefronts per step is +3 % (launch tails and host work amortised; 64: +0.3 % more): 217 -> 224 at 4096^2
         args.batch = max(32, 32 * (4096 // args.grid) ** 2)
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher: start the ranks ourselves, before anything here touches a GPU
+        sys.exit(self_launch(args.gpus, sys.argv[1:] if argv is None else argv, timeout=args.launch_timeout))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
         args.gpus = world
 
     # forked CPU workers: before anything initialises the GPU in this process
@@ -377,17 +511,16 @@ def main():
     if world == 1 and not args.no_traffic:
         traffic_result = measure_traffic(args.grid, args.batch, args.precision)
 
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     from paos_amd import _lib
-    from paos_amd.chains import syn20_chain
+    from paos_amd.chains import syn20_chain, syn20_wavelength
     from paos_amd.dist import broadcast_work, shard_bounds, syn20_work
 
     comm = None
     if world > 1 or os.environ.get("PAOS_BENCH_FORCE_COMM") == "1":
-        from paos_amd.comm import Comm
+        from paos_amd.comm import Comm  # (exports HSA_ENABLE_IPC_MODE_LEGACY=0 unless set: before the first HIP call)
 
         if os.environ.get("PAOS_BENCH_REHEARSAL") == "1":
-            # several ranks sharing ONE GPU over the TCP transport: rehearses the N > 1 control flow (broadcast,
+            # several ranks sharing ONE GPU over the TCP transport: rehearses the N > 1 control flow (launch, broadcast,
             # shards, barrier, MAX reduction) on a single-GPU box; the numbers mean nothing
             local_rank = 0
             comm = Comm.from_env(transport="socket")
@@ -395,27 +528,33 @@ def main():
             comm = Comm.from_env(transport="rccl", timeout=900.0)  # one process per GPU, RCCL over xGMI
             if comm.transport != "rccl" and world > 1 and not args.allow_tcp:
                 # the agreement is collective (paos_comm_init_rank): every rank sees the same transport and leaves here
+                no_rccl_line(args, comm, world, local_rank)
                 if rank == 0:
                     print("bench.py: --gpus %d was asked for but RCCL did not come up on every rank (the ranks agreed on the "
                           "TCP transport); pass --allow-tcp to measure anyway" % world, file=sys.stderr)
+                comm.barrier()
                 comm.close()
                 sys.exit(3)
 
     n, nb = args.grid, args.batch
     total = nb * world
+    # the ONE broadcast: the sweep's coefficient table (rank 0 -> everybody); wavelengths follow from the step number
     work = syn20_work(total, "wavelengths") if rank == 0 else None
-    work = broadcast_work(work, comm)  # the ONE broadcast
+    work = broadcast_work(work, comm)
     lo, hi = shard_bounds(total, rank, world)
-    wavelengths = work["wavelengths"][lo:hi]
     chains = [syn20_chain(coefficients=c) for c in work["coefficients"][lo:hi]]
 
+    def wavelengths_of(g):
+        return [syn20_wavelength(k) for k in sweep_block(g, total, lo, hi)]
+
     dev = _lib.DeviceFields(n, nb, args.precision, device=local_rank)
-    m = measure(dev, n, nb, args.precision, wavelengths, chains, args.steps, args.warmup, comm)
+    m = measure(dev, n, args.precision, wavelengths_of, chains, args.steps, args.warmup, comm)
     if args.traffic_child:  # measure_traffic's child: one step, every dispatch of which is counted
         dev.close()
         return
     # who took part, as the communicator saw it: rank r's device ordinal, gathered over the data plane
     ranks_seen = [int(p[0]) for p in comm.allgather_scalars([float(local_rank)])] if comm is not None else [local_rank]
+    notes = comm.gather_text(comm.bringup_note or "") if comm is not None else []
     esz = 16 if args.precision == "fp64" else 8
     frugal = n >= (1024 if args.precision == "fp64" else 2048)
     kernel_name = ("frugal_pass_kernel" if frugal else "fused_pass_kernel") + " (every FFT pass launch, rows and columns)"
@@ -425,7 +564,7 @@ def main():
         # alone with the pass timer (3 launches: rows | cols x2 fused | rows).
         from paos_amd.planner import PilotBeam
 
-        blk = [PilotBeam(1.0, wl, n, 4).ptp(2.5) for wl in wavelengths]
+        blk = [PilotBeam(1.0, wl, n, 4).ptp(2.5) for wl in wavelengths_of(0)]
         for _ in range(2):
             dev.ptp(blk)
         dev.profile_begin(_lib.KERNEL_PASS_ANY, max_launches=64)
@@ -442,13 +581,14 @@ def main():
 
             ppasses.PTP_ALGEBRA = False
             try:
-                mp = measure(dev, n, nb, args.precision, wavelengths, chains, min(args.steps, 3), 1, None)
-                plain = {"value": nb * min(args.steps, 3) / mp["elapsed"], "unit": "wavefronts/s",
+                mp = measure(dev, n, args.precision, wavelengths_of, chains, args.steps, 1, None, first_step=args.warmup - 1)
+                plain = {"value": nb * args.steps / mp["elapsed"], "unit": "wavefronts/s", "steps": args.steps,
                          "fused_passes_per_wavefront": mp["fused_passes"],
-                         "what": "PAOS_PTP_ALGEBRA=0: consecutive ptp neither share a middle pass nor cancel"}
+                         "what": "PAOS_PTP_ALGEBRA=0 over the same steps of the walked sweep: consecutive ptp neither share a "
+                                 "middle pass nor cancel, a wts and the stw that undoes it both run"}
             finally:
                 ppasses.PTP_ALGEBRA = True
-        n_ptp, n_stw, n_wts = chain_fft_counts(wavelengths[0], n)
+        n_ptp, n_stw, n_wts = chain_fft_counts(wavelengths_of(0)[0], n)
         ffts = 2 * n_ptp + n_stw + n_wts
         survey_bytes = (ffts * 4 * esz + 8) * n * n  # 2 passes x (read + write) per 2-D FFT + the 8 B/px PSF write
         # bytes the fused path really moves: every dispatch of one step under the FETCH_SIZE / WRITE_SIZE counters
@@ -459,6 +599,7 @@ def main():
                            sum(k["read"] + k["written"] for k in traffic["other"].values())) / nb
         per_gpu = value / world
         dtype = "c128 (f64)" if args.precision == "fp64" else "c64 (f32, f64 phase arguments)"
+        passes_seen = sorted(set(c for c in m["per_step_passes"] if c is not None))
         out = {
             "metric": f"wavefronts/sec ({n}^2 {'c128' if esz == 16 else 'c64'}, 20-surface chain) + achieved HBM GB/s",
             "value": value,
@@ -472,18 +613,23 @@ def main():
             "vs_baseline": None,
             "dtype": dtype,
             "data": "synthetic",
-            "config": {"workload": f"SYN20 20-surface chain, {n}x{n} {args.precision}, wavelength sweep 1um*(1+k/512), "
-                                   f"{nb} wavefronts/GPU/step, {ffts} 2-D FFTs per wavefront ({n_ptp} ptp, {n_stw} stw, "
-                                   f"{n_wts} wts as the reference executes them; the pass compiler runs them as "
-                                   f"{m['fused_passes']} fused passes: at each of the chain's five foci the reference steps "
-                                   f"ptp(+d), ptp(-d) with d = 1.6 nm, which cancel algebraically (H(-d) H(d) = 1, "
-                                   f"fft2(ifft2(X)) = X; same results to 1e-15, `without_ptp_algebra` gives the rate with every "
-                                   f"ptp run on its own); the final |u|^2 of every wavefront is written to HBM (8 B/px) and stays "
-                                   f"there, powers of the saved surfaces are reduced on the GPU; aperture line records are "
-                                   f"kept per context and found again by later steps (same optics)",
+            "config": {"workload": f"SYN20 20-surface chain, {n}x{n} {args.precision}, WALKED wavelength sweep 1um*(1+k/512): step g "
+                                   f"runs k = g*{total} ... (mod 512), {nb} wavefronts/GPU/step, {ffts} 2-D FFTs per wavefront "
+                                   f"({n_ptp} ptp, {n_stw} stw, {n_wts} wts as the reference executes them at the first "
+                                   f"wavelength; the pass compiler runs a step as {passes_seen} fused passes: at each of the "
+                                   f"chain's five foci the reference steps ptp(+d), ptp(-d) with d = 1.6 nm, which cancel "
+                                   f"algebraically (H(-d) H(d) = 1, fft2(ifft2(X)) = X; same results to 1e-15, "
+                                   f"`without_ptp_algebra` gives the rate with every ptp run on its own); the final |u|^2 of "
+                                   f"every wavefront is written to HBM (8 B/px) and stays there, powers of the saved surfaces "
+                                   f"are reduced on the GPU; aperture line records are kept per context and found again "
+                                   f"where the next batch samples an aperture alike (`sweep`)",
                        "grid": n, "batch_per_gpu": nb, "parallelism": f"wavefront-sharded x{world}",
                        "transport": comm.transport if comm is not None else "none (single process)",
-                       "ranks_seen": len(ranks_seen), "devices_seen": ranks_seen},
+                       "launcher": "self (bench.py started the ranks)" if os.environ.get("PAOS_BENCH_SELF_LAUNCHED") == "1"
+                                   else ("external (WORLD_SIZE from the environment)" if world > 1 else "none"),
+                       "ranks_seen": len(ranks_seen), "devices_seen": ranks_seen,
+                       "bringup_notes": {str(r): t for r, t in enumerate(notes) if t}},
+            "sweep": sweep_report(m),
             "roofline": roofline_block(m, n, nb, esz, dev, kernel_name, args.steps, traffic),
             "chain_vs_survey_model": {
                 "survey_model_bytes_per_wavefront": survey_bytes,
@@ -507,21 +653,9 @@ def main():
         }
         dev.close()
         if world == 1 and not args.no_extras and n == 4096:
-            extra = {}
-            for n2, nb2 in ((2048, 64), (1024, 256)):
-                w2 = syn20_work(nb2, "wavelengths")
-                ch2 = [syn20_chain(coefficients=c) for c in w2["coefficients"]]
-                dev2 = _lib.DeviceFields(n2, nb2, args.precision)
-                m2 = measure(dev2, n2, nb2, args.precision, w2["wavelengths"], ch2, max(args.steps, 5), max(args.warmup, 2))
-                fr2 = n2 >= (1024 if args.precision == "fp64" else 2048)
-                extra[f"{n2}^2"] = {
-                    "value": nb2 * max(args.steps, 5) / m2["elapsed"], "unit": "wavefronts/s", "batch": nb2,
-                    "ms_per_step": 1e3 * m2["elapsed"] / max(args.steps, 5),
-                    "roofline": roofline_block(m2, n2, nb2, esz, dev2,
-                                               ("frugal_pass_kernel" if fr2 else "fused_pass_kernel") + " (every FFT pass launch)",
-                                               max(args.steps, 5))}
-                dev2.close()
-            out["extra"] = extra
+            from bench_extras import extras
+
+            out["extra"] = extras(args, esz, measure, roofline_block, sweep_report)
         if traffic_result is not None:
             out["roofline"]["counters_note"] = traffic_result[1]
         if world == 1 and not args.no_cpu_baseline:

@@ -15,7 +15,13 @@
  * Bootstrap: rank 0 listens on an ephemeral port and publishes it in the rendezvous file
  * `<dir>/paos_comm_<key>` (written atomically); the other ranks poll the file and connect.  `key` must
  * be the same on every rank of one job and unique per job on the host (bench.py uses
- * MASTER_PORT + TORCHELASTIC_RUN_ID of the launcher).  Single node, like the launch contract.
+ * MASTER_PORT + TORCHELASTIC_RUN_ID of the launcher, or a key of its own when it starts the ranks itself).
+ * Single node, like the launch contract.  The two ends of a fresh connection exchange hello / reply / acknowledgement
+ * (magic, hash of the key, world size, rank); rank 0 counts a rank only once the acknowledgement is in.
+ * Environment: paos_comm_init_rank(PAOS_COMM_RCCL) exports HSA_ENABLE_IPC_MODE_LEGACY=0 unless the variable is
+ * already set (dmabuf IPC, which RCCL needs on these hosts); it takes effect only when no HIP call has been made
+ * in the process before -- create the communicator first, or export the variable yourself.
+ * If paos_comm_init_rank fails with "ncclCommInitRank did not return" the process must exit (never re-exec it).
  *
  * Every function returns 0 on success, a PAOS_E* code of paos_hip.h otherwise; paos_comm_last_error()
  * gives the message of the calling thread's last failure.
@@ -44,6 +50,11 @@ int paos_comm_rank(const paos_comm* comm);
 int paos_comm_size(const paos_comm* comm);
 int paos_comm_transport(const paos_comm* comm);
 const char* paos_comm_last_error(void);
+/* After a PAOS_COMM_RCCL request that ended on the TCP transport: what kept RCCL from coming up on THIS rank
+ * (library not found, device error, the text of the ncclCommInitRank failure), or that it did come up here but not
+ * on every rank; "" when RCCL is in use or was never asked for.  bench.py --gpus N gathers these into the record
+ * it prints when a scaling run cannot use RCCL (a diagnosable failure instead of a silent one). */
+const char* paos_comm_bringup_note(const paos_comm* comm);
 
 /* Size first: root passes its length in *bytes, the others receive it (so that they can allocate). */
 int paos_comm_bcast_size(paos_comm* comm, unsigned long long* bytes, int root);

@@ -217,6 +217,10 @@ int paos_run_passes(paos_ctx* ctx, const paos_pass* passes, int n_passes, const 
  * 16 B per lane, unit stride), `reps` launches timed with HIP events on the context's stream: the
  * yardstick bench.py prints next to the pass kernels' rate.  The field is left as it was. */
 int paos_copy_yardstick(paos_ctx* ctx, int reps, double* ms_per_launch, double* bytes_per_launch);
+/* Measurement aid: how often, since the context was created, a pass that carries an aperture (WFO.aperture,
+ * wfo.py:246-276, riding on a pass as line records) found its records in one of the context's kept sets
+ * (*found) and how often it had to render them (*rendered).  bench.py reports both per step of its walked sweep. */
+int paos_record_set_stats(paos_ctx* ctx, unsigned long long* found, unsigned long long* rendered);
 /* Measurement / test aid: on = 0 makes every pass process every tile (no dead-line pruning). */
 int paos_ctx_set_pruning(paos_ctx* ctx, int on);
 int paos_run_passes_live(paos_ctx* ctx, const paos_pass* passes, int n_passes, const double* blocks,

@@ -80,6 +80,7 @@ SYMBOLS = {
     "paos_wts": (ctypes.c_int, [_c_ctx, _dbl_p, ctypes.c_int]),
     "paos_run_passes": (ctypes.c_int, [_c_ctx, ctypes.POINTER(Pass), ctypes.c_int, _dbl_p, ctypes.c_int]),
     "paos_copy_yardstick": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p, _dbl_p]),
+    "paos_record_set_stats": (ctypes.c_int, [_c_ctx, ctypes.POINTER(ctypes.c_ulonglong), ctypes.POINTER(ctypes.c_ulonglong)]),
     "paos_ctx_set_pruning": (ctypes.c_int, [_c_ctx, ctypes.c_int]),
     "paos_run_passes_live": (ctypes.c_int, [_c_ctx, ctypes.POINTER(Pass), ctypes.c_int, _dbl_p, ctypes.c_int, _dbl_p]),
     "paos_zernike": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, _dbl_p, _dbl_p, ctypes.c_int, _dbl_p]),
@@ -435,6 +436,13 @@ class DeviceFields:
         self._check(self._lib.paos_copy_yardstick(self._ctx, int(reps), ctypes.byref(ms), ctypes.byref(nbytes)),
                     "paos_copy_yardstick")
         return ms.value, nbytes.value
+
+    def record_set_stats(self):
+        """(found, rendered): aperture line records found in the context's kept sets / rendered anew, since creation."""
+        found, rendered = ctypes.c_ulonglong(0), ctypes.c_ulonglong(0)
+        self._check(self._lib.paos_record_set_stats(self._ctx, ctypes.byref(found), ctypes.byref(rendered)),
+                    "paos_record_set_stats")
+        return int(found.value), int(rendered.value)
 
     def set_pruning(self, on):
         """Dead-line pruning of the pass programs on (default) / off -- results are identical."""

@@ -12,6 +12,11 @@ import numpy as np
 
 from . import _lib
 
+# RCCL's buffer exchange between processes needs dmabuf IPC on these hosts; the variable is read when the HSA runtime
+# starts, i.e. it must be in the environment before the FIRST HIP call of the process -- so it is set when this module
+# is imported (paos_comm_init_rank sets it too, for callers of the C ABI).  A value the user exported is kept.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 SOCKET, RCCL = 0, 1
 _c_comm = ctypes.c_void_p
 _dbl_p = ctypes.POINTER(ctypes.c_double)
@@ -24,6 +29,7 @@ SYMBOLS = {
     "paos_comm_size": (ctypes.c_int, [_c_comm]),
     "paos_comm_transport": (ctypes.c_int, [_c_comm]),
     "paos_comm_last_error": (ctypes.c_char_p, []),
+    "paos_comm_bringup_note": (ctypes.c_char_p, [_c_comm]),
     "paos_comm_bcast_size": (ctypes.c_int, [_c_comm, ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]),
     "paos_comm_bcast_blob": (ctypes.c_int, [_c_comm, ctypes.c_void_p, ctypes.c_ulonglong, ctypes.c_int]),
     "paos_comm_allgather_scalars": (ctypes.c_int, [_c_comm, _dbl_p, ctypes.c_int, _dbl_p]),
@@ -67,6 +73,9 @@ class Comm:
         # the transport in use: "rccl" falls back to "socket" on every rank when RCCL cannot come up on all of them
         actual = {SOCKET: "socket", RCCL: "rccl"}[self._lib.paos_comm_transport(self._h)]
         self.rank, self.size, self.transport, self.device = int(rank), int(nranks), actual, int(device)
+        self.requested = transport
+        # why an RCCL request ended on TCP, as seen from this rank ("" otherwise)
+        self.bringup_note = (self._lib.paos_comm_bringup_note(self._h) or b"").decode()
 
     @classmethod
     def from_env(cls, transport=None, timeout=300.0):
@@ -133,6 +142,12 @@ class Comm:
             parts.append(out[o:o + counts[r]].copy())
             o += counts[r]
         return parts
+
+    def gather_text(self, text, limit=240):
+        """Every rank's short ASCII note (e.g. ``bringup_note``), indexed by rank -- over the scalar gather, one
+        double per character: diagnostics only."""
+        codes = [float(b) for b in text.encode("ascii", "replace")[:limit]]
+        return ["".join(chr(int(x)) for x in part) for part in self.allgather_scalars(codes)]
 
     def max(self, value):
         x = ctypes.c_double(float(value))

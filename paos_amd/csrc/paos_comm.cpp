@@ -141,6 +141,7 @@ struct paos_comm {
   hipStream_t stream = nullptr;
   void* dbuf = nullptr;  // device staging
   size_t dcap = 0;
+  std::string bringup_note;  // why RCCL is not in use on THIS rank ("" = it is, or it was never asked for)
 };
 
 namespace {
@@ -258,14 +259,28 @@ int connect_star(paos_comm* c, const std::string& path, unsigned key_hash, doubl
         ::close(fd);  // a stranger (port scan, a rank of another job reading a stale file): keep waiting
         continue;
       }
-      if (hi.rank <= 0 || hi.rank >= c->nranks || c->fds[hi.rank] != -1) {
+      if (hi.rank <= 0 || hi.rank >= c->nranks) {
         ::close(fd);
         ::unlink(path.c_str());
-        return cfail(PAOS_EINVAL, "a peer announced an invalid or duplicate rank");
+        return cfail(PAOS_EINVAL, "a peer announced an invalid rank");
       }
+      // Three-way: the rank acknowledges the reply before its socket is committed.  A rank that had queued in the
+      // backlog while a stranger was being waited for may have given up on this connection and come back on a new
+      // one: its hello is still buffered here and the reply would "succeed" into a closed peer -- the missing
+      // acknowledgement (EOF / timeout) tells, and the connection is dropped instead of being counted.
       const Hello reply{kHelloMagic, key_hash, c->nranks, 0};
-      if (!send_all(fd, &reply, sizeof(reply))) { ::close(fd); continue; }
+      Hello ack{};
+      if (!send_all(fd, &reply, sizeof(reply)) || !recv_all(fd, &ack, sizeof(ack)) || ack.magic != kHelloMagic ||
+          ack.key_hash != key_hash || ack.nranks != c->nranks || ack.rank != hi.rank) {
+        ::close(fd);
+        continue;
+      }
       set_recv_timeout(fd, 0.0);
+      if (c->fds[hi.rank] != -1) {  // the same rank again on a fresh connection: the newer one is the live one
+        ::close(c->fds[hi.rank]);
+        c->fds[hi.rank] = fd;
+        continue;
+      }
       c->fds[hi.rank] = fd;
       ++got;
     }
@@ -294,9 +309,10 @@ int connect_star(paos_comm* c, const std::string& path, unsigned key_hash, doubl
         // does not know the job's key, and the connection is dropped and retried
         const Hello hi{kHelloMagic, key_hash, c->nranks, c->rank};
         Hello reply{};
-        set_recv_timeout(fd, 2.0);
+        // (rank 0 serialises its accepts and gives a silent stranger 2 s: allow for a few of those ahead of us)
+        set_recv_timeout(fd, 2.0 * c->nranks + 4.0);
         if (send_all(fd, &hi, sizeof(hi)) && recv_all(fd, &reply, sizeof(reply)) && reply.magic == kHelloMagic &&
-            reply.key_hash == key_hash && reply.nranks == c->nranks && reply.rank == 0) {
+            reply.key_hash == key_hash && reply.nranks == c->nranks && reply.rank == 0 && send_all(fd, &hi, sizeof(hi))) {
           set_recv_timeout(fd, 0.0);
           c->fds.assign(1, fd);
           return PAOS_OK;
@@ -314,6 +330,7 @@ int connect_star(paos_comm* c, const std::string& path, unsigned key_hash, doubl
 extern "C" {
 
 const char* paos_comm_last_error(void) { return g_comm_err.c_str(); }
+const char* paos_comm_bringup_note(const paos_comm* c) { return c ? c->bringup_note.c_str() : ""; }
 int paos_comm_rank(const paos_comm* c) { return c ? c->rank : -1; }
 int paos_comm_size(const paos_comm* c) { return c ? c->nranks : -1; }
 int paos_comm_transport(const paos_comm* c) { return c ? c->transport : -1; }
@@ -354,6 +371,11 @@ int paos_comm_init_rank(int nranks, int rank, int device, int transport, const c
     if (rc) { paos_comm_destroy(c); return rc; }
   }
   if (transport == PAOS_COMM_RCCL) {
+    // The host driver of these nodes only supports dmabuf IPC: without this RCCL's cross-process buffer exchange fails
+    // with "hipIpcGetMemHandle: invalid argument".  It is read when the HSA runtime initialises, i.e. it only takes
+    // effect if this is (before) the first HIP call of the process -- paos_amd.comm.Comm also sets it at import.  A
+    // value the user has exported is left alone.
+    ::setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
     // RCCL is the data plane when every rank can bring it up; the ranks agree over the control plane after each
     // step that may fail on some of them only, and otherwise ALL continue on the TCP transport -- a rank that
     // skipped ncclCommInitRank would leave the others waiting in it.
@@ -408,9 +430,13 @@ int paos_comm_init_rank(int nranks, int rank, int device, int transport, const c
       }
       if (!finished) {
         // the communicator object stays allocated: the helper thread may still touch what it was given
+        // ... but it never sees the sockets or the stream: those go.  The caller must treat this as fatal and let the
+        // process EXIT (non-zero) -- never re-exec it: a thread is still inside RCCL and holds the GPU.
         for (int fd : c->fds)
           if (fd >= 0) ::close(fd);
         c->fds.clear();
+        if (c->listen_fd >= 0) { ::close(c->listen_fd); c->listen_fd = -1; }
+        if (c->stream) { (void)hipStreamDestroy(c->stream); c->stream = nullptr; }
         return cfail(PAOS_EHIP, "ncclCommInitRank did not return within " + std::to_string((int)timeout_s) +
                                     " s (a rank is missing or its device is stuck): giving up");
       }
@@ -426,6 +452,7 @@ int paos_comm_init_rank(int nranks, int rank, int device, int transport, const c
     if (!all_ok) {
       if (c->nccl) { (void)c->rccl.CommDestroy(c->nccl); c->nccl = nullptr; }
       c->transport = PAOS_COMM_SOCKET;
+      c->bringup_note = ok ? "RCCL came up here, but not on every rank" : why;
       std::fprintf(stderr, "paos_comm: rank %d of %d continues on the TCP transport, RCCL is not usable on every rank%s%s\n", rank, nranks,
                    ok ? "" : " -- here: ", ok ? "" : why.c_str());
     }

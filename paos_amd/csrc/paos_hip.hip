@@ -116,6 +116,7 @@ struct paos_ctx {
   static constexpr int kMaskSets = 8;  // (SYN20: five relay apertures whose pixel radii differ in the last digits + the field stop)
   MaskSet mask_sets[kMaskSets];
   unsigned long long mask_clock = 0;
+  unsigned long long mask_hits = 0, mask_rendered = 0;  // paos_record_set_stats
   int* mask_overflow = nullptr;    // device counter: partial runs that did not fit (must stay 0)
   double* partial = nullptr;
   double* norm2 = nullptr;
@@ -268,6 +269,22 @@ struct FftCfg {
   static constexpr int MINW = 1;
 };
 
+// The launch timer (paos_profile_begin): every timed launch site brackets its launch with this pair, so that event
+// pair i and tag i always belong to the same launch -- the tag is stored where (and only where) the closing event is.
+bool timed_launch_begin(paos_ctx* c, int kind) {
+  const bool timed = (c->prof_kind == kind || c->prof_kind == PAOS_KERNEL_PASS_ANY) && (c->prof_used + 2 <= c->prof_events.size());
+  // (a failure to record the opening event switches the timing of this launch off; the launch itself goes ahead)
+  return timed && hipEventRecord(c->prof_events[c->prof_used], c->stream) == hipSuccess;
+}
+hipError_t timed_launch_end(paos_ctx* c, int tag) {
+  const hipError_t e = hipEventRecord(c->prof_events[c->prof_used + 1], c->stream);
+  if (e != hipSuccess) return e;
+  c->prof_tags.resize(c->prof_used / 2, 0);  // pair i <-> tag i, whatever happened before
+  c->prof_tags.push_back(tag);
+  c->prof_used += 2;
+  return hipSuccess;
+}
+
 int opt_in_lds(paos_ctx* c, const void* kern, size_t lds) {
   static std::mutex mu;
   static std::set<std::pair<int, const void*>> configured;
@@ -287,16 +304,10 @@ int launch_pass(paos_ctx* c, Kern kern, dim3 grid, dim3 block, size_t lds, const
     int rc = opt_in_lds(c, (const void*)kern, lds);
     if (rc) return rc;
   }
-  const bool timed = (c->prof_kind == kind || c->prof_kind == PAOS_KERNEL_PASS_ANY) &&
-                     (c->prof_used + 2 <= c->prof_events.size());
-  if (timed) HIPCHK(c, hipEventRecord(c->prof_events[c->prof_used], c->stream));
+  const bool timed = timed_launch_begin(c, kind);
   hipLaunchKernelGGL(kern, grid, block, lds, c->stream, a);
   HIPCHK(c, hipGetLastError());
-  if (timed) {
-    HIPCHK(c, hipEventRecord(c->prof_events[c->prof_used + 1], c->stream));
-    c->prof_tags.push_back(0);
-    c->prof_used += 2;
-  }
+  if (timed) HIPCHK(c, timed_launch_end(c, 0));
   return PAOS_OK;
 }
 
@@ -590,16 +601,10 @@ int frugal_launch(paos_ctx* c, const FrugalArgs& args) {
     if (rc) return rc;
   }
   const int kind = AXIS == 0 ? PAOS_KERNEL_PASS_ROWS : PAOS_KERNEL_PASS_COLS;
-  const bool timed = (c->prof_kind == kind || c->prof_kind == PAOS_KERNEL_PASS_ANY) &&
-                     (c->prof_used + 2 <= c->prof_events.size());
-  if (timed) HIPCHK(c, hipEventRecord(c->prof_events[c->prof_used], c->stream));
+  const bool timed = timed_launch_begin(c, kind);
   hipLaunchKernelGGL(kern, grid, block, lds, c->stream, PAOS_FRUGAL_PASS(a));
   HIPCHK(c, hipGetLastError());
-  if (timed) {
-    HIPCHK(c, hipEventRecord(c->prof_events[c->prof_used + 1], c->stream));
-    c->prof_tags.push_back(c->prof_next_tag);
-    c->prof_used += 2;
-  }
+  if (timed) HIPCHK(c, timed_launch_end(c, c->prof_next_tag));
   return PAOS_OK;
 }
 
@@ -722,7 +727,7 @@ int assign_mask_set(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const doub
   ms.used = ++c->mask_clock;
   lp.mask_set = k;
   lp.mask_render = hit < 0;
-  if (hit < 0) ms.key = std::move(key);
+  if (hit < 0) { ms.key = std::move(key); ++c->mask_rendered; } else ++c->mask_hits;
   for (int it = 0; it < c->batch; ++it) {
     if (lp.mask_rep[it] < 0) continue;
     FrugalSlot& sl = lp.mask_slot == 0 ? lp.items[it].pre : lp.items[it].mid;
@@ -894,6 +899,10 @@ int run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double*
 int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks, int n_blocks,
                     const double* entry_rows, bool entry_stale, int* final_ticket) {
   if (!c || !passes || !blocks || n_passes < 0 || n_blocks < 1) return fail(c, PAOS_EINVAL, "bad pass program");
+  // A program that ends on the PSF gives the field up for it: the free power-ticket slot it will need is checked
+  // BEFORE anything is launched (found full afterwards, the context held neither field nor ticket).
+  if (final_ticket && c->norm_busy[c->norm_slot])
+    return fail(c, PAOS_EINVAL, "64 power reductions outstanding: fetch earlier tickets (paos_norm2_fetch) first");
   // The device sincos has no huge-argument path: bound every enabled phase operator here.
   for (int i = 0; i < n_passes; ++i) {
     const paos_pw_op* lists[3] = {passes[i].pre, passes[i].mid, passes[i].post};
@@ -1809,6 +1818,13 @@ int paos_phase_map(paos_ctx* c, int item, const double* host_wfe, double wl) {
 int paos_run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks, int n_blocks) {
   if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   return run_passes(c, passes, n_passes, blocks, n_blocks);
+}
+
+int paos_record_set_stats(paos_ctx* c, unsigned long long* found, unsigned long long* rendered) {
+  if (!c || !found || !rendered) return fail(c, PAOS_EINVAL, "bad record-set request");
+  *found = c->mask_hits;
+  *rendered = c->mask_rendered;
+  return PAOS_OK;
 }
 
 int paos_copy_yardstick(paos_ctx* c, int reps, double* ms_per_launch, double* bytes_per_launch) {

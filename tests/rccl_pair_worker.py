@@ -24,3 +24,20 @@ def run(rank, key, out):
         out.put((rank, comm.transport, text, comm.max(float(rank)), [list(p) for p in parts]))
     finally:
         comm.close()
+
+
+def run_bench(argv, env_extra, out):
+    """Started from the fork server (a process that never touched the GPU): runs bench.py as a child program and
+    hands back (exit code, stdout, tail of stderr)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "PAOS_COMM_KEY"):
+        env.pop(k, None)
+    env.update(env_extra)
+    run = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), env=env, cwd=root,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    out.put((run.returncode, run.stdout.decode(errors="replace"), run.stderr.decode(errors="replace")[-2000:]))

@@ -526,3 +526,52 @@ def test_record_sets_are_reused_and_evicted_correctly():
     for (k, x), (kk, y) in zip(b1, alone):
         assert k == kk and rel_err(x, y) < 1e-12, k
     assert rel_err(b1[-1][1], a1[-1][1]) > 1e-6  # the two chains really differ
+
+
+def test_bench_two_self_launched_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` with no launcher in the environment: bench.py starts its own two ranks before it
+    touches the GPU, they share this box's one GPU over the TCP transport (PAOS_BENCH_REHEARSAL=1: the N > 1 control
+    flow -- launch, rendezvous, ONE broadcast, shards, barrier, MAX -- end to end; the rate means nothing), and the
+    parent relays rank 0's JSON line.  Without --allow-tcp a run that did not end on RCCL exits 3 AND prints a line
+    with value null and every rank's bring-up note.  bench.py is started from the fork server (no exec from this
+    process, which holds a GPU context)."""
+    import json
+    import multiprocessing as mp
+
+    import rccl_pair_worker
+
+    ctx = mp.get_context("forkserver")
+    small = ["--gpus", "2", "--grid", "1024", "--batch", "4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline",
+             "--no-extras", "--no-traffic"]
+
+    def bench(argv, env):
+        out = ctx.Queue()
+        p = ctx.Process(target=rccl_pair_worker.run_bench, args=(argv, env, out))
+        p.start()
+        res = out.get(timeout=700)
+        p.join(timeout=60)
+        return res
+
+    rc, stdout, stderr = bench(small + ["--allow-tcp"], {"PAOS_BENCH_REHEARSAL": "1"})
+    assert rc == 0, (rc, stderr)
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["ranks_seen"] == 2
+    assert line["config"]["devices_seen"] == [0, 0] and line["config"]["transport"] == "socket"
+    assert line["config"]["launcher"].startswith("self") and line["sweep"]["walked"] is True
+    assert abs(line["power_check"] - 1.0) < 1e-9 or line["power_check"] > 0.0
+    print("two self-launched ranks on one GPU:", round(line["value"], 1), "wavefronts/s (rehearsal)", line["config"]["transport"])
+
+    # asking for RCCL with two ranks on a ONE-GPU box: rank 1 finds no device 1 -> the ranks agree on TCP -> exit 3
+    # with a null line that says so
+    rc, stdout, stderr = bench(small, {})
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    if rc == 3:
+        assert len(lines) == 1, (stdout, stderr)
+        line = json.loads(lines[0])
+        assert line["value"] is None and line["config"]["transport"] == "socket" and line["config"]["ranks_seen"] == 2
+        assert any(line["config"]["bringup_notes"].values()), line
+        print("no-RCCL record:", line["config"]["bringup_notes"])
+    else:  # RCCL accepted two ranks on one device (not seen so far), or the bring-up failed loudly: never a silent number
+        assert rc != 0 or (len(lines) == 1 and json.loads(lines[0])["config"]["transport"] == "rccl"), (rc, stdout, stderr)

@@ -9,10 +9,10 @@ from paos_amd.chains import syn20_chain, syn20_wavelength
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 precision = sys.argv[2] if len(sys.argv) > 2 else "fp64"
 nb = max(32, 32 * (4096 // n) ** 2)
-wls = [syn20_wavelength(k) for k in range(nb)]
 chains = [syn20_chain() for _ in range(nb)]
 dev = _lib.DeviceFields(n, nb, precision)
-m = bench.measure(dev, n, nb, precision, wls, chains, 4, 1)
+# (the same 32 wavelengths every step: per-launch times of ONE program; bench.py itself walks the sweep)
+m = bench.measure(dev, n, precision, lambda g: [syn20_wavelength(k) for k in range(nb)], chains, 4, 1)
 ms, tags = m["launch_ms"], m["launch_tags"]
 per = len(ms) // 4
 ms = ms.reshape(4, per).mean(axis=0); tags = tags[:per]
