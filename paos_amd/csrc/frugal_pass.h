@@ -628,6 +628,8 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
     if (l0 + TILES * LINES <= (int)h_line_lo || l0 >= (int)h_line_hi) {
       if constexpr (STORE == 1) {  // the PSF of a dead tile is zero (and so is its share of the power)
         if (h_line_fill == 0.0) return;  // ... and the buffer is known to hold those zeros already (host: psf_zero_*)
+        // ... or holds something only on the lines [spos_lo, spos_hi) the previous storing pass left live
+        if (l0 + TILES * LINES <= (int)h_spos_lo || l0 >= (int)h_spos_hi) return;
         double* ps = a.psf + (size_t)item * a.item_stride;
 #pragma unroll
         for (int k = 0; k < E; ++k) ps[m.base + (unsigned)k * m.stride] = 0.0;

@@ -782,7 +782,12 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const
       if (fi.active == 0.0) continue;
       lo = fi.line_lo < lo ? fi.line_lo : lo;
       hi = fi.line_hi > hi ? fi.line_hi : hi;
-      fill = fill || fi.line_fill != 0.0;
+      if (fi.line_fill != 0.0 && store_psf) {  // dead tiles write PSF zeros inside [spos_lo, spos_hi) only (run_passes_impl)
+        lo = fi.spos_lo < lo ? fi.spos_lo : lo;
+        hi = fi.spos_hi > hi ? fi.spos_hi : hi;
+      } else {
+        fill = fill || fi.line_fill != 0.0;
+      }
     }
     a.live_lo = a.live_hi = a.wg0 = 0;
     if (want && !fill && hi > lo && (lo > 0.0 || hi < (double)c->n)) {
@@ -798,7 +803,7 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const
     if (fi.active == 0.0) continue;
     if (fi.line_lo > 0.0 || fi.line_hi < (double)c->n) c->prof_next_tag |= 1;
     if (fi.pos_lo > 0.0 || fi.pos_hi < (double)c->n) c->prof_next_tag |= 2;
-    if (fi.spos_lo > 0.0 || fi.spos_hi < (double)c->n) c->prof_next_tag |= 4;
+    if (!store_psf && (fi.spos_lo > 0.0 || fi.spos_hi < (double)c->n)) c->prof_next_tag |= 4;
   }
   if (c->precision == PAOS_F64) {
     switch (c->n) {
@@ -988,12 +993,18 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
       static const bool reuse = [] { const char* e = getenv("PAOS_PSF_ZERO_REUSE"); return !(e && e[0] == '0'); }();
       const int axis = passes[n_passes - 1].axis;
       std::vector<FrugalItem>& last = low[n_passes - 1].items;
-      bool same = reuse && c->psf_zero_axis == axis && (int)c->psf_zero_lo.size() == c->batch;
-      for (int it = 0; it < c->batch && same; ++it)
-        same = c->psf_zero_lo[it] == last[it].line_lo && c->psf_zero_hi[it] == last[it].line_hi;
+      // Round 4: per item.  What the buffer may still hold of the previous storing pass lies inside that pass's live
+      // lines [psf_zero_lo, psf_zero_hi); only dead tiles of THIS pass that meet them write zeros (the range travels in
+      // the item's -- here otherwise unused -- store-position fields).  A walked sweep changes the sampling at the
+      // image plane from batch to batch, so the live lines are never the same twice, but they move by a few lines.
+      const bool known = reuse && c->psf_zero_axis == axis && (int)c->psf_zero_lo.size() == c->batch;
       c->psf_zero_lo.resize(c->batch); c->psf_zero_hi.resize(c->batch);
       for (int it = 0; it < c->batch; ++it) {
-        last[it].line_fill = same ? 0.0 : 1.0;
+        const double old_lo = known ? c->psf_zero_lo[it] : 0.0, old_hi = known ? c->psf_zero_hi[it] : (double)c->n;
+        const bool covered = old_lo >= last[it].line_lo && old_hi <= last[it].line_hi;  // every old line is rewritten
+        last[it].line_fill = covered ? 0.0 : 1.0;
+        last[it].spos_lo = covered ? 0.0 : old_lo;
+        last[it].spos_hi = covered ? (double)c->n : old_hi;
         c->psf_zero_lo[it] = last[it].line_lo; c->psf_zero_hi[it] = last[it].line_hi;
       }
       c->psf_zero_axis = -1;  // set again below once the pass is on the stream
