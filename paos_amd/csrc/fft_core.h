@@ -451,7 +451,9 @@ __device__ __forceinline__ void fft_stages(cx<T>* v, void* lds, int t,
       }
       PAOS_FENCE();
     }
-    dft<R, DIR>(v + s * R);
+    // (timing diagnostics, results wrong: PAOS_DIAG bit 3 drops the butterflies of every FIRST stage, bit 4 of every
+    // LAST stage -- what a zero-aware first / last stage could save at the very most, profiles/r04_zero_aware_stages.txt)
+    if constexpr (!(((PAOS_DIAG & 8) && NS == 1) || ((PAOS_DIAG & 16) && S::LAST))) dft<R, DIR>(v + s * R);
     // (PAOS_TAIL_FENCE = 0, experiment: no fence behind the LAST stage's butterflies, so that the scheduler may start
     // the tile's stores while the remaining outputs are still being computed)
     if constexpr (!(S::LAST && PAOS_TAIL_FENCE == 0)) PAOS_FENCE();

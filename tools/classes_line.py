@@ -1,0 +1,14 @@
+#!/usr/bin/env python3
+"""Per class of pass launch: mean HIP-event time of bench.py output files -- python tools/classes_line.py a.json [b.json ...]"""
+import json
+import sys
+
+ORDER = ["full", "skips tiles of dead lines", "skips loads of dead positions", "skips stores nobody reads",
+         "skips loads of dead positions + skips stores nobody reads",
+         "skips tiles of dead lines + stores the PSF instead of the field"]
+for path in sys.argv[1:]:
+    d = json.load(open(path))
+    cl = d["roofline"].get("classes", {})
+    parts = [f"{d['value']:.1f} wf/s"] + [f"{cl[k]['avg_launch_ms']:.3f}" if k in cl else "-" for k in ORDER]
+    print(f"{path}: " + "  ".join(parts))
+print("# columns: value | " + " | ".join(ORDER) + "  (ms per launch)")

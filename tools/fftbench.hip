@@ -120,7 +120,7 @@ void bench_variant(const char* name, int batch, int reps, int pad_blocks = 0) {
 
   a.n_mid = 1; a.mid[0] = {PWK_SCALE, 0, 3};  // keep magnitudes bounded over repeated launches
   Timer tm;
-  float ms = tm.run([&] { hipLaunchKernelGGL(kf, grid, block, lds, 0, PAOS_FRUGAL_PASS(a)); }, reps);
+  float ms = tm.run([&] { hipLaunchKernelGGL(kf, grid, block, lds, 0, a); }, reps);
   const double bytes = 2.0 * elems * sizeof(cx<T>);
   int nb = 0;
   CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kf, block.x, lds));

@@ -20,7 +20,7 @@ python3 "$ROOT/tools/pmc_summary.py" $(find "$OUT/sq" -name "*counter_collection
 # keep the merge-back small
 find "$OUT" -name "*.csv" -size +8M -delete
 cd "$ROOT"
-./build/fftbench_new 10 > "$OUT/fftbench.txt" 2>&1
+./build/fftbench 10 > "$OUT/fftbench.txt" 2>&1
 ./build/timeline > "$OUT/timeline.txt" 2>&1
 python3 bench.py --steps 20 --warmup 5 > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
 python3 bench.py --precision fp32 --steps 10 --warmup 2 --no-cpu-baseline --no-traffic > "$OUT/bench_fp32.json" 2>&1
