@@ -121,6 +121,10 @@ struct paos_ctx {
   // sweep renders six sets per SYN20 step: ~1.8 ms of an otherwise idle chip in front of the passes that read them)
   hipStream_t aux = nullptr;
   hipEvent_t aux_go = nullptr, aux_done = nullptr;
+  // experiment (tools/two_streams.py): extra dynamic LDS per pass workgroup of THIS context (PAOS_LDS_PAD when the
+  // context is created): 6 KiB make two of its workgroups too big for one CU but leave room for one of another
+  // context's -- two contexts then share every CU one workgroup each
+  size_t lds_pad = 0;
   int* mask_overflow = nullptr;    // device counter: partial runs that did not fit (must stay 0)
   double* partial = nullptr;
   double* norm2 = nullptr;
@@ -599,10 +603,11 @@ int frugal_launch(paos_ctx* c, const FrugalArgs& args) {
     groups = end - a.wg0;
   }
   const dim3 grid(groups, c->batch), block(TILES * LINES * N / C::E);
-  const size_t lds = frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, C::E, STORE>();
+  constexpr size_t kMaxPad = 8192;
+  const size_t lds = frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, C::E, STORE>() + (c->lds_pad < kMaxPad ? c->lds_pad : kMaxPad);
   auto kern = frugal_pass_kernel<T, N, C::E, LINES, TILES, AXIS, C::BR, C::BC, SPLIT, KPRE, KMID, NFFT, STORE>;
   {
-    int rc = opt_in_lds(c, (const void*)kern, lds);
+    int rc = opt_in_lds(c, (const void*)kern, frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, C::E, STORE>() + kMaxPad);
     if (rc) return rc;
   }
   const int kind = AXIS == 0 ? PAOS_KERNEL_PASS_ROWS : PAOS_KERNEL_PASS_COLS;
@@ -1234,6 +1239,7 @@ int paos_ctx_create(int device, int n, int batch, int precision, paos_ctx** out)
   hipError_t e;
   if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
+  if (const char* pad = getenv("PAOS_LDS_PAD")) c->lds_pad = (size_t)std::max(0, std::atoi(pad));
   if ((e = hipMalloc(&c->field, (size_t)c->item_stride * batch * eb)) != hipSuccess) return bail(e, "hipMalloc(field)");
   if ((e = hipMemsetAsync(c->field, 0, (size_t)c->item_stride * batch * eb, c->stream)) != hipSuccess) return bail(e, "hipMemset(field)");
   if ((e = hipMalloc(&c->tw, (size_t)n * eb)) != hipSuccess) return bail(e, "hipMalloc(tw)");

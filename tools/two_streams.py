@@ -15,9 +15,13 @@ from paos_amd.run import run_batch  # noqa: E402
 ON_AXIS = {"us": 0.0, "ut": 0.0}
 
 
-def measure(n, total, k, steps=20, warmup=5, stagger=0):
+def measure(n, total, k, steps=20, warmup=5, stagger=0, pads=None):
     nb = total // k
-    devs = [_lib.DeviceFields(n, nb) for _ in range(k)]
+    devs = []
+    for i in range(k):  # PAOS_LDS_PAD is read when a context is created (round 4: one context's workgroups padded so
+        os.environ["PAOS_LDS_PAD"] = str(pads[i] if pads else 0)  # that a CU holds ONE of them + one of the other's)
+        devs.append(_lib.DeviceFields(n, nb))
+    os.environ["PAOS_LDS_PAD"] = "0"
     wls = [[syn20_wavelength(i * nb + j) for j in range(nb)] for i in range(k)]
     chains = [[syn20_chain() for _ in range(nb)] for _ in range(k)]
     pending = [None] * k
@@ -50,5 +54,6 @@ def measure(n, total, k, steps=20, warmup=5, stagger=0):
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     total = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-    for k in (1, 2, 4, 1, 2):
-        print(f"{n}^2, {total} wavefronts per step on {k} context(s) / stream(s): {measure(n, total, k):.1f} wavefronts/s", flush=True)
+    for k, pads in ((1, None), (2, None), (2, (6144, 0)), (1, None), (2, None), (2, (6144, 0)), (2, (6144, 6144))):
+        print(f"{n}^2, {total} wavefronts per step on {k} context(s) / stream(s), LDS padding {pads}: "
+              f"{measure(n, total, k, pads=pads):.1f} wavefronts/s", flush=True)
