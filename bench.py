@@ -31,6 +31,8 @@ seen and every rank's bring-up note).  Rank 0 prints one JSON line (contract in 
                      the bytes the launches of one step really moved under the counters.
   without_ptp_algebra  the rate over the SAME number of steps with the pass compiler's ptp identities switched off
                      (PAOS_PTP_ALGEBRA=0: 44 passes per wavefront instead of 24).
+  same_wavelengths_every_step  the rate when every step repeats the first block of the sweep (how rounds 1-3 quoted
+                     the headline; the walked sweep costs ~3 %: records rendered, PSF zeros rewritten).
   extra              2048^2 / 1024^2 (the north star's sweep); fp32_4096 (SYN20 in fp32 mode with its roofline);
                      dense (SYN20 behind a white-noise grid-sag screen: rough fields everywhere, per-class times);
                      configs (BASELINE.json configs 3-5 on one GPU: AIRS-CH0 64 wavelengths @2048^2, FGS1 256
@@ -588,6 +590,13 @@ def main(argv=None):
                                  "middle pass nor cancel, a wts and the stw that undoes it both run"}
             finally:
                 ppasses.PTP_ALGEBRA = True
+        # ... and with the SAME wavelengths every step (rounds 1-3 measured this way): what the walk costs
+        repeated = None
+        if world == 1:
+            mr = measure(dev, n, args.precision, lambda g: wavelengths_of(0), chains, args.steps, max(args.warmup, 1), None, timer=False)
+            repeated = {"value": nb * args.steps / mr["elapsed"], "unit": "wavefronts/s", "steps": args.steps,
+                        "what": "every step runs the first block of the sweep again (how rounds 1-3 quoted the headline): the "
+                                "context's kept aperture records and PSF zeros are found every time"}
         n_ptp, n_stw, n_wts = chain_fft_counts(wavelengths_of(0)[0], n)
         ffts = 2 * n_ptp + n_stw + n_wts
         survey_bytes = (ffts * 4 * esz + 8) * n * n  # 2 passes x (read + write) per 2-D FFT + the 8 B/px PSF write
@@ -648,6 +657,7 @@ def main(argv=None):
                          "frac_bytes_moved": 6 * esz * n * n * nb / (ptp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "note": "SURVEY 8d prices a ptp at 128 B/px (4 passes); the fused path moves 96 B/px"},
             "without_ptp_algebra": plain,
+            "same_wavelengths_every_step": repeated,
             "power_check": float(dev.norm2_fetch(m["res"][0][20]["power_ticket"])[0]),
             "build": dev.build_info(),
         }

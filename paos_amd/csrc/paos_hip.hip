@@ -117,13 +117,9 @@ struct paos_ctx {
   MaskSet mask_sets[kMaskSets];
   unsigned long long mask_clock = 0;
   unsigned long long mask_hits = 0, mask_rendered = 0;  // paos_record_set_stats
-  // Round 4: the records a program needs are rendered AHEAD on a second stream while its first passes run (a walked
-  // sweep renders six sets per SYN20 step: ~1.8 ms of an otherwise idle chip in front of the passes that read them)
-  hipStream_t aux = nullptr;
-  hipEvent_t aux_go = nullptr, aux_done = nullptr;
   // experiment (tools/two_streams.py): extra dynamic LDS per pass workgroup of THIS context (PAOS_LDS_PAD when the
   // context is created): 6 KiB make two of its workgroups too big for one CU but leave room for one of another
-  // context's -- two contexts then share every CU one workgroup each
+  // context's -- two contexts then share every CU one workgroup each (measured: -14 %, profiles/r04_membench6_mixed_kinds.txt)
   size_t lds_pad = 0;
   int* mask_overflow = nullptr;    // device counter: partial runs that did not fit (must stay 0)
   double* partial = nullptr;
@@ -492,7 +488,6 @@ struct LoweredPass {
   std::vector<double> mask_shared;  // [batch] 1: the item reads the line records of an earlier, identical item
   std::vector<int> mask_rep;        // [batch] item whose records this item reads (-1: none)
   int mask_set = -1;                // which of the context's record sets this pass reads
-  const double* mask_dshared = nullptr;  // device copy of mask_shared when the records were rendered ahead
   bool mask_render = false;         // ... and whether it has to be rendered first
 };
 
@@ -751,21 +746,6 @@ void forget_mask_sets(paos_ctx* c) {  // after a failed program: what the sets h
   for (auto& ms : c->mask_sets) ms.key.clear();
 }
 
-// the line records of the aperture riding on pass `p`, into the record set the pass was assigned (assign_mask_set)
-int render_records(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const double* dblocks, const double* dshared,
-                   hipStream_t stream) {
-  const double* ap = dblocks + (size_t)lp.mask_block * c->batch * FP_STRIDE;
-  const double* ap2 = ap + (size_t)c->batch * FP_STRIDE;
-  const dim3 grid((c->n + 3) / 4, c->batch), block(256);
-  const paos_ctx::MaskSet& ms = c->mask_sets[lp.mask_set];
-  hipLaunchKernelGGL(mask_lines_kernel<0>, grid, block, 0, stream, ap, ap2, (int)FP_STRIDE, c->n, p.axis,
-                     ms.lines, ms.vals, c->mask_overflow, dshared);
-  hipLaunchKernelGGL(mask_lines_kernel<1>, grid, block, 0, stream, ap, ap2, (int)FP_STRIDE, c->n, p.axis,
-                     ms.lines, ms.vals, c->mask_overflow, dshared);
-  HIPCHK(c, hipGetLastError());
-  return PAOS_OK;
-}
-
 // launch a pass that lower_frugal accepted
 int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const double* dblocks, bool store_psf = false) {
   // PAOS_DUMP_PASSES=1: one line per pass launch on stderr (shape and what item 0's two slots carry)
@@ -778,10 +758,18 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const
                  f.line_lo, f.line_hi, f.line_fill, f.pos_lo, f.pos_hi, f.spos_lo, f.spos_hi);
   }
   if (lp.mask_block >= 0 && lp.mask_render) {  // render the records along the pass axis, right before the pass
+    const double* ap = dblocks + (size_t)lp.mask_block * c->batch * FP_STRIDE;
+    const double* ap2 = ap + (size_t)c->batch * FP_STRIDE;
+    const dim3 grid((c->n + 3) / 4, c->batch), block(256);
     const double* dshared = nullptr;
     int rcs = arena_push(c, lp.mask_shared.data(), lp.mask_shared.size(), &dshared);
     if (rcs) return rcs;
-    if ((rcs = render_records(c, p, lp, dblocks, dshared, c->stream))) return rcs;
+    const paos_ctx::MaskSet& ms = c->mask_sets[lp.mask_set];
+    hipLaunchKernelGGL(mask_lines_kernel<0>, grid, block, 0, c->stream, ap, ap2, (int)FP_STRIDE, c->n, p.axis,
+                       ms.lines, ms.vals, c->mask_overflow, dshared);
+    hipLaunchKernelGGL(mask_lines_kernel<1>, grid, block, 0, c->stream, ap, ap2, (int)FP_STRIDE, c->n, p.axis,
+                       ms.lines, ms.vals, c->mask_overflow, dshared);
+    HIPCHK(c, hipGetLastError());
   }
   const double* ditems = nullptr;
   static_assert(sizeof(FrugalItem) % sizeof(double) == 0, "record of doubles");
@@ -914,10 +902,7 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
 int run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks, int n_blocks,
                const double* entry_rows = nullptr, bool entry_stale = false, int* final_ticket = nullptr) {
   const int rc = run_passes_impl(c, passes, n_passes, blocks, n_blocks, entry_rows, entry_stale, final_ticket);
-  if (rc != PAOS_OK && c) {
-    forget_mask_sets(c);  // a program that stopped half way: which records were rendered is moot
-    if (c->aux) (void)hipStreamSynchronize(c->aux);  // ... and nothing rendered ahead is still in flight
-  }
+  if (rc != PAOS_OK && c) forget_mask_sets(c);  // a program that stopped half way: which records were rendered is moot
   return rc;
 }
 
@@ -1030,45 +1015,6 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
       c->psf_zero_axis = -1;  // set again below once the pass is on the stream
     }
   }
-  // Aperture line records that have to be rendered (not found in the context's kept sets): all of them AHEAD, on the
-  // auxiliary stream, while the passes in front of the first one that reads records run -- when every rendering goes
-  // to a set no earlier pass of this program reads (always, unless a program carries more distinct apertures than
-  // there are sets; then each is rendered in place, right before its pass, as before).  The auxiliary stream starts
-  // behind everything already on the main stream (the previous program may still read the sets) and the first pass
-  // that carries an aperture waits for it.  PAOS_EARLY_RECORDS=0 switches it off.
-  int wait_aux_before = -1;
-  {
-    static const bool want = [] { const char* e = getenv("PAOS_EARLY_RECORDS"); return !(e && e[0] == '0'); }();
-    std::vector<int> todo;
-    bool safe = want && all_frugal;
-    for (int q = 0; q < n_passes && safe; ++q) {
-      if (low[q].mask_block < 0) continue;
-      if (low[q].mask_render) {
-        for (int r = 0; r < q; ++r) safe = safe && !(low[r].mask_block >= 0 && low[r].mask_set == low[q].mask_set);
-        todo.push_back(q);
-      }
-    }
-    int first_reader = -1;
-    for (int q = 0; q < n_passes && first_reader < 0; ++q)
-      if (low[q].mask_block >= 0) first_reader = q;
-    if (safe && !todo.empty() && first_reader > 0) {  // (a reader at the very front leaves nothing to overlap with)
-      if (!c->aux) {
-        HIPCHK(c, hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking));
-        HIPCHK(c, hipEventCreateWithFlags(&c->aux_go, hipEventDisableTiming));
-        HIPCHK(c, hipEventCreateWithFlags(&c->aux_done, hipEventDisableTiming));
-      }
-      for (int q : todo)
-        if ((rc = arena_push(c, low[q].mask_shared.data(), low[q].mask_shared.size(), &low[q].mask_dshared))) return rc;
-      HIPCHK(c, hipEventRecord(c->aux_go, c->stream));  // the blocks, the "shared" vectors and all earlier work
-      HIPCHK(c, hipStreamWaitEvent(c->aux, c->aux_go, 0));
-      for (int q : todo) {
-        if ((rc = render_records(c, passes[q], low[q], dblocks, low[q].mask_dshared, c->aux))) return rc;
-        low[q].mask_render = false;
-      }
-      HIPCHK(c, hipEventRecord(c->aux_done, c->aux));
-      wait_aux_before = first_reader;
-    }
-  }
   // Walk the program in chunks whose phase operators fit the table store: fill the tables of
   // a chunk with one small launch, then run its passes.
   int i = 0;
@@ -1111,7 +1057,6 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
       HIPCHK(c, hipGetLastError());
     }
     for (int q = i; q < j; ++q) {
-      if (q == wait_aux_before) HIPCHK(c, hipStreamWaitEvent(c->stream, c->aux_done, 0));
       if (low[q].ok) {
         if ((rc = launch_lowered(c, passes[q], low[q], dblocks, fused_store && q == n_passes - 1))) return rc;
         continue;
@@ -1356,9 +1301,6 @@ int paos_ctx_destroy(paos_ctx* c) {
   }
   if (c->arena.host) (void)hipHostFree(c->arena.host);
   if (c->arena.dev) (void)hipFree(c->arena.dev);
-  if (c->aux_go) (void)hipEventDestroy(c->aux_go);
-  if (c->aux_done) (void)hipEventDestroy(c->aux_done);
-  if (c->aux) (void)hipStreamDestroy(c->aux);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return PAOS_OK;
