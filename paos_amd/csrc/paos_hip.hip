@@ -112,6 +112,7 @@ struct paos_ctx {
     double* vals = nullptr;     // batch x n x 2 kMaskW partial weights
     std::vector<double> key;    // empty: holds nothing valid
     unsigned long long used = 0;
+    int line_lo = 0, line_hi = 0;  // the lines whose records were rendered (the others hold whatever was there before)
   };
   static constexpr int kMaskSets = 8;  // (SYN20: five relay apertures whose pixel radii differ in the last digits + the field stop)
   MaskSet mask_sets[kMaskSets];
@@ -488,6 +489,8 @@ struct LoweredPass {
   std::vector<double> mask_shared;  // [batch] 1: the item reads the line records of an earlier, identical item
   std::vector<int> mask_rep;        // [batch] item whose records this item reads (-1: none)
   int mask_set = -1;                // which of the context's record sets this pass reads
+  int mask_shapes = 3;              // bit s: some item's aperture has shape s (0 ellipse, 1 rectangle) and renders its own records
+  int mask_lo = 0, mask_hi = 0;     // lines whose records this pass reads (run_passes_impl, behind the pruning plan)
   bool mask_render = false;         // ... and whether it has to be rendered first
 };
 
@@ -732,6 +735,12 @@ int assign_mask_set(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const doub
   ms.used = ++c->mask_clock;
   lp.mask_set = k;
   lp.mask_render = hit < 0;
+  lp.mask_shapes = 0;  // which of the two renderers have anything to do (the other one's launch would only exit)
+  for (int it = 0; it < c->batch; ++it) {
+    const double* a1 = ap + (size_t)it * FP_STRIDE;
+    const double* a2 = a1 + (size_t)c->batch * FP_STRIDE;
+    if (a1[0] != 0.0 && (it >= (int)lp.mask_shared.size() || lp.mask_shared[it] == 0.0)) lp.mask_shapes |= (int)a2[3] == 0 ? 1 : 2;
+  }
   if (hit < 0) { ms.key = std::move(key); ++c->mask_rendered; } else ++c->mask_hits;
   for (int it = 0; it < c->batch; ++it) {
     if (lp.mask_rep[it] < 0) continue;
@@ -760,15 +769,18 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const
   if (lp.mask_block >= 0 && lp.mask_render) {  // render the records along the pass axis, right before the pass
     const double* ap = dblocks + (size_t)lp.mask_block * c->batch * FP_STRIDE;
     const double* ap2 = ap + (size_t)c->batch * FP_STRIDE;
-    const dim3 grid((c->n + 3) / 4, c->batch), block(256);
+    const int line0 = lp.mask_lo, line_end = lp.mask_hi > lp.mask_lo ? lp.mask_hi : c->n;
+    const dim3 grid((line_end - line0 + 3) / 4, c->batch), block(256);
     const double* dshared = nullptr;
     int rcs = arena_push(c, lp.mask_shared.data(), lp.mask_shared.size(), &dshared);
     if (rcs) return rcs;
     const paos_ctx::MaskSet& ms = c->mask_sets[lp.mask_set];
-    hipLaunchKernelGGL(mask_lines_kernel<0>, grid, block, 0, c->stream, ap, ap2, (int)FP_STRIDE, c->n, p.axis,
-                       ms.lines, ms.vals, c->mask_overflow, dshared);
-    hipLaunchKernelGGL(mask_lines_kernel<1>, grid, block, 0, c->stream, ap, ap2, (int)FP_STRIDE, c->n, p.axis,
-                       ms.lines, ms.vals, c->mask_overflow, dshared);
+    if (lp.mask_shapes & 1)
+      hipLaunchKernelGGL(mask_lines_kernel<0>, grid, block, 0, c->stream, ap, ap2, (int)FP_STRIDE, c->n, p.axis,
+                         ms.lines, ms.vals, c->mask_overflow, dshared, line0, line_end);
+    if (lp.mask_shapes & 2)
+      hipLaunchKernelGGL(mask_lines_kernel<1>, grid, block, 0, c->stream, ap, ap2, (int)FP_STRIDE, c->n, p.axis,
+                         ms.lines, ms.vals, c->mask_overflow, dshared, line0, line_end);
     HIPCHK(c, hipGetLastError());
   }
   const double* ditems = nullptr;
@@ -959,6 +971,31 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
   }
   const bool pruned = all_frugal && use_pruning() && c->prune;
   if (pruned) plan_pruning(c, passes, n_passes, blocks, low, entry_rows, entry_stale);
+  // Which lines' aperture records does each pass read?  Those of its live tiles only: a workgroup whose lines are dead
+  // for its item (frugal_pass_kernel: outside [line_lo, line_hi), bounds that are multiples of the tile height)
+  // leaves before it looks at a record.  Only these lines are rendered (a quarter of them behind a clear aperture at
+  // zoom 4), and a set found in the context's store is good only if it was rendered that far.
+  {
+    for (int q = 0; q < n_passes; ++q) {
+      LoweredPass& lp = low[q];
+      if (!lp.ok || lp.mask_block < 0) continue;
+      double lo = (double)c->n, hi = 0.0;
+      for (const FrugalItem& fi : lp.items) {
+        if (fi.active == 0.0) continue;
+        lo = fi.line_lo < lo ? fi.line_lo : lo;
+        hi = fi.line_hi > hi ? fi.line_hi : hi;
+      }
+      const bool window = hi > lo;
+      lp.mask_lo = window ? (int)lo : 0;
+      lp.mask_hi = window ? (int)hi : c->n;
+      paos_ctx::MaskSet& ms = c->mask_sets[lp.mask_set];
+      if (!lp.mask_render && !(ms.line_lo <= lp.mask_lo && ms.line_hi >= lp.mask_hi)) {
+        lp.mask_render = true;  // found, but rendered for a narrower window than this pass reads
+        --c->mask_hits; ++c->mask_rendered;
+      }
+      if (lp.mask_render) { ms.line_lo = lp.mask_lo; ms.line_hi = lp.mask_hi; }
+    }
+  }
   if (entry_stale && entry_rows) {
     // Rows that merely stand for zeros must become zeros wherever the program will not consume them: everywhere when
     // the planner is off, and for an item no pass of the program touches.

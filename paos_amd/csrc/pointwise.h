@@ -612,12 +612,15 @@ constexpr int kMaskWaves = 4;  // waves (= lines) per workgroup of mask_lines_ke
 
 template <int SHAPE>
 __global__ void __launch_bounds__(kMaskWaves * 64) mask_lines_kernel(const double* params, const double* params2, int param_stride, int n,
-                                  int axis, MaskLine* lines, double* vals, int* overflow, const double* shared) {
+                                  int axis, MaskLine* lines, double* vals, int* overflow, const double* shared,
+                                  int line0, int line_end) {
+  // [line0, line_end): the lines whose records anybody will read (the pass that carries the aperture skips the tiles of
+  // dead lines: three quarters of a grid that covers every line were workgroups that only found out they had nothing to do)
   const int item = blockIdx.y;
   if (shared[item] != 0.0) return;  // reads the records of an earlier, identical item
-  const int line = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int line = line0 + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (line >= n) return;
+  if (line >= line_end || line >= n) return;
   const double* p = params + (size_t)item * param_stride;
   const double* p2 = params2 + (size_t)item * param_stride;
   MaskLine* out = lines + (size_t)item * n + line;
