@@ -154,7 +154,7 @@ def sweep_block(step, per_step, lo, hi):
     return [(step * per_step + i) % SWEEP for i in range(lo, hi)]
 
 
-def measure(dev, n, precision, wavelengths_of, chains, steps, warmup, comm=None, first_step=0, timer=True):
+def measure(dev, n, precision, wavelengths_of, chains, steps, warmup, comm=None, first_step=0, timer=True, keep_last=False):
     """Timed region of the contract: W untimed steps, then exactly K steps between barriers; every pass launch is
     event-timed.  ``wavelengths_of(g)`` lists this rank's wavelengths of global step g (warm-up steps are
     g = first_step ... first_step + W - 1).  Returns a dict of raw numbers."""
@@ -201,6 +201,9 @@ def measure(dev, n, precision, wavelengths_of, chains, steps, warmup, comm=None,
             seen = now
     barrier()
     elapsed = time.perf_counter() - t0
+    if not keep_last:  # the ticket ring is a ring: a ticket left outstanding blocks its slot when the ring comes round
+        release(res)
+        res = None
     if timer:
         ms, tags = dev.profile_end_launches()
     else:
@@ -550,7 +553,12 @@ def main(argv=None):
         return [syn20_wavelength(k) for k in sweep_block(g, total, lo, hi)]
 
     dev = _lib.DeviceFields(n, nb, args.precision, device=local_rank)
-    m = measure(dev, n, args.precision, wavelengths_of, chains, args.steps, args.warmup, comm)
+    m = measure(dev, n, args.precision, wavelengths_of, chains, args.steps, args.warmup, comm, keep_last=True)
+    # the power behind the last surface of the last step (a sanity figure of the line); its tickets are given back here
+    last = m.pop("res")
+    power_check = float(dev.norm2_fetch(last[0][20]["power_ticket"])[0])
+    for t in {rec["power_ticket"] for r in last for rec in r.values() if "power_ticket" in rec} - {last[0][20]["power_ticket"]}:
+        dev.norm2_release(t)
     if args.traffic_child:  # measure_traffic's child: one step, every dispatch of which is counted
         dev.close()
         return
@@ -658,7 +666,7 @@ def main(argv=None):
                          "note": "SURVEY 8d prices a ptp at 128 B/px (4 passes); the fused path moves 96 B/px"},
             "without_ptp_algebra": plain,
             "same_wavelengths_every_step": repeated,
-            "power_check": float(dev.norm2_fetch(m["res"][0][20]["power_ticket"])[0]),
+            "power_check": power_check,
             "build": dev.build_info(),
         }
         dev.close()

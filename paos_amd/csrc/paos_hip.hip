@@ -290,6 +290,16 @@ hipError_t timed_launch_end(paos_ctx* c, int tag) {
   return hipSuccess;
 }
 
+// The power tickets are handed out round the ring, but a caller may keep a ticket for long (a result it reads at the
+// end): the next free slot is looked for instead of declaring the ring full at the first busy one.
+int next_norm_slot(paos_ctx* c) {
+  for (int k = 0; k < kNormSlots; ++k) {
+    const int slot = (c->norm_slot + k) % kNormSlots;
+    if (!c->norm_busy[slot]) { c->norm_slot = slot; return slot; }
+  }
+  return c->norm_slot;  // every slot is outstanding: the caller's check of norm_busy[] reports it
+}
+
 int opt_in_lds(paos_ctx* c, const void* kern, size_t lds) {
   static std::mutex mu;
   static std::set<std::pair<int, const void*>> configured;
@@ -923,7 +933,7 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
   if (!c || !passes || !blocks || n_passes < 0 || n_blocks < 1) return fail(c, PAOS_EINVAL, "bad pass program");
   // A program that ends on the PSF gives the field up for it: the free power-ticket slot it will need is checked
   // BEFORE anything is launched (found full afterwards, the context held neither field nor ticket).
-  if (final_ticket && c->norm_busy[c->norm_slot])
+  if (final_ticket && c->norm_busy[next_norm_slot(c)])
     return fail(c, PAOS_EINVAL, "64 power reductions outstanding: fetch earlier tickets (paos_norm2_fetch) first");
   // The device sincos has no huge-argument path: bound every enabled phase operator here.
   for (int i = 0; i < n_passes; ++i) {
@@ -1682,7 +1692,7 @@ int paos_psf_metrics(paos_ctx* c, int nr, const double* radii_px, double cx_px, 
 int paos_norm2_enqueue(paos_ctx* c, int* ticket) {
   if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c || !ticket) return fail(c, PAOS_EINVAL, "null argument");
-  const int slot = c->norm_slot;
+  const int slot = next_norm_slot(c);
   if (c->norm_busy[slot])  // the ring is full: the oldest ticket has not been fetched
     return fail(c, PAOS_EINVAL, "64 power reductions outstanding: fetch earlier tickets (paos_norm2_fetch) first");
   int rc = norm2_launch(c, nullptr);
@@ -1701,7 +1711,7 @@ namespace {
 
 // partial sums -> norm2 -> a ticket of the power ring
 int psf_power_ticket(paos_ctx* c, const double* partial, int nparts, int* ticket, const double* source) {
-  const int slot = c->norm_slot;
+  const int slot = next_norm_slot(c);
   if (c->norm_busy[slot])
     return fail(c, PAOS_EINVAL, "64 power reductions outstanding: fetch earlier tickets (paos_norm2_fetch) first");
   hipLaunchKernelGGL(norm2_final_kernel, dim3(c->batch), dim3(kPwThreads), 0, c->stream, partial, c->norm2, nparts,
@@ -1716,7 +1726,7 @@ int psf_power_ticket(paos_ctx* c, const double* partial, int nparts, int* ticket
 }
 
 int psf_keep_power_impl(paos_ctx* c, int* ticket) {
-  if (c->norm_busy[c->norm_slot])
+  if (c->norm_busy[next_norm_slot(c)])
     return fail(c, PAOS_EINVAL, "64 power reductions outstanding: fetch earlier tickets (paos_norm2_fetch) first");
   if (!c->psf) HIPCHK(c, hipMalloc(&c->psf, (size_t)c->batch * c->item_stride * sizeof(double)));
   c->psf_zero_axis = -1;  // the whole buffer is rewritten
@@ -1775,7 +1785,7 @@ static int norm2_enqueue_rows_impl(paos_ctx* c, const double* live_rows, const d
   if (!c || !ticket || !live_rows) return fail(c, PAOS_EINVAL, "null argument");
   int rc = check_rows(c, live_rows);
   if (rc) return rc;
-  const int slot = c->norm_slot;
+  const int slot = next_norm_slot(c);
   if (c->norm_busy[slot])
     return fail(c, PAOS_EINVAL, "64 power reductions outstanding: fetch earlier tickets (paos_norm2_fetch) first");
   const double *drows = nullptr, *dlead = nullptr, *dsame = nullptr;

@@ -38,6 +38,15 @@ def run_bench(argv, env_extra, out):
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "PAOS_COMM_KEY"):
         env.pop(k, None)
     env.update(env_extra)
-    run = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), env=env, cwd=root,
-                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    cmd = [sys.executable, os.path.join(root, "bench.py")] + list(argv)
+    if env.pop("LAUNCH_WITH_TORCHRUN", "") == "1":  # the driver's way: an external launcher exports the job
+        import socket
+
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        n = argv[argv.index("--gpus") + 1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", n, "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.join(root, "bench.py")] + list(argv)
+    run = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     out.put((run.returncode, run.stdout.decode(errors="replace"), run.stderr.decode(errors="replace")[-2000:]))

@@ -548,7 +548,7 @@ def test_bench_two_self_launched_ranks_on_one_gpu():
         out = ctx.Queue()
         p = ctx.Process(target=rccl_pair_worker.run_bench, args=(argv, env, out))
         p.start()
-        res = out.get(timeout=700)
+        res = out.get(timeout=1000)
         p.join(timeout=60)
         return res
 
@@ -563,6 +563,14 @@ def test_bench_two_self_launched_ranks_on_one_gpu():
     assert abs(line["power_check"] - 1.0) < 1e-9 or line["power_check"] > 0.0
     print("two self-launched ranks on one GPU:", round(line["value"], 1), "wavefronts/s (rehearsal)", line["config"]["transport"])
 
+    # the driver's command: an external launcher (python -m torch.distributed.run) starts the ranks, bench.py joins them
+    rc, stdout, stderr = bench(small + ["--allow-tcp"], {"PAOS_BENCH_REHEARSAL": "1", "LAUNCH_WITH_TORCHRUN": "1"})
+    assert rc == 0, (rc, stderr)
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["launcher"].startswith("external")
+
     # asking for RCCL with two ranks on a ONE-GPU box: rank 1 finds no device 1 -> the ranks agree on TCP -> exit 3
     # with a null line that says so
     rc, stdout, stderr = bench(small, {})
@@ -575,3 +583,28 @@ def test_bench_two_self_launched_ranks_on_one_gpu():
         print("no-RCCL record:", line["config"]["bringup_notes"])
     else:  # RCCL accepted two ranks on one device (not seen so far), or the bring-up failed loudly: never a silent number
         assert rc != 0 or (len(lines) == 1 and json.loads(lines[0])["config"]["transport"] == "rccl"), (rc, stdout, stderr)
+
+
+def test_a_ticket_kept_for_long_does_not_block_the_ring():
+    """The power tickets come off a ring of 64 slots; a caller that keeps one ticket for long (bench.py keeps the last
+    step's) must not make the library report "64 outstanding" when the ring comes round to it (round 4: found with
+    bench.py --steps 20).  65 outstanding tickets are still refused."""
+    from paos_amd import _lib
+
+    dev = _lib.DeviceFields(256, 2)
+    try:
+        dev.fill(1.0 + 0.0j)
+        keep = dev.norm2_enqueue()
+        for _ in range(200):
+            t = dev.norm2_enqueue()
+            assert t != keep
+            assert np.array_equal(dev.norm2_fetch(t), [256.0 * 256.0] * 2)
+        held = [dev.norm2_enqueue() for _ in range(_lib.NORM_SLOTS - 1)]
+        with pytest.raises(_lib.PaosHipError, match="outstanding"):
+            dev.norm2_enqueue()
+        assert np.array_equal(dev.norm2_fetch(keep), [256.0 * 256.0] * 2)
+        for t in held:
+            dev.norm2_release(t)
+        assert np.array_equal(dev.norm2_fetch(dev.norm2_enqueue()), [256.0 * 256.0] * 2)
+    finally:
+        dev.close()
