@@ -39,6 +39,12 @@ PTP_ALGEBRA = os.environ.get("PAOS_PTP_ALGEBRA", "1") != "0"
 # the identity (PassCompiler._undoes): a tenth of the 1e-10 field gate the parity tests assert.
 PARITY_GATE = 1.0e-10
 UNDO_MAX_RESIDUAL = 1.0e-11  # = PARITY_GATE / 10
+# A pair whose transforms cancel but whose two phases leave MORE than that (the separately computed coefficients of a
+# real prescription differ by a few 1e-15 of a 1e4 rad corner phase: 3e-11 ... 9e-11 rad for Ariel_FGS-FGS1 at 4096^2)
+# still loses its two transforms -- they are exact inverses whatever the phases do -- and the residual phase is KEPT,
+# as one more diagonal operator, so nothing above UNDO_MAX_RESIDUAL is ever dropped.  Beyond this many radians the two
+# hops are not each other's inverse in any sense (another distance, a magnification in between) and both run.
+UNDO_COMPENSATE_MAX = 1.0e-6
 FIRST_AXIS = 1 if os.environ.get("PAOS_FIRST_AXIS", "0") == "1" else 0
 
 
@@ -158,9 +164,17 @@ class PassCompiler:
         # go, and the stw in front meets the wts behind -- the two hops become the one hop they are.
         ls = self.last_single if PTP_ALGEBRA else None
         if (ls is not None and kind == "stw" and ls["kind"] == "wts" and self.open is ls["open"] and not self.tail and
-                self.open["mid"] == ls["open_mid"] and self._undoes(ls["arr"], ls["inv"], arr, inv)):
-            self._restore(ls["undo"])
-            return
+                self.open["mid"] == ls["open_mid"]):
+            if self._undoes(ls["arr"], ls["inv"], arr, inv):
+                self._restore(ls["undo"])
+                return
+            if self._undoes(ls["arr"], ls["inv"], arr, inv, max_residual=UNDO_COMPENSATE_MAX):
+                leftovers = self._residual_phase(ls["arr"], arr)
+                self._restore(ls["undo"])
+                for blk in leftovers:
+                    self.tail.append((_lib.PW_QPHASE_CENTRED, 0, self._block(blk)))
+                self.last_single = None
+                return
         undo = self._snapshot()
         par = self._block(arr)
         ctl = self._derived(arr, v1=inv)
@@ -196,6 +210,25 @@ class PassCompiler:
             if np.any((np.abs(rx) + np.abs(ry)) * half >= max_residual):
                 return False
         return True
+
+    def _residual_phase(self, first, second):
+        """What the phases of a wts and the stw behind it leave when their transforms have cancelled:
+        exp(i (rx gx^2 + ry gy^2)) (g: pixels from the centre), rx = c1 sx1^2 + c2 sx2^2 per item, as one centred
+        quadratic-phase block [enable, sqrt|rx|, sqrt|ry|, 1, sign] -- or two (an x-only and a y-only one) when the
+        two leftovers differ in sign, which noise-level leftovers do."""
+        on = second[:, 0] != 0.0
+        rx = np.where(on, first[:, 3] * first[:, 4] * first[:, 1] ** 2 + second[:, 3] * second[:, 4] * second[:, 1] ** 2, 0.0)
+        ry = np.where(on, first[:, 3] * first[:, 4] * first[:, 2] ** 2 + second[:, 3] * second[:, 4] * second[:, 2] ** 2, 0.0)
+        out = []
+        same = (rx >= 0.0) == (ry >= 0.0)
+        if np.all(same | (rx == 0.0) | (ry == 0.0)):
+            sgn = np.where((rx < 0.0) | (ry < 0.0), -1.0, 1.0)
+            out.append(np.stack([on.astype(float), np.sqrt(np.abs(rx)), np.sqrt(np.abs(ry)), np.ones_like(rx), sgn], axis=1))
+        else:
+            zero = np.zeros_like(rx)
+            out.append(np.stack([on.astype(float), np.sqrt(np.abs(rx)), zero, np.ones_like(rx), np.where(rx < 0.0, -1.0, 1.0)], axis=1))
+            out.append(np.stack([on.astype(float), zero, np.sqrt(np.abs(ry)), np.ones_like(rx), np.where(ry < 0.0, -1.0, 1.0)], axis=1))
+        return [b for b in out if np.any(b[:, 0] != 0.0) and np.any((b[:, 1] != 0.0) | (b[:, 2] != 0.0))]
 
     def stw(self, rows, inverse):
         self._single(rows, inverse, "stw")

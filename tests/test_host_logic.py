@@ -552,14 +552,22 @@ def test_undoes_threshold_sits_a_decade_inside_the_parity_gate():
         resid = 2.0 * abs(c + cw) * half
         assert abs(resid - target) < 1e-3 * target, (resid, target)
         assert comp._undoes(small, fwd, blk, inv) is cancels, (target, resid)
-    # through the operator interface: the 1e-10 pair keeps both operators (two more passes), the 1e-13 pair leaves none
-    for target, extra in ((1.0e-10, 2), (1.0e-13, 0)):
+    # through the operator interface: the 1e-13 pair leaves nothing; the 1e-10 pair loses its transforms (exact
+    # inverses whatever the phases do) but its residual phase is KEPT as a diagonal operator -- nothing above the
+    # threshold is dropped; a pair that leaves 1e-5 rad is no inverse pair and keeps both operators (two more passes)
+    for target, extra, kept in ((1.0e-13, 0, 0), (1.0e-10, 0, 1), (1.0e-5, 2, 0)):
         comp = PassCompiler(1, n)
         comp.stw(np.array([[1.0, 1.0, 1.0, -0.5, 1.0]]), fwd)
         n0 = len(comp.passes)
         comp.wts(small, fwd)
         comp.stw(np.array([[1.0, 1.0, 1.0, target / (2.0 * half) - cw, 1.0]]), inv)
         assert len(comp.passes) == n0 + extra, (target, len(comp.passes), n0)
+        if extra == 0:
+            assert len(comp.tail) == kept, (target, comp.tail)
+            if kept:
+                blk = comp.blocks[comp.tail[0][2]][0]
+                left = blk[4] * blk[3] * (blk[1] ** 2 + blk[2] ** 2) * half  # phase at the corner
+                assert abs(left - target) < 1e-3 * target, (left, target)
 
 
 def _short_chain(surfaces):
@@ -672,3 +680,35 @@ def test_ptp_algebra_on_and_off_agree_on_random_chains(seed):
             a, b = fast[i][k]["wfo"], plain[i][k]["wfo"]
             assert np.isfinite(a).all() and np.isfinite(b).all()
             assert rel_err(a, b) < 1e-11, (seed, i, k, rel_err(a, b), st_fast, st_plain)
+
+
+def test_a_near_inverse_wts_stw_pair_keeps_its_residual_phase():
+    """The numbers behind the rewrite: wts then stw whose phases leave 5e-8 rad at the corner along x and -2e-8 along
+    y, on a random field, against the two operators run one after the other (PTP_ALGEBRA off): equal to rounding,
+    with two passes less; dropping the residual instead would show at 1e-8."""
+    import paos_amd.passes as ppasses
+    from paos_amd.passes import PassCompiler
+
+    n, nb = 64, 2
+    half = (n / 2.0) ** 2
+    rng = np.random.default_rng(5)
+    u0 = rng.standard_normal((nb, n, n)) + 1j * rng.standard_normal((nb, n, n))
+    cw = 3.0e-3
+    wts = np.array([[1.0, 1.0, 1.0, cw, 1.0]] * nb)
+    stw = np.array([[1.0, np.sqrt(1.0 - 5.0e-8 / (cw * half)), np.sqrt(1.0 + 2.0e-8 / (cw * half)), cw, -1.0]] * nb)
+    fwd, inv = np.zeros(nb), np.ones(nb)
+    out = {}
+    for algebra in (True, False):
+        ppasses.PTP_ALGEBRA = algebra
+        try:
+            dev = ModelDevice(n, nb)
+            dev.u[:] = u0
+            comp = PassCompiler(nb, n)
+            comp.wts(wts, fwd)
+            comp.stw(stw, inv)
+            out[algebra] = (comp.flush(dev), dev.u.copy())
+        finally:
+            ppasses.PTP_ALGEBRA = True
+    assert out[True][0] < out[False][0], (out[True][0], out[False][0])
+    assert rel_err(out[True][1], out[False][1]) < 1e-13
+    assert rel_err(u0, out[False][1]) > 1e-9  # ... and the residual is really there
