@@ -608,3 +608,36 @@ def test_a_ticket_kept_for_long_does_not_block_the_ring():
         assert np.array_equal(dev.norm2_fetch(dev.norm2_enqueue()), [256.0 * 256.0] * 2)
     finally:
         dev.close()
+
+
+def test_record_windows_follow_the_lines_a_pass_reads():
+    """Round 4: aperture line records are rendered only for the lines a pass's live tiles read (a quarter of them
+    behind a clear aperture at zoom 4).  A set found in the context's store is good only if it was rendered that far:
+    the same chain on the same context with the pruning on (narrow windows), off (every line is read: the kept sets
+    must be rendered again, not trusted) and on again -- every run equal to a fresh context's, bit for bit."""
+    import paos_amd.run as prun
+    from paos_amd import _lib
+    from paos_amd.chains import syn20_chain, syn20_wavelength
+
+    n = 1024
+    wls = [syn20_wavelength(3), syn20_wavelength(77)]
+    chains = [syn20_chain() for _ in wls]
+
+    def psfs(dev):
+        return [r[20]["psf"] for r in prun.run_batch(1.0, wls, n, 4, ON_AXIS, chains, outputs=("psf",), dev=dev)]
+
+    fresh = psfs(None)
+    dev = _lib.DeviceFields(n, len(wls))
+    try:
+        runs = []
+        for prune in (True, False, True, False):
+            dev.set_pruning(prune)
+            runs.append(psfs(dev))
+            found, rendered = dev.record_set_stats()
+            print(f"pruning {prune}: records found {found}, rendered {rendered}")
+    finally:
+        dev.close()
+    for got in runs:
+        assert all(np.array_equal(a, b) for a, b in zip(got, fresh))
+    # the un-pruned runs could not use what the pruned ones had rendered (narrower windows): they rendered again
+    assert rendered >= 12
