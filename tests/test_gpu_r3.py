@@ -641,3 +641,47 @@ def test_record_windows_follow_the_lines_a_pass_reads():
         assert all(np.array_equal(a, b) for a, b in zip(got, fresh))
     # the un-pruned runs could not use what the pruned ones had rendered (narrower windows): they rendered again
     assert rendered >= 12
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_chains_on_the_production_kernels_vs_the_numpy_model(seed):
+    """Differential test of the pass kernels beyond the fixed prescriptions: random chains (lenses, gaps, nanometre
+    hops, flat windows, apertures, saved flats -- tests/test_host_logic.py::_random_chain) at 1024^2, the smallest grid
+    of the production kernel, two wavelengths per batch, on the GPU against the NumPy model of the device contract
+    (tests/fakes.py) driven by the same planner and pass compiler: every saved field to 1e-11, max-norm and L2."""
+    from fakes import ModelDevice
+    from test_host_logic import _random_chain
+
+    import paos_amd.run as prun
+    from paos_amd.run import _Item, _walk, run_batch
+
+    rng = np.random.default_rng(4200 + seed)
+    chain = _random_chain(rng, int(rng.integers(6, 12)))
+    wls = [1.0e-6, float(rng.choice([1.3e-6, 1.7e-6, 2.3e-6]))]
+    n = 1024
+    prun.FUSE_APERTURES = [True, "auto"][seed % 2]
+    try:
+        try:
+            got = run_batch(1.0, wls, n, 4, ON_AXIS, [chain, chain], outputs=("wfo",))
+        except (ValueError, AssertionError, TypeError) as exc:
+            pytest.skip(f"the planner refuses this draw like the reference would ({type(exc).__name__}: {exc})")
+        dev = ModelDevice(n, 2)
+        states = [_Item(1.0, wl, n, 4, ON_AXIS) for wl in wls]
+        want = {}
+
+        def on_saved(key, items, plans, wfe):
+            for i, it in enumerate(items):
+                if it["save"]:
+                    want.setdefault(i, {})[it["num"]] = dev.download(i)
+
+        _walk(dev, states, [chain, chain], on_saved, fresh=1.0 + 0.0j)
+    finally:
+        prun.FUSE_APERTURES = "auto"
+    worst = 0.0
+    for i in range(2):
+        assert sorted(got[i]) == sorted(want[i])
+        for k in want[i]:
+            e, e2 = rel_err(got[i][k]["wfo"], want[i][k]), l2_rel_err(got[i][k]["wfo"], want[i][k])
+            worst = max(worst, e, e2)
+            assert e < 1e-11 and e2 < 1e-11, (seed, i, k, e, e2)
+    print(f"seed {seed}: {len(chain)} surfaces, {len(want[0])} saved, worst error {worst:.1e}")
