@@ -72,7 +72,11 @@ typedef struct {
  *                  ends with, not the field: the last pass stores |u|^2 into the context's PSF buffer (as
  *                  paos_psf_keep_power would afterwards) and *power_ticket receives a ticket for paos_norm2_fetch.
  *                  The field content is UNDEFINED after the call.  (Saves writing the last field and reading it
- *                  back: 32 B/px.) */
+ *                  back: 32 B/px.)
+ *                  == 2 (round 4): the field is stored as usual AND *power_ticket receives the ticket of its
+ *                  sum |u|^2 -- the power a caller reports next to a saved surface (push_results, run.py:12-27,
+ *                  218-223) -- summed by the last pass while it stores its tiles instead of by a separate sweep
+ *                  that reads the field back (16 B/px). */
 typedef struct {
   const double* live_rows;
   int rows_stale;

@@ -452,8 +452,10 @@ class DeviceFields:
         """passes: list of dicts {axis, fft1, fft2, pre, mid, post} with operator tuples
         (kind, flags, block); blocks: array [n_blocks][batch][PHASE_STRIDE].  ``live_rows``
         ([batch][2], optional): rows outside [lo, hi) of item i are exactly zero in memory -- or, with
-        ``rows_stale``, hold old data that stands for zeros.  ``final_intensity``: the last pass writes |u|^2 to
-        the PSF buffer instead of the field (which is undefined afterwards); returns the power ticket."""
+        ``rows_stale``, hold old data that stands for zeros.  ``final_intensity``: True / 1 -- the last pass writes |u|^2 to
+        the PSF buffer instead of the field (which is undefined afterwards); 2 -- the field is stored as usual and its
+        sum |u|^2 is reduced by the last pass on the way (the power of a saved surface without reading the field
+        back); either way the power ticket is returned."""
         b = np.ascontiguousarray(blocks, dtype=np.float64)
         if b.ndim != 3 or b.shape[1:] != (self.batch, PHASE_STRIDE):
             raise ValueError("blocks must be [n_blocks][batch][5]")
@@ -472,7 +474,7 @@ class DeviceFields:
             lr = self._rows(live_rows) if live_rows is not None else None
             ticket = ctypes.c_int(-1)
             opts = ProgramOpts(_dptr(lr) if lr is not None else None, 1 if (rows_stale and lr is not None) else 0,
-                               1 if final_intensity else 0, ctypes.pointer(ticket))
+                               int(final_intensity), ctypes.pointer(ticket))
             self._check(self._lib.paos_run_program(self._ctx, arr, len(passes), _dptr(b), b.shape[0], ctypes.byref(opts)),
                         "paos_run_program")
             return ticket.value if final_intensity else None

@@ -107,6 +107,12 @@ struct FrugalArgs {
   // `psf_partial[item * (workgroups per item) + workgroup]`; the field itself is not written
   double* psf;
   double* psf_partial;
+  // STORE = 2 builds (round 4; the shapes without phases in front of their first transform -- what a program that ends on a
+  // saved surface ends with; as a run-time switch in every build it cost the whole chain 0.4 %, profiles/r04_ab_variants_bench.txt):
+  // the pass stores the field as usual AND the sum of |u|^2 over the workgroup's tile
+  // to pow_partial[item * (workgroups per item) + workgroup] -- the power of a saved surface (run.py:218-223 callers'
+  // sum |wfo|^2) without a separate sweep that reads the field back.  Dead tiles write nothing: the host zeroes the array.
+  double* pow_partial;
 #if PAOS_STAMPS
   unsigned long long* stamps;  // [gridDim.y][gridDim.x][kStampSlots]
 #endif
@@ -564,12 +570,12 @@ __device__ __forceinline__ void tile_power_out(double acc, double* scratch, doub
 // that every workgroup waits for before it can even ask for its item's record.  Launch with PAOS_FRUGAL_PASS(args).
 #if PAOS_STAMPS
 #define PAOS_FRUGAL_PARAMS const FrugalItem *k_items, void *k_field, unsigned k_pitch, unsigned k_item_stride, unsigned k_wg0, \
-                           const void *k_tw, double *k_psf, double *k_psf_partial, unsigned long long *k_stamps
-#define PAOS_FRUGAL_PASS(a) (a).items, (a).field, (a).pitch, (a).item_stride, (a).wg0, (a).tw, (a).psf, (a).psf_partial, (a).stamps
+                           const void *k_tw, double *k_psf, double *k_psf_partial, double *k_pow_partial, unsigned long long *k_stamps
+#define PAOS_FRUGAL_PASS(a) (a).items, (a).field, (a).pitch, (a).item_stride, (a).wg0, (a).tw, (a).psf, (a).psf_partial, (a).pow_partial, (a).stamps
 #else
 #define PAOS_FRUGAL_PARAMS const FrugalItem *k_items, void *k_field, unsigned k_pitch, unsigned k_item_stride, unsigned k_wg0, \
-                           const void *k_tw, double *k_psf, double *k_psf_partial
-#define PAOS_FRUGAL_PASS(a) (a).items, (a).field, (a).pitch, (a).item_stride, (a).wg0, (a).tw, (a).psf, (a).psf_partial
+                           const void *k_tw, double *k_psf, double *k_psf_partial, double *k_pow_partial
+#define PAOS_FRUGAL_PASS(a) (a).items, (a).field, (a).pitch, (a).item_stride, (a).wg0, (a).tw, (a).psf, (a).psf_partial, (a).pow_partial
 #endif
 template <typename T, int N, int E, int LINES, int TILES, int AXIS, int BR, int BC, bool SPLIT,
           int KPRE, int KMID, int NFFT, int STORE = 0>
@@ -577,7 +583,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
     frugal_pass_kernel(PAOS_FRUGAL_PARAMS) {
   FrugalArgs a;
   a.items = k_items; a.field = k_field; a.pitch = k_pitch; a.item_stride = k_item_stride; a.wg0 = k_wg0;
-  a.tw = k_tw; a.psf = k_psf; a.psf_partial = k_psf_partial; a.live_lo = a.live_hi = 0;
+  a.tw = k_tw; a.psf = k_psf; a.psf_partial = k_psf_partial; a.pow_partial = k_pow_partial; a.live_lo = a.live_hi = 0;
 #if PAOS_STAMPS
   a.stamps = k_stamps;
 #endif
@@ -866,6 +872,17 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
       const int pos = m.t + k * (N / E);
       if (pos >= slo && pos < shi) stream_store<NT>(at(k), v[k]);
     }
+  }
+  if constexpr (STORE == 2) {  // the power of the field just stored, summed like the PSF-storing builds do
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+      const double x = (double)v[k].x, y = (double)v[k].y;
+      acc += __dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y));
+    }
+    double* scratch = reinterpret_cast<double*>(smem + frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, E, 0>() - kStoreScratch -
+                                                (kRecMode == 1 ? (size_t)TILES * LINES * sizeof(MaskLine) : 0));
+    tile_power_out<TILES * LINES * N / E>(acc, scratch, a.pow_partial + (size_t)item * (N / LINES / TILES) + wg);
   }
   PAOS_STAMP(6);
   PAOS_STAMP_WAIT_VM();

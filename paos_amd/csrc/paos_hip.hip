@@ -87,6 +87,8 @@ struct paos_ctx {
   double* psf = nullptr;  // batch x item_stride intensities kept on the device, blocked like the field (paos_psf_keep)
   double* psf_partial = nullptr;  // per-workgroup sums of a pass that stores the PSF (paos_run_program: final_intensity)
   int psf_nparts = 0;
+  double* pow_partial = nullptr;  // per-workgroup sums of |u|^2 of a pass that stores the FIELD (final_intensity = 2)
+  int pow_nparts = 0;
   // What the PSF buffer (and psf_partial) is known to hold after a pass stored it: for item i the lines along
   // psf_zero_axis outside [psf_zero_lo[i], psf_zero_hi[i]) are zero (their per-workgroup sums too).  The next
   // PSF-storing pass with the same live lines need not write those zeros again; -1 = nothing known.
@@ -642,6 +644,11 @@ int frugal_nfft(paos_ctx* c, const FrugalArgs& a, int nfft) {
   } else {
     if (a.psf) return fail(c, PAOS_EUNSUPPORTED, "no PSF-storing build of this pass shape");
   }
+  if constexpr (KPRE == 0) {  // ... and the shapes a program that ends on a saved surface ends with: field + its power
+    if (a.pow_partial) return nfft >= 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2, 2>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1, 2>(c, a);
+  } else {
+    if (a.pow_partial) return fail(c, PAOS_EUNSUPPORTED, "no power-summing build of this pass shape");
+  }
   return nfft >= 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1>(c, a);
 }
 template <typename T, int N, int AXIS, int KPRE>
@@ -766,7 +773,8 @@ void forget_mask_sets(paos_ctx* c) {  // after a failed program: what the sets h
 }
 
 // launch a pass that lower_frugal accepted
-int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const double* dblocks, bool store_psf = false) {
+int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const double* dblocks, bool store_psf = false,
+                   bool sum_power = false) {
   // PAOS_DUMP_PASSES=1: one line per pass launch on stderr (shape and what item 0's two slots carry)
   static const bool dump = [] { const char* e = getenv("PAOS_DUMP_PASSES"); return e && e[0] == '1'; }();
   if (dump && !lp.items.empty()) {
@@ -798,8 +806,9 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const
   int rc = arena_push(c, reinterpret_cast<const double*>(lp.items.data()),
                       lp.items.size() * sizeof(FrugalItem) / sizeof(double), &ditems);
   if (rc) return rc;
-  FrugalArgs a{c->field, c->tw, reinterpret_cast<const FrugalItem*>(ditems), c->pitch, c->item_stride, nullptr, nullptr};
+  FrugalArgs a{c->field, c->tw, reinterpret_cast<const FrugalItem*>(ditems), c->pitch, c->item_stride, nullptr, nullptr, nullptr};
   if (store_psf) { a.psf = c->psf; a.psf_partial = c->psf_partial; }
+  if (sum_power) a.pow_partial = c->pow_partial;
   {  // the lines some item still works on: the grid need not cover the others when their tiles have nothing to write
     // PAOS_COMPACT_GRID=0 launches the full grid (dead workgroups exit in their prologue)
     static const bool want = [] { const char* e = getenv("PAOS_COMPACT_GRID"); return !(e && e[0] == '0'); }();
@@ -919,17 +928,18 @@ int psf_keep_power_impl(paos_ctx* c, int* ticket);
 // entry_rows / entry_stale: see paos_program_opts.  final_ticket != nullptr: the caller wants |u|^2 and its sum of
 // the field the program ends with, not the field.
 int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks, int n_blocks,
-                    const double* entry_rows, bool entry_stale, int* final_ticket);
+                    const double* entry_rows, bool entry_stale, int* final_ticket, int final_mode);
 
+// final_mode (with final_ticket): 1 = the PSF instead of the field, 2 = the field as usual plus the ticket of its power
 int run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks, int n_blocks,
-               const double* entry_rows = nullptr, bool entry_stale = false, int* final_ticket = nullptr) {
-  const int rc = run_passes_impl(c, passes, n_passes, blocks, n_blocks, entry_rows, entry_stale, final_ticket);
+               const double* entry_rows = nullptr, bool entry_stale = false, int* final_ticket = nullptr, int final_mode = 1) {
+  const int rc = run_passes_impl(c, passes, n_passes, blocks, n_blocks, entry_rows, entry_stale, final_ticket, final_mode);
   if (rc != PAOS_OK && c) forget_mask_sets(c);  // a program that stopped half way: which records were rendered is moot
   return rc;
 }
 
 int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks, int n_blocks,
-                    const double* entry_rows, bool entry_stale, int* final_ticket) {
+                    const double* entry_rows, bool entry_stale, int* final_ticket, int final_mode) {
   if (!c || !passes || !blocks || n_passes < 0 || n_blocks < 1) return fail(c, PAOS_EINVAL, "bad pass program");
   // A program that ends on the PSF gives the field up for it: the free power-ticket slot it will need is checked
   // BEFORE anything is launched (found full afterwards, the context held neither field nor ticket).
@@ -1024,8 +1034,29 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
   // The PSF instead of the field: the last pass stores |u|^2 and its per-workgroup sums (frugal_pass.h: STORE) when
   // it runs on the frugal kernels in a shape built for it and every item takes part; otherwise the program runs as
   // usual and the intensity sweep follows.
-  bool fused_store = false;
-  if (final_ticket) {
+  bool fused_store = false, fused_power = false;
+  int power_groups = 0;
+  if (final_ticket && final_mode == 2) {
+    // The field is kept AND its power is wanted (a saved surface, run.py:218-223 callers): the last pass sums |u|^2 of
+    // its tiles while it stores them (FrugalArgs::pow_partial) -- when it runs on the frugal kernels and every item
+    // takes part; otherwise the ordinary reduction follows the program.
+    fused_power = n_passes > 0 && low[n_passes - 1].ok && low[n_passes - 1].kpre == 0;  // (the shapes built with STORE = 2)
+    if (fused_power)
+      for (const FrugalItem& fi : low[n_passes - 1].items) fused_power = fused_power && fi.active != 0.0;
+    if (fused_power) {
+      const int lines = passes[n_passes - 1].axis == 0 ? (c->n >= 2048 ? c->br / 2 : c->br) : 2;  // FftCfg: FR_ROW_LINES / COL_LINES
+      power_groups = c->n / lines;
+      if (c->pow_nparts < c->n / 2) {  // (sized for the finest tiling of either axis)
+        if (c->pow_partial) (void)hipFree(c->pow_partial);
+        c->pow_partial = nullptr; c->pow_nparts = 0;
+        HIPCHK(c, hipMalloc(&c->pow_partial, (size_t)c->batch * (c->n / 2) * sizeof(double)));
+        c->pow_nparts = c->n / 2;
+      }
+      // dead tiles and workgroups that are not launched at all contribute nothing: zeros
+      HIPCHK(c, hipMemsetAsync(c->pow_partial, 0, (size_t)c->batch * power_groups * sizeof(double), c->stream));
+    }
+  }
+  if (final_ticket && final_mode != 2) {
     if (!c->psf) HIPCHK(c, hipMalloc(&c->psf, (size_t)c->batch * c->item_stride * sizeof(double)));
     fused_store = n_passes > 0 && low[n_passes - 1].ok && low[n_passes - 1].kpre == 0 && low[n_passes - 1].kmid <= 1;
     if (fused_store)
@@ -1105,12 +1136,16 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
     }
     for (int q = i; q < j; ++q) {
       if (low[q].ok) {
-        if ((rc = launch_lowered(c, passes[q], low[q], dblocks, fused_store && q == n_passes - 1))) return rc;
+        if ((rc = launch_lowered(c, passes[q], low[q], dblocks, fused_store && q == n_passes - 1, fused_power && q == n_passes - 1))) return rc;
         continue;
       }
       if ((rc = launch_one_pass(c, passes[q], dblocks, n_blocks, &assign[(size_t)(q - i) * 3 * PAOS_MAX_PW]))) return rc;
     }
     i = j;
+  }
+  if (final_ticket && final_mode == 2) {
+    if (fused_power) return psf_power_ticket(c, c->pow_partial, power_groups, final_ticket);
+    return paos_norm2_enqueue(c, final_ticket);  // (a generic-kernel pass, or an item that sat the last pass out)
   }
   if (final_ticket) {
     if (fused_store) {
@@ -1341,6 +1376,7 @@ int paos_ctx_destroy(paos_ctx* c) {
   if (c->norm2) (void)hipFree(c->norm2);
   if (c->norm2_host) (void)hipHostFree(c->norm2_host);
   if (c->psf) (void)hipFree(c->psf);
+  if (c->pow_partial) (void)hipFree(c->pow_partial);
   if (c->psf_partial) (void)hipFree(c->psf_partial);
   for (int i = 0; i < 2; ++i) {
     if (c->bounce[i]) (void)hipHostFree(c->bounce[i]);
@@ -1776,8 +1812,9 @@ int paos_run_program(paos_ctx* c, const paos_pass* passes, int n_passes, const d
     if (rc) return rc;
   }
   if (opts->final_intensity && !opts->power_ticket) return fail(c, PAOS_EINVAL, "final_intensity needs a place for the power ticket");
+  if (opts->final_intensity < 0 || opts->final_intensity > 2) return fail(c, PAOS_EINVAL, "final_intensity: 0, 1 (PSF instead of the field) or 2 (field + its power)");
   return run_passes(c, passes, n_passes, blocks, n_blocks, opts->live_rows, opts->live_rows && opts->rows_stale != 0,
-                    opts->final_intensity ? opts->power_ticket : nullptr);
+                    opts->final_intensity ? opts->power_ticket : nullptr, opts->final_intensity == 2 ? 2 : 1);
 }
 
 static int norm2_enqueue_rows_impl(paos_ctx* c, const double* live_rows, const double* same_as, int* ticket) {

@@ -327,7 +327,8 @@ class PassCompiler:
         """``live_rows`` ([batch][2], optional): rows of each item outside [lo, hi) are exactly zero in
         memory on entry (a stand-alone aperture has just been applied) -- the library then skips them;
         ``rows_stale``: they hold old data standing for zeros instead.  ``final_intensity``: the last pass
-        stores |u|^2 (PSF buffer) instead of the field; returns (passes run, power ticket)."""
+        stores |u|^2 (PSF buffer) instead of the field (True / 1), or stores the field and sums its power on the way (2);
+        returns (passes run, power ticket -- None when there was no pass to do it)."""
         if not self.pending():
             return (0, None) if final_intensity else 0
         passes, blocks = self.program()
@@ -340,6 +341,6 @@ class PassCompiler:
                 dev.run_passes(passes, blocks)
             else:
                 dev.run_passes(passes, blocks, live_rows=live_rows)
-        elif final_intensity:
+        elif final_intensity and final_intensity != 2:
             raise RuntimeError("a program without passes cannot store the PSF")
         return (len(passes), ticket) if final_intensity else len(passes)

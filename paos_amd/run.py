@@ -40,6 +40,9 @@ from .zernike import zernike_tables
 import os as _os
 
 FUSE_APERTURES = {"0": False, "1": True}.get(_os.environ.get("PAOS_FUSE_APERTURES", "auto"), "auto")
+# The power of a saved surface whose field is exactly what its pass program stored is summed by that program's last pass
+# (csrc/frugal_pass.h: STORE = 2) instead of by a reduction that reads the field back; PAOS_POWER_ON_STORE=0 switches it off.
+POWER_ON_STORE = _os.environ.get("PAOS_POWER_ON_STORE", "1") != "0"
 _MASK_RUN = 192  # kMaskW of csrc/frugal_pass.h
 
 
@@ -321,7 +324,7 @@ class _WalkState:
         self.rows, self.psf_ticket, self.same_as = None, None, None
 
 
-def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_at=None):
+def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_at=None, power_state=None):
     """Drive all items through their chains in lock-step, one surface at a time.  ``fresh``: the
     constant the field is meant to hold but has not been filled with yet (see _start_field).
     ``lean`` (a _WalkState, optional): the caller reads no arrays at saved surfaces, only powers (through
@@ -361,7 +364,7 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
         if psf_at is not None and key == psf_at and lean.psf_ticket is None:
             settle()
 
-    def flush(final_intensity=False):
+    def flush(final_intensity=False, final_power=False):
         if dead[0]:
             comp.program()  # drop what was queued behind the PSF store
             return 0
@@ -372,6 +375,12 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
             done, ticket = comp.flush(dev, live_rows=rows, rows_stale=stale[0] and rows is not None, final_intensity=True)
             lean.psf_ticket = ticket
             dead[0] = True
+        elif final_power:
+            # the surface reached by this program is saved and nothing but the program touches its field: the last pass
+            # sums |u|^2 while it stores (paos_run_program: final_intensity = 2) -- no sweep that reads the field back
+            power_state["before"]()  # (the ticket is taken inside: room in the ring first)
+            done, ticket = comp.flush(dev, live_rows=rows, rows_stale=stale[0] and rows is not None, final_intensity=2)
+            power_state["ticket"] = ticket if done else None
         else:
             done = comp.flush(dev, live_rows=rows, rows_stale=stale[0] and rows is not None)
         if done:
@@ -382,6 +391,8 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
 
     for key in keys[0]:
         items = [c[key] for c in chains]
+        if power_state is not None:
+            power_state["ticket"] = None  # (a ticket belongs to the surface its program ended on)
         dxs, dys, wls = state[:, beams.DX].tolist(), state[:, beams.DY].tolist(), state[:, beams.WL].tolist()
         readout = []
 
@@ -464,8 +475,11 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
             only_saved = saved and all(it["save"] for it in items) and not any(
                 p["stop"] or p["zernike"] is not None or p["phase_map"] is not None or
                 (p["aperture"] is not None and not fuse_ap) for p in plans)
-            npass += flush(final_intensity=(lean is not None and psf_at is not None and key == psf_at and only_saved
-                                            and comp.pending() and not dead[0]))
+            as_psf = (lean is not None and psf_at is not None and key == psf_at and only_saved and comp.pending()
+                      and not dead[0])
+            npass += flush(final_intensity=as_psf,
+                           final_power=(not as_psf and power_state is not None and only_saved and comp.pending()
+                                        and not dead[0]))
         if not fuse_ap:
             _launch_apertures(dev, plans)
             if not comp.pending():
@@ -628,6 +642,14 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
                 rec["power"] = float(values[i])
         drained[0] = len(tickets)
 
+    def room_in_the_ring():
+        if len(tickets) - drained[0] >= _lib.NORM_SLOTS - 2:
+            drain()
+
+    # the power of a saved surface summed by the pass that stores its field (csrc/frugal_pass.h: pow_partial): _walk
+    # leaves the ticket here when the surface's field is exactly what its pass program stored
+    power_state = {"ticket": None, "before": room_in_the_ring} if (power and POWER_ON_STORE) else None
+
     def on_saved(key, items, plans, wfe):
         pending = []
         for i, (item, plan) in enumerate(zip(items, plans)):
@@ -653,7 +675,11 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
             # the saved last surface of a run that keeps its PSFs: |u|^2 written and summed in one sweep
             if fused is not None:
                 tickets.append((fused, pending))
+            elif power_state is not None and power_state["ticket"] is not None and not keep:
+                tickets.append((power_state["ticket"], pending))
             elif keep:
+                if power_state is not None and power_state["ticket"] is not None:  # (the kept PSF brings its own sum)
+                    dev.norm2_release(power_state["ticket"])
                 tickets.append((dev.psf_keep_power(), pending))
             else:
                 like = lean.same_as if lean is not None else None
@@ -668,7 +694,7 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
 
     try:
         _walk(dev, states, list(opt_chains), on_saved, stats=stats, fresh=1.0 + 0.0j, lean=lean,
-              psf_at=last_key if (keep_psf and lean is not None) else None)
+              psf_at=last_key if (keep_psf and lean is not None) else None, power_state=power_state)
         if sync or own:
             drain()
         else:  # caller synchronises later: hand out the tickets still outstanding

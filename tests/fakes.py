@@ -286,6 +286,11 @@ class ModelDevice:
                         ax = 1 if ps["axis"] == 0 else 0  # "along rows" = NumPy axis 1
                         u = np.fft.ifft(u, axis=ax) * self.n if blocks[ctl, i, 1] else np.fft.fft(u, axis=ax)
                 self.u[i] = u
+        if final_intensity == 2:  # the field is kept; its power comes back as a ticket (the last pass sums it on the way)
+            self.log.append(("power_on_store", None))
+            self._tickets = getattr(self, "_tickets", [])
+            self._tickets.append(self.norm2())
+            return len(self._tickets) - 1
         if final_intensity:  # the PSF and its sum instead of the field, which is given up
             self.log.append(("psf_store", None))
             self.psf = self.u.real**2 + self.u.imag**2

@@ -685,3 +685,33 @@ def test_random_chains_on_the_production_kernels_vs_the_numpy_model(seed):
             worst = max(worst, e, e2)
             assert e < 1e-11 and e2 < 1e-11, (seed, i, k, e, e2)
     print(f"seed {seed}: {len(chain)} surfaces, {len(want[0])} saved, worst error {worst:.1e}")
+
+
+def test_power_summed_by_the_storing_pass_equals_the_separate_reduction():
+    """Round 4: the power of a saved surface rides on the pass that stores its field (STORE = 2 builds of the pass kernel,
+    paos_run_program: final_intensity = 2).  Ariel_AIRS-CH0 (12 saved surfaces, apertures riding on passes) and
+    Excite_TEL at 1024^2 / 2048^2, fp64 and fp32: the powers equal those of the ordinary reductions
+    (PAOS_POWER_ON_STORE off) and the sum over the downloaded field."""
+    import paos_amd.run as prun
+    from paos_amd.chains import parse_config_variant
+    from paos_amd.run import run_batch
+
+    for name, n, sweep in (("Ariel_AIRS-CH0", 1024, [1.95, 3.9]), ("Excite_TEL", 2048, [1.0, 3.4])):
+        pup, par, wls, fields, chains = parse_config_variant(os.path.join(LENS, name + ".ini"), sweep)
+        w = [1.0e-6 * x for x in wls]
+        for precision, tol in (("fp64", 1e-12), ("fp32", 2e-6)):
+            got = run_batch(pup, w, n, par["zoom"], fields[0], chains, outputs=(), precision=precision)
+            prun.POWER_ON_STORE = False
+            try:
+                want = run_batch(pup, w, n, par["zoom"], fields[0], chains, outputs=("wfo",), precision=precision)
+            finally:
+                prun.POWER_ON_STORE = True
+            worst = 0.0
+            for i in range(len(w)):
+                assert sorted(got[i]) == sorted(want[i])
+                for k in want[i]:
+                    direct = float(np.sum(np.abs(want[i][k]["wfo"].astype(np.complex128)) ** 2))
+                    worst = max(worst, abs(got[i][k]["power"] - want[i][k]["power"]) / want[i][k]["power"])
+                    assert abs(got[i][k]["power"] - want[i][k]["power"]) <= tol * want[i][k]["power"], (name, precision, i, k)
+                    assert abs(got[i][k]["power"] - direct) <= max(tol, 1e-12) * direct * 10, (name, precision, i, k)
+            print(f"{name} {n}^2 {precision}: {len(want[0])} saved surfaces, worst power difference {worst:.1e}")

@@ -712,3 +712,33 @@ def test_a_near_inverse_wts_stw_pair_keeps_its_residual_phase():
     assert out[True][0] < out[False][0], (out[True][0], out[False][0])
     assert rel_err(out[True][1], out[False][1]) < 1e-13
     assert rel_err(u0, out[False][1]) > 1e-9  # ... and the residual is really there
+
+
+def test_power_of_a_saved_surface_rides_on_the_pass_that_stores_it():
+    """Round 4: where a saved surface's field is exactly what its pass program stored (no stop, Zernike, phase map or
+    stand-alone aperture on the surface), the last pass sums |u|^2 on the way (paos_run_program: final_intensity = 2)
+    and no separate reduction reads the field back.  On the model device: SYN20 with every relay surface saved -- the
+    powers equal those of the ordinary reductions, and the fused path was really taken."""
+    import paos_amd.run as prun
+    from paos_amd.run import run_batch
+
+    wls = [1.0e-6, 1.4e-6]
+    chain = syn20_chain()
+    for k, it in chain.items():
+        if it["name"].endswith("b") or it["name"].endswith("c"):
+            chain[k] = dict(it, save=True)
+    prun.FUSE_APERTURES = True
+    try:
+        dev = ModelDevice(128, 2)
+        got = run_batch(1.0, wls, 128, 4, FIELD, [chain, chain], outputs=(), dev=dev, keep_psf=True)
+        kinds = [name for name, _ in dev.log]
+        assert kinds.count("power_on_store") >= 8, kinds.count("power_on_store")
+        want = run_batch(1.0, wls, 128, 4, FIELD, [chain, chain], outputs=("wfo",), dev=ModelDevice(128, 2), keep_psf=True)
+    finally:
+        prun.FUSE_APERTURES = "auto"
+    for i in range(2):
+        assert sorted(got[i]) == sorted(want[i])
+        for k in want[i]:
+            direct = float(np.sum(np.abs(want[i][k]["wfo"]) ** 2))
+            assert abs(got[i][k]["power"] - direct) <= 1e-12 * direct, (i, k, got[i][k]["power"], direct)
+            assert abs(want[i][k]["power"] - direct) <= 1e-12 * direct
