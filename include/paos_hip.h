@@ -161,6 +161,11 @@ int paos_aperture_render(paos_ctx* ctx, int shape, const double* params1, double
 /* WFO.make_stop (wfo.py:195-201): u /= sqrt(sum |u|^2), per enabled item.
  * enable may be NULL (= all). */
 int paos_make_stop(paos_ctx* ctx, const double* enable);
+/* make_stop (wfo.py:195-201) for a field whose power the context has JUST reduced: the pass program that stored the
+ * field ended with final_intensity = 2 (paos_run_program) and nothing has run on the context since.  Only the scaling
+ * sweep u *= 1/sqrt(power) is launched -- the reduction that would read the field back has already been done by the
+ * pass that stored it.  The caller vouches for the precondition (paos_amd/run.py: _walk is the one caller). */
+int paos_stop_scale_last_power(paos_ctx* ctx, const double* enable);
 /* sum |u|^2 per item to the host (np.sum(np.abs(u)**2), wfo.py:200).  Synchronises. */
 int paos_norm2(paos_ctx* ctx, double* host_out);
 /* The same without stalling the host: enqueue the reduction and its copy to pinned memory,

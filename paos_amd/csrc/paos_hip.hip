@@ -1700,6 +1700,23 @@ int paos_make_stop(paos_ctx* c, const double* enable) {
   return PAOS_OK;
 }
 
+int paos_stop_scale_last_power(paos_ctx* c, const double* enable) {
+  if (c) (void)hipSetDevice(c->device);
+  if (!c) return fail(c, PAOS_EINVAL, "null context");
+  const double* den = nullptr;
+  if (enable) {
+    int rc = arena_push(c, enable, (size_t)c->batch, &den);
+    if (rc) return rc;
+  }
+  const dim3 grid(pw_blocks(c), c->batch), block(kPwThreads);
+  if (c->precision == PAOS_F64)
+    hipLaunchKernelGGL(stop_scale_kernel<double>, grid, block, 0, c->stream, (cx<double>*)c->field, c->norm2, c->item_stride, den, 1);
+  else
+    hipLaunchKernelGGL(stop_scale_kernel<float>, grid, block, 0, c->stream, (cx<float>*)c->field, c->norm2, c->item_stride, den, 1);
+  HIPCHK(c, hipGetLastError());
+  return PAOS_OK;
+}
+
 int paos_psf_metrics(paos_ctx* c, int nr, const double* radii_px, double cx_px, double cy_px, double* host_out) {
   if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c || !host_out || nr < 0 || nr > kMaxRadii || (nr > 0 && !radii_px)) return fail(c, PAOS_EINVAL, "bad metrics request");

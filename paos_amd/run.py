@@ -43,6 +43,9 @@ FUSE_APERTURES = {"0": False, "1": True}.get(_os.environ.get("PAOS_FUSE_APERTURE
 # The power of a saved surface whose field is exactly what its pass program stored is summed by that program's last pass
 # (csrc/frugal_pass.h: STORE = 2) instead of by a reduction that reads the field back; PAOS_POWER_ON_STORE=0 switches it off.
 POWER_ON_STORE = _os.environ.get("PAOS_POWER_ON_STORE", "1") != "0"
+# ... and a stop right behind a pass program scales by the power that program's last pass has summed (make_stop's own
+# reduction would read the field back); PAOS_STOP_FROM_PROGRAM=0 switches it off.
+STOP_FROM_PROGRAM = _os.environ.get("PAOS_STOP_FROM_PROGRAM", "1") != "0"
 _MASK_RUN = 192  # kMaskW of csrc/frugal_pass.h
 
 
@@ -347,6 +350,8 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
     stale = [False]  # rows outside ``live`` hold old data that stands for zeros (lean start)
     dead = [False]   # the field has been given up for its PSF (lean end): nothing may run on it any more
 
+    prog_power = [None]  # ticket of the power of the field a program has just stored (flush(final_power=True))
+
     def known_rows():
         return [list(r) for r in live] if any(r[0] > 0 or r[1] < dev.n for r in live) else None
 
@@ -376,11 +381,13 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
             lean.psf_ticket = ticket
             dead[0] = True
         elif final_power:
-            # the surface reached by this program is saved and nothing but the program touches its field: the last pass
-            # sums |u|^2 while it stores (paos_run_program: final_intensity = 2) -- no sweep that reads the field back
-            power_state["before"]()  # (the ticket is taken inside: room in the ring first)
+            # the surface reached by this program is saved (or a stop) and nothing but the program touches its field
+            # first: the last pass sums |u|^2 while it stores (paos_run_program: final_intensity = 2) -- no sweep that
+            # reads the field back
+            if power_state is not None:
+                power_state["before"]()  # (the ticket is taken inside: room in the ring first)
             done, ticket = comp.flush(dev, live_rows=rows, rows_stale=stale[0] and rows is not None, final_intensity=2)
-            power_state["ticket"] = ticket if done else None
+            prog_power[0] = ticket if done else None
         else:
             done = comp.flush(dev, live_rows=rows, rows_stale=stale[0] and rows is not None)
         if done:
@@ -392,7 +399,9 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
     for key in keys[0]:
         items = [c[key] for c in chains]
         if power_state is not None:
-            power_state["ticket"] = None  # (a ticket belongs to the surface its program ended on)
+            if power_state["ticket"] is not None and not power_state.get("used"):
+                dev.norm2_release(power_state["ticket"])  # (taken for a stop on a surface nobody saved)
+            power_state["ticket"], power_state["post"], power_state["used"] = None, None, False  # (a ticket belongs to its surface)
         dxs, dys, wls = state[:, beams.DX].tolist(), state[:, beams.DY].tolist(), state[:, beams.WL].tolist()
         readout = []
 
@@ -477,16 +486,37 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
                 (p["aperture"] is not None and not fuse_ap) for p in plans)
             as_psf = (lean is not None and psf_at is not None and key == psf_at and only_saved and comp.pending()
                       and not dead[0])
+            # a stop right behind the program needs the power of what the program stores; a saved surface whose
+            # field IS what the program stores reports it
+            stop_rides = (STOP_FROM_PROGRAM and any(p["stop"] for p in plans) and comp.pending() and not dead[0] and
+                          not any(p["aperture"] is not None and not fuse_ap for p in plans))
             npass += flush(final_intensity=as_psf,
-                           final_power=(not as_psf and power_state is not None and only_saved and comp.pending()
-                                        and not dead[0]))
+                           final_power=(not as_psf and comp.pending() and not dead[0] and
+                                        (stop_rides or (power_state is not None and only_saved))))
         if not fuse_ap:
             _launch_apertures(dev, plans)
             if not comp.pending():
                 _live_rows_after(plans, live, dev.n)
         if any(p["stop"] for p in plans):
             settle()
-            dev.make_stop([1.0 if p["stop"] else 0.0 for p in plans])
+            flags = [1.0 if p["stop"] else 0.0 for p in plans]
+            if prog_power[0] is not None:  # the program's last pass has summed the power on its way out
+                dev.make_stop(flags, power_known=True)
+                if power_state is not None:
+                    # should the surface be saved: the power BEHIND the stop is P (1 / sqrt P)^2 where the stop applies
+                    power_state["ticket"] = prog_power[0]
+                    power_state["post"] = lambda v, f=np.array(flags): np.where(f != 0.0, v * (1.0 / np.sqrt(v)) ** 2, v)
+                else:
+                    dev.norm2_release(prog_power[0])
+                prog_power[0] = None
+            else:
+                dev.make_stop(flags)
+        elif prog_power[0] is not None:
+            if power_state is not None:
+                power_state["ticket"], power_state["post"] = prog_power[0], None
+            else:
+                dev.norm2_release(prog_power[0])
+            prog_power[0] = None
         want_wfe = len(plans) == 1 and bool(items[0]["save"])
         wfe = _launch_zernike(dev, plans, want_wfe=want_wfe)
         wfe = _launch_phase_maps(dev, plans, wfe)
@@ -500,6 +530,9 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
             if lean is not None:
                 lean.rows, lean.psf_ticket = None, None
         _queue_steps(comp, lens, stw, ptp, wts, inv_stw, inv_wts)
+    if power_state is not None and power_state["ticket"] is not None and not power_state.get("used"):
+        dev.norm2_release(power_state["ticket"])  # (taken for a stop on the last surface, which nobody saved)
+        power_state["ticket"] = None
     if fresh is not None:  # an empty chain still yields the initial wavefront
         dev.fill(fresh)
     npass += flush()
@@ -636,8 +669,11 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
     drained = [0]
 
     def drain():
-        for ticket, pending in tickets[drained[0]:]:
+        for entry in tickets[drained[0]:]:
+            ticket, pending = entry[0], entry[1]
             values = dev.norm2_fetch(ticket)
+            if len(entry) > 2 and entry[2] is not None:
+                values = entry[2](values)
             for i, rec in pending:
                 rec["power"] = float(values[i])
         drained[0] = len(tickets)
@@ -648,7 +684,8 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
 
     # the power of a saved surface summed by the pass that stores its field (csrc/frugal_pass.h: pow_partial): _walk
     # leaves the ticket here when the surface's field is exactly what its pass program stored
-    power_state = {"ticket": None, "before": room_in_the_ring} if (power and POWER_ON_STORE) else None
+    power_state = ({"ticket": None, "post": None, "used": False, "before": room_in_the_ring}
+                   if (power and POWER_ON_STORE) else None)
 
     def on_saved(key, items, plans, wfe):
         pending = []
@@ -676,10 +713,12 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
             if fused is not None:
                 tickets.append((fused, pending))
             elif power_state is not None and power_state["ticket"] is not None and not keep:
-                tickets.append((power_state["ticket"], pending))
+                tickets.append((power_state["ticket"], pending, power_state.get("post")))
+                power_state["used"] = True
             elif keep:
                 if power_state is not None and power_state["ticket"] is not None:  # (the kept PSF brings its own sum)
                     dev.norm2_release(power_state["ticket"])
+                    power_state["used"] = True
                 tickets.append((dev.psf_keep_power(), pending))
             else:
                 like = lean.same_as if lean is not None else None
@@ -698,9 +737,14 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
         if sync or own:
             drain()
         else:  # caller synchronises later: hand out the tickets still outstanding
-            for ticket, pending in tickets[drained[0]:]:
-                for i, rec in pending:
-                    rec["power_ticket"] = ticket
+            for entry in tickets[drained[0]:]:
+                if len(entry) > 2 and entry[2] is not None:  # (a derived value: it cannot be handed out as a bare ticket)
+                    values = entry[2](dev.norm2_fetch(entry[0]))
+                    for i, rec in entry[1]:
+                        rec["power"] = float(values[i])
+                    continue
+                for i, rec in entry[1]:
+                    rec["power_ticket"] = entry[0]
     finally:
         if own:
             dev.close()

@@ -85,8 +85,10 @@ class ModelDevice:
     def norm2_fetch(self, ticket):
         return self._tickets[ticket]
 
-    def make_stop(self, enable=None):
-        self.log.append(("make_stop", None))
+    def make_stop(self, enable=None, power_known=False):
+        self.log.append(("make_stop", "power_known" if power_known else None))
+        if power_known:  # the precondition the library cannot check: a program with final_intensity = 2 came right before
+            assert self.log[-2][0] == "power_on_store", self.log[-3:]
         for i in range(self.batch):
             if enable is None or enable[i]:
                 self.u[i] /= np.sqrt(np.sum(np.abs(self.u[i]) ** 2))

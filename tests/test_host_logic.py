@@ -742,3 +742,32 @@ def test_power_of_a_saved_surface_rides_on_the_pass_that_stores_it():
             direct = float(np.sum(np.abs(want[i][k]["wfo"]) ** 2))
             assert abs(got[i][k]["power"] - direct) <= 1e-12 * direct, (i, k, got[i][k]["power"], direct)
             assert abs(want[i][k]["power"] - direct) <= 1e-12 * direct
+
+
+@pytest.mark.parametrize("name", ["Excite_TEL", "Ariel_AIRS-CH0", "Ariel_FGS-FGS1"])
+def test_a_stop_behind_a_pass_program_takes_its_power_from_the_program(name):
+    """Round 4: the stop of a real prescription sits on a mirror the beam has propagated to; the pass program that
+    brings it there sums |u|^2 on its way out (final_intensity = 2) and make_stop only scales
+    (paos_stop_scale_last_power).  Fields and powers equal those of the ordinary make_stop; the power reported behind
+    the stop is P (1 / sqrt P)^2."""
+    import paos_amd.run as prun
+    from paos_amd.run import run_batch
+
+    spec = _spec(name)
+    out = {}
+    for fused in (True, False):
+        prun.STOP_FROM_PROGRAM = fused
+        prun.FUSE_APERTURES = True  # as at the production sizes: the mirror's aperture rides on the pass that reaches it
+        try:
+            dev = ModelDevice(64, 2)
+            out[fused] = (run_batch(spec["pup"], [spec["wl"], 1.1 * spec["wl"]], 64, spec["zoom"], spec["field"], [spec["chain"]] * 2,
+                                    outputs=("wfo",), dev=dev), [k for k, d in dev.log if k == "make_stop" and d == "power_known"])
+        finally:
+            prun.STOP_FROM_PROGRAM = True
+            prun.FUSE_APERTURES = "auto"
+    assert len(out[True][1]) == 1 and len(out[False][1]) == 0  # the fused path was taken exactly where a stop follows a program
+    for i in range(2):
+        for k in out[False][0][i]:
+            a, b = out[True][0][i][k], out[False][0][i][k]
+            assert rel_err(a["wfo"], b["wfo"]) < 1e-14, (name, i, k)
+            assert abs(a["power"] - b["power"]) <= 1e-13 * b["power"], (name, i, k, a["power"], b["power"])
