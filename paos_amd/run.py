@@ -46,6 +46,9 @@ POWER_ON_STORE = _os.environ.get("PAOS_POWER_ON_STORE", "1") != "0"
 # ... and a stop right behind a pass program scales by the power that program's last pass has summed (make_stop's own
 # reduction would read the field back); PAOS_STOP_FROM_PROGRAM=0 switches it off.
 STOP_FROM_PROGRAM = _os.environ.get("PAOS_STOP_FROM_PROGRAM", "1") != "0"
+# ... and the pass program that reaches the last surface that does anything (a saved slit with the image plane right behind
+# it) stores the PSF for the inert surfaces behind it as well; PAOS_INERT_TAIL=0 switches it off.
+INERT_TAIL = _os.environ.get("PAOS_INERT_TAIL", "1") != "0"
 _MASK_RUN = 192  # kMaskW of csrc/frugal_pass.h
 
 
@@ -167,6 +170,16 @@ def _surface_gates(items):
     T = [g[2] for g in gt]
     n1n2 = [g[3] for g in gt]
     return Mt, Ms, fl, T, n1n2
+
+
+def _inert(item):
+    """A surface that does nothing to the field whatever the beam: no aperture, no stop, no phase, and identity ABCD
+    matrices (zero thickness, no power, unit magnification, no change of medium) -- the image plane right behind a slit,
+    a coordinate break.  (What run.py:181-207 would gate on: Mt = Ms = 1, fl = inf, T = 0, n1n2 = 1.)"""
+    if item.get("aperture") is not None or item.get("is_stop") or item["type"] in ("Zernike", "Grid Sag", "PSD"):
+        return False
+    (Mt,), (Ms,), (fl,), (T,), (n1n2,) = _surface_gates([item])
+    return Mt == 1.0 and Ms == 1.0 and math.isinf(fl) and T == 0.0 and n1n2 == 1.0
 
 
 def _live_rows_after(plans, live, n):
@@ -325,6 +338,9 @@ class _WalkState:
 
     def __init__(self):
         self.rows, self.psf_ticket, self.same_as = None, None, None
+        # set once a pass program has stored the PSF for good (nothing but inert surfaces follows): the saved surfaces
+        # still to come report this ticket's power, and the PSF is already where keep_psf wants it
+        self.final_ticket = None
 
 
 def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_at=None, power_state=None):
@@ -378,7 +394,7 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
             return 0
         if final_intensity:
             done, ticket = comp.flush(dev, live_rows=rows, rows_stale=stale[0] and rows is not None, final_intensity=True)
-            lean.psf_ticket = ticket
+            lean.psf_ticket = lean.final_ticket = ticket
             dead[0] = True
         elif final_power:
             # the surface reached by this program is saved (or a stop) and nothing but the program touches its field
@@ -396,7 +412,12 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
                 r[0], r[1] = 0, dev.n
         return done
 
-    for key in keys[0]:
+    # from which surface on nothing touches the field any more (index into keys[0]; len = never)
+    order = keys[0]
+    inert_from = len(order)
+    while inert_from > 0 and all(_inert(c[order[inert_from - 1]]) for c in chains):
+        inert_from -= 1
+    for pos, key in enumerate(order):
         items = [c[key] for c in chains]
         if power_state is not None:
             if power_state["ticket"] is not None and not power_state.get("used"):
@@ -484,7 +505,10 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
             only_saved = saved and all(it["save"] for it in items) and not any(
                 p["stop"] or p["zernike"] is not None or p["phase_map"] is not None or
                 (p["aperture"] is not None and not fuse_ap) for p in plans)
-            as_psf = (lean is not None and psf_at is not None and key == psf_at and only_saved and comp.pending()
+            # ... the last surface -- or a surface behind which only inert ones follow (the image plane right behind a
+            # saved slit): what the program stores here is what the chain ends with
+            ends_here = key == psf_at or (INERT_TAIL and pos + 1 >= inert_from and psf_at == order[-1])
+            as_psf = (lean is not None and psf_at is not None and ends_here and only_saved and comp.pending()
                       and not dead[0])
             # a stop right behind the program needs the power of what the program stores; a saved surface whose
             # field IS what the program stores reports it
@@ -668,10 +692,15 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
     # saves more surfaces than the library has ticket slots: then the oldest are fetched early
     drained = [0]
 
+    fetched, released = {}, set()  # (one ticket may answer for several surfaces: fetched / given back once)
+
     def drain():
         for entry in tickets[drained[0]:]:
             ticket, pending = entry[0], entry[1]
-            values = dev.norm2_fetch(ticket)
+            if ticket not in fetched:
+                fetched.clear()  # (slots are handed out again once fetched: only the latest value is worth keeping)
+                fetched[ticket] = dev.norm2_fetch(ticket)
+            values = fetched[ticket]
             if len(entry) > 2 and entry[2] is not None:
                 values = entry[2](values)
             for i, rec in pending:
@@ -704,7 +733,8 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
             for i, rec in pending:
                 rec["metrics"] = met[i]
         keep = keep_psf and key == last_key
-        fused = lean.psf_ticket if lean is not None else None  # the last pass has stored |u|^2 and enqueued its sum
+        # the last pass has stored |u|^2 and enqueued its sum -- for this surface, or for good (inert surfaces behind it)
+        fused = (lean.psf_ticket if lean.psf_ticket is not None else lean.final_ticket) if lean is not None else None
         rows = lean.rows if lean is not None else None
         if power:
             if len(tickets) - drained[0] >= _lib.NORM_SLOTS - 1 and fused is None:
@@ -727,7 +757,9 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
                 else:
                     tickets.append((dev.norm2_enqueue(rows) if rows is not None else dev.norm2_enqueue(), pending))
         elif fused is not None:
-            dev.norm2_release(fused)
+            if fused not in released:
+                released.add(fused)
+                dev.norm2_release(fused)
         elif keep:
             dev.psf_keep()
 

@@ -771,3 +771,39 @@ def test_a_stop_behind_a_pass_program_takes_its_power_from_the_program(name):
             a, b = out[True][0][i][k], out[False][0][i][k]
             assert rel_err(a["wfo"], b["wfo"]) < 1e-14, (name, i, k)
             assert abs(a["power"] - b["power"]) <= 1e-13 * b["power"], (name, i, k, a["power"], b["power"])
+
+
+def test_the_image_plane_right_behind_a_saved_slit_shares_its_pass():
+    """Round 4: Excite_TEL ends "slit (saved, aperture) | IMAGE_PLANE (saved, zero thickness)": nothing touches the field
+    behind the slit, so in a lean walk that keeps its PSFs the pass program that reaches the slit stores |u|^2 for the
+    image plane as well (one psf_store, no psf_keep sweep, no separate reduction for the slit), and both surfaces
+    report that pass's power.  Equal to the ordinary walk; PAOS_INERT_TAIL=0 gives the round-3 behaviour."""
+    import paos_amd.run as prun
+    from paos_amd.run import run_batch
+
+    spec = _spec("Excite_TEL")
+    wls = [spec["wl"], 1.2 * spec["wl"]]
+    args = (spec["pup"], wls, 64, spec["zoom"], spec["field"], [spec["chain"]] * 2)
+    prun.FUSE_APERTURES = True
+    try:
+        want = run_batch(*args, outputs=("psf",), dev=ModelDevice(64, 2), keep_psf=True)
+        dev = ModelDevice(64, 2)
+        got = run_batch(*args, outputs=(), dev=dev, keep_psf=True)
+        prun.INERT_TAIL = False
+        try:
+            dev_old = ModelDevice(64, 2)
+            old = run_batch(*args, outputs=(), dev=dev_old, keep_psf=True)
+        finally:
+            prun.INERT_TAIL = True
+    finally:
+        prun.FUSE_APERTURES = "auto"
+    kinds, kinds_old = [k for k, _ in dev.log], [k for k, _ in dev_old.log]
+    assert kinds.count("psf_store") == 1 and kinds.count("psf_keep") == 0 and kinds.count("psf_keep_power") == 0, kinds
+    assert kinds_old.count("psf_store") == 0  # round 3: the slit's program stores the field, the image plane sweeps it again
+    last, slit = max(want[0]), sorted(want[0])[-2]
+    for i in range(2):
+        assert np.allclose(dev.psf_fetch(i), want[i][last]["psf"], rtol=0, atol=1e-13 * want[i][last]["psf"].max())
+        for k in (slit, last):
+            assert abs(got[i][k]["power"] - want[i][k]["power"]) <= 1e-12 * want[i][k]["power"], (i, k)
+            assert abs(old[i][k]["power"] - want[i][k]["power"]) <= 1e-12 * want[i][k]["power"], (i, k)
+        assert got[i][slit]["power"] == got[i][last]["power"]
