@@ -166,6 +166,13 @@ int paos_make_stop(paos_ctx* ctx, const double* enable);
  * sweep u *= 1/sqrt(power) is launched -- the reduction that would read the field back has already been done by the
  * pass that stored it.  The caller vouches for the precondition (paos_amd/run.py: _walk is the one caller). */
 int paos_stop_scale_last_power(paos_ctx* ctx, const double* enable);
+/* The same stop, with even the scaling sweep left out: 1 / sqrt(power) is kept per item on the device and the NEXT pass
+ * program's first pass multiplies it into its middle slot (one more factor in a multiplication it performs anyway), so
+ * the stop costs neither a read nor a write of the field.  Anything else that touches the field first -- a download, a
+ * reduction, an aperture, another stop, a pass program whose first pass cannot take it (generic kernel, an item that
+ * sits it out) -- applies it then, by the sweep paos_stop_scale_last_power would have run: same factor, same products,
+ * bit-identical.  Same precondition as above. */
+int paos_stop_defer_last_power(paos_ctx* ctx, const double* enable);
 /* sum |u|^2 per item to the host (np.sum(np.abs(u)**2), wfo.py:200).  Synchronises. */
 int paos_norm2(paos_ctx* ctx, double* host_out);
 /* The same without stalling the host: enqueue the reduction and its copy to pinned memory,

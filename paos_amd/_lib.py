@@ -69,6 +69,7 @@ SYMBOLS = {
     "paos_aperture_render": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p, _dbl_p]),
     "paos_make_stop": (ctypes.c_int, [_c_ctx, _dbl_p]),
     "paos_stop_scale_last_power": (ctypes.c_int, [_c_ctx, _dbl_p]),
+    "paos_stop_defer_last_power": (ctypes.c_int, [_c_ctx, _dbl_p]),
     "paos_norm2": (ctypes.c_int, [_c_ctx, _dbl_p]),
     "paos_norm2_enqueue": (ctypes.c_int, [_c_ctx, ctypes.POINTER(ctypes.c_int)]),
     "paos_norm2_fetch": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p]),
@@ -345,10 +346,13 @@ class DeviceFields:
                     "paos_aperture_render")
         return out
 
-    def make_stop(self, enable=None, power_known=False):
+    def make_stop(self, enable=None, power_known=False, defer=False):
         """``power_known``: the pass program that stored the field has just reduced its power (run_passes with
-        final_intensity = 2, nothing since): only the scaling sweep runs."""
-        fn, name = ((self._lib.paos_stop_scale_last_power, "paos_stop_scale_last_power") if power_known
+        final_intensity = 2, nothing since): only the scaling sweep runs -- or, with ``defer``, not even that: the
+        next pass program's first pass takes the factor along (the library applies it earlier if anything else touches
+        the field first)."""
+        fn, name = ((self._lib.paos_stop_defer_last_power, "paos_stop_defer_last_power") if (power_known and defer)
+                    else (self._lib.paos_stop_scale_last_power, "paos_stop_scale_last_power") if power_known
                     else (self._lib.paos_make_stop, "paos_make_stop"))
         if enable is None:
             self._check(fn(self._ctx, None), name)

@@ -113,6 +113,10 @@ struct FrugalArgs {
   // to pow_partial[item * (workgroups per item) + workgroup] -- the power of a saved surface (run.py:218-223 callers'
   // sum |wfo|^2) without a separate sweep that reads the field back.  Dead tiles write nothing: the host zeroes the array.
   double* pow_partial;
+  // [batch] factors the slot between the transforms multiplies its scale by: ones, except right behind a stop whose
+  // 1 / sqrt(power) has been left for this pass to apply (paos_stop_defer_last_power: the stop's own sweep over the field
+  // -- a read and a write of every element -- is gone; make_stop, wfo.py:195-201).  Never null.
+  const double* dyn_scale;
 #if PAOS_STAMPS
   unsigned long long* stamps;  // [gridDim.y][gridDim.x][kStampSlots]
 #endif
@@ -204,7 +208,7 @@ template <typename T, int N, int E, int K, typename Map, int PLAIN = 0, bool SHA
 __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, const FrugalPhase* ph,
                                             const Map& m, const cx<double>* circle, bool conj_in, bool conj_out, int tpos,
                                             void* area = nullptr, bool area_busy = false, const MaskLine* recs = nullptr,
-                                            int lbase = 0) {
+                                            int lbase = 0, double extra_scale = 1.0) {
   if constexpr (PLAIN == 1) {  // column passes: the conjugation, nothing else
     static_assert(K == 0, "a plain slot has no phases");
     const unsigned mask = (conj_out != conj_in) ? 0x80000000u : 0u;
@@ -234,7 +238,7 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
   // order, swap_nibbles(m.t) between the two transforms of a digit-swapped pass
   constexpr int TL = N / E;
   static_assert(TL % 2 == 0, "the checkerboard sign is constant along a thread's elements");
-  const double sc = sl.scale;
+  const double sc = __dmul_rn(sl.scale, extra_scale);  // (extra_scale: 1 exactly, except behind a deferred stop)
   const int line = Map::kAxis == 0 ? m.row(0) : m.col(0);  // this thread's row (column): constant
   if (sl.mask_on != 0.0) {  // wave-uniform: an aperture rides on this slot
     MaskLine ml;
@@ -570,12 +574,13 @@ __device__ __forceinline__ void tile_power_out(double acc, double* scratch, doub
 // that every workgroup waits for before it can even ask for its item's record.  Launch with PAOS_FRUGAL_PASS(args).
 #if PAOS_STAMPS
 #define PAOS_FRUGAL_PARAMS const FrugalItem *k_items, void *k_field, unsigned k_pitch, unsigned k_item_stride, unsigned k_wg0, \
-                           const void *k_tw, double *k_psf, double *k_psf_partial, double *k_pow_partial, unsigned long long *k_stamps
-#define PAOS_FRUGAL_PASS(a) (a).items, (a).field, (a).pitch, (a).item_stride, (a).wg0, (a).tw, (a).psf, (a).psf_partial, (a).pow_partial, (a).stamps
+                           const void *k_tw, double *k_psf, double *k_psf_partial, double *k_pow_partial, const double *k_dyn_scale, \
+                           unsigned long long *k_stamps
+#define PAOS_FRUGAL_PASS(a) (a).items, (a).field, (a).pitch, (a).item_stride, (a).wg0, (a).tw, (a).psf, (a).psf_partial, (a).pow_partial, (a).dyn_scale, (a).stamps
 #else
 #define PAOS_FRUGAL_PARAMS const FrugalItem *k_items, void *k_field, unsigned k_pitch, unsigned k_item_stride, unsigned k_wg0, \
-                           const void *k_tw, double *k_psf, double *k_psf_partial, double *k_pow_partial
-#define PAOS_FRUGAL_PASS(a) (a).items, (a).field, (a).pitch, (a).item_stride, (a).wg0, (a).tw, (a).psf, (a).psf_partial, (a).pow_partial
+                           const void *k_tw, double *k_psf, double *k_psf_partial, double *k_pow_partial, const double *k_dyn_scale
+#define PAOS_FRUGAL_PASS(a) (a).items, (a).field, (a).pitch, (a).item_stride, (a).wg0, (a).tw, (a).psf, (a).psf_partial, (a).pow_partial, (a).dyn_scale
 #endif
 template <typename T, int N, int E, int LINES, int TILES, int AXIS, int BR, int BC, bool SPLIT,
           int KPRE, int KMID, int NFFT, int STORE = 0>
@@ -583,7 +588,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
     frugal_pass_kernel(PAOS_FRUGAL_PARAMS) {
   FrugalArgs a;
   a.items = k_items; a.field = k_field; a.pitch = k_pitch; a.item_stride = k_item_stride; a.wg0 = k_wg0;
-  a.tw = k_tw; a.psf = k_psf; a.psf_partial = k_psf_partial; a.pow_partial = k_pow_partial; a.live_lo = a.live_hi = 0;
+  a.tw = k_tw; a.psf = k_psf; a.psf_partial = k_psf_partial; a.pow_partial = k_pow_partial; a.dyn_scale = k_dyn_scale; a.live_lo = a.live_hi = 0;
 #if PAOS_STAMPS
   a.stamps = k_stamps;
 #endif
@@ -608,12 +613,18 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   // instead of costing two more dependent scalar loads behind the header)
   const double h_mask_on = it.mid.mask_on;
   const MaskLine* const h_lines = it.mid.lines;
+  // (... and the item's dynamic scale factor: one more scalar load in the same round trip)
+#if defined(PAOS_NO_DYN)  // (A/B build: what the dynamic factor costs the passes that never see one)
+  const double h_dyn = 1.0;
+#else
+  const double h_dyn = *((const __attribute__((address_space(4))) double*)a.dyn_scale + item);
+#endif
   if constexpr (frugal_record_mode<LINES, TILES, KPRE>() != 0)
     asm volatile("" ::"s"(h_active), "s"(h_line_lo), "s"(h_line_hi), "s"(h_line_fill), "s"(h_pos_lo), "s"(h_pos_hi), "s"(h_spos_lo),
-                 "s"(h_spos_hi), "s"(h_mask_on), "s"(h_lines));
+                 "s"(h_spos_hi), "s"(h_mask_on), "s"(h_lines), "s"(h_dyn));
   else
     asm volatile("" ::"s"(h_active), "s"(h_line_lo), "s"(h_line_hi), "s"(h_line_fill), "s"(h_pos_lo), "s"(h_pos_hi), "s"(h_spos_lo),
-                 "s"(h_spos_hi));
+                 "s"(h_spos_hi), "s"(h_dyn));
   if (h_active == 0.0) return;
   if constexpr (PAOS_PRIO_LOAD > 0) __builtin_amdgcn_s_setprio(PAOS_PRIO_LOAD);
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -834,7 +845,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   PAOS_STAMP(3);
   constexpr bool kShareMid = kShare && KPRE == 0 && KMID < 3;
   frugal_slot<T, N, E, KMID, decltype(m), 0, kShareMid, (kRecMode == 1 ? -1 : kRecs)>(
-      v, it.mid, it.mid_ph, m, circle, inv1, ran2 && it.fft2_inv != 0.0, m.t, lds, ran1, kRecMode == 1 ? rec_lds : mrec, lbase);
+      v, it.mid, it.mid_ph, m, circle, inv1, ran2 && it.fft2_inv != 0.0, m.t, lds, ran1, kRecMode == 1 ? rec_lds : mrec, lbase, h_dyn);
   PAOS_STAMP(4);
   if constexpr (NFFT == 2) {
     if (ran2) {

@@ -89,6 +89,10 @@ struct paos_ctx {
   int psf_nparts = 0;
   double* pow_partial = nullptr;  // per-workgroup sums of |u|^2 of a pass that stores the FIELD (final_intensity = 2)
   int pow_nparts = 0;
+  // [batch] factors every frugal pass multiplies into the scale of its middle slot (FrugalArgs::dyn_scale): ones, except
+  // between paos_stop_defer_last_power and the pass (or settle_scale) that applies the stop's 1 / sqrt(power)
+  double* dyn_scale = nullptr;
+  bool dyn_pending = false;
   // What the PSF buffer (and psf_partial) is known to hold after a pass stored it: for item i the lines along
   // psf_zero_axis outside [psf_zero_lo[i], psf_zero_hi[i]) are zero (their per-workgroup sums too).  The next
   // PSF-storing pass with the same live lines need not write those zeros again; -1 = nothing known.
@@ -713,6 +717,44 @@ int paos_frugal_f4096(paos_ctx* c, const FrugalArgs& a, int axis, int kpre, int 
 #if PAOS_PART <= 0  // ---- everything below belongs to the main translation unit ----------------
 namespace {
 
+// ---- a stop whose scaling is left to the next pass (paos_stop_defer_last_power) ---------------------------------------
+__global__ void dyn_scale_set_kernel(double* dyn, const double* norm2, const double* enable, int batch) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < batch) dyn[i] = (!enable || enable[i] != 0.0) ? 1.0 / sqrt(norm2[i]) : 1.0;  // stop_scale_kernel's own expression
+}
+__global__ void dyn_scale_reset_kernel(double* dyn, int batch) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < batch) dyn[i] = 1.0;
+}
+template <typename T>
+__global__ void scale_by_kernel(cx<T>* field, const double* dyn, unsigned item_stride) {
+  const int item = blockIdx.y;
+  const double s = dyn[item];
+  if (s == 1.0) return;
+  cx<T>* f = field + (size_t)item * item_stride;
+  for (size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x; m < item_stride; m += (size_t)gridDim.x * blockDim.x)
+    f[m] = {(T)__dmul_rn((double)f[m].x, s), (T)__dmul_rn((double)f[m].y, s)};
+}
+// Whatever is about to read or rewrite the field other than a pass program that can take the factor along: the stop's
+// scaling is applied now, by the sweep make_stop would have run (same factor, same products: bit-identical).
+int settle_scale(paos_ctx* c, bool field_is_overwritten = false) {
+  if (!c->dyn_pending) return PAOS_OK;
+  if (!field_is_overwritten) {
+    const dim3 grid(pw_blocks(c), c->batch), block(kPwThreads);
+    if (c->precision == PAOS_F64)
+      hipLaunchKernelGGL(scale_by_kernel<double>, grid, block, 0, c->stream, (cx<double>*)c->field, c->dyn_scale, c->item_stride);
+    else
+      hipLaunchKernelGGL(scale_by_kernel<float>, grid, block, 0, c->stream, (cx<float>*)c->field, c->dyn_scale, c->item_stride);
+  }
+  hipLaunchKernelGGL(dyn_scale_reset_kernel, dim3((c->batch + 255) / 256), dim3(256), 0, c->stream, c->dyn_scale, c->batch);
+  HIPCHK(c, hipGetLastError());
+  c->dyn_pending = false;
+  return PAOS_OK;
+}
+#define SETTLE_SCALE(c) do { if ((c) && (c)->dyn_pending) { int rc_ = settle_scale(c); if (rc_) return rc_; } } while (0)
+#define DROP_SCALE(c) do { if ((c) && (c)->dyn_pending) { int rc_ = settle_scale(c, true); if (rc_) return rc_; } } while (0)
+
+
 bool frugal_sizes(const paos_ctx* c) {
   // instantiated for complex128 at N >= 1024 and complex64 at N >= 2048
   return use_frugal() && c->n >= (c->precision == PAOS_F64 ? 1024 : 2048);
@@ -809,6 +851,7 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const
   FrugalArgs a{c->field, c->tw, reinterpret_cast<const FrugalItem*>(ditems), c->pitch, c->item_stride, nullptr, nullptr, nullptr};
   if (store_psf) { a.psf = c->psf; a.psf_partial = c->psf_partial; }
   if (sum_power) a.pow_partial = c->pow_partial;
+  a.dyn_scale = c->dyn_scale;
   {  // the lines some item still works on: the grid need not cover the others when their tiles have nothing to write
     // PAOS_COMPACT_GRID=0 launches the full grid (dead workgroups exit in their prologue)
     static const bool want = [] { const char* e = getenv("PAOS_COMPACT_GRID"); return !(e && e[0] == '0'); }();
@@ -989,6 +1032,14 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
       all_frugal = all_frugal && lp.ok;
     }
   }
+  if (c->dyn_pending) {
+    // a stop's scaling is waiting: the first pass takes it along in its middle slot when it is a frugal pass every item
+    // takes part in; otherwise the field gets it now
+    bool ride = n_passes > 0 && low[0].ok;
+    if (ride)
+      for (const FrugalItem& fi : low[0].items) ride = ride && fi.active != 0.0;
+    if (!ride && (rc = settle_scale(c))) return rc;
+  }
   const bool pruned = all_frugal && use_pruning() && c->prune;
   if (pruned) plan_pruning(c, passes, n_passes, blocks, low, entry_rows, entry_stale);
   // Which lines' aperture records does each pass read?  Those of its live tiles only: a workgroup whose lines are dead
@@ -1048,6 +1099,7 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
       power_groups = c->n / lines;
       if (c->pow_nparts < c->n / 2) {  // (sized for the finest tiling of either axis)
         if (c->pow_partial) (void)hipFree(c->pow_partial);
+  if (c->dyn_scale) (void)hipFree(c->dyn_scale);
         c->pow_partial = nullptr; c->pow_nparts = 0;
         HIPCHK(c, hipMalloc(&c->pow_partial, (size_t)c->batch * (c->n / 2) * sizeof(double)));
         c->pow_nparts = c->n / 2;
@@ -1137,6 +1189,11 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
     for (int q = i; q < j; ++q) {
       if (low[q].ok) {
         if ((rc = launch_lowered(c, passes[q], low[q], dblocks, fused_store && q == n_passes - 1, fused_power && q == n_passes - 1))) return rc;
+        if (q == 0 && c->dyn_pending) {  // the stop's factor has gone into the field with this pass: ones again for the next
+          hipLaunchKernelGGL(dyn_scale_reset_kernel, dim3((c->batch + 255) / 256), dim3(256), 0, c->stream, c->dyn_scale, c->batch);
+          HIPCHK(c, hipGetLastError());
+          c->dyn_pending = false;
+        }
         continue;
       }
       if ((rc = launch_one_pass(c, passes[q], dblocks, n_blocks, &assign[(size_t)(q - i) * 3 * PAOS_MAX_PW]))) return rc;
@@ -1267,6 +1324,11 @@ int paos_ctx_create(int device, int n, int batch, int precision, paos_ctx** out)
   if ((e = hipSetDevice(device)) != hipSuccess) return bail(e, "hipSetDevice");
   if ((e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess) return bail(e, "hipStreamCreate");
   if (const char* pad = getenv("PAOS_LDS_PAD")) c->lds_pad = (size_t)std::max(0, std::atoi(pad));
+  if ((e = hipMalloc(&c->dyn_scale, (size_t)batch * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(dyn_scale)");
+  {
+    std::vector<double> ones((size_t)batch, 1.0);
+    if ((e = hipMemcpy(c->dyn_scale, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice)) != hipSuccess) return bail(e, "hipMemcpy(dyn_scale)");
+  }
   if ((e = hipMalloc(&c->field, (size_t)c->item_stride * batch * eb)) != hipSuccess) return bail(e, "hipMalloc(field)");
   if ((e = hipMemsetAsync(c->field, 0, (size_t)c->item_stride * batch * eb, c->stream)) != hipSuccess) return bail(e, "hipMemset(field)");
   if ((e = hipMalloc(&c->tw, (size_t)n * eb)) != hipSuccess) return bail(e, "hipMalloc(tw)");
@@ -1410,6 +1472,7 @@ int paos_sync(paos_ctx* c) {
 }
 
 int paos_fill(paos_ctx* c, double re, double im) {
+  DROP_SCALE(c);
   if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c) return fail(c, PAOS_EINVAL, "null context");
   const size_t total = (size_t)c->item_stride * c->batch;
@@ -1510,15 +1573,18 @@ static int start_impl(paos_ctx* c, double re, double im, int shape, const double
 }
 
 int paos_start(paos_ctx* c, double re, double im, int shape, const double* aperture, const double* stop) {
+  DROP_SCALE(c);
   return start_impl(c, re, im, shape, aperture, stop, nullptr);
 }
 
 int paos_start_rows(paos_ctx* c, double re, double im, int shape, const double* aperture, const double* stop,
                     const double* write_rows) {
+  DROP_SCALE(c);
   return start_impl(c, re, im, shape, aperture, stop, write_rows);
 }
 
 int paos_zero_outside_rows(paos_ctx* c, const double* live_rows) {
+  SETTLE_SCALE(c);
   if (c) (void)hipSetDevice(c->device);
   if (!c || !live_rows) return fail(c, PAOS_EINVAL, "null argument");
   int rc = check_rows(c, live_rows);
@@ -1527,6 +1593,7 @@ int paos_zero_outside_rows(paos_ctx* c, const double* live_rows) {
 }
 
 int paos_import(paos_ctx* c, int item, const void* host) {
+  SETTLE_SCALE(c);
   if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c || !host || item < 0 || item >= c->batch) return fail(c, PAOS_EINVAL, "bad item or null buffer");
   const size_t bytes = (size_t)c->n * c->n * 16;
@@ -1568,16 +1635,19 @@ static int export_impl(paos_ctx* c, int item, int what, void* host_out, bool pin
 }
 
 int paos_export(paos_ctx* c, int item, int what, void* host_out) {
+  SETTLE_SCALE(c);
   if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   return export_impl(c, item, what, host_out, false);
 }
 
 int paos_export_pinned(paos_ctx* c, int item, int what, void* pinned_out) {
+  SETTLE_SCALE(c);
   if (c) (void)hipSetDevice(c->device);
   return export_impl(c, item, what, pinned_out, true);
 }
 
 int paos_psf_keep(paos_ctx* c) {
+  SETTLE_SCALE(c);
   if (c) (void)hipSetDevice(c->device);
   if (!c) return fail(c, PAOS_EINVAL, "null context");
   if (!c->psf) HIPCHK(c, hipMalloc(&c->psf, (size_t)c->batch * c->item_stride * sizeof(double)));
@@ -1643,6 +1713,7 @@ static int aperture_launch(paos_ctx* c, int shape, const double* dp, int nitems,
 }
 
 int paos_aperture(paos_ctx* c, int shape, const double* params) {
+  SETTLE_SCALE(c);
   if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c || !params) return fail(c, PAOS_EINVAL, "null argument");
   if (shape != PAOS_SHAPE_ELLIPSE && shape != PAOS_SHAPE_RECT) return fail(c, PAOS_EINVAL, "unknown aperture shape");
@@ -1680,6 +1751,7 @@ static int norm2_launch(paos_ctx* c, const double* den) {
 }
 
 int paos_make_stop(paos_ctx* c, const double* enable) {
+  SETTLE_SCALE(c);
   if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c) return fail(c, PAOS_EINVAL, "null context");
   const double* den = nullptr;
@@ -1701,6 +1773,7 @@ int paos_make_stop(paos_ctx* c, const double* enable) {
 }
 
 int paos_stop_scale_last_power(paos_ctx* c, const double* enable) {
+  SETTLE_SCALE(c);
   if (c) (void)hipSetDevice(c->device);
   if (!c) return fail(c, PAOS_EINVAL, "null context");
   const double* den = nullptr;
@@ -1717,7 +1790,23 @@ int paos_stop_scale_last_power(paos_ctx* c, const double* enable) {
   return PAOS_OK;
 }
 
+int paos_stop_defer_last_power(paos_ctx* c, const double* enable) {
+  if (c) (void)hipSetDevice(c->device);
+  if (!c) return fail(c, PAOS_EINVAL, "null context");
+  SETTLE_SCALE(c);  // (a second stop with nothing in between: the first one's factor goes into the field first)
+  const double* den = nullptr;
+  if (enable) {
+    int rc = arena_push(c, enable, (size_t)c->batch, &den);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(dyn_scale_set_kernel, dim3((c->batch + 255) / 256), dim3(256), 0, c->stream, c->dyn_scale, c->norm2, den, c->batch);
+  HIPCHK(c, hipGetLastError());
+  c->dyn_pending = true;
+  return PAOS_OK;
+}
+
 int paos_psf_metrics(paos_ctx* c, int nr, const double* radii_px, double cx_px, double cy_px, double* host_out) {
+  SETTLE_SCALE(c);
   if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c || !host_out || nr < 0 || nr > kMaxRadii || (nr > 0 && !radii_px)) return fail(c, PAOS_EINVAL, "bad metrics request");
   const int nvals = 4 + nr, nblocks = 512;
@@ -1743,6 +1832,7 @@ int paos_psf_metrics(paos_ctx* c, int nr, const double* radii_px, double cx_px, 
 }
 
 int paos_norm2_enqueue(paos_ctx* c, int* ticket) {
+  SETTLE_SCALE(c);
   if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c || !ticket) return fail(c, PAOS_EINVAL, "null argument");
   const int slot = next_norm_slot(c);
@@ -1815,6 +1905,7 @@ int zero_outside_rows(paos_ctx* c, const double* live_rows) {
 extern "C" {
 
 int paos_psf_keep_power(paos_ctx* c, int* ticket) {
+  SETTLE_SCALE(c);
   if (c) (void)hipSetDevice(c->device);
   if (!c || !ticket) return fail(c, PAOS_EINVAL, "null argument");
   return psf_keep_power_impl(c, ticket);
@@ -1869,10 +1960,12 @@ static int norm2_enqueue_rows_impl(paos_ctx* c, const double* live_rows, const d
 }
 
 int paos_norm2_enqueue_rows(paos_ctx* c, const double* live_rows, int* ticket) {
+  SETTLE_SCALE(c);
   return norm2_enqueue_rows_impl(c, live_rows, nullptr, ticket);
 }
 
 int paos_norm2_enqueue_rows_like(paos_ctx* c, const double* live_rows, const double* same_as, int* ticket) {
+  SETTLE_SCALE(c);
   if (!same_as) return fail(c, PAOS_EINVAL, "null argument");
   return norm2_enqueue_rows_impl(c, live_rows, same_as, ticket);
 }
@@ -1894,6 +1987,7 @@ int paos_norm2_release(paos_ctx* c, int ticket) {
 }
 
 int paos_norm2(paos_ctx* c, double* host_out) {
+  SETTLE_SCALE(c);
   if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c || !host_out) return fail(c, PAOS_EINVAL, "null argument");
   int rc = norm2_launch(c, nullptr);
@@ -1905,6 +1999,7 @@ int paos_norm2(paos_ctx* c, double* host_out) {
 }
 
 int paos_phase(paos_ctx* c, const double* params, int mul2pi) {
+  SETTLE_SCALE(c);
   if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   if (!c || !params) return fail(c, PAOS_EINVAL, "null argument");
   Program g(c->batch);
@@ -1915,6 +2010,7 @@ int paos_phase(paos_ctx* c, const double* params, int mul2pi) {
 }
 
 int paos_phase_map(paos_ctx* c, int item, const double* host_wfe, double wl) {
+  SETTLE_SCALE(c);
   if (c) (void)hipSetDevice(c->device);
   if (!c || !host_wfe || item < 0 || item >= c->batch) return fail(c, PAOS_EINVAL, "bad item or null buffer");
   if (!(wl > 0.0) || !std::isfinite(wl)) return fail(c, PAOS_EINVAL, "wavelength must be positive and finite");
@@ -1946,6 +2042,7 @@ int paos_record_set_stats(paos_ctx* c, unsigned long long* found, unsigned long 
 }
 
 int paos_copy_yardstick(paos_ctx* c, int reps, double* ms_per_launch, double* bytes_per_launch) {
+  SETTLE_SCALE(c);
   if (c) (void)hipSetDevice(c->device);
   if (!c || !ms_per_launch || !bytes_per_launch || reps < 1) return fail(c, PAOS_EINVAL, "bad yardstick request");
   const size_t total = (size_t)c->item_stride * c->batch;
@@ -2088,12 +2185,14 @@ static int zernike_apply(paos_ctx* c, int nmax, int kdim, const double* table, c
 
 int paos_zernike(paos_ctx* c, int nmax, int kdim, const double* table, const double* params,
                  int param_stride, double* host_wfe) {
+  SETTLE_SCALE(c);
   if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   return zernike_apply(c, nmax, kdim, table, params, param_stride, host_wfe, false);
 }
 
 int paos_zernike_pupil(paos_ctx* c, int nmax, int kdim, const double* table, const double* params,
                        int param_stride, double* host_wfe) {
+  SETTLE_SCALE(c);
   if (c) (void)hipSetDevice(c->device);
   return zernike_apply(c, nmax, kdim, table, params, param_stride, host_wfe, true);
 }
@@ -2141,6 +2240,7 @@ int paos_pupil_upload(paos_ctx* c, int item, const double* host_weights) {
 
 int paos_zernike_gram(paos_ctx* c, int nmax, int kdim, const double* table, const double* params,
                       int param_stride, int K, const double* poly, int use_pupil, double* host_out) {
+  SETTLE_SCALE(c);
   if (c) (void)hipSetDevice(c->device);
   if (!c || !table || !params || !poly || !host_out) return fail(c, PAOS_EINVAL, "null argument");
   if (nmax < 0 || kdim < nmax / 2 + 1 || param_stride < ZP_HEAD)

@@ -49,6 +49,9 @@ STOP_FROM_PROGRAM = _os.environ.get("PAOS_STOP_FROM_PROGRAM", "1") != "0"
 # ... and the pass program that reaches the last surface that does anything (a saved slit with the image plane right behind
 # it) stores the PSF for the inert surfaces behind it as well; PAOS_INERT_TAIL=0 switches it off.
 INERT_TAIL = _os.environ.get("PAOS_INERT_TAIL", "1") != "0"
+# ... and such a stop leaves even its scaling to the next pass program's first pass (paos_stop_defer_last_power);
+# PAOS_STOP_DEFERRED=0 runs the scaling sweep at the stop.
+STOP_DEFERRED = _os.environ.get("PAOS_STOP_DEFERRED", "1") != "0"
 _MASK_RUN = 192  # kMaskW of csrc/frugal_pass.h
 
 
@@ -455,6 +458,10 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
                 p["ABCDt"] = ABCDProduct(tuple(st.factors_t))
                 p["ABCDs"] = ABCDProduct(tuple(st.factors_s))
 
+        if fresh is not None and not saved and all(_inert(it) for it in items):
+            # (coordinate breaks in front of the first mirror: the field is still the constant it will be filled with;
+            # the first surface that does something -- usually aperture + stop -- then writes it in one go, _start_field)
+            continue
         if fresh is not None:
             value, fresh = fresh, None
             rows0 = None
@@ -525,7 +532,7 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
             settle()
             flags = [1.0 if p["stop"] else 0.0 for p in plans]
             if prog_power[0] is not None:  # the program's last pass has summed the power on its way out
-                dev.make_stop(flags, power_known=True)
+                dev.make_stop(flags, power_known=True, defer=STOP_DEFERRED)
                 if power_state is not None:
                     # should the surface be saved: the power BEHIND the stop is P (1 / sqrt P)^2 where the stop applies
                     power_state["ticket"] = prog_power[0]

@@ -85,7 +85,8 @@ class ModelDevice:
     def norm2_fetch(self, ticket):
         return self._tickets[ticket]
 
-    def make_stop(self, enable=None, power_known=False):
+    def make_stop(self, enable=None, power_known=False, defer=False):
+        # (defer: the real device leaves the scaling to the next pass; the model has no such thing as a cost and scales now)
         self.log.append(("make_stop", "power_known" if power_known else None))
         if power_known:  # the precondition the library cannot check: a program with final_intensity = 2 came right before
             assert self.log[-2][0] == "power_on_store", self.log[-3:]

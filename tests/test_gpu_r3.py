@@ -715,3 +715,57 @@ def test_power_summed_by_the_storing_pass_equals_the_separate_reduction():
                     assert abs(got[i][k]["power"] - want[i][k]["power"]) <= tol * want[i][k]["power"], (name, precision, i, k)
                     assert abs(got[i][k]["power"] - direct) <= max(tol, 1e-12) * direct * 10, (name, precision, i, k)
             print(f"{name} {n}^2 {precision}: {len(want[0])} saved surfaces, worst power difference {worst:.1e}")
+
+
+def test_a_stop_whose_scaling_rides_on_the_next_pass():
+    """Round 4: Excite_TEL's stop (M1) sits behind a pass program; its power comes off that program's last pass and its
+    scaling 1 / sqrt(P) is multiplied into the middle slot of the NEXT program's first pass (paos_stop_defer_last_power):
+    the stop costs no sweep over the field.  A lean walk (the ride) against the same walk with the scaling sweep at the
+    stop and against the round-3 make_stop: PSFs and powers to 1e-13 (fp32: 1e-6); with arrays downloaded at the stop
+    (the library applies the factor before anything else reads the field) bit-identical to the sweep."""
+    import paos_amd.run as prun
+    from paos_amd import _lib
+    from paos_amd.chains import parse_config_variant
+    from paos_amd.run import run_batch
+
+    n = 2048
+    pup, par, wls, fields, chains = parse_config_variant(os.path.join(LENS, "Excite_TEL.ini"), [1.0, 2.2, 3.4])
+    w = [1.0e-6 * x for x in wls]
+    args = (pup, w, n, par["zoom"], fields[0], chains)
+
+    def lean(precision):
+        dev = _lib.DeviceFields(n, len(w), precision)
+        try:
+            res = run_batch(*args, outputs=(), dev=dev, keep_psf=True, precision=precision)
+            return res, [dev.psf_fetch(i) for i in range(len(w))]
+        finally:
+            dev.close()
+
+    for precision, tol in (("fp64", 1e-13), ("fp32", 2e-6)):
+        ride, ride_psf = lean(precision)
+        prun.STOP_DEFERRED = False
+        try:
+            sweep, sweep_psf = lean(precision)
+            prun.STOP_FROM_PROGRAM = False
+            try:
+                old, old_psf = lean(precision)
+            finally:
+                prun.STOP_FROM_PROGRAM = True
+        finally:
+            prun.STOP_DEFERRED = True
+        for i in range(len(w)):
+            assert rel_err(ride_psf[i], old_psf[i]) < tol and rel_err(sweep_psf[i], old_psf[i]) < tol, (precision, i)
+            for k in old[i]:
+                for got in (ride, sweep):
+                    assert abs(got[i][k]["power"] - old[i][k]["power"]) <= max(tol, 1e-12) * old[i][k]["power"], (precision, i, k)
+        print(f"Excite_TEL {n}^2 {precision}: ride vs make_stop PSF {max(rel_err(a, b) for a, b in zip(ride_psf, old_psf)):.1e}")
+    # arrays downloaded at the stop: the pending factor is applied first, by the same sweep
+    a = run_batch(*args, outputs=("wfo",))
+    prun.STOP_DEFERRED = False
+    try:
+        b = run_batch(*args, outputs=("wfo",))
+    finally:
+        prun.STOP_DEFERRED = True
+    for i in range(len(w)):
+        for k in b[i]:
+            assert np.array_equal(a[i][k]["wfo"], b[i][k]["wfo"]), (i, k)

@@ -765,7 +765,10 @@ def test_a_stop_behind_a_pass_program_takes_its_power_from_the_program(name):
         finally:
             prun.STOP_FROM_PROGRAM = True
             prun.FUSE_APERTURES = "auto"
-    assert len(out[True][1]) == 1 and len(out[False][1]) == 0  # the fused path was taken exactly where a stop follows a program
+    # the fused path is taken exactly where a stop follows a program: Excite_TEL's M1 behind the obstruction and 0.74 m of
+    # free space; the Ariel channels open with coordinate breaks, which no longer spend the start field (_inert), so their
+    # M1 -- aperture + stop -- is written in one go by the start kernels
+    assert len(out[True][1]) == (1 if name == "Excite_TEL" else 0) and len(out[False][1]) == 0
     for i in range(2):
         for k in out[False][0][i]:
             a, b = out[True][0][i][k], out[False][0][i][k]

@@ -201,7 +201,12 @@ void bench_frugal(const char* name, int batch, int reps, int pad_blocks) {
   FrugalItem* ditems;
   CK(hipMalloc(&ditems, items.size() * sizeof(FrugalItem)));
   CK(hipMemcpy(ditems, items.data(), items.size() * sizeof(FrugalItem), hipMemcpyHostToDevice));
+  std::vector<double> ones((size_t)batch, 1.0);
+  double* dones;
+  CK(hipMalloc(&dones, ones.size() * sizeof(double)));
+  CK(hipMemcpy(dones, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice));
   FrugalArgs a{d, dtw, ditems, pitch, item_stride};
+  a.dyn_scale = dones;
   const dim3 grid(N / LINES / TILES, batch), block(TILES * LINES * N / E);
 #ifndef PAOS_F32_SPLIT
 #define PAOS_F32_SPLIT 0

@@ -66,7 +66,11 @@ void timeline(const char* name, int batch, int pad_blocks) {
   unsigned long long* dst;
   CK(hipMalloc(&dst, nwg * kStampSlots * sizeof(unsigned long long)));
   CK(hipMemset(dst, 0, nwg * kStampSlots * sizeof(unsigned long long)));
-  FrugalArgs a{d, dtw, ditems, pitch, item_stride, nullptr, nullptr, nullptr, dst};
+  std::vector<double> ones((size_t)batch, 1.0);
+  double* dones;
+  CK(hipMalloc(&dones, ones.size() * sizeof(double)));
+  CK(hipMemcpy(dones, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice));
+  FrugalArgs a{d, dtw, ditems, pitch, item_stride, nullptr, nullptr, nullptr, dones, dst};
   constexpr bool SPLIT = sizeof(T) == 8;
   const size_t lds = frugal_lds_bytes<T, N, LINES, 1, SPLIT, KPRE, KMID, E>();
   auto kf = frugal_pass_kernel<T, N, E, LINES, 1, AXIS, BR, BC, SPLIT, KPRE, KMID, NFFT>;
