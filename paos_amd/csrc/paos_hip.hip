@@ -1099,7 +1099,6 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
       power_groups = c->n / lines;
       if (c->pow_nparts < c->n / 2) {  // (sized for the finest tiling of either axis)
         if (c->pow_partial) (void)hipFree(c->pow_partial);
-  if (c->dyn_scale) (void)hipFree(c->dyn_scale);
         c->pow_partial = nullptr; c->pow_nparts = 0;
         HIPCHK(c, hipMalloc(&c->pow_partial, (size_t)c->batch * (c->n / 2) * sizeof(double)));
         c->pow_nparts = c->n / 2;
@@ -1439,6 +1438,7 @@ int paos_ctx_destroy(paos_ctx* c) {
   if (c->norm2_host) (void)hipHostFree(c->norm2_host);
   if (c->psf) (void)hipFree(c->psf);
   if (c->pow_partial) (void)hipFree(c->pow_partial);
+  if (c->dyn_scale) (void)hipFree(c->dyn_scale);
   if (c->psf_partial) (void)hipFree(c->psf_partial);
   for (int i = 0; i < 2; ++i) {
     if (c->bounce[i]) (void)hipHostFree(c->bounce[i]);
