@@ -814,6 +814,26 @@ void forget_mask_sets(paos_ctx* c) {  // after a failed program: what the sets h
   for (auto& ms : c->mask_sets) ms.key.clear();
 }
 
+MaskJob mask_job(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const double* ap, const double* dshared) {
+  const paos_ctx::MaskSet& ms = c->mask_sets[lp.mask_set];
+  const int line0 = lp.mask_lo, line_end = lp.mask_hi > lp.mask_lo ? lp.mask_hi : c->n;
+  return MaskJob{ap, dshared, ms.lines, ms.vals, p.axis, line0, line_end, lp.mask_shapes};
+}
+// one launch per shape that occurs for `count` renderings (blockIdx.z), the grid sized for the widest line window
+int launch_mask_jobs(paos_ctx* c, MaskJobs& jobs, int count) {
+  jobs.batch_stride = c->batch * (int)FP_STRIDE; jobs.param_stride = (int)FP_STRIDE; jobs.n = c->n; jobs.overflow = c->mask_overflow;
+  int widest = 0, shapes = 0;
+  for (int j = 0; j < count; ++j) {
+    widest = std::max(widest, jobs.job[j].line_end - jobs.job[j].line0);
+    shapes |= jobs.job[j].shapes;
+  }
+  const dim3 grid((widest + 3) / 4, c->batch, count), block(256);
+  if (shapes & 1) hipLaunchKernelGGL(mask_lines_kernel<0>, grid, block, 0, c->stream, jobs);
+  if (shapes & 2) hipLaunchKernelGGL(mask_lines_kernel<1>, grid, block, 0, c->stream, jobs);
+  HIPCHK(c, hipGetLastError());
+  return PAOS_OK;
+}
+
 // launch a pass that lower_frugal accepted
 int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const double* dblocks, bool store_psf = false,
                    bool sum_power = false) {
@@ -829,19 +849,13 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const
   if (lp.mask_block >= 0 && lp.mask_render) {  // render the records along the pass axis, right before the pass
     const double* ap = dblocks + (size_t)lp.mask_block * c->batch * FP_STRIDE;
     const double* ap2 = ap + (size_t)c->batch * FP_STRIDE;
-    const int line0 = lp.mask_lo, line_end = lp.mask_hi > lp.mask_lo ? lp.mask_hi : c->n;
-    const dim3 grid((line_end - line0 + 3) / 4, c->batch), block(256);
+    (void)ap2;
     const double* dshared = nullptr;
     int rcs = arena_push(c, lp.mask_shared.data(), lp.mask_shared.size(), &dshared);
     if (rcs) return rcs;
-    const paos_ctx::MaskSet& ms = c->mask_sets[lp.mask_set];
-    if (lp.mask_shapes & 1)
-      hipLaunchKernelGGL(mask_lines_kernel<0>, grid, block, 0, c->stream, ap, ap2, (int)FP_STRIDE, c->n, p.axis,
-                         ms.lines, ms.vals, c->mask_overflow, dshared, line0, line_end);
-    if (lp.mask_shapes & 2)
-      hipLaunchKernelGGL(mask_lines_kernel<1>, grid, block, 0, c->stream, ap, ap2, (int)FP_STRIDE, c->n, p.axis,
-                         ms.lines, ms.vals, c->mask_overflow, dshared, line0, line_end);
-    HIPCHK(c, hipGetLastError());
+    MaskJobs jobs{};
+    jobs.job[0] = mask_job(c, p, lp, ap, dshared);
+    if ((rcs = launch_mask_jobs(c, jobs, 1))) return rcs;
   }
   const double* ditems = nullptr;
   static_assert(sizeof(FrugalItem) % sizeof(double) == 0, "record of doubles");
@@ -1142,6 +1156,36 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
         c->psf_zero_lo[it] = last[it].line_lo; c->psf_zero_hi[it] = last[it].line_hi;
       }
       c->psf_zero_axis = -1;  // set again below once the pass is on the stream
+    }
+  }
+  // The aperture line records this program has to render (not found in the context's kept sets): all of them in ONE
+  // launch per shape, in front of the first pass -- when every rendering goes to a set no EARLIER pass of this program
+  // reads (always, unless a program carries more distinct apertures than there are sets; then each is rendered in place,
+  // right before its pass).  PAOS_BATCHED_RECORDS=0: in place, one launch per aperture, as before.
+  {
+    static const bool want = [] { const char* e = getenv("PAOS_BATCHED_RECORDS"); return !(e && e[0] == '0'); }();
+    std::vector<int> todo;
+    bool safe = want && all_frugal;
+    for (int q = 0; q < n_passes && safe; ++q) {
+      if (low[q].mask_block < 0) continue;
+      if (low[q].mask_render) {
+        for (int r = 0; r < q; ++r) safe = safe && !(low[r].mask_block >= 0 && low[r].mask_set == low[q].mask_set);
+        todo.push_back(q);
+      }
+    }
+    if (safe && todo.size() > 1) {
+      for (size_t at = 0; at < todo.size(); at += kMaskJobs) {
+        MaskJobs jobs{};
+        const int count = (int)std::min<size_t>(kMaskJobs, todo.size() - at);
+        for (int j = 0; j < count; ++j) {
+          LoweredPass& lp = low[todo[at + j]];
+          const double* dshared = nullptr;
+          if ((rc = arena_push(c, lp.mask_shared.data(), lp.mask_shared.size(), &dshared))) return rc;
+          jobs.job[j] = mask_job(c, passes[todo[at + j]], lp, dblocks + (size_t)lp.mask_block * c->batch * FP_STRIDE, dshared);
+          lp.mask_render = false;
+        }
+        if ((rc = launch_mask_jobs(c, jobs, count))) return rc;
+      }
     }
   }
   // Walk the program in chunks whose phase operators fit the table store: fill the tables of

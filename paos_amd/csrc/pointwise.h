@@ -610,21 +610,43 @@ __global__ void start_write_kernel(cx<T>* field, const double* params, int n, un
 //              separable as 1 - mask and stay on the stand-alone kernel.
 constexpr int kMaskWaves = 4;  // waves (= lines) per workgroup of mask_lines_kernel
 
+// One rendering: the aperture's two consecutive parameter block sets (`params`, [batch][param_stride] each), the pass
+// axis, where the records go, which items only read an earlier item's records (`shared`), and [line0, line_end): the
+// lines whose records anybody will read (the pass that carries the aperture skips the tiles of dead lines: three
+// quarters of a grid that covers every line were workgroups that only found out they had nothing to do).
+struct MaskJob {
+  const double* params;
+  const double* shared;
+  MaskLine* lines;
+  double* vals;
+  int axis, line0, line_end, shapes;  // shapes: bit s set = some item's aperture has shape s
+};
+constexpr int kMaskJobs = 8;
+// Round 4: the renderings a pass program needs go out in ONE launch (blockIdx.z = job): five relay apertures of a SYN20
+// step as five launches of a latency-bound kernel were 1.3 ms of a 62 ms step.
+struct MaskJobs {
+  MaskJob job[kMaskJobs];
+  int batch_stride;  // doubles between the two parameter block sets of a job (= batch * param_stride)
+  int param_stride, n;
+  int* overflow;
+};
+
 template <int SHAPE>
-__global__ void __launch_bounds__(kMaskWaves * 64) mask_lines_kernel(const double* params, const double* params2, int param_stride, int n,
-                                  int axis, MaskLine* lines, double* vals, int* overflow, const double* shared,
-                                  int line0, int line_end) {
-  // [line0, line_end): the lines whose records anybody will read (the pass that carries the aperture skips the tiles of
-  // dead lines: three quarters of a grid that covers every line were workgroups that only found out they had nothing to do)
+__global__ void __launch_bounds__(kMaskWaves * 64) mask_lines_kernel(MaskJobs jobs) {
+  const MaskJob& jb = jobs.job[blockIdx.z];
+  if (!(jb.shapes & (1 << SHAPE))) return;
   const int item = blockIdx.y;
+  const double* shared = jb.shared;
   if (shared[item] != 0.0) return;  // reads the records of an earlier, identical item
-  const int line = line0 + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int n = jobs.n, axis = jb.axis, param_stride = jobs.param_stride;
+  int* const overflow = jobs.overflow;
+  const int line = jb.line0 + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  if (line >= line_end || line >= n) return;
-  const double* p = params + (size_t)item * param_stride;
-  const double* p2 = params2 + (size_t)item * param_stride;
-  MaskLine* out = lines + (size_t)item * n + line;
-  double* vout = vals + ((size_t)item * n + line) * (2 * kMaskW);
+  if (line >= jb.line_end || line >= n) return;
+  const double* p = jb.params + (size_t)item * param_stride;
+  const double* p2 = jb.params + jobs.batch_stride + (size_t)item * param_stride;
+  MaskLine* out = jb.lines + (size_t)item * n + line;
+  double* vout = jb.vals + ((size_t)item * n + line) * (2 * kMaskW);
   if (p[AP_ENABLE] == 0.0 || SHAPE != (int)p2[3]) return;
   const double xc = p[AP_XC], yc = p[AP_YC], a = p[AP_A], b = p[AP_B];
   const bool obsc = p2[1] != 0.0;
