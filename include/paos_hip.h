@@ -36,7 +36,10 @@ enum { PAOS_KERNEL_PASS_ROWS = 0, PAOS_KERNEL_PASS_COLS = 1, PAOS_KERNEL_PASS_AN
 /* pointwise operators that ride on an FFT pass (paos_run_passes) */
 enum { PAOS_PW_SIGN = 1, PAOS_PW_QPHASE_CENTRED = 2, PAOS_PW_QPHASE_NATURAL = 3, PAOS_PW_SCALE = 4,
        PAOS_PW_MASK = 5 };
-enum { PAOS_PWF_MUL2PI = 1 };
+enum { PAOS_PWF_MUL2PI = 1,
+       /* PAOS_PW_SIGN only (round 4, the separable pass programs): (-1)^column, resp. (-1)^row, instead of the
+          checkerboard (-1)^(row + column) -- the two factors the checkerboard of wfo.py:491-545 splits into */
+       PAOS_PWF_X_ONLY = 2, PAOS_PWF_Y_ONLY = 4 };
 enum { PAOS_MAX_PW = 6 };
 enum { PAOS_NORM_SLOTS = 64 };  /* outstanding paos_norm2_enqueue tickets */
 enum { PAOS_WHAT_FIELD = 0, PAOS_WHAT_AMPLITUDE = 1, PAOS_WHAT_PHASE = 2, PAOS_WHAT_INTENSITY = 3 };

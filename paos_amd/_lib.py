@@ -22,6 +22,7 @@ WHAT_FIELD, WHAT_AMPLITUDE, WHAT_PHASE, WHAT_INTENSITY = 0, 1, 2, 3
 KERNEL_PASS_ROWS, KERNEL_PASS_COLS, KERNEL_PASS_ANY = 0, 1, 2
 PW_SIGN, PW_QPHASE_CENTRED, PW_QPHASE_NATURAL, PW_SCALE, PW_MASK = 1, 2, 3, 4, 5
 PWF_MUL2PI = 1
+PWF_X_ONLY, PWF_Y_ONLY = 2, 4  # PW_SIGN: (-1)^column / (-1)^row instead of the checkerboard (-1)^(row + column)
 MAX_PW = 6
 NORM_SLOTS = 64  # PAOS_NORM_SLOTS: tickets of paos_norm2_enqueue that may be outstanding
 

@@ -30,7 +30,8 @@ enum : int {
   PWK_SCALE = 4,      // multiply by block[FP_COEF] (exact power of two: the ortho 1/N)
   PWK_MASK = 5,       // multiply by the aperture weight map rendered just before the pass
 };
-enum : int { PWF_MUL2PI = 1 };  // argument gets an extra factor 2 pi (lens form, wfo.py:363-366)
+enum : int { PWF_MUL2PI = 1,   // argument gets an extra factor 2 pi (lens form, wfo.py:363-366)
+             PWF_X_ONLY = 2, PWF_Y_ONLY = 4 };  // SIGN: (-1)^column / (-1)^row, the two halves of the checkerboard
 // Bits 8.. of PwOp::flags: 1 + index of this operator's separable phase table (0 = no table:
 // the phase is evaluated per pixel with sincos).
 constexpr int kTableShift = 8;
@@ -113,7 +114,8 @@ template <int FEAT>
 __device__ __forceinline__ cx<double> pw_factor(const PwOp& op, const double* p, int row, int col,
                                                 int n, const cx<double>* tab, const double* mask_at) {
   if ((FEAT & 2) && op.kind == PWK_MASK) return {*mask_at, 0.0};
-  if (op.kind == PWK_SIGN) return {((row + col) & 1) ? -1.0 : 1.0, 0.0};
+  if (op.kind == PWK_SIGN)
+    return {((((op.flags & PWF_Y_ONLY) ? 0 : col) + ((op.flags & PWF_X_ONLY) ? 0 : row)) & 1) ? -1.0 : 1.0, 0.0};
   if (op.kind == PWK_SCALE) return {p[FP_COEF], 0.0};
   int gx, gy;
   if (op.kind == PWK_QPHASE_C) {

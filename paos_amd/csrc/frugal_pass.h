@@ -301,7 +301,10 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
     __builtin_amdgcn_sched_barrier(0);
   }
   // (-1)^(row+col): the position along the line advances by TL (even) from element to element
-  const double f = (sl.sign_on != 0.0 && ((line + tpos) & 1)) ? -sc : sc;
+  // sign_on: 1 the checkerboard, 2 its half along the line (-1)^position, 3 its half across (-1)^line (the separable
+  // pass programs: passes.py, SeparableCompiler)
+  const int parity = sl.sign_on == 1.0 ? line + tpos : (sl.sign_on == 2.0 ? tpos : line);
+  const double f = (sl.sign_on != 0.0 && (parity & 1)) ? -sc : sc;
   // The conjugations around an inverse transform (IFFT x = conj FFT conj x) ride on this slot: the one in
   // front of the transform that FOLLOWS flips the sign of the imaginary scale; the one behind the transform
   // that PRECEDES (conj_in: the values in ``v`` are the conjugates of the true ones) does too, since

@@ -448,8 +448,10 @@ bool lower_frugal(const paos_ctx* c, const paos_pass& p, const double* blocks /*
     bool active = fi.fft1_on != 0.0 || fi.fft2_on != 0.0;
     FrugalSlot* slots[2] = {&fi.pre, &fi.mid};
     FrugalPhase* phases[2] = {fi.pre_ph, fi.mid_ph};
+    int sign_bits[2] = {0, 0};
     for (int l = 0; l < 2; ++l) {
       slots[l]->sign_on = 0.0; slots[l]->scale = 1.0;
+      sign_bits[l] = 0;
       slots[l]->mask_on = 0.0; slots[l]->w_in = 1.0; slots[l]->w_out = 0.0;
       slots[l]->lines = nullptr; slots[l]->vals = nullptr;
       int j = 0;
@@ -471,7 +473,15 @@ bool lower_frugal(const paos_ctx* c, const paos_pass& p, const double* blocks /*
                 !std::memcmp(blk(op.block + 1, j), q2, FP_STRIDE * sizeof(double))) { rep = j; break; }
           mask_shared[it] = rep != it ? 1.0 : 0.0;
           mask_rep[it] = rep;  // the record set is chosen later (assign_mask_set): pointers are filled in there
-        } else if (op.kind == PAOS_PW_SIGN) { if (on) slots[l]->sign_on = slots[l]->sign_on != 0.0 ? 0.0 : 1.0; }
+        } else if (op.kind == PAOS_PW_SIGN) {
+          // bit 0: (-1)^position along the line, bit 1: (-1)^line; the checkerboard flips both
+          if (on) {
+            const bool x_only = op.flags & PAOS_PWF_X_ONLY, y_only = op.flags & PAOS_PWF_Y_ONLY;
+            const int along = p.axis == 0 ? (y_only ? 0 : 1) : (x_only ? 0 : 1);
+            const int across = p.axis == 0 ? (x_only ? 0 : 1) : (y_only ? 0 : 1);
+            sign_bits[l] ^= along | (across << 1);
+          }
+        }
         else if (op.kind == PAOS_PW_SCALE) { if (on) slots[l]->scale *= q[FP_COEF]; }
         else {
           FrugalPhase& ph = phases[l][j++];
@@ -481,6 +491,8 @@ bool lower_frugal(const paos_ctx* c, const paos_pass& p, const double* blocks /*
           else { ph.sx = ph.sy = 0.0; ph.coef = 0.0; ph.sgn = 1.0; ph.m2 = 1.0; }  // exp(i 0) = 1 exactly
         }
       }
+      // frugal_slot: 1 = (-1)^(line + position), 2 = (-1)^position, 3 = (-1)^line
+      slots[l]->sign_on = sign_bits[l] == 3 ? 1.0 : (sign_bits[l] == 1 ? 2.0 : (sign_bits[l] == 2 ? 3.0 : 0.0));
     }
     fi.active = active ? 1.0 : 0.0;
     fi.line_lo = 0.0; fi.line_hi = (double)c->n; fi.line_fill = 0.0; fi.pos_lo = 0.0; fi.pos_hi = (double)c->n;
@@ -532,68 +544,94 @@ bool mask_live_range(const paos_ctx* c, const double* q, const double* q2, int a
   return true;
 }
 
-// Fill in the pruning fields of a whole program.  Per item the planner carries which lines are
-// known to be zero: DENSE, or "lines along `axis` outside [lo, hi) are zero" -- physically (zeros in
-// memory: the state a stand-alone aperture leaves, passed in through entry_rows) or virtually (the
-// tiles were skipped and hold stale data).  A pass along the same axis skips the dead tiles; a pass
-// along the other axis does not load the dead positions and, writing every element, makes the field
-// dense again.  Virtual zeros must be consumed by such a pass before the program ends; where none
-// follows, the last pass that skipped them writes zeros instead (line_fill).
+// Fill in the pruning fields of a whole program.  Per item the planner carries, forwards, the BOX outside which the
+// field is known to be zero -- rows [r.lo, r.hi) x columns [c.lo, c.hi); physically (zeros in memory: what a stand-alone
+// aperture leaves, passed in through entry_rows) or virtually (tiles that were skipped hold stale data that STANDS for
+// zeros) -- and, backwards, the box of each pass's output that the next pass reads at all:
+//   forwards   a pass keeps dead lines dead; its transforms spread the live positions over the whole line; an aperture
+//              riding on it clips both ranges to its bounding box (positions: unless a transform follows it);
+//   backwards  a pass processes the lines that are alive AND wanted, loads the live positions of those lines and stores
+//              the positions the next pass reads; what it reads is what the pass in front of it has to deliver.
+// Every load therefore falls inside what the previous pass stored (or is known to be zero and not loaded), and nothing
+// else is ever looked at: tiles nobody processes keep whatever they held.  The last pass an item takes part in delivers
+// the whole grid: it stores every position of its lines and writes zeros to the dead ones (line_fill).
+// Round 4: the box (both axes at once, and the backward half) is what lets the separable pass programs (passes.py:
+// SeparableCompiler) run an aperture-to-aperture stretch on the live rows and the wanted columns only; for the
+// operator-by-operator programs it yields the ranges of round 2's one-axis planner and round 3's "stores nobody reads".
+struct LineRange { int lo, hi; };
 void plan_pruning(const paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks,
                   std::vector<LoweredPass>& low, const double* entry_rows, bool entry_stale) {
-  const int n = c->n;
+  const int n = c->n, br = c->br;
+  // never empty, always inside `a`: an aperture off the live range keeps one block row of `a` (which it then zeroes)
+  auto meet = [br](LineRange a, LineRange b) {
+    LineRange r{a.lo > b.lo ? a.lo : b.lo, a.hi < b.hi ? a.hi : b.hi};
+    if (r.lo >= r.hi) { r.lo = a.lo; r.hi = a.lo + br < a.hi ? a.lo + br : a.hi; }
+    return r;
+  };
+  std::vector<int> act;
+  std::vector<LineRange> lines, loads;
   for (int it = 0; it < c->batch; ++it) {
-    bool zl = false, virt = false;
-    int axis = 0, lo = 0, hi = n, last_skip = -1;
+    act.clear();
+    for (int q = 0; q < n_passes; ++q)
+      if (low[q].items[it].active != 0.0) act.push_back(q);
+    if (act.empty()) continue;
+    LineRange box[2] = {{0, n}, {0, n}};  // [0]: rows, [1]: columns
+    bool clean = false;                   // rows outside box[0] are zeros in memory and nothing has touched them
+    LineRange rows0{0, n};
     if (entry_rows) {
       int l = (int)entry_rows[2 * it], h = (int)entry_rows[2 * it + 1];
-      l = l < 0 ? 0 : (l / c->br) * c->br;
-      h = h > n ? n : ((h + c->br - 1) / c->br) * c->br;
+      l = l < 0 ? 0 : (l / br) * br;
+      h = h > n ? n : ((h + br - 1) / br) * br;
       if (h > n) h = n;
-      // entry_stale: the rows outside hold old data that STANDS for zeros (paos_start_rows): virtual from the start
-      if (l < h && (l > 0 || h < n)) { zl = true; axis = 0; lo = l; hi = h; virt = entry_stale; }
+      if (l < h && (l > 0 || h < n)) { box[0] = {l, h}; clean = !entry_stale; }
+      rows0 = box[0];
     }
-    for (int q = 0; q < n_passes; ++q) {
-      FrugalItem& fi = low[q].items[it];
-      if (fi.active == 0.0) continue;
-      const int ax = passes[q].axis;
-      if (zl && ax != axis) {  // reads across the dead lines: skip their loads; output is dense
-        fi.pos_lo = lo; fi.pos_hi = hi;
-        zl = false; virt = false; last_skip = -1;
-      }
-      int mlo = 0, mhi = n;
+    // forwards
+    lines.assign(act.size(), LineRange{0, n});
+    loads.assign(act.size(), LineRange{0, n});
+    for (size_t k = 0; k < act.size(); ++k) {
+      const int q = act[k], ax = passes[q].axis;
+      const FrugalItem& fi = low[q].items[it];
+      LineRange& L = box[ax];      // along the lines of this pass (rows for a row pass)
+      LineRange& P = box[1 - ax];  // along the positions of a line
+      LineRange ml{0, n}, mp{0, n};
       bool masked = false;
       if (low[q].mask_block >= 0) {
         const double* mq = blocks + ((size_t)low[q].mask_block * c->batch + it) * FP_STRIDE;
         const double* mq2 = blocks + ((size_t)(low[q].mask_block + 1) * c->batch + it) * FP_STRIDE;
-        masked = mask_live_range(c, mq, mq2, ax, &mlo, &mhi);
+        masked = mask_live_range(c, mq, mq2, ax, &ml.lo, &ml.hi) && mask_live_range(c, mq, mq2, 1 - ax, &mp.lo, &mp.hi);
       }
-      if (zl) {  // same axis: the dead lines stay dead
-        if (masked) {
-          const int l2 = lo > mlo ? lo : mlo, h2 = hi < mhi ? hi : mhi;
-          if (l2 != lo || h2 != hi) virt = true;  // newly dead lines still hold data
-          lo = l2; hi = h2;
-          if (lo >= hi) { lo = 0; hi = c->br; virt = true; }
-        }
-      } else if (masked && (mlo > 0 || mhi < n)) {
-        zl = true; virt = true; axis = ax; lo = mlo; hi = mhi;
-      }
-      if (zl) { fi.line_lo = lo; fi.line_hi = hi; last_skip = q; }
+      if (masked) L = meet(L, ml);
+      lines[k] = L;
+      LineRange pos = P;
+      if (masked && low[q].mask_slot == 0) pos = meet(pos, mp);  // in front of the first transform: no need to load what it zeroes
+      loads[k] = pos;
+      if (fi.fft1_on != 0.0) pos = {0, n};
+      if (masked && low[q].mask_slot == 1) pos = meet(pos, mp);
+      if (low[q].nfft >= 2 && fi.fft2_on != 0.0) pos = {0, n};
+      P = pos;
     }
-    if (zl && virt && last_skip >= 0) low[last_skip].items[it].line_fill = 1.0;
-    // Stores nobody reads: when the next pass the item takes part in runs along the other axis and does not
-    // process the tiles of the lines outside [line_lo, line_hi) (its aperture zeroes them whatever they hold; it
-    // writes zeros there itself if somebody will read them), this pass need not store those positions.
-    int prev = -1;
-    for (int q = 0; q < n_passes; ++q) {
+    // backwards
+    LineRange want[2] = {{0, n}, {0, n}};
+    for (size_t k = act.size(); k-- > 0;) {
+      const int q = act[k], ax = passes[q].axis;
       FrugalItem& fi = low[q].items[it];
-      if (fi.active == 0.0) continue;
-      if (prev >= 0 && passes[prev].axis != passes[q].axis && (fi.line_lo > 0.0 || fi.line_hi < (double)n)) {
-        low[prev].items[it].spos_lo = fi.line_lo;
-        low[prev].items[it].spos_hi = fi.line_hi;
-      }
-      prev = q;
+      const LineRange proc = meet(lines[k], want[ax]);
+      fi.line_lo = proc.lo; fi.line_hi = proc.hi;
+      fi.pos_lo = loads[k].lo; fi.pos_hi = loads[k].hi;
+      fi.spos_lo = want[1 - ax].lo; fi.spos_hi = want[1 - ax].hi;
+      want[ax] = proc;
+      want[1 - ax] = loads[k];
     }
+    // zeros nobody has written: the last pass writes them
+    for (size_t k = 0; k < act.size(); ++k) {
+      const FrugalItem& fi = low[act[k]].items[it];
+      if (passes[act[k]].axis != 0 || (int)fi.line_lo != rows0.lo || (int)fi.line_hi != rows0.hi || fi.spos_lo > 0.0 ||
+          fi.spos_hi < (double)n)
+        clean = false;
+    }
+    FrugalItem& last = low[act.back()].items[it];
+    if ((last.line_lo > 0.0 || last.line_hi < (double)n) && !clean) last.line_fill = 1.0;
   }
 }
 
@@ -643,12 +681,13 @@ template <typename T, int N, int AXIS, int KPRE, int KMID>
 int frugal_nfft(paos_ctx* c, const FrugalArgs& a, int nfft) {
   // (the digit-swapped two-transform variant NFFT = 3 of frugal_pass.h is built by tools/fftbench.hip only:
   // measured in round 2 with parity unchanged and no gain, profiles/r02_fftbench_digit_swapped_experiment.txt)
-  if constexpr (KPRE == 0 && KMID <= 1) {  // the shapes a chain can end on: also built with the PSF store
+  if constexpr (KPRE <= 1 && KMID <= 1) {  // the shapes a chain can end on: also built with the PSF store (KPRE = 1: round 4,
+    // the last column pass of a separable program usually has the column half of a phase in front of its first transform)
     if (a.psf) return nfft >= 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2, 1>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1, 1>(c, a);
   } else {
     if (a.psf) return fail(c, PAOS_EUNSUPPORTED, "no PSF-storing build of this pass shape");
   }
-  if constexpr (KPRE == 0) {  // ... and the shapes a program that ends on a saved surface ends with: field + its power
+  if constexpr (KPRE <= 1) {  // ... and the shapes a program that ends on a saved surface ends with: field + its power
     if (a.pow_partial) return nfft >= 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2, 2>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1, 2>(c, a);
   } else {
     if (a.pow_partial) return fail(c, PAOS_EUNSUPPORTED, "no power-summing build of this pass shape");
@@ -1105,7 +1144,7 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
     // The field is kept AND its power is wanted (a saved surface, run.py:218-223 callers): the last pass sums |u|^2 of
     // its tiles while it stores them (FrugalArgs::pow_partial) -- when it runs on the frugal kernels and every item
     // takes part; otherwise the ordinary reduction follows the program.
-    fused_power = n_passes > 0 && low[n_passes - 1].ok && low[n_passes - 1].kpre == 0;  // (the shapes built with STORE = 2)
+    fused_power = n_passes > 0 && low[n_passes - 1].ok && low[n_passes - 1].kpre <= 1;  // (the shapes built with STORE = 2)
     if (fused_power)
       for (const FrugalItem& fi : low[n_passes - 1].items) fused_power = fused_power && fi.active != 0.0;
     if (fused_power) {
@@ -1123,7 +1162,7 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
   }
   if (final_ticket && final_mode != 2) {
     if (!c->psf) HIPCHK(c, hipMalloc(&c->psf, (size_t)c->batch * c->item_stride * sizeof(double)));
-    fused_store = n_passes > 0 && low[n_passes - 1].ok && low[n_passes - 1].kpre == 0 && low[n_passes - 1].kmid <= 1;
+    fused_store = n_passes > 0 && low[n_passes - 1].ok && low[n_passes - 1].kpre <= 1 && low[n_passes - 1].kmid <= 1;
     if (fused_store)
       for (const FrugalItem& fi : low[n_passes - 1].items) fused_store = fused_store && fi.active != 0.0;
     if (fused_store) {

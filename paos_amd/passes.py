@@ -344,3 +344,238 @@ class PassCompiler:
         elif final_intensity and final_intensity != 2:
             raise RuntimeError("a program without passes cannot store the PSF")
         return (len(passes), ticket) if final_intensity else len(passes)
+
+
+# The separable pass programs (round 4).  PAOS_SEPARABLE=0 (or SEPARABLE = False): the compiler above.
+SEPARABLE = os.environ.get("PAOS_SEPARABLE", "1") != "0"
+
+
+class SeparableCompiler(PassCompiler):
+    """Every operator between two apertures is a product of a factor that acts along the rows and a factor that acts
+    along the columns:
+
+        lens, Qc, P, H : exp(i c (x^2 + y^2)) = exp(i c x^2) exp(i c y^2)          wfo.py:359-366, 462-545
+        checkerboard S : (-1)^(row + column)  = (-1)^column (-1)^row
+        fft2 / ifft2   : F_rows F_columns
+
+    and an operator along the rows commutes with every operator along the columns, so a whole stretch
+
+        aperture_k . [lens ptp lens stw wts ...] . aperture_k+1   =   aperture_k . X . Y . aperture_k+1
+
+    with X = all the row factors in their order, Y = all the column factors in theirs.  X runs first, on the rows
+    aperture_k left alive only (rows of zeros stay rows of zeros under X); Y then runs on the columns aperture_k+1 will
+    keep only (a column nobody reads need not be computed), reading the live rows and storing the rows that aperture keeps.
+    For SYN20 at zoom 4 (a 1024-pixel pupil on a 4096 grid) that is 4 x 1024 + 4 x 1024 line transforms per relay
+    instead of the 2 x 1024 + 6 x 4096 of the operator-by-operator order (PassCompiler), with every pass touching a
+    sixteenth of the grid on the way in and on the way out.  Which lines are alive / wanted is the library's planner's
+    business (csrc/paos_hip.hip: plan_pruning); this class only orders the factors.
+
+    The identities of PassCompiler (consecutive ptp share their transforms, ptp(+d) ptp(-d) = 1, a wts and the stw that
+    undoes it) are applied to the operator stream before it is split.  Arguments: the reference rounds
+    c (x^2 + y^2) once, the two factors round c x^2 and c y^2 separately -- a few 1e-12 rad where the light is (measured
+    end to end: tests/test_host_logic.py, tests/test_gpu_r4.py)."""
+
+    def _reset(self):
+        super()._reset()
+        self.ops = []  # the operator stream since the last program(): diag / ptp / single / mask entries
+
+    # ---- operators -----------------------------------------------------------------------
+    def aperture(self, records):
+        if all(r is None for r in records):
+            return
+        first = [list(r[0][:5]) if r is not None else None for r in records]
+        second = [[r[0][5], r[0][6], r[0][7], float(r[1]), 0.0] if r is not None else None for r in records]
+        self.ops.append({"k": "mask", "first": _rows(first, self.batch), "second": _rows(second, self.batch)})
+
+    def lens(self, rows):
+        arr = _rows(rows, self.batch)
+        if arr[:, 0].any():
+            self.ops.append({"k": "diag", "kind": _lib.PW_QPHASE_CENTRED, "flags": _lib.PWF_MUL2PI, "arr": arr.copy()})
+
+    def _single(self, rows, inverse, kind):
+        arr = _rows(rows, self.batch)
+        if not arr[:, 0].any():
+            return
+        inv = np.where(np.asarray(inverse, dtype=bool), 1.0, 0.0) * np.ones(self.batch)
+        last = self.ops[-1] if self.ops else None
+        if PTP_ALGEBRA and kind == "stw" and last is not None and last["k"] == "single" and last["kind"] == "wts":
+            # (see PassCompiler._single: a wts straight into the stw that undoes it)
+            if self._undoes(last["arr"], last["inv"], arr, inv):
+                self.ops.pop()
+                return
+            if self._undoes(last["arr"], last["inv"], arr, inv, max_residual=UNDO_COMPENSATE_MAX):
+                leftovers = self._residual_phase(last["arr"], arr)
+                self.ops.pop()
+                for blk in leftovers:
+                    self.ops.append({"k": "diag", "kind": _lib.PW_QPHASE_CENTRED, "flags": 0, "arr": blk})
+                return
+        self.ops.append({"k": "single", "kind": kind, "arr": arr.copy(), "inv": inv})
+
+    def ptp(self, rows):
+        arr = _rows(rows, self.batch)
+        if not arr[:, 0].any():
+            return
+        on = arr[:, 0] != 0.0
+        last = self.ops[-1] if self.ops else None
+        if PTP_ALGEBRA and last is not None and last["k"] == "ptp" and len(last["H"]) < MAX_MERGED_PTP:
+            first = last["H"][0]
+            # (see PassCompiler.ptp: H(-d) H(d) = 1; otherwise the second transfer function joins the first)
+            if (len(last["H"]) == 1 and np.array_equal(first[:, 0] != 0.0, on) and
+                    np.array_equal(first[on, 1:3], arr[on, 1:3]) and np.array_equal(first[on, 3], -arr[on, 3]) and
+                    np.array_equal(first[on, 4], arr[on, 4])):
+                self.ops.pop()
+                return
+            last["H"].append(arr.copy())
+            last["on"] = last["on"] | on
+            return
+        self.ops.append({"k": "ptp", "H": [arr.copy()], "on": on.copy()})
+
+    def open_takes_mask(self):
+        """An aperture queued now ends up behind the last transform of the last pass -- when that pass has one transform
+        only (an odd number of transforms since the last aperture) and carries no aperture yet."""
+        count = 0
+        for op in reversed(self.ops):
+            if op["k"] == "mask":
+                return False if count == 0 else count % 2 == 1
+            count += {"ptp": 2, "single": 1}.get(op["k"], 0)
+        return count % 2 == 1
+
+    def pending(self):
+        return bool(self.ops)
+
+    # ---- lowering ------------------------------------------------------------------------
+    def _axis_block(self, arr, axis):
+        """The factor of a quadratic phase along one axis: the other axis' sampling set to zero."""
+        out = arr.copy()
+        out[:, 2 if axis == 0 else 1] = 0.0
+        out[out[:, 0] == 0.0] = 0.0
+        return self._block(out)
+
+    def _chains(self, stretch):
+        """The row factors (axis 0) and the column factors (axis 1) of a run of separable operators: lists of
+        ("d", (kind, flags, block)) and ("t", control block)."""
+        only = {0: _lib.PWF_X_ONLY, 1: _lib.PWF_Y_ONLY}
+        chains = {0: [], 1: []}
+        for op in stretch:
+            if op["k"] == "diag":
+                for ax in (0, 1):
+                    chains[ax].append(("d", (op["kind"], op["flags"], self._axis_block(op["arr"], ax))))
+            elif op["k"] == "single":
+                arr, kind = op["arr"], op["kind"]
+                par = self._block(arr)  # (the sign reads the enable flags only)
+                ctl = self._derived(arr, v1=op["inv"])
+                scl = self._derived(arr, v3=1.0 / self.n)
+                for ax in (0, 1):
+                    sign = ("d", (_lib.PW_SIGN, only[ax], par))
+                    phase = ("d", (_lib.PW_QPHASE_CENTRED, 0, self._axis_block(arr, ax)))
+                    ch = chains[ax]
+                    ch += [phase, sign] if kind == "wts" else [sign]
+                    if ax == 0:
+                        ch.append(("d", (_lib.PW_SCALE, 0, scl)))  # 1 / N for the 2-D pair: once (a scalar: in front)
+                    ch.append(("t", ctl))
+                    ch += [sign, phase] if kind == "stw" else [sign]
+            else:  # ptp: F . H1 [H2 H3] . F^-1, the transforms on for every item that takes any of them
+                union = np.zeros((self.batch, 5))
+                union[:, 0] = np.where(op["on"], 1.0, 0.0)
+                fwd = self._derived(union, v1=0.0)
+                inv = self._derived(union, v1=1.0)
+                scl = self._derived(union, v3=1.0 / self.n)
+                for ax in (0, 1):
+                    ch = chains[ax]
+                    ch.append(("t", fwd))
+                    for h in op["H"]:
+                        ch.append(("d", (_lib.PW_QPHASE_NATURAL, 0, self._axis_block(h, ax))))
+                    ch.append(("d", (_lib.PW_SCALE, 0, scl)))
+                    ch.append(("t", inv))
+        return chains
+
+    @staticmethod
+    def _phases(ops):
+        return sum(op[0] in (_lib.PW_QPHASE_CENTRED, _lib.PW_QPHASE_NATURAL) for op in ops)
+
+    def _room(self, slot_ops, extra, limit):
+        ops = slot_ops + extra
+        return (len(ops) <= _lib.MAX_PW and self._phases(ops) <= limit and
+                sum(op[0] == _lib.PW_MASK for op in ops) <= 1)
+
+    def _emit_chain(self, axis, chain, lone_first=False):
+        """Pack one axis' factors into passes of up to two transforms.  ``lone_first``: the first pass takes one
+        transform only, so that a chain with an even number of them ends on a pass whose slot behind the transform is
+        free for what trails the chain (the program ends there: no later pass could carry it)."""
+        cur = None
+        lone = lone_first
+        for what, val in chain:
+            if what == "d":
+                if cur is not None and cur["fft2"] == -1 and not self.tail and self._room(cur["mid"], [val], _MAX_MID) and \
+                        not (val[0] == _lib.PW_MASK and self._has_mask(cur)):
+                    cur["mid"].append(val)
+                else:
+                    cur = None
+                    self.tail.append(val)
+            else:
+                if cur is not None and cur["fft2"] == -1 and not self.tail and not lone:
+                    cur["fft2"] = val
+                    continue
+                if cur is not None:
+                    lone = False
+                if not self._room([], self.tail, _MAX_PRE):
+                    self._standalone(self.tail)
+                    self.tail = []
+                cur = {"axis": axis, "fft1": val, "fft2": -1, "pre": self.tail, "mid": [], "post": []}
+                self.tail = []
+                self.passes.append(cur)
+        self.open = cur if cur is not None and cur["fft2"] == -1 and not self.tail else None
+
+    @staticmethod
+    def _has_mask(ps):
+        return any(op[0] == _lib.PW_MASK for op in ps["pre"] + ps["mid"])
+
+    def _lower(self):
+        # segments: a run of separable operators and the aperture behind it (None at the end of the program)
+        segments, stretch = [], []
+        for op in self.ops:
+            if op["k"] == "mask":
+                segments.append((stretch, op))
+                stretch = []
+            else:
+                stretch.append(op)
+        if stretch:
+            segments.append((stretch, None))
+        for s, (stretch, mask_op) in enumerate(segments):
+            if stretch:
+                chains = self._chains(stretch)
+                self._emit_chain(0, chains[0])
+                # The program ends with this stretch [and its aperture]: what trails the column factors (a checkerboard
+                # half, a phase, the aperture) needs a slot behind the last transform.
+                count = sum(w == "t" for w, _ in chains[1])
+                trails = bool(chains[1]) and chains[1][-1][0] == "d"
+                self._emit_chain(1, chains[1], lone_first=(s == len(segments) - 1 and count > 0 and count % 2 == 0 and
+                                                            (trails or mask_op is not None)))
+            if mask_op is None:
+                continue
+            first = self._block(mask_op["first"])
+            self._block(mask_op["second"])
+            mask = (_lib.PW_MASK, 0, first)
+            o = self.open
+            if o is not None and not self._has_mask(o) and self._room(o["mid"], [mask], _MAX_MID):
+                o["mid"].append(mask)  # behind the last transform of the pass that ends the stretch
+            else:
+                self.open = None
+                if any(t[0] == _lib.PW_MASK for t in self.tail):  # two apertures with nothing between them
+                    self._standalone(self.tail)
+                    self.tail = []
+                self.tail.append(mask)
+        self.ops = []
+
+    def _close_open(self):
+        self.open = None
+        if self.tail:
+            self._standalone(self.tail)
+            self.tail = []
+
+    def program(self):
+        self._lower()
+        return super().program()
+
+
+_MAX_PRE, _MAX_MID = 2, 3  # phases a slot of the frugal kernels can carry (kFrugalMaxPre / kFrugalMaxMid of csrc/frugal_pass.h)

@@ -26,7 +26,8 @@ from . import _lib
 from .abcd import ABCD
 from .aperture import EllipticalAperture, bbox_misses_grid, make_aperture
 from .coordinate_break import coordinate_break
-from .passes import PassCompiler
+from . import passes as _passes
+from .passes import PassCompiler, SeparableCompiler
 from .phase_maps import grid_sag_map, psd_map
 from .planner import (BeamBatch, gram_polynomials, jacobi_recurrence, orthonorm_matrix,
                       zernike_block)
@@ -360,7 +361,7 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
         raise ValueError("the wavefronts of a batch share beam diameter, grid and zoom")
     beams = BeamBatch(st0.pupil_diameter, [st.wavelength for st in states], st0.gridsize, st0.zoom)
     state, n = beams.state, beams.n
-    comp = PassCompiler(len(states), dev.n)
+    comp = (SeparableCompiler if _passes.SEPARABLE else PassCompiler)(len(states), dev.n)
     npass = 0
     # rows of each item known to be exactly zero in memory (outside [lo, hi)): set by stand-alone
     # apertures, kept by stops / Zernike / phase screens (they multiply), handed to the next pass

@@ -237,6 +237,10 @@ class ModelDevice:
         n = self.n
         if kind == _lib.PW_SIGN:
             i = np.arange(n)
+            if flags & _lib.PWF_X_ONLY:
+                return u * np.where(i[None, :] & 1, -1.0, 1.0)
+            if flags & _lib.PWF_Y_ONLY:
+                return u * np.where(i[:, None] & 1, -1.0, 1.0)
             return u * np.where((i[:, None] + i[None, :]) & 1, -1.0, 1.0)
         if kind == _lib.PW_SCALE:
             return u * p[3]
