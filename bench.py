@@ -204,17 +204,20 @@ def measure(dev, n, precision, wavelengths_of, chains, steps, warmup, comm=None,
     if not keep_last:  # the ticket ring is a ring: a ticket left outstanding blocks its slot when the ring comes round
         release(res)
         res = None
-    if timer:
-        ms, tags = dev.profile_end_launches()
-    else:
-        import numpy as np
+    import numpy as np
 
-        ms, tags = np.zeros(0), np.zeros(0, dtype=np.int32)
+    if timer:
+        planned = dev.profile_planned_bytes() if hasattr(dev, "profile_planned_bytes") else None
+        ms, tags = dev.profile_end_launches()
+        if planned is None or planned.size != ms.size:
+            planned = np.zeros(ms.size)
+    else:
+        ms, tags, planned = np.zeros(0), np.zeros(0, dtype=np.int32), np.zeros(0)
     if comm is not None:
         elapsed = comm.max(elapsed)
     full = tags == 0
     return {"elapsed": elapsed, "launches": int(ms.size), "kern_ms": float(ms.sum()), "pruned": int((~full).sum()),
-            "pruned_ms": float(ms[~full].sum()), "launch_ms": ms, "launch_tags": tags,
+            "pruned_ms": float(ms[~full].sum()), "launch_ms": ms, "launch_tags": tags, "launch_bytes": planned,
             "fused_passes": stats.get("fused_passes"), "per_step_passes": per_step_passes,
             "per_step_sets": per_step_sets, "first_timed_step": first_step + warmup, "res": res}
 
@@ -313,35 +316,50 @@ def class_name(tag):
     return " + ".join(CLASS_NAMES[b] for b in (1, 2, 4, 8) if tag & b) if tag else CLASS_NAMES[0]
 
 
-def roofline_block(m, n, nb, esz, dev, kernel_name, steps, traffic=None, traffic_step=1):
-    """`achieved` = algorithmic bytes of one pass over the batch / mean HIP-event time of the launches that skip nothing.
-    `classes`: per class of launch the mean event time over every timed launch of that class and -- with ``traffic``
-    (measure_traffic: the launches of global step ``traffic_step``) -- the bytes the counters saw for the launches of
-    that class: no estimate anywhere."""
+def roofline_block(m, n, nb, esz, dev, kernel_name, steps, traffic=None, traffic_step=1, dense=None):
+    """The pass kernel against the HBM roofline, over EVERY pass launch of the timed steps:
+    `achieved` = the launches' algorithmic bytes / their HIP-event time, where a launch's algorithmic bytes are what the
+    library's pruning plan has it load and store (live lines x (loaded + stored positions) x element size, summed over
+    the batch: paos_profile_planned_bytes) -- for a launch that skips nothing that is the whole batch read and written
+    once.  `traffic`: what the FETCH_SIZE / WRITE_SIZE counters saw per launch (``traffic``: measure_traffic, the launches
+    of global step ``traffic_step``).  `dense` (``dense``: a measure() of one step with the pruning switched off): the
+    same kernel when every line is alive -- the figure rounds 1-3 reported as `achieved`.  `classes`: per class of launch
+    the mean event time, planned and counted bytes."""
     import numpy as np
 
     pass_bytes = 2 * esz * n * n * nb  # one pass over the batch: every element read + written once
-    ms, tags = m["launch_ms"], m["launch_tags"]
-    full = tags == 0
-    full_ms = float(ms[full].mean()) if full.any() else 0.0
-    achieved = pass_bytes / (full_ms * 1e-3) / 1e9 if full.any() else 0.0
+    ms, tags, planned = m["launch_ms"], m["launch_tags"], m["launch_bytes"]
+    known = ms.size > 0 and planned.size == ms.size and float(planned.sum()) > 0.0
+    achieved = float(planned.sum()) / (float(ms.sum()) * 1e-3) / 1e9 if known else 0.0
     y_ms, y_bytes = dev.copy_yardstick(10)
     block = {
         "bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
         "traffic_note": "not measured in this run (--no-traffic, an `extra` entry, or N > 1); per-kernel FETCH_SIZE / WRITE_SIZE "
                         "of the default command under rocprofv3: profiles/r04_pmc_hbm_traffic_bench.txt",
-        "launches": int(full.sum()), "avg_launch_ms": full_ms, "algorithmic_bytes_per_launch": pass_bytes,
-        "pruned": {"launches": int((~full).sum()), "avg_launch_ms": float(ms[~full].mean()) if (~full).any() else 0.0,
-                   "what": "pass launches next to an aperture that skip the tiles / loads of rows or columns it has zeroed, "
-                           "or the stores of rows it is about to zero, and the last pass that stores the PSF (they move "
-                           "fewer bytes and are kept out of `achieved`)"},
-        "all_pass_launches_avg_ms": float(ms.mean()) if ms.size else 0.0,
+        "launches": int(ms.size), "avg_launch_ms": float(ms.mean()) if ms.size else 0.0,
+        "algorithmic_bytes_per_launch": float(planned.mean()) if known else None,
+        "full_pass_bytes": pass_bytes,
+        "what": "every pass launch of the timed steps: bytes the pruning plan has them load + store (their algorithmic bytes) "
+                "over their HIP-event time.  Round 4: between two apertures the row factors of every operator run on the "
+                "live rows and the column factors on the wanted columns only, so a launch moves about an eighth of the "
+                "batch and is bound by the fp64 issue rate of its butterflies, not by HBM (profiles/r04_sq_counters.txt); "
+                "`dense` is the same kernel with every line alive",
         "fused_passes_per_wavefront": m["fused_passes"],
         "copy_yardstick": {"ms_per_launch": y_ms, "GBps": y_bytes / (y_ms * 1e-3) / 1e9,
                            "what": "measured in this run (paos_copy_yardstick): in-place copy of the same batch buffer, "
                                    "16 B per lane, unit stride, no transform"},
     }
+    if dense is not None and dense["launch_ms"].size:
+        dms = dense["launch_ms"]
+        full = dense["launch_tags"] == 0
+        if full.any():
+            block["dense"] = {"launches": int(full.sum()), "avg_launch_ms": float(dms[full].mean()),
+                              "achieved": pass_bytes / (float(dms[full].mean()) * 1e-3) / 1e9,
+                              "frac": pass_bytes / (float(dms[full].mean()) * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                              "algorithmic_bytes_per_launch": pass_bytes,
+                              "what": "one step of the same chain with the pruning switched off (paos_ctx_set_pruning 0), "
+                                      "measured in this run: every launch reads and writes the whole batch once"}
     counts = [c for c in m["per_step_passes"] if c is not None]
     if not ms.size or len(counts) != steps or sum(counts) != ms.size:
         return block  # (a generic-kernel pass that is not timed: the launches cannot be cut into steps)
@@ -350,12 +368,13 @@ def roofline_block(m, n, nb, esz, dev, kernel_name, steps, traffic=None, traffic
     for t in sorted(set(int(x) for x in tags)):
         sel = tags == t
         classes[class_name(t)] = {"launches_per_step": float(sel.sum()) / steps, "avg_launch_ms": float(ms[sel].mean()),
-                                  "bytes_measured": None}
+                                  "bytes_planned": float(planned[sel].mean()) if known else None, "bytes_measured": None}
     block["classes"] = classes
-    block["all_launches"] = {"launches_per_step": float(ms.size) / steps, "ms": float(ms.sum()) / steps, "bytes_measured": None,
+    block["all_launches"] = {"launches_per_step": float(ms.size) / steps, "ms": float(ms.sum()) / steps,
+                             "bytes_planned": float(planned.sum()) / steps if known else None, "bytes_measured": None,
                              "frac": None,
-                             "what": "every pass launch of one step: HIP-event time (mean over the timed steps) and, when "
-                                     "the counters were collected, the HBM bytes they saw for the launches of one step"}
+                             "what": "every pass launch of one step: HIP-event time (mean over the timed steps), planned bytes "
+                                     "and, when the counters were collected, the HBM bytes they saw for the launches of one step"}
     # the counted step of the traffic children is global step `traffic_step`: its launches carry the tags of the same
     # step of this run when it lies in the timed region, of the first timed step otherwise (same chain, other wavelengths)
     s = traffic_step - m["first_timed_step"]
@@ -371,16 +390,14 @@ def roofline_block(m, n, nb, esz, dev, kernel_name, steps, traffic=None, traffic
             rec["GBps_measured"] = rec["bytes_measured"] / (rec["avg_launch_ms"] * 1e-3) / 1e9
             rec["frac_measured"] = rec["GBps_measured"] / HBM_PEAK_GBS
         total = sum(r + w for r, w in traffic["pass"])
+        reads = sum(r for r, w in traffic["pass"])
         block["all_launches"]["bytes_measured"] = total
         block["all_launches"]["frac"] = total / (block["all_launches"]["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
-        fulls = [r + w for t, (r, w) in zip(step_tags, traffic["pass"]) if t == 0]
-        reads = [r for t, (r, w) in zip(step_tags, traffic["pass"]) if t == 0]
-        if fulls:
-            block["traffic"] = sum(fulls) / len(fulls)
-            block["traffic_over_algorithmic"] = block["traffic"] / pass_bytes
-            block["traffic_note"] = (f"mean over the {len(fulls)} of {len(step_tags)} pass launches of a step that skip nothing: read "
-                                     f"{sum(reads) / len(reads) / 1e9:.3f} GB + written "
-                                     f"{(sum(fulls) - sum(reads)) / len(fulls) / 1e9:.3f} GB per launch")
+        block["traffic"] = total / len(step_tags)
+        if known:
+            block["traffic_over_algorithmic"] = total / (float(planned[bounds[s]:bounds[s + 1]].sum()) or 1.0)
+        block["traffic_note"] = (f"mean over the {len(step_tags)} pass launches of one step: read {reads / len(step_tags) / 1e9:.3f} GB "
+                                 f"+ written {(total - reads) / len(step_tags) / 1e9:.3f} GB per launch")
     return block
 
 
@@ -598,6 +615,31 @@ def main(argv=None):
                                  "middle pass nor cancel, a wts and the stw that undoes it both run"}
             finally:
                 ppasses.PTP_ALGEBRA = True
+        # ... and operator by operator (rounds 2-3: every operator's transforms glued to its neighbours', all rows / columns
+        # that are not known to be zero processed)
+        by_operator = None
+        if world == 1:
+            import paos_amd.passes as ppasses
+
+            ppasses.SEPARABLE = False
+            try:
+                mo = measure(dev, n, args.precision, wavelengths_of, chains, args.steps, 1, None, first_step=args.warmup - 1)
+                by_operator = {"value": nb * args.steps / mo["elapsed"], "unit": "wavefronts/s", "steps": args.steps,
+                               "fused_passes_per_wavefront": mo["fused_passes"],
+                               "pass_launch_ms_per_step": float(mo["launch_ms"].sum()) / args.steps,
+                               "what": "PAOS_SEPARABLE=0 over the same steps: the pass compiler of rounds 2-3 (a 2-D transform's "
+                                       "second half glued to the next one's first; the column passes behind an aperture run on "
+                                       "all 4096 columns)"}
+            finally:
+                ppasses.SEPARABLE = True
+        # ... and one step with the pruning off: the pass kernel when every line is alive (roofline.dense)
+        dense = None
+        if hasattr(dev, "set_pruning"):
+            dev.set_pruning(False)
+            try:
+                dense = measure(dev, n, args.precision, wavelengths_of, chains, 1, 1, None, first_step=args.warmup - 1)
+            finally:
+                dev.set_pruning(True)
         # ... and with the SAME wavelengths every step (rounds 1-3 measured this way): what the walk costs
         repeated = None
         if world == 1:
@@ -647,7 +689,7 @@ def main(argv=None):
                        "ranks_seen": len(ranks_seen), "devices_seen": ranks_seen,
                        "bringup_notes": {str(r): t for r, t in enumerate(notes) if t}},
             "sweep": sweep_report(m),
-            "roofline": roofline_block(m, n, nb, esz, dev, kernel_name, args.steps, traffic),
+            "roofline": roofline_block(m, n, nb, esz, dev, kernel_name, args.steps, traffic, dense=dense),
             "chain_vs_survey_model": {
                 "survey_model_bytes_per_wavefront": survey_bytes,
                 "frac_of_hbm_peak_vs_survey_model": survey_bytes * per_gpu / 1e9 / HBM_PEAK_GBS,
@@ -665,6 +707,7 @@ def main(argv=None):
                          "frac_bytes_moved": 6 * esz * n * n * nb / (ptp_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "note": "SURVEY 8d prices a ptp at 128 B/px (4 passes); the fused path moves 96 B/px"},
             "without_ptp_algebra": plain,
+            "operator_by_operator": by_operator,
             "same_wavelengths_every_step": repeated,
             "power_check": power_check,
             "build": dev.build_info(),

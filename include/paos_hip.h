@@ -111,6 +111,9 @@ int paos_profile_end_split(paos_ctx* ctx, int* launches, double* total_ms, int* 
  * lines, bit 1: loads of dead positions, bit 2: stores nobody reads, bit 3: it stored the PSF instead of the
  * field; 0 = a full pass); *count launches, at most `capacity` */
 int paos_profile_end_launches(paos_ctx* ctx, int capacity, double* ms_out, int* tag_out, int* count);
+/* round 4: the bytes the pruning plan had each launch timed so far load + store (live lines x (loaded + stored positions)
+ * x element size, summed over the batch items): the launch's algorithmic bytes.  Call before paos_profile_end_*. */
+int paos_profile_planned_bytes(paos_ctx* ctx, int capacity, double* bytes_out, int* count);
 
 /* ---- field I/O ---------------------------------------------------------------------- */
 /* u[:] = re + i im for every batch item -- np.ones(..., complex128), wfo.py:118 */

@@ -61,6 +61,7 @@ SYMBOLS = {
     "paos_profile_begin": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int]),
     "paos_profile_end": (ctypes.c_int, [_c_ctx, ctypes.POINTER(ctypes.c_int), _dbl_p]),
     "paos_profile_end_split": (ctypes.c_int, [_c_ctx, ctypes.POINTER(ctypes.c_int), _dbl_p, ctypes.POINTER(ctypes.c_int), _dbl_p]),
+    "paos_profile_planned_bytes": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p, ctypes.POINTER(ctypes.c_int)]),
     "paos_profile_end_launches": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p, ctypes.POINTER(ctypes.c_int),
                                                  ctypes.POINTER(ctypes.c_int)]),
     "paos_fill": (ctypes.c_int, [_c_ctx, ctypes.c_double, ctypes.c_double]),
@@ -284,6 +285,14 @@ class DeviceFields:
         self._check(self._lib.paos_profile_end_split(self._ctx, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(pn),
                                                      ctypes.byref(pms)), "paos_profile_end_split")
         return n.value, ms.value, pn.value, pms.value
+
+    def profile_planned_bytes(self, capacity=1 << 16):
+        """Bytes the pruning plan had every launch timed so far load + store (call before profile_end_launches)."""
+        out = np.empty(capacity, dtype=np.float64)
+        n = ctypes.c_int(0)
+        self._check(self._lib.paos_profile_planned_bytes(self._ctx, int(capacity), _dptr(out), ctypes.byref(n)),
+                    "paos_profile_planned_bytes")
+        return out[:n.value].copy()
 
     def profile_end_launches(self, capacity=1 << 16):
         """(ms[i], tag[i]) of every timed launch, in launch order; tag bits: 1 skipped tiles, 2 skipped loads,

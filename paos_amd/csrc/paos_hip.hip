@@ -143,6 +143,8 @@ struct paos_ctx {
   std::vector<hipEvent_t> prof_events;  // start/stop pairs
   std::vector<int> prof_tags;           // per pair: 1 = the launch skipped dead tiles / loads (pruned)
   int prof_next_tag = 0;
+  double prof_next_bytes = 0.0;         // bytes the planner has the next timed launch load + store (its algorithmic bytes)
+  std::vector<double> prof_bytes;       // per pair, like prof_tags
   size_t prof_used = 0;
 };
 
@@ -292,6 +294,8 @@ hipError_t timed_launch_end(paos_ctx* c, int tag) {
   if (e != hipSuccess) return e;
   c->prof_tags.resize(c->prof_used / 2, 0);  // pair i <-> tag i, whatever happened before
   c->prof_tags.push_back(tag);
+  c->prof_bytes.resize(c->prof_tags.size() - 1, 0.0);
+  c->prof_bytes.push_back(c->prof_next_bytes);
   c->prof_used += 2;
   return hipSuccess;
 }
@@ -931,11 +935,15 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const
   // for the launch timer: what does this launch skip?  bit 0: whole tiles of dead lines, bit 1: loads of dead
   // positions, bit 2: stores nobody reads, bit 3: it stores the PSF instead of the field
   c->prof_next_tag = store_psf ? 8 : 0;
+  c->prof_next_bytes = 0.0;
   for (const FrugalItem& fi : lp.items) {
     if (fi.active == 0.0) continue;
     if (fi.line_lo > 0.0 || fi.line_hi < (double)c->n) c->prof_next_tag |= 1;
     if (fi.pos_lo > 0.0 || fi.pos_hi < (double)c->n) c->prof_next_tag |= 2;
     if (!store_psf && (fi.spos_lo > 0.0 || fi.spos_hi < (double)c->n)) c->prof_next_tag |= 4;
+    // what the plan has this launch move: its live lines' loaded and stored positions (the PSF store: doubles, every position)
+    c->prof_next_bytes += (fi.line_hi - fi.line_lo) * ((fi.pos_hi - fi.pos_lo) * (double)elem_bytes(c) +
+                                                        (store_psf ? (double)c->n * 8.0 : (fi.spos_hi - fi.spos_lo) * (double)elem_bytes(c)));
   }
   if (c->precision == PAOS_F64) {
     switch (c->n) {
@@ -1447,6 +1455,7 @@ int paos_profile_begin(paos_ctx* c, int kernel_kind, int max_launches) {
   c->prof_kind = kernel_kind;
   c->prof_used = 0;
   c->prof_tags.clear();
+  c->prof_bytes.clear();
   return PAOS_OK;
 }
 
@@ -1486,6 +1495,16 @@ int paos_profile_end_launches(paos_ctx* c, int capacity, double* ms_out, int* ta
   *count = n;
   c->prof_kind = -1;
   c->prof_used = 0;
+  return PAOS_OK;
+}
+
+// bytes the pruning plan had each timed launch so far load + store (call BEFORE paos_profile_end_launches, which resets)
+int paos_profile_planned_bytes(paos_ctx* c, int capacity, double* bytes_out, int* count) {
+  if (!c || !bytes_out || !count || capacity < 0) return fail(c, PAOS_EINVAL, "null argument");
+  const int n = (int)(c->prof_used / 2);
+  if (n > capacity) return fail(c, PAOS_EINVAL, "more launches were timed than the caller's array holds");
+  for (int i = 0; i < n; ++i) bytes_out[i] = (size_t)i < c->prof_bytes.size() ? c->prof_bytes[i] : 0.0;
+  *count = n;
   return PAOS_OK;
 }
 

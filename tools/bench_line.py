@@ -10,5 +10,7 @@ for path in sys.argv[1:]:
         continue
     d = json.loads(lines[-1])
     r = d.get("roofline", {})
+    dense = r.get("dense") or {}
     print(f"{path}: {d['value']:.1f} {d['unit']}, {d['ms_per_step']:.2f} ms/step, roofline {r.get('frac', 0):.3f} "
-          f"({r.get('avg_launch_ms', 0):.4f} ms x {r.get('launches')} launches)")
+          f"({r.get('avg_launch_ms', 0):.4f} ms x {r.get('launches')} launches), dense pass {dense.get('frac', 0):.3f} "
+          f"({dense.get('avg_launch_ms', 0):.3f} ms)")

@@ -3,9 +3,12 @@
 import json
 import sys
 
-ORDER = ["full", "skips tiles of dead lines", "skips loads of dead positions", "skips stores nobody reads",
-         "skips loads of dead positions + skips stores nobody reads",
-         "skips tiles of dead lines + stores the PSF instead of the field"]
+T = "skips tiles of dead lines"
+ORDER = ["full", T, "skips loads of dead positions", "skips stores nobody reads",
+         "skips loads of dead positions + skips stores nobody reads", T + " + stores the PSF instead of the field",
+         # the separable programs of round 4: every launch skips the tiles of dead / unwanted lines
+         T + " + skips loads of dead positions", T + " + skips stores nobody reads",
+         T + " + skips loads of dead positions + skips stores nobody reads"]
 for path in sys.argv[1:]:
     d = json.load(open(path))
     cl = d["roofline"].get("classes", {})
