@@ -59,8 +59,13 @@ struct FrugalSlot {
   double mask_on, w_in, w_out;   // aperture riding on this slot (0/1), interior / exterior weight
   const MaskLine* lines;          // [N] records of THIS item for the pass axis
   const double* vals;             // [N][2 * kMaskW]
+  // Round 4 (complex128): when every phase of the slot varies ALONG the line only -- the row / column factors of the
+  // separable pass programs -- its factor is the same on every line of the pass: [N] factors of THIS item by position,
+  // filled by phase_table_kernel right before the pass with the arithmetic of frugal_slot (slot_factor) and read back
+  // instead of being evaluated 16 times per thread on each of a thousand lines.  nullptr: the slot evaluates.
+  const cx<double>* table;
 };
-static_assert(sizeof(FrugalSlot) == 7 * sizeof(double), "record of 8-byte fields");
+static_assert(sizeof(FrugalSlot) == 8 * sizeof(double), "record of 8-byte fields");
 // per-item record, doubles: [fft1_on, fft1_inv, fft2_on, fft2_inv, pruning ranges, pre slot, pre phases[2],
 // mid slot, mid phases[3]]
 struct FrugalItem {
@@ -125,6 +130,8 @@ struct FrugalArgs {
   // covers the workgroups of these lines only and workgroup blockIdx.x stands for wg0 + blockIdx.x (frugal_launch
   // sets wg0, a multiple of 16: TileMap renumbers the tiles inside aligned groups of 16 workgroups).
   unsigned live_lo, live_hi, wg0;
+  // host only: launch the TAB build of the shape (every slot with phases reads FrugalSlot::table)
+  int tab = 0;
 };
 #if PAOS_STAMPS
 #define PAOS_STAMP(i)                                                                              \
@@ -198,13 +205,57 @@ __device__ __forceinline__ T flip_sign(T x, unsigned mask_hi) {
 #ifndef PAOS_MERGE_PHASES
 #define PAOS_MERGE_PHASES 1  // two phases of one slot through one sincos of their exactly summed arguments
 #endif
+#ifndef PAOS_TABLE_FENCE
+#define PAOS_TABLE_FENCE 8   // table slots (TAB builds): factors fetched and applied in groups of this many elements
+#endif
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The factor prod_j exp(i q_j) of a slot's K phases at one position: g[j] the signed pixel index along the line
+// (centred or natural order, exact in a double), step[j] the sampling along the line, across2[j] the squared coordinate
+// across it, coefq[j] the coefficient (its sign flipped behind a conjugated transform), m2[j] = 1 or 2 pi.  Each argument
+// is rounded like the reference's (x = g dx; s = x^2 + y^2; q = coef s).  Shared by frugal_slot and phase_table_kernel:
+// a table entry IS the value the slot would have computed.
+template <int K>
+__device__ __forceinline__ cx<double> slot_factor(const double* g, const double* step, const double* across2,
+                                                  const double* coefq, const double* m2, const cx<double>* circle) {
+  cx<double> p = {1.0, 0.0};
+  if constexpr (K == 2 && PAOS_MERGE_PHASES != 0) {
+    // Two phases of one slot through ONE sincos: exp(i q0) exp(i q1) = exp(i (q0 + q1)).  The sum of the two rounded
+    // arguments is taken exactly (TwoSum: a = fl(q0 + q1), e = q0 + q1 - a, |e| <= ulp(a) / 2 ~ 1e-10 at 1e6 rad)
+    // and the tail applied to first order, exp(i (a + e)) = exp(i a) (1 + i e) + O(e^2 ~ 1e-20): 12 + 6 + 17 + 2
+    // instructions instead of 2 x 23 + 4.  (Each argument is still the reference's rounded one.)
+    const double x0 = __dmul_rn(g[0], step[0]);
+    const double q0 = __dmul_rn(m2[0], __dmul_rn(coefq[0], __dadd_rn(__dmul_rn(x0, x0), across2[0])));
+    const double x1 = __dmul_rn(g[1], step[1]);
+    const double q1 = __dmul_rn(m2[1], __dmul_rn(coefq[1], __dadd_rn(__dmul_rn(x1, x1), across2[1])));
+    const double a = __dadd_rn(q0, q1);
+    const double bb = __dsub_rn(a, q0);
+    const double e = __dadd_rn(__dsub_rn(q0, __dsub_rn(a, bb)), __dsub_rn(q1, bb));
+    double sn, cs;
+    sincos_tab(a, circle, &sn, &cs);
+    return cx<double>{fma(-e, sn, cs), fma(e, cs, sn)};
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const double x = __dmul_rn(g[j], step[j]);
+    // x^2 + y^2 in the reference's order (addition commutes, so which of the two is "x" is moot)
+    const double s = __dadd_rn(__dmul_rn(x, x), across2[j]);
+    // the host stores coef * sgn (lower_frugal): fl(-c s) = -fl(c s), so the argument is the reference's up to
+    // its sign, and sin is odd -- no multiply by sgn here
+    const double q = __dmul_rn(m2[j], __dmul_rn(coefq[j], s));
+    double sn, cs;
+    sincos_tab(q, circle, &sn, &cs);
+    // only the phase ARGUMENT is rounded like the reference's; the products themselves may use FMA
+    p = j == 0 ? cx<double>{cs, sn} : cx<double>{fma(p.x, cs, -(p.y * sn)), fma(p.x, sn, p.y * cs)};
+  }
+  return p;
+}
 
 // RECS > 0: the aperture line records of the workgroup's RECS lines (first line ``lbase``) were fetched by the kernel
 // before the tile's loads (wave-uniform: scalar registers); RECS < 0: the kernel staged them in LDS (``recs``);
 // RECS = 0: the slot loads its line's record itself.
-template <typename T, int N, int E, int K, typename Map, int PLAIN = 0, bool SHARE = false, int RECS = 0>
+template <typename T, int N, int E, int K, typename Map, int PLAIN = 0, bool SHARE = false, int RECS = 0, int TAB = 0>
 __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, const FrugalPhase* ph,
                                             const Map& m, const cx<double>* circle, bool conj_in, bool conj_out, int tpos,
                                             void* area = nullptr, bool area_busy = false, const MaskLine* recs = nullptr,
@@ -405,44 +456,33 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
     }
     return;
   }
-  // the factor prod_j exp(i q_j) of element k: each argument rounded like the reference's
-  auto factor = [&](int k) __attribute__((always_inline)) {
-    cx<double> p = {1.0, 0.0};
-    if constexpr (K == 2 && PAOS_MERGE_PHASES != 0) {
-      // Two phases of one slot through ONE sincos: exp(i q0) exp(i q1) = exp(i (q0 + q1)).  The sum of the two rounded
-      // arguments is taken exactly (TwoSum: a = fl(q0 + q1), e = q0 + q1 - a, |e| <= ulp(a) / 2 ~ 1e-10 at 1e6 rad)
-      // and the tail applied to first order, exp(i (a + e)) = exp(i a) (1 + i e) + O(e^2 ~ 1e-20): 12 + 6 + 17 + 2
-      // instructions instead of 2 x 23 + 4.  (Each argument is still the reference's rounded one.)
-      const double x0 = __dmul_rn((k < E / 2 ? g_lo[0] : g_hi[0]) + (double)(k * TL), step[0]);
-      const double q0 = __dmul_rn(ph[0].m2, __dmul_rn(coefq[0], __dadd_rn(__dmul_rn(x0, x0), across2[0])));
-      const double x1 = __dmul_rn((k < E / 2 ? g_lo[KK - 1] : g_hi[KK - 1]) + (double)(k * TL), step[KK - 1]);
-      const double q1 = __dmul_rn(ph[KK - 1].m2, __dmul_rn(coefq[KK - 1], __dadd_rn(__dmul_rn(x1, x1), across2[KK - 1])));
-      const double a = __dadd_rn(q0, q1);
-      const double bb = __dsub_rn(a, q0);
-      const double e = __dadd_rn(__dsub_rn(q0, __dsub_rn(a, bb)), __dsub_rn(q1, bb));
-      double sn, cs;
-      sincos_tab(a, circle, &sn, &cs);
-      return cx<double>{fma(-e, sn, cs), fma(e, cs, sn)};
-    }
+  // the factor prod_j exp(i q_j) of element k: each argument rounded like the reference's (slot_factor)
+  double m2s[KK];
 #pragma unroll
-    for (int j = 0; j < K; ++j) {
-      const double x = __dmul_rn((k < E / 2 ? g_lo[j] : g_hi[j]) + (double)(k * TL), step[j]);
-      // x^2 + y^2 in the reference's order (addition commutes, so which of the two is "x" is moot)
-      const double s = __dadd_rn(__dmul_rn(x, x), across2[j]);
-      // the host stores coef * sgn (lower_frugal): fl(-c s) = -fl(c s), so the argument is the reference's up to
-      // its sign, and sin is odd -- no multiply by sgn here
-      const double q = __dmul_rn(ph[j].m2, __dmul_rn(coefq[j], s));
-      double sn, cs;
-      sincos_tab(q, circle, &sn, &cs);
-      // only the phase ARGUMENT is rounded like the reference's; the products themselves may use FMA
-      p = j == 0 ? cx<double>{cs, sn} : cx<double>{fma(p.x, cs, -(p.y * sn)), fma(p.x, sn, p.y * cs)};
-    }
-    return p;
+  for (int j = 0; j < K; ++j) m2s[j] = ph[j].m2;
+  auto factor = [&](int k) __attribute__((always_inline)) {
+    double gk[KK];
+#pragma unroll
+    for (int j = 0; j < K; ++j) gk[j] = (k < E / 2 ? g_lo[j] : g_hi[j]) + (double)(k * TL);
+    return slot_factor<K>(gk, step, across2, coefq, m2s, circle);
   };
   auto apply = [&](int k, cx<double> p) __attribute__((always_inline)) {
     const cx<double> vd = {(double)v[k].x, (double)v[k].y};
     v[k] = {(T)(fma(vd.x, p.x, -(vd.y * p.y)) * f), (T)(fma(vd.x, p.y, vd.y * p.x) * fy)};
   };
+  if constexpr (K > 0 && TAB != 0) {
+    // TAB builds (round 4): the factors of this item's slot by position, from phase_table_kernel's table -- a compile-time
+    // variant, not a branch: as a wave-uniform branch next to the evaluating code it cost most shapes their spill-free
+    // register allocation (60-100 bytes of scratch; both variants 15 % slower, profiles/r04_ab_variants_bench.txt)
+    static_assert(!SHARE, "a table slot does not stand for a barrier");
+    const cx<double>* tb = sl.table + tpos;
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+      apply(k, tb[k * TL]);
+      if ((k + 1) % PAOS_TABLE_FENCE == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+  }
   if constexpr (SHARE && K > 0) {
     cx<double>* fac = reinterpret_cast<cx<double>*>(area);
     if (area_busy) lds_barrier();
@@ -469,6 +509,49 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
     else v[k] = {(T)((double)v[k].x * f), (T)((double)v[k].y * fy)};
     if ((k + 1) % PAOS_FENCE_EVERY == 0) __builtin_amdgcn_sched_barrier(0);
   }
+}
+
+// The factors of the slots of one pass whose phases vary along the line only (FrugalSlot::table), for every item and
+// position: blockIdx = (position / 256, item, slot), complex128 passes.  The unit circle of sincos_tab is rebuilt from
+// the context's twiddle table exactly as frugal_pass_kernel builds it, the arguments are formed by slot_factor: an entry
+// is bit for bit what the slot would have evaluated at that position on any line.
+struct PhaseTableArgs {
+  const FrugalItem* items;  // [batch], as handed to the pass
+  const cx<double>* tw;     // the context's twiddle table for n
+  int n, axis, kpre, kmid;
+};
+template <int UNIT = 0>  // (a template: the header is compiled into several translation units)
+__global__ void __launch_bounds__(256) phase_table_kernel(PhaseTableArgs a) {
+  __shared__ cx<double> circle[kCircleLds];
+  {
+    const cx<double> w = a.tw[threadIdx.x * (a.n / kCircleLds)];
+    circle[threadIdx.x] = {w.x, -w.y};
+  }
+  __syncthreads();
+  const FrugalItem& it = a.items[blockIdx.y];
+  const bool mid = blockIdx.z != 0;
+  const FrugalSlot& sl = mid ? it.mid : it.pre;
+  if (it.active == 0.0 || sl.table == nullptr) return;
+  const FrugalPhase* ph = mid ? it.mid_ph : it.pre_ph;
+  const int K = mid ? a.kmid : a.kpre;
+  // behind a conjugated transform the slot runs its phases with -q (frugal_slot: qflip)
+  const int qflip = (mid && it.fft1_on != 0.0 && it.fft1_inv != 0.0) ? (int)0x80000000 : 0;
+  const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+  double g[kFrugalMaxMid], step[kFrugalMaxMid], across2[kFrugalMaxMid], coefq[kFrugalMaxMid], m2[kFrugalMaxMid];
+#pragma unroll
+  for (int j = 0; j < kFrugalMaxMid; ++j) {
+    const FrugalPhase& q = ph[j < K ? j : 0];
+    g[j] = (double)(q.natural != 0.0 ? (pos < a.n / 2 ? pos : pos - a.n) : pos - a.n / 2);
+    step[j] = a.axis == 0 ? q.sx : q.sy;
+    across2[j] = 0.0;
+    coefq[j] = __hiloint2double(__double2hiint(q.coef) ^ qflip, __double2loint(q.coef));
+    m2[j] = q.m2;
+  }
+  cx<double> p;
+  if (K == 1) p = slot_factor<1>(g, step, across2, coefq, m2, circle);
+  else if (K == 2) p = slot_factor<2>(g, step, across2, coefq, m2, circle);
+  else p = slot_factor<3>(g, step, across2, coefq, m2, circle);
+  const_cast<cx<double>*>(sl.table)[pos] = p;
 }
 
 // Column tiles move whole 128-byte lines that no other workgroup touches during the pass, so
@@ -585,8 +668,10 @@ __device__ __forceinline__ void tile_power_out(double acc, double* scratch, doub
                            const void *k_tw, double *k_psf, double *k_psf_partial, double *k_pow_partial, const double *k_dyn_scale
 #define PAOS_FRUGAL_PASS(a) (a).items, (a).field, (a).pitch, (a).item_stride, (a).wg0, (a).tw, (a).psf, (a).psf_partial, (a).pow_partial, (a).dyn_scale
 #endif
+// TAB != 0 (complex128): every slot that has phases (KPRE / KMID = 1: however many) reads its factors from the item's
+// table by position (FrugalSlot::table) instead of evaluating them.
 template <typename T, int N, int E, int LINES, int TILES, int AXIS, int BR, int BC, bool SPLIT,
-          int KPRE, int KMID, int NFFT, int STORE = 0>
+          int KPRE, int KMID, int NFFT, int STORE = 0, int TAB = 0>
 __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, TILES * LINES * N / E>()))
     frugal_pass_kernel(PAOS_FRUGAL_PARAMS) {
   FrugalArgs a;
@@ -839,15 +924,15 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   const bool ran1 = it.fft1_on != 0.0;
   const bool ran2 = NFFT == 2 && it.fft2_on != 0.0;
   const bool inv1 = ran1 && it.fft1_inv != 0.0;
-  constexpr bool kShare = PAOS_SHARE_PHASES != 0;
+  constexpr bool kShare = PAOS_SHARE_PHASES != 0 && TAB == 0;
   // (with phases in BOTH slots the second sharing loop costs the shape its spill-free register allocation: there
   // only the slot between the transforms shares)
-  frugal_slot<T, N, E, KPRE, decltype(m), kPlainPre, kShare && KMID == 0>(v, it.pre, it.pre_ph, m, circle, false, inv1, m.t, lds, false);
+  frugal_slot<T, N, E, KPRE, decltype(m), kPlainPre, kShare && KMID == 0, 0, TAB>(v, it.pre, it.pre_ph, m, circle, false, inv1, m.t, lds, false);
   PAOS_STAMP(2);
   if (ran1) frugal_fft<T, N, E, SPLIT, false>(v, lds, m.t, tw, circle, it.fft1_inv);
   PAOS_STAMP(3);
   constexpr bool kShareMid = kShare && KPRE == 0 && KMID < 3;
-  frugal_slot<T, N, E, KMID, decltype(m), 0, kShareMid, (kRecMode == 1 ? -1 : kRecs)>(
+  frugal_slot<T, N, E, KMID, decltype(m), 0, kShareMid, (kRecMode == 1 ? -1 : kRecs), TAB>(
       v, it.mid, it.mid_ph, m, circle, inv1, ran2 && it.fft2_inv != 0.0, m.t, lds, ran1, kRecMode == 1 ? rec_lds : mrec, lbase, h_dyn);
   PAOS_STAMP(4);
   if constexpr (NFFT == 2) {

@@ -91,6 +91,7 @@ struct paos_ctx {
   int pow_nparts = 0;
   // [batch] factors every frugal pass multiplies into the scale of its middle slot (FrugalArgs::dyn_scale): ones, except
   // between paos_stop_defer_last_power and the pass (or settle_scale) that applies the stop's 1 / sqrt(power)
+  cx<double>* ptab = nullptr;  // [2 slots][batch][n] phase factors by position of the pass about to run (FrugalSlot::table)
   double* dyn_scale = nullptr;
   bool dyn_pending = false;
   // What the PSF buffer (and psf_partial) is known to hold after a pass stored it: for item i the lines along
@@ -639,7 +640,7 @@ void plan_pruning(const paos_ctx* c, const paos_pass* passes, int n_passes, cons
   }
 }
 
-template <typename T, int N, int AXIS, int KPRE, int KMID, int NFFT, int STORE = 0>
+template <typename T, int N, int AXIS, int KPRE, int KMID, int NFFT, int STORE = 0, int TAB = 0>
 int frugal_launch(paos_ctx* c, const FrugalArgs& args) {
   using C = FftCfg<T, N>;
   constexpr int LINES = AXIS == 0 ? C::FR_ROW_LINES : C::COL_LINES;
@@ -661,7 +662,7 @@ int frugal_launch(paos_ctx* c, const FrugalArgs& args) {
   const dim3 grid(groups, c->batch), block(TILES * LINES * N / C::E);
   constexpr size_t kMaxPad = 8192;
   const size_t lds = frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, C::E, STORE>() + (c->lds_pad < kMaxPad ? c->lds_pad : kMaxPad);
-  auto kern = frugal_pass_kernel<T, N, C::E, LINES, TILES, AXIS, C::BR, C::BC, SPLIT, KPRE, KMID, NFFT, STORE>;
+  auto kern = frugal_pass_kernel<T, N, C::E, LINES, TILES, AXIS, C::BR, C::BC, SPLIT, KPRE, KMID, NFFT, STORE, TAB>;
   {
     int rc = opt_in_lds(c, (const void*)kern, frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, C::E, STORE>() + kMaxPad);
     if (rc) return rc;
@@ -685,6 +686,15 @@ template <typename T, int N, int AXIS, int KPRE, int KMID>
 int frugal_nfft(paos_ctx* c, const FrugalArgs& a, int nfft) {
   // (the digit-swapped two-transform variant NFFT = 3 of frugal_pass.h is built by tools/fftbench.hip only:
   // measured in round 2 with parity unchanged and no gain, profiles/r02_fftbench_digit_swapped_experiment.txt)
+  if (a.tab) {  // the slots read their factors from tables: one build for any number of phases per slot
+    if constexpr (sizeof(T) == 8 && KPRE <= 1 && KMID <= 1 && KPRE + KMID > 0) {
+      if (a.psf) return nfft >= 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2, 1, 1>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1, 1, 1>(c, a);
+      if (a.pow_partial) return nfft >= 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2, 2, 1>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1, 2, 1>(c, a);
+      return nfft >= 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2, 0, 1>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1, 0, 1>(c, a);
+    } else {
+      return fail(c, PAOS_EINVAL, "no table build of this pass shape");
+    }
+  }
   if constexpr (KPRE <= 1 && KMID <= 1) {  // the shapes a chain can end on: also built with the PSF store (KPRE = 1: round 4,
     // the last column pass of a separable program usually has the column half of a phase in front of its first transform)
     if (a.psf) return nfft >= 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2, 1>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1, 1>(c, a);
@@ -878,7 +888,7 @@ int launch_mask_jobs(paos_ctx* c, MaskJobs& jobs, int count) {
 }
 
 // launch a pass that lower_frugal accepted
-int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const double* dblocks, bool store_psf = false,
+int launch_lowered(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const double* dblocks, bool store_psf = false,
                    bool sum_power = false) {
   // PAOS_DUMP_PASSES=1: one line per pass launch on stderr (shape and what item 0's two slots carry)
   static const bool dump = [] { const char* e = getenv("PAOS_DUMP_PASSES"); return e && e[0] == '1'; }();
@@ -900,11 +910,43 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const
     jobs.job[0] = mask_job(c, p, lp, ap, dshared);
     if ((rcs = launch_mask_jobs(c, jobs, 1))) return rcs;
   }
+  // Slots whose phases vary along the line only (the row / column factors of the separable programs): their factors
+  // come from a table by position, built once per pass instead of on each of its lines (frugal_pass.h: FrugalSlot::table).
+  // complex128 only (the complex64 slots use the hardware sin / cos).  PAOS_LINE_TABLES=0: every slot evaluates.
+  bool tables = false;
+  {
+    static const bool want = [] { const char* e = getenv("PAOS_LINE_TABLES"); return !(e && e[0] == '0'); }();
+    for (FrugalItem& fi : lp.items) fi.pre.table = fi.mid.table = nullptr;
+    if (want && c->precision == PAOS_F64) {
+      const int counts[2] = {lp.kpre, lp.kmid};
+      bool along = lp.kpre + lp.kmid > 0;  // every slot that has phases, or none (one TAB build per shape)
+      for (int l = 0; l < 2; ++l)
+        for (const FrugalItem& fi : lp.items) {
+          if (fi.active == 0.0) continue;
+          const FrugalPhase* ph = l == 0 ? fi.pre_ph : fi.mid_ph;
+          for (int j = 0; j < counts[l]; ++j) along = along && (p.axis == 0 ? ph[j].sy : ph[j].sx) == 0.0;
+        }
+      if (along) {
+        if (!c->ptab) HIPCHK(c, hipMalloc(&c->ptab, (size_t)2 * c->batch * c->n * sizeof(cx<double>)));
+        for (int l = 0; l < 2; ++l)
+          if (counts[l] > 0)
+            for (int it = 0; it < c->batch; ++it)
+              (l == 0 ? lp.items[it].pre : lp.items[it].mid).table = c->ptab + ((size_t)l * c->batch + it) * c->n;
+        tables = true;
+      }
+    }
+  }
   const double* ditems = nullptr;
   static_assert(sizeof(FrugalItem) % sizeof(double) == 0, "record of doubles");
   int rc = arena_push(c, reinterpret_cast<const double*>(lp.items.data()),
                       lp.items.size() * sizeof(FrugalItem) / sizeof(double), &ditems);
   if (rc) return rc;
+  if (tables) {
+    const PhaseTableArgs ta{reinterpret_cast<const FrugalItem*>(ditems), reinterpret_cast<const cx<double>*>(c->tw), c->n, p.axis,
+                            lp.kpre, lp.kmid};
+    hipLaunchKernelGGL(phase_table_kernel<0>, dim3(c->n / 256, c->batch, 2), dim3(256), 0, c->stream, ta);
+    HIPCHK(c, hipGetLastError());
+  }
   FrugalArgs a{c->field, c->tw, reinterpret_cast<const FrugalItem*>(ditems), c->pitch, c->item_stride, nullptr, nullptr, nullptr};
   if (store_psf) { a.psf = c->psf; a.psf_partial = c->psf_partial; }
   if (sum_power) a.pow_partial = c->pow_partial;
@@ -946,10 +988,12 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const
                                                         (store_psf ? (double)c->n * 8.0 : (fi.spos_hi - fi.spos_lo) * (double)elem_bytes(c)));
   }
   if (c->precision == PAOS_F64) {
+    a.tab = tables ? 1 : 0;  // (the TAB builds take "has phases" for the number of phases: their slots read one factor)
+    const int kpre = tables && lp.kpre > 1 ? 1 : lp.kpre, kmid = tables && lp.kmid > 1 ? 1 : lp.kmid;
     switch (c->n) {
-      case 1024: return paos_frugal_d1024(c, a, p.axis, lp.kpre, lp.kmid, nfft);
-      case 2048: return paos_frugal_d2048(c, a, p.axis, lp.kpre, lp.kmid, nfft);
-      default: return paos_frugal_d4096(c, a, p.axis, lp.kpre, lp.kmid, nfft);
+      case 1024: return paos_frugal_d1024(c, a, p.axis, kpre, kmid, nfft);
+      case 2048: return paos_frugal_d2048(c, a, p.axis, kpre, kmid, nfft);
+      default: return paos_frugal_d4096(c, a, p.axis, kpre, kmid, nfft);
     }
   }
   switch (c->n) {
@@ -1541,6 +1585,7 @@ int paos_ctx_destroy(paos_ctx* c) {
   if (c->psf) (void)hipFree(c->psf);
   if (c->pow_partial) (void)hipFree(c->pow_partial);
   if (c->dyn_scale) (void)hipFree(c->dyn_scale);
+  if (c->ptab) (void)hipFree(c->ptab);
   if (c->psf_partial) (void)hipFree(c->psf_partial);
   for (int i = 0; i < 2; ++i) {
     if (c->bounce[i]) (void)hipHostFree(c->bounce[i]);
