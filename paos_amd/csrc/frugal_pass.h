@@ -205,12 +205,11 @@ __device__ __forceinline__ T flip_sign(T x, unsigned mask_hi) {
 #ifndef PAOS_MERGE_PHASES
 #define PAOS_MERGE_PHASES 1  // two phases of one slot through one sincos of their exactly summed arguments
 #endif
-#ifndef PAOS_TABLE_EARLY
-#define PAOS_TABLE_EARLY 0   // TAB builds: this many factors of the first slot fetched with the tile.  Measured with 8 and 12: the
-                             // main shapes spill 40-90 bytes and the chain is 6 % slower (profiles/r04_ab_variants_bench.txt): off
-#endif
 #ifndef PAOS_TABLE_FENCE
-#define PAOS_TABLE_FENCE 8   // table slots (TAB builds): factors fetched and applied in groups of this many elements
+#define PAOS_TABLE_FENCE 8   // table slots (TAB builds): factors fetched and applied in groups of this many elements.  Measured
+                             // (profiles/r04_ab_variants_bench.txt, 11c-f): 2 / 4 / 16 are 12 / 5 / 4 % slower; the next group's loads issued
+                             // before the current one is applied (groups of 2 or 4): -2 %; the first 8-12 factors of the slot in front
+                             // of the first transform fetched behind the tile's loads: the main shapes spill, -6 %
 #endif
 
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -259,11 +258,11 @@ __device__ __forceinline__ cx<double> slot_factor(const double* g, const double*
 // RECS > 0: the aperture line records of the workgroup's RECS lines (first line ``lbase``) were fetched by the kernel
 // before the tile's loads (wave-uniform: scalar registers); RECS < 0: the kernel staged them in LDS (``recs``);
 // RECS = 0: the slot loads its line's record itself.
-template <typename T, int N, int E, int K, typename Map, int PLAIN = 0, bool SHARE = false, int RECS = 0, int TAB = 0, int EARLY = 0>
+template <typename T, int N, int E, int K, typename Map, int PLAIN = 0, bool SHARE = false, int RECS = 0, int TAB = 0>
 __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, const FrugalPhase* ph,
                                             const Map& m, const cx<double>* circle, bool conj_in, bool conj_out, int tpos,
                                             void* area = nullptr, bool area_busy = false, const MaskLine* recs = nullptr,
-                                            int lbase = 0, double extra_scale = 1.0, const cx<double>* early = nullptr) {
+                                            int lbase = 0, double extra_scale = 1.0) {
   if constexpr (PLAIN == 1) {  // column passes: the conjugation, nothing else
     static_assert(K == 0, "a plain slot has no phases");
     const unsigned mask = (conj_out != conj_in) ? 0x80000000u : 0u;
@@ -480,26 +479,6 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
     // register allocation (60-100 bytes of scratch; both variants 15 % slower, profiles/r04_ab_variants_bench.txt)
     static_assert(!SHARE, "a table slot does not stand for a barrier");
     const cx<double>* tb = sl.table + tpos;
-    if constexpr (EARLY > 0) {
-      // the first EARLY factors were fetched behind the tile's loads (``early``: registers of the caller) and are here;
-      // the rest is fetched once four of those have been used up (their registers), and applied last
-      static_assert(EARLY % 4 == 0 && EARLY >= 8 && EARLY < E, "groups of four");
-      cx<double> late[E - EARLY];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) apply(k, early[k]);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k = EARLY; k < E; ++k) late[k - EARLY] = tb[k * TL];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int k = 4; k < EARLY; ++k) {
-        apply(k, early[k]);
-        if ((k + 1) % 4 == 0) __builtin_amdgcn_sched_barrier(0);
-      }
-#pragma unroll
-      for (int k = EARLY; k < E; ++k) apply(k, late[k - EARLY]);
-      return;
-    }
 #pragma unroll
     for (int k = 0; k < E; ++k) {
 #if defined(PAOS_DIAG_NOTABLE)  // (timing diagnostic: what the table loads cost -- results wrong)
@@ -870,16 +849,6 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
     }
   }
   __builtin_amdgcn_sched_barrier(0);
-  // TAB builds: the first factors of the slot in front of the first transform ride behind the tile's loads (they are
-  // L2 hits and arrive with the tile): the slot then waits for the last few only.
-  constexpr int kEarly = (TAB != 0 && KPRE > 0 && sizeof(T) == 8 && E == 16) ? PAOS_TABLE_EARLY : 0;
-  cx<double> early[kEarly > 0 ? kEarly : 1];
-  if constexpr (kEarly > 0) {
-    const cx<double>* tb = it.pre.table + m.t;
-#pragma unroll
-    for (int k = 0; k < kEarly; ++k) early[k] = tb[k * (N / E)];
-    __builtin_amdgcn_sched_barrier(0);
-  }
   // The LDS tables are fetched BEHIND the tile's loads (they are L2 hits and return in order right after the
   // tile) and written once everything has arrived: nothing stands between the prologue and the first tile load.
   cx<T> tw_fetch[kTwIt], cl_fetch[kClIt];
@@ -965,8 +934,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   constexpr bool kShare = PAOS_SHARE_PHASES != 0 && TAB == 0;
   // (with phases in BOTH slots the second sharing loop costs the shape its spill-free register allocation: there
   // only the slot between the transforms shares)
-  frugal_slot<T, N, E, KPRE, decltype(m), kPlainPre, kShare && KMID == 0, 0, TAB, kEarly>(v, it.pre, it.pre_ph, m, circle, false, inv1, m.t, lds, false,
-                                                                                          nullptr, 0, 1.0, early);
+  frugal_slot<T, N, E, KPRE, decltype(m), kPlainPre, kShare && KMID == 0, 0, TAB>(v, it.pre, it.pre_ph, m, circle, false, inv1, m.t, lds, false);
   PAOS_STAMP(2);
   if (ran1) frugal_fft<T, N, E, SPLIT, false>(v, lds, m.t, tw, circle, it.fft1_inv);
   PAOS_STAMP(3);
