@@ -187,7 +187,8 @@ def measure(dev, n, precision, wavelengths_of, chains, steps, warmup, comm=None,
     barrier()
     if timer:
         dev.profile_begin(_lib.KERNEL_PASS_ANY, max_launches=64 * 1024)
-    per_step_passes, per_step_sets = [], []
+    per_step_passes, per_step_sets, per_step_launches = [], [], []
+    launched = 0
     seen = dev.record_set_stats() if has_sets else (0, 0)
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -195,6 +196,11 @@ def measure(dev, n, precision, wavelengths_of, chains, steps, warmup, comm=None,
         res = step(g)
         g += 1
         per_step_passes.append(stats.get("fused_passes"))
+        if timer and hasattr(dev, "profile_planned_bytes"):
+            # launches timed so far (a launch may run two passes of the program: frugal_pass.h, LONG builds)
+            now_launched = int(dev.profile_planned_bytes().size)
+            per_step_launches.append(now_launched - launched)
+            launched = now_launched
         if has_sets:
             now = dev.record_set_stats()
             per_step_sets.append((now[0] - seen[0], now[1] - seen[1]))
@@ -219,6 +225,7 @@ def measure(dev, n, precision, wavelengths_of, chains, steps, warmup, comm=None,
     return {"elapsed": elapsed, "launches": int(ms.size), "kern_ms": float(ms.sum()), "pruned": int((~full).sum()),
             "pruned_ms": float(ms[~full].sum()), "launch_ms": ms, "launch_tags": tags, "launch_bytes": planned,
             "fused_passes": stats.get("fused_passes"), "per_step_passes": per_step_passes,
+            "per_step_launches": per_step_launches,
             "per_step_sets": per_step_sets, "first_timed_step": first_step + warmup, "res": res}
 
 
@@ -309,11 +316,11 @@ def measure_traffic(grid, batch, precision):
 
 
 CLASS_NAMES = {0: "full", 1: "skips tiles of dead lines", 2: "skips loads of dead positions", 4: "skips stores nobody reads",
-               8: "stores the PSF instead of the field"}
+               8: "stores the PSF instead of the field", 16: "runs two passes of a row / column chain"}
 
 
 def class_name(tag):
-    return " + ".join(CLASS_NAMES[b] for b in (1, 2, 4, 8) if tag & b) if tag else CLASS_NAMES[0]
+    return " + ".join(CLASS_NAMES[b] for b in (1, 2, 4, 8, 16) if tag & b) if tag else CLASS_NAMES[0]
 
 
 def roofline_block(m, n, nb, esz, dev, kernel_name, steps, traffic=None, traffic_step=1, dense=None):
@@ -346,6 +353,7 @@ def roofline_block(m, n, nb, esz, dev, kernel_name, steps, traffic=None, traffic
                 "batch and is bound by the fp64 issue rate of its butterflies, not by HBM (profiles/r04_sq_counters.txt); "
                 "`dense` is the same kernel with every line alive",
         "fused_passes_per_wavefront": m["fused_passes"],
+        "launches_per_step": float(ms.size) / steps if steps else None,
         "copy_yardstick": {"ms_per_launch": y_ms, "GBps": y_bytes / (y_ms * 1e-3) / 1e9,
                            "what": "measured in this run (paos_copy_yardstick): in-place copy of the same batch buffer, "
                                    "16 B per lane, unit stride, no transform"},
@@ -360,7 +368,7 @@ def roofline_block(m, n, nb, esz, dev, kernel_name, steps, traffic=None, traffic
                               "algorithmic_bytes_per_launch": pass_bytes,
                               "what": "one step of the same chain with the pruning switched off (paos_ctx_set_pruning 0), "
                                       "measured in this run: every launch reads and writes the whole batch once"}
-    counts = [c for c in m["per_step_passes"] if c is not None]
+    counts = m.get("per_step_launches") or [c for c in m["per_step_passes"] if c is not None]
     if not ms.size or len(counts) != steps or sum(counts) != ms.size:
         return block  # (a generic-kernel pass that is not timed: the launches cannot be cut into steps)
     bounds = np.concatenate([[0], np.cumsum(counts)])
@@ -495,8 +503,10 @@ def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC child runs that measure roofline.traffic")
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    # (defaults: a step is 22 ms since the separable programs; the first two or three steps of a context still allocate the
+    # aperture record sets and the phase tables lazily, which `--warmup 1` left inside a five-step timed region)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--grid", type=int, default=4096)
     ap.add_argument("--batch", type=int, default=0, help="wavefronts per GPU per step (default: 32 at 4096^2 = 8 GiB of fields + 4 GiB of PSFs of the 288 GB)")
     ap.add_argument("--precision", default="fp64", choices=["fp64", "fp32"])

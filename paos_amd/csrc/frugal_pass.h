@@ -132,6 +132,9 @@ struct FrugalArgs {
   unsigned live_lo, live_hi, wg0;
   // host only: launch the TAB build of the shape (every slot with phases reads FrugalSlot::table)
   int tab = 0;
+  // host only: 1 / 2 = the launch also runs the NEXT pass of the program (same axis, one / two transforms, no aperture, the
+  // same lines), whose item records follow this pass's in `items` ([2][batch]): LONG builds
+  int fuse = 0;
 };
 #if PAOS_STAMPS
 #define PAOS_STAMP(i)                                                                              \
@@ -523,9 +526,9 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
 // the context's twiddle table exactly as frugal_pass_kernel builds it, the arguments are formed by slot_factor: an entry
 // is bit for bit what the slot would have evaluated at that position on any line.
 struct PhaseTableArgs {
-  const FrugalItem* items;  // [batch], as handed to the pass
+  const FrugalItem* items;  // [batch], as handed to the pass ([2][batch] for a LONG launch: gridDim.z = 4)
   const cx<double>* tw;     // the context's twiddle table for n
-  int n, axis, kpre, kmid;
+  int n, axis, kpre, kmid, kpre2, kmid2;
 };
 template <int UNIT = 0>  // (a template: the header is compiled into several translation units)
 __global__ void __launch_bounds__(256) phase_table_kernel(PhaseTableArgs a) {
@@ -535,12 +538,13 @@ __global__ void __launch_bounds__(256) phase_table_kernel(PhaseTableArgs a) {
     circle[threadIdx.x] = {w.x, -w.y};
   }
   __syncthreads();
-  const FrugalItem& it = a.items[blockIdx.y];
-  const bool mid = blockIdx.z != 0;
+  const bool second = (blockIdx.z >> 1) != 0;
+  const FrugalItem& it = a.items[blockIdx.y + (second ? gridDim.y : 0)];
+  const bool mid = (blockIdx.z & 1) != 0;
   const FrugalSlot& sl = mid ? it.mid : it.pre;
   if (it.active == 0.0 || sl.table == nullptr) return;
   const FrugalPhase* ph = mid ? it.mid_ph : it.pre_ph;
-  const int K = mid ? a.kmid : a.kpre;
+  const int K = second ? (mid ? a.kmid2 : a.kpre2) : (mid ? a.kmid : a.kpre);
   // behind a conjugated transform the slot runs its phases with -q (frugal_slot: qflip)
   const int qflip = (mid && it.fft1_on != 0.0 && it.fft1_inv != 0.0) ? (int)0x80000000 : 0;
   const int pos = blockIdx.x * blockDim.x + threadIdx.x;
@@ -677,10 +681,15 @@ __device__ __forceinline__ void tile_power_out(double acc, double* scratch, doub
 #endif
 // TAB != 0 (complex128): every slot that has phases (KPRE / KMID = 1: however many) reads its factors from the item's
 // table by position (FrugalSlot::table) instead of evaluating them.
+// LONG = 1 / 2 (TAB builds with phases in both slots): the launch goes on with the NEXT pass of the program -- same axis,
+// same lines, one / two transforms, phases in both of its slots, no aperture -- whose item records follow this pass's
+// (items[batch + item]): load | slot F slot F | slot F slot [F] | store.  The tile never leaves the registers between the
+// two passes: one load, one store, one prologue and one launch less per pair; results are bit-identical.
 template <typename T, int N, int E, int LINES, int TILES, int AXIS, int BR, int BC, bool SPLIT,
-          int KPRE, int KMID, int NFFT, int STORE = 0, int TAB = 0>
+          int KPRE, int KMID, int NFFT, int STORE = 0, int TAB = 0, int LONG = 0>
 __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, TILES * LINES * N / E>()))
     frugal_pass_kernel(PAOS_FRUGAL_PARAMS) {
+  static_assert(LONG == 0 || (TAB != 0 && NFFT == 2 && KPRE == 1 && KMID == 1 && sizeof(T) == 8), "LONG builds: see above");
   FrugalArgs a;
   a.items = k_items; a.field = k_field; a.pitch = k_pitch; a.item_stride = k_item_stride; a.wg0 = k_wg0;
   a.tw = k_tw; a.psf = k_psf; a.psf_partial = k_psf_partial; a.pow_partial = k_pow_partial; a.dyn_scale = k_dyn_scale; a.live_lo = a.live_hi = 0;
@@ -702,8 +711,10 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   constexpr int kTwiddleLds = twiddle_lds_entries<N, E>();
   constexpr int kTwIt = (kTwiddleLds + kThreads - 1) / kThreads;
   constexpr int kClIt = sizeof(T) == 8 ? (kCircleLds + kThreads - 1) / kThreads : 1;
-  const double h_active = it.active, h_line_lo = it.line_lo, h_line_hi = it.line_hi, h_line_fill = it.line_fill,
-               h_pos_lo = it.pos_lo, h_pos_hi = it.pos_hi, h_spos_lo = it.spos_lo, h_spos_hi = it.spos_hi;
+  // (LONG builds: what is written, and what becomes of dead tiles, is the second pass's business)
+  const FrugalItem& it2 = *(const FrugalItem*)((ConstItemPtr)a.items + item + (LONG != 0 ? gridDim.y : 0));
+  const double h_active = it.active, h_line_lo = it.line_lo, h_line_hi = it.line_hi, h_line_fill = it2.line_fill,
+               h_pos_lo = it.pos_lo, h_pos_hi = it.pos_hi, h_spos_lo = it2.spos_lo, h_spos_hi = it2.spos_hi;
   // (shapes that fetch their aperture line records in front of the tile: the switch and the pointer ride along
   // instead of costing two more dependent scalar loads behind the header)
   const double h_mask_on = it.mid.mask_on;
@@ -946,6 +957,23 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
     if (ran2) {
       if (ran1 && !(kShareMid && KMID > 0)) __syncthreads();  // (a sharing slot ends on a barrier of its own)
       frugal_fft<T, N, E, SPLIT>(v, lds, m.t, tw, circle, it.fft2_inv);
+    }
+  }
+  if constexpr (LONG != 0) {
+    const bool ran3 = it2.fft1_on != 0.0;
+    const bool ran4 = LONG == 2 && it2.fft2_on != 0.0;
+    const bool inv3 = ran3 && it2.fft1_inv != 0.0;
+    frugal_slot<T, N, E, 1, decltype(m), 0, false, 0, TAB>(v, it2.pre, it2.pre_ph, m, circle, false, inv3, m.t, lds, false);
+    if (ran3) {
+      if (ran1 || ran2) __syncthreads();  // the exchange area may still be read by the transform in front
+      frugal_fft<T, N, E, SPLIT, false>(v, lds, m.t, tw, circle, it2.fft1_inv);
+    }
+    frugal_slot<T, N, E, 1, decltype(m), 0, false, 0, TAB>(v, it2.mid, it2.mid_ph, m, circle, inv3, ran4 && it2.fft2_inv != 0.0, m.t, lds, ran3);
+    if constexpr (LONG == 2) {
+      if (ran4) {
+        if (ran1 || ran2 || ran3) __syncthreads();
+        frugal_fft<T, N, E, SPLIT>(v, lds, m.t, tw, circle, it2.fft2_inv);
+      }
     }
   }
   PAOS_STAMP(5);

@@ -640,7 +640,7 @@ void plan_pruning(const paos_ctx* c, const paos_pass* passes, int n_passes, cons
   }
 }
 
-template <typename T, int N, int AXIS, int KPRE, int KMID, int NFFT, int STORE = 0, int TAB = 0>
+template <typename T, int N, int AXIS, int KPRE, int KMID, int NFFT, int STORE = 0, int TAB = 0, int LONG = 0>
 int frugal_launch(paos_ctx* c, const FrugalArgs& args) {
   using C = FftCfg<T, N>;
   constexpr int LINES = AXIS == 0 ? C::FR_ROW_LINES : C::COL_LINES;
@@ -662,7 +662,7 @@ int frugal_launch(paos_ctx* c, const FrugalArgs& args) {
   const dim3 grid(groups, c->batch), block(TILES * LINES * N / C::E);
   constexpr size_t kMaxPad = 8192;
   const size_t lds = frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, C::E, STORE>() + (c->lds_pad < kMaxPad ? c->lds_pad : kMaxPad);
-  auto kern = frugal_pass_kernel<T, N, C::E, LINES, TILES, AXIS, C::BR, C::BC, SPLIT, KPRE, KMID, NFFT, STORE, TAB>;
+  auto kern = frugal_pass_kernel<T, N, C::E, LINES, TILES, AXIS, C::BR, C::BC, SPLIT, KPRE, KMID, NFFT, STORE, TAB, LONG>;
   {
     int rc = opt_in_lds(c, (const void*)kern, frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, C::E, STORE>() + kMaxPad);
     if (rc) return rc;
@@ -686,6 +686,16 @@ template <typename T, int N, int AXIS, int KPRE, int KMID>
 int frugal_nfft(paos_ctx* c, const FrugalArgs& a, int nfft) {
   // (the digit-swapped two-transform variant NFFT = 3 of frugal_pass.h is built by tools/fftbench.hip only:
   // measured in round 2 with parity unchanged and no gain, profiles/r02_fftbench_digit_swapped_experiment.txt)
+  if (a.tab && a.fuse) {  // ... and the launch runs the next pass of the program as well (LONG builds)
+    if constexpr (sizeof(T) == 8 && KPRE == 1 && KMID == 1) {
+      if (nfft < 2) return fail(c, PAOS_EINVAL, "a fused pair starts with a two-transform pass");
+      if (a.psf) return a.fuse >= 2 ? frugal_launch<T, N, AXIS, 1, 1, 2, 1, 1, 2>(c, a) : frugal_launch<T, N, AXIS, 1, 1, 2, 1, 1, 1>(c, a);
+      if (a.pow_partial) return a.fuse >= 2 ? frugal_launch<T, N, AXIS, 1, 1, 2, 2, 1, 2>(c, a) : frugal_launch<T, N, AXIS, 1, 1, 2, 2, 1, 1>(c, a);
+      return a.fuse >= 2 ? frugal_launch<T, N, AXIS, 1, 1, 2, 0, 1, 2>(c, a) : frugal_launch<T, N, AXIS, 1, 1, 2, 0, 1, 1>(c, a);
+    } else {
+      return fail(c, PAOS_EINVAL, "no fused build of this pass shape");
+    }
+  }
   if (a.tab) {  // the slots read their factors from tables: one build for any number of phases per slot
     if constexpr (sizeof(T) == 8 && KPRE <= 1 && KMID <= 1 && KPRE + KMID > 0) {
       if (a.psf) return nfft >= 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2, 1, 1>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1, 1, 1>(c, a);
@@ -887,9 +897,43 @@ int launch_mask_jobs(paos_ctx* c, MaskJobs& jobs, int count) {
   return PAOS_OK;
 }
 
-// launch a pass that lower_frugal accepted
+// Do all phases of the pass vary along its lines only (the row / column factors of the separable programs)?  Then their
+// factors come from tables by position (frugal_pass.h: FrugalSlot::table).  complex128 only (the complex64 slots use the
+// hardware sin / cos).  PAOS_LINE_TABLES=0: every slot evaluates.
+bool phases_along_lines(const paos_ctx* c, const paos_pass& p, const LoweredPass& lp) {
+  static const bool want = [] { const char* e = getenv("PAOS_LINE_TABLES"); return !(e && e[0] == '0'); }();
+  if (!want || c->precision != PAOS_F64 || lp.kpre + lp.kmid == 0) return false;
+  const int counts[2] = {lp.kpre, lp.kmid};
+  for (int l = 0; l < 2; ++l)
+    for (const FrugalItem& fi : lp.items) {
+      if (fi.active == 0.0) continue;
+      const FrugalPhase* ph = l == 0 ? fi.pre_ph : fi.mid_ph;
+      for (int j = 0; j < counts[l]; ++j)
+        if ((p.axis == 0 ? ph[j].sy : ph[j].sx) != 0.0) return false;
+    }
+  return true;
+}
+
+// Can the launch of pass `p` go on with the next pass `p2` of the program (frugal_pass.h: LONG builds)?  Same axis, both on
+// table slots with phases in every slot, a two-transform pass in front, no aperture on the second, and every item takes both
+// or neither, on the same lines.  PAOS_FUSE_PAIRS=0: never.
+bool can_fuse_pair(const paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const paos_pass& p2, const LoweredPass& lp2) {
+  const char* e = getenv("PAOS_FUSE_PAIRS");
+  if (e && e[0] == '0') return false;
+  if (!lp.ok || !lp2.ok || p.axis != p2.axis || lp.nfft != 2 || lp2.mask_block >= 0) return false;
+  if (lp.kpre < 1 || lp.kmid < 1 || lp2.kpre < 1 || lp2.kmid < 1) return false;
+  if (!phases_along_lines(c, p, lp) || !phases_along_lines(c, p2, lp2)) return false;
+  for (int it = 0; it < c->batch; ++it) {
+    const FrugalItem &f1 = lp.items[it], &f2 = lp2.items[it];
+    if ((f1.active != 0.0) != (f2.active != 0.0)) return false;
+    if (f1.active != 0.0 && (f1.line_lo != f2.line_lo || f1.line_hi != f2.line_hi || f1.line_fill != 0.0)) return false;
+  }
+  return true;
+}
+
+// launch a pass that lower_frugal accepted -- and, with `next`, the pass behind it in the same launch (can_fuse_pair)
 int launch_lowered(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const double* dblocks, bool store_psf = false,
-                   bool sum_power = false) {
+                   bool sum_power = false, LoweredPass* next = nullptr) {
   // PAOS_DUMP_PASSES=1: one line per pass launch on stderr (shape and what item 0's two slots carry)
   static const bool dump = [] { const char* e = getenv("PAOS_DUMP_PASSES"); return e && e[0] == '1'; }();
   if (dump && !lp.items.empty()) {
@@ -910,41 +954,36 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const doubl
     jobs.job[0] = mask_job(c, p, lp, ap, dshared);
     if ((rcs = launch_mask_jobs(c, jobs, 1))) return rcs;
   }
-  // Slots whose phases vary along the line only (the row / column factors of the separable programs): their factors
-  // come from a table by position, built once per pass instead of on each of its lines (frugal_pass.h: FrugalSlot::table).
-  // complex128 only (the complex64 slots use the hardware sin / cos).  PAOS_LINE_TABLES=0: every slot evaluates.
-  bool tables = false;
+  // Slots whose phases vary along the line only: their factors come from a table by position, built once per pass
+  // instead of on each of its lines (phases_along_lines).  All slots of the pass that have phases, or none.
+  const bool tables = next != nullptr || phases_along_lines(c, p, lp);
   {
-    static const bool want = [] { const char* e = getenv("PAOS_LINE_TABLES"); return !(e && e[0] == '0'); }();
-    for (FrugalItem& fi : lp.items) fi.pre.table = fi.mid.table = nullptr;
-    if (want && c->precision == PAOS_F64) {
-      const int counts[2] = {lp.kpre, lp.kmid};
-      bool along = lp.kpre + lp.kmid > 0;  // every slot that has phases, or none (one TAB build per shape)
-      for (int l = 0; l < 2; ++l)
-        for (const FrugalItem& fi : lp.items) {
-          if (fi.active == 0.0) continue;
-          const FrugalPhase* ph = l == 0 ? fi.pre_ph : fi.mid_ph;
-          for (int j = 0; j < counts[l]; ++j) along = along && (p.axis == 0 ? ph[j].sy : ph[j].sx) == 0.0;
-        }
-      if (along) {
-        if (!c->ptab) HIPCHK(c, hipMalloc(&c->ptab, (size_t)2 * c->batch * c->n * sizeof(cx<double>)));
-        for (int l = 0; l < 2; ++l)
-          if (counts[l] > 0)
-            for (int it = 0; it < c->batch; ++it)
-              (l == 0 ? lp.items[it].pre : lp.items[it].mid).table = c->ptab + ((size_t)l * c->batch + it) * c->n;
-        tables = true;
-      }
-    }
+    auto point = [&](LoweredPass& l, int first) {
+      const int counts[2] = {l.kpre, l.kmid};
+      for (int it = 0; it < c->batch; ++it)
+        for (int k = 0; k < 2; ++k)
+          (k == 0 ? l.items[it].pre : l.items[it].mid).table =
+              tables && counts[k] > 0 ? c->ptab + ((size_t)(first + k) * c->batch + it) * c->n : nullptr;
+    };
+    if (tables && !c->ptab) HIPCHK(c, hipMalloc(&c->ptab, (size_t)4 * c->batch * c->n * sizeof(cx<double>)));
+    point(lp, 0);
+    if (next) point(*next, 2);
   }
+  std::vector<FrugalItem> both;
+  if (next) {  // the second pass's records follow the first's
+    both = lp.items;
+    both.insert(both.end(), next->items.begin(), next->items.end());
+  }
+  const std::vector<FrugalItem>& launch_items = next ? both : lp.items;
   const double* ditems = nullptr;
   static_assert(sizeof(FrugalItem) % sizeof(double) == 0, "record of doubles");
-  int rc = arena_push(c, reinterpret_cast<const double*>(lp.items.data()),
-                      lp.items.size() * sizeof(FrugalItem) / sizeof(double), &ditems);
+  int rc = arena_push(c, reinterpret_cast<const double*>(launch_items.data()),
+                      launch_items.size() * sizeof(FrugalItem) / sizeof(double), &ditems);
   if (rc) return rc;
   if (tables) {
     const PhaseTableArgs ta{reinterpret_cast<const FrugalItem*>(ditems), reinterpret_cast<const cx<double>*>(c->tw), c->n, p.axis,
-                            lp.kpre, lp.kmid};
-    hipLaunchKernelGGL(phase_table_kernel<0>, dim3(c->n / 256, c->batch, 2), dim3(256), 0, c->stream, ta);
+                            lp.kpre, lp.kmid, next ? next->kpre : 0, next ? next->kmid : 0};
+    hipLaunchKernelGGL(phase_table_kernel<0>, dim3(c->n / 256, c->batch, next ? 4 : 2), dim3(256), 0, c->stream, ta);
     HIPCHK(c, hipGetLastError());
   }
   FrugalArgs a{c->field, c->tw, reinterpret_cast<const FrugalItem*>(ditems), c->pitch, c->item_stride, nullptr, nullptr, nullptr};
@@ -956,7 +995,9 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const doubl
     static const bool want = [] { const char* e = getenv("PAOS_COMPACT_GRID"); return !(e && e[0] == '0'); }();
     double lo = (double)c->n, hi = 0.0;
     bool fill = false;
-    for (const FrugalItem& fi : lp.items) {
+    // (a fused pair: the lines are the same for both passes, what is stored and filled is the second pass's business)
+    const std::vector<FrugalItem>& out_items = next ? next->items : lp.items;
+    for (const FrugalItem& fi : out_items) {
       if (fi.active == 0.0) continue;
       lo = fi.line_lo < lo ? fi.line_lo : lo;
       hi = fi.line_hi > hi ? fi.line_hi : hi;
@@ -978,17 +1019,21 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const doubl
   // positions, bit 2: stores nobody reads, bit 3: it stores the PSF instead of the field
   c->prof_next_tag = store_psf ? 8 : 0;
   c->prof_next_bytes = 0.0;
-  for (const FrugalItem& fi : lp.items) {
+  if (next) c->prof_next_tag |= 16;  // bit 4: the launch ran two passes of the program
+  for (int it = 0; it < c->batch; ++it) {
+    const FrugalItem& fi = lp.items[it];
+    const FrugalItem& fo = next ? next->items[it] : fi;  // the pass whose stores leave the launch
     if (fi.active == 0.0) continue;
     if (fi.line_lo > 0.0 || fi.line_hi < (double)c->n) c->prof_next_tag |= 1;
     if (fi.pos_lo > 0.0 || fi.pos_hi < (double)c->n) c->prof_next_tag |= 2;
-    if (!store_psf && (fi.spos_lo > 0.0 || fi.spos_hi < (double)c->n)) c->prof_next_tag |= 4;
+    if (!store_psf && (fo.spos_lo > 0.0 || fo.spos_hi < (double)c->n)) c->prof_next_tag |= 4;
     // what the plan has this launch move: its live lines' loaded and stored positions (the PSF store: doubles, every position)
     c->prof_next_bytes += (fi.line_hi - fi.line_lo) * ((fi.pos_hi - fi.pos_lo) * (double)elem_bytes(c) +
-                                                        (store_psf ? (double)c->n * 8.0 : (fi.spos_hi - fi.spos_lo) * (double)elem_bytes(c)));
+                                                        (store_psf ? (double)c->n * 8.0 : (fo.spos_hi - fo.spos_lo) * (double)elem_bytes(c)));
   }
   if (c->precision == PAOS_F64) {
     a.tab = tables ? 1 : 0;  // (the TAB builds take "has phases" for the number of phases: their slots read one factor)
+    a.fuse = next ? next->nfft : 0;
     const int kpre = tables && lp.kpre > 1 ? 1 : lp.kpre, kmid = tables && lp.kmid > 1 ? 1 : lp.kmid;
     switch (c->n) {
       case 1024: return paos_frugal_d1024(c, a, p.axis, kpre, kmid, nfft);
@@ -1322,8 +1367,13 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
     }
     for (int q = i; q < j; ++q) {
       if (low[q].ok) {
-        if ((rc = launch_lowered(c, passes[q], low[q], dblocks, fused_store && q == n_passes - 1, fused_power && q == n_passes - 1))) return rc;
-        if (q == 0 && c->dyn_pending) {  // the stop's factor has gone into the field with this pass: ones again for the next
+        // two passes of one row / column chain in ONE launch (frugal_pass.h: LONG builds) where the pair allows it
+        const bool pair = pruned && q + 1 < j && can_fuse_pair(c, passes[q], low[q], passes[q + 1], low[q + 1]);
+        const int last = pair ? q + 1 : q;
+        if ((rc = launch_lowered(c, passes[q], low[q], dblocks, fused_store && last == n_passes - 1, fused_power && last == n_passes - 1,
+                                 pair ? &low[q + 1] : nullptr))) return rc;
+        if (pair) ++q;
+        if (c->dyn_pending) {  // (first launch of the program) the stop's factor has gone into the field: ones again for the next
           hipLaunchKernelGGL(dyn_scale_reset_kernel, dim3((c->batch + 255) / 256), dim3(256), 0, c->stream, c->dyn_scale, c->batch);
           HIPCHK(c, hipGetLastError());
           c->dyn_pending = false;

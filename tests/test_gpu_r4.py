@@ -87,7 +87,8 @@ def test_what_the_plan_has_a_syn20_step_move():
 
         planned, tags, psf = step()
         dense = 2.0 * 16 * n * n * nb
-        assert tags.size == 24 and planned.size == 24
+        # (a launch may run two passes of a row / column chain -- bit 4 of its tag: 24 passes in fewer launches)
+        assert tags.size == planned.size and tags.size + int(np.sum((tags & 16) != 0)) == 24
         assert np.all(tags & 1), tags
         assert np.all(planned > 0.0) and np.all(planned < 0.5 * dense)
         assert planned.sum() < 0.2 * 24 * dense, planned.sum() / (24 * dense)
@@ -96,7 +97,7 @@ def test_what_the_plan_has_a_syn20_step_move():
             planned_d, tags_d, psf_d = step()
         finally:
             dev.set_pruning(True)
-        assert np.all(tags_d[:-1] == 0) and np.all(planned_d[:-1] == dense)
+        assert tags_d.size == 24 and np.all(tags_d[:-1] == 0) and np.all(planned_d[:-1] == dense)
         for a, b in zip(psf, psf_d):
             assert np.array_equal(a, b)
     finally:
@@ -150,5 +151,42 @@ def test_half_checkerboards_through_the_c_abi(n):
         dev.upload(0, u)
         dev.run_passes([{"axis": -1, "pre": [X]}, {"axis": -1, "pre": [Y, (_lib.PW_SIGN, 0, 0)]}], on)
         assert np.array_equal(dev.download(0), u * sx * sy * (sx * sy))
+    finally:
+        dev.close()
+
+
+@pytest.mark.parametrize("n", [1024, 4096])
+def test_two_passes_in_one_launch_change_no_bit(n):
+    """Where two consecutive passes of a row / column chain allow it the library runs them in one launch (frugal_pass.h:
+    LONG builds; PAOS_FUSE_PAIRS=0 switches it off): the tile stays in registers between them -- the same arithmetic in
+    the same order, so the PSFs are equal bit for bit, in fewer launches."""
+    import os
+
+    from paos_amd import _lib
+    from paos_amd.chains import syn20_chain, syn20_wavelength
+    from paos_amd.run import run_batch
+
+    wls = [syn20_wavelength(k) for k in (1, 255)]
+    chains = [syn20_chain() for _ in wls]
+    dev = _lib.DeviceFields(n, len(wls), "fp64")
+    try:
+        def step():
+            dev.profile_begin(_lib.KERNEL_PASS_ANY, max_launches=256)
+            res = run_batch(1.0, wls, n, 4, ON_AXIS, chains, outputs=(), dev=dev, keep_psf=True)
+            _, tags = dev.profile_end_launches()
+            return tags, [dev.psf_fetch(i) for i in range(len(wls))], [r[20]["power"] for r in res]
+
+        tags, psf, power = step()
+        assert os.environ.get("PAOS_FUSE_PAIRS") is None
+        os.environ["PAOS_FUSE_PAIRS"] = "0"
+        try:
+            tags0, psf0, power0 = step()
+        finally:
+            del os.environ["PAOS_FUSE_PAIRS"]
+        assert tags0.size == 24 and not np.any(tags0 & 16)
+        assert tags.size < 24 and tags.size + int(np.sum((tags & 16) != 0)) == 24
+        for a, b in zip(psf, psf0):
+            assert np.array_equal(a, b)
+        assert power == power0
     finally:
         dev.close()
