@@ -132,7 +132,7 @@ struct FrugalArgs {
   unsigned live_lo, live_hi, wg0;
   // host only: launch the TAB build of the shape (every slot with phases reads FrugalSlot::table)
   int tab = 0;
-  // host only: 1 / 2 = the launch also runs the NEXT pass of the program (same axis, one / two transforms, no aperture, the
+  // host only: 1 / 2 = the launch also runs the NEXT pass of the program (same axis, one / two transforms, the
   // same lines), whose item records follow this pass's in `items` ([2][batch]): LONG builds
   int fuse = 0;
 };
@@ -682,7 +682,7 @@ __device__ __forceinline__ void tile_power_out(double acc, double* scratch, doub
 // TAB != 0 (complex128): every slot that has phases (KPRE / KMID = 1: however many) reads its factors from the item's
 // table by position (FrugalSlot::table) instead of evaluating them.
 // LONG = 1 / 2 (TAB builds with phases in both slots): the launch goes on with the NEXT pass of the program -- same axis,
-// same lines, one / two transforms, phases in both of its slots, no aperture -- whose item records follow this pass's
+// same lines, one / two transforms, phases in both of its slots -- whose item records follow this pass's
 // (items[batch + item]): load | slot F slot F | slot F slot [F] | store.  The tile never leaves the registers between the
 // two passes: one load, one store, one prologue and one launch less per pair; results are bit-identical.
 template <typename T, int N, int E, int LINES, int TILES, int AXIS, int BR, int BC, bool SPLIT,

@@ -915,12 +915,14 @@ bool phases_along_lines(const paos_ctx* c, const paos_pass& p, const LoweredPass
 }
 
 // Can the launch of pass `p` go on with the next pass `p2` of the program (frugal_pass.h: LONG builds)?  Same axis, both on
-// table slots with phases in every slot, a two-transform pass in front, no aperture on the second, and every item takes both
-// or neither, on the same lines.  PAOS_FUSE_PAIRS=0: never.
+// table slots with phases in every slot, a two-transform pass in front, and every item takes both or neither, on the same lines.  PAOS_FUSE_PAIRS=0: never.
 bool can_fuse_pair(const paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const paos_pass& p2, const LoweredPass& lp2) {
   const char* e = getenv("PAOS_FUSE_PAIRS");
   if (e && e[0] == '0') return false;
-  if (!lp.ok || !lp2.ok || p.axis != p2.axis || lp.nfft != 2 || lp2.mask_block >= 0) return false;
+  if (!lp.ok || !lp2.ok || p.axis != p2.axis || lp.nfft != 2) return false;
+  // (an aperture may ride on either pass -- the second one's slots read their line records themselves -- but the two must not
+  // share a record set that the second would have to re-render between them: sets are assigned per pass, in program order)
+  if (lp.mask_block >= 0 && lp2.mask_block >= 0 && lp.mask_set == lp2.mask_set) return false;
   if (lp.kpre < 1 || lp.kmid < 1 || lp2.kpre < 1 || lp2.kmid < 1) return false;
   if (!phases_along_lines(c, p, lp) || !phases_along_lines(c, p2, lp2)) return false;
   for (int it = 0; it < c->batch; ++it) {
@@ -943,16 +945,16 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const doubl
                  f.pre.scale, f.pre.mask_on, f.fft1_on, f.fft1_inv, f.mid.sign_on, f.mid.scale, f.mid.mask_on, f.fft2_on, f.fft2_inv,
                  f.line_lo, f.line_hi, f.line_fill, f.pos_lo, f.pos_hi, f.spos_lo, f.spos_hi);
   }
-  if (lp.mask_block >= 0 && lp.mask_render) {  // render the records along the pass axis, right before the pass
-    const double* ap = dblocks + (size_t)lp.mask_block * c->batch * FP_STRIDE;
-    const double* ap2 = ap + (size_t)c->batch * FP_STRIDE;
-    (void)ap2;
+  for (LoweredPass* l : {&lp, next}) {  // render the records along the pass axis, right before the pass (both passes of a pair)
+    if (!l || l->mask_block < 0 || !l->mask_render) continue;
+    const double* ap = dblocks + (size_t)l->mask_block * c->batch * FP_STRIDE;
     const double* dshared = nullptr;
-    int rcs = arena_push(c, lp.mask_shared.data(), lp.mask_shared.size(), &dshared);
+    int rcs = arena_push(c, l->mask_shared.data(), l->mask_shared.size(), &dshared);
     if (rcs) return rcs;
     MaskJobs jobs{};
-    jobs.job[0] = mask_job(c, p, lp, ap, dshared);
+    jobs.job[0] = mask_job(c, p, *l, ap, dshared);  // (a pair runs along one axis)
     if ((rcs = launch_mask_jobs(c, jobs, 1))) return rcs;
+    l->mask_render = false;
   }
   // Slots whose phases vary along the line only: their factors come from a table by position, built once per pass
   // instead of on each of its lines (phases_along_lines).  All slots of the pass that have phases, or none.
