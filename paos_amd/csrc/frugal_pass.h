@@ -558,8 +558,9 @@ __global__ void __launch_bounds__(256) phase_table_kernel(PhaseTableArgs a) {
     coefq[j] = __hiloint2double(__double2hiint(q.coef) ^ qflip, __double2loint(q.coef));
     m2[j] = q.m2;
   }
-  cx<double> p;
-  if (K == 1) p = slot_factor<1>(g, step, across2, coefq, m2, circle);
+  cx<double> p = {1.0, 0.0};  // (K = 0: a slot without phases that rides in a fused pair)
+  if (K <= 0) {}
+  else if (K == 1) p = slot_factor<1>(g, step, across2, coefq, m2, circle);
   else if (K == 2) p = slot_factor<2>(g, step, across2, coefq, m2, circle);
   else p = slot_factor<3>(g, step, across2, coefq, m2, circle);
   const_cast<cx<double>*>(sl.table)[pos] = p;

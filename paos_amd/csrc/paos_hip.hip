@@ -900,9 +900,9 @@ int launch_mask_jobs(paos_ctx* c, MaskJobs& jobs, int count) {
 // Do all phases of the pass vary along its lines only (the row / column factors of the separable programs)?  Then their
 // factors come from tables by position (frugal_pass.h: FrugalSlot::table).  complex128 only (the complex64 slots use the
 // hardware sin / cos).  PAOS_LINE_TABLES=0: every slot evaluates.
-bool phases_along_lines(const paos_ctx* c, const paos_pass& p, const LoweredPass& lp) {
+bool phases_along_lines(const paos_ctx* c, const paos_pass& p, const LoweredPass& lp, bool or_none = false) {
   static const bool want = [] { const char* e = getenv("PAOS_LINE_TABLES"); return !(e && e[0] == '0'); }();
-  if (!want || c->precision != PAOS_F64 || lp.kpre + lp.kmid == 0) return false;
+  if (!want || c->precision != PAOS_F64 || (lp.kpre + lp.kmid == 0 && !or_none)) return false;
   const int counts[2] = {lp.kpre, lp.kmid};
   for (int l = 0; l < 2; ++l)
     for (const FrugalItem& fi : lp.items) {
@@ -923,8 +923,8 @@ bool can_fuse_pair(const paos_ctx* c, const paos_pass& p, const LoweredPass& lp,
   // (an aperture may ride on either pass -- the second one's slots read their line records themselves -- but the two must not
   // share a record set that the second would have to re-render between them: sets are assigned per pass, in program order)
   if (lp.mask_block >= 0 && lp2.mask_block >= 0 && lp.mask_set == lp2.mask_set) return false;
-  if (lp.kpre < 1 || lp.kmid < 1 || lp2.kpre < 1 || lp2.kmid < 1) return false;
-  if (!phases_along_lines(c, p, lp) || !phases_along_lines(c, p2, lp2)) return false;
+  // (a slot without phases takes part with a table of ones: (v 1) f is v f bit for bit)
+  if (!phases_along_lines(c, p, lp, true) || !phases_along_lines(c, p2, lp2, true)) return false;
   for (int it = 0; it < c->batch; ++it) {
     const FrugalItem &f1 = lp.items[it], &f2 = lp2.items[it];
     if ((f1.active != 0.0) != (f2.active != 0.0)) return false;
@@ -965,7 +965,7 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const doubl
       for (int it = 0; it < c->batch; ++it)
         for (int k = 0; k < 2; ++k)
           (k == 0 ? l.items[it].pre : l.items[it].mid).table =
-              tables && counts[k] > 0 ? c->ptab + ((size_t)(first + k) * c->batch + it) * c->n : nullptr;
+              tables && (counts[k] > 0 || next) ? c->ptab + ((size_t)(first + k) * c->batch + it) * c->n : nullptr;
     };
     if (tables && !c->ptab) HIPCHK(c, hipMalloc(&c->ptab, (size_t)4 * c->batch * c->n * sizeof(cx<double>)));
     point(lp, 0);
@@ -1036,7 +1036,8 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const doubl
   if (c->precision == PAOS_F64) {
     a.tab = tables ? 1 : 0;  // (the TAB builds take "has phases" for the number of phases: their slots read one factor)
     a.fuse = next ? next->nfft : 0;
-    const int kpre = tables && lp.kpre > 1 ? 1 : lp.kpre, kmid = tables && lp.kmid > 1 ? 1 : lp.kmid;
+    // (a fused pair runs on the one build whose four slots all read tables)
+    const int kpre = next ? 1 : (tables && lp.kpre > 1 ? 1 : lp.kpre), kmid = next ? 1 : (tables && lp.kmid > 1 ? 1 : lp.kmid);
     switch (c->n) {
       case 1024: return paos_frugal_d1024(c, a, p.axis, kpre, kmid, nfft);
       case 2048: return paos_frugal_d2048(c, a, p.axis, kpre, kmid, nfft);
