@@ -316,11 +316,12 @@ def measure_traffic(grid, batch, precision):
 
 
 CLASS_NAMES = {0: "full", 1: "skips tiles of dead lines", 2: "skips loads of dead positions", 4: "skips stores nobody reads",
-               8: "stores the PSF instead of the field", 16: "runs two passes of a row / column chain"}
+               8: "stores the PSF instead of the field", 16: "runs two passes of a row / column chain",
+               32: "runs three passes of a row / column chain"}
 
 
 def class_name(tag):
-    return " + ".join(CLASS_NAMES[b] for b in (1, 2, 4, 8, 16) if tag & b) if tag else CLASS_NAMES[0]
+    return " + ".join(CLASS_NAMES[b] for b in (1, 2, 4, 8, 16, 32) if tag & b) if tag else CLASS_NAMES[0]
 
 
 def roofline_block(m, n, nb, esz, dev, kernel_name, steps, traffic=None, traffic_step=1, dense=None):

@@ -109,7 +109,8 @@ int paos_profile_end(paos_ctx* ctx, int* launches, double* total_ms);
 int paos_profile_end_split(paos_ctx* ctx, int* launches, double* total_ms, int* pruned_launches, double* pruned_ms);
 /* the same launch by launch, in launch order: ms_out[i], tag_out[i] (bit 0: the launch skipped whole tiles of dead
  * lines, bit 1: loads of dead positions, bit 2: stores nobody reads, bit 3: it stored the PSF instead of the
- * field; 0 = a full pass); *count launches, at most `capacity` */
+ * field, bits 4 / 5 (round 4): the launch ran two / three consecutive passes of the program; 0 = a full pass); *count
+ * launches, at most `capacity` */
 int paos_profile_end_launches(paos_ctx* ctx, int capacity, double* ms_out, int* tag_out, int* count);
 /* round 4: the bytes the pruning plan had each launch timed so far load + store (live lines x (loaded + stored positions)
  * x element size, summed over the batch items): the launch's algorithmic bytes.  Call before paos_profile_end_*. */

@@ -132,8 +132,8 @@ struct FrugalArgs {
   unsigned live_lo, live_hi, wg0;
   // host only: launch the TAB build of the shape (every slot with phases reads FrugalSlot::table)
   int tab = 0;
-  // host only: 1 / 2 = the launch also runs the NEXT pass of the program (same axis, one / two transforms, the
-  // same lines), whose item records follow this pass's in `items` ([2][batch]): LONG builds
+  // host only: the LONG value of the build to launch -- the transforms of the NEXT one or two passes of the program that the
+  // launch runs as well (same axis, same lines; their item records follow this pass's in `items`: [2 or 3][batch])
   int fuse = 0;
 };
 #if PAOS_STAMPS
@@ -526,9 +526,9 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
 // the context's twiddle table exactly as frugal_pass_kernel builds it, the arguments are formed by slot_factor: an entry
 // is bit for bit what the slot would have evaluated at that position on any line.
 struct PhaseTableArgs {
-  const FrugalItem* items;  // [batch], as handed to the pass ([2][batch] for a LONG launch: gridDim.z = 4)
+  const FrugalItem* items;  // [batch], as handed to the pass ([2 or 3][batch] for a LONG launch: gridDim.z = 4 or 6)
   const cx<double>* tw;     // the context's twiddle table for n
-  int n, axis, kpre, kmid, kpre2, kmid2;
+  int n, axis, k[6];  // phases per slot: pre, mid of the first pass, of the second, of the third
 };
 template <int UNIT = 0>  // (a template: the header is compiled into several translation units)
 __global__ void __launch_bounds__(256) phase_table_kernel(PhaseTableArgs a) {
@@ -538,13 +538,12 @@ __global__ void __launch_bounds__(256) phase_table_kernel(PhaseTableArgs a) {
     circle[threadIdx.x] = {w.x, -w.y};
   }
   __syncthreads();
-  const bool second = (blockIdx.z >> 1) != 0;
-  const FrugalItem& it = a.items[blockIdx.y + (second ? gridDim.y : 0)];
+  const FrugalItem& it = a.items[blockIdx.y + (blockIdx.z >> 1) * gridDim.y];
   const bool mid = (blockIdx.z & 1) != 0;
   const FrugalSlot& sl = mid ? it.mid : it.pre;
   if (it.active == 0.0 || sl.table == nullptr) return;
   const FrugalPhase* ph = mid ? it.mid_ph : it.pre_ph;
-  const int K = second ? (mid ? a.kmid2 : a.kpre2) : (mid ? a.kmid : a.kpre);
+  const int K = a.k[blockIdx.z];
   // behind a conjugated transform the slot runs its phases with -q (frugal_slot: qflip)
   const int qflip = (mid && it.fft1_on != 0.0 && it.fft1_inv != 0.0) ? (int)0x80000000 : 0;
   const int pos = blockIdx.x * blockDim.x + threadIdx.x;
@@ -682,9 +681,10 @@ __device__ __forceinline__ void tile_power_out(double acc, double* scratch, doub
 #endif
 // TAB != 0 (complex128): every slot that has phases (KPRE / KMID = 1: however many) reads its factors from the item's
 // table by position (FrugalSlot::table) instead of evaluating them.
-// LONG = 1 / 2 (TAB builds with phases in both slots): the launch goes on with the NEXT pass of the program -- same axis,
+// LONG = 1 ... 4 (TAB builds with phases in both slots): the launch goes on with the NEXT pass -- or the next two: LONG counts
+// their transforms, [1], [2], [2][1], [2][2] -- of the program: same axis,
 // same lines, one / two transforms, phases in both of its slots -- whose item records follow this pass's
-// (items[batch + item]): load | slot F slot F | slot F slot [F] | store.  The tile never leaves the registers between the
+// (items[batch + item], items[2 batch + item]): load | slot F slot F | slot F slot [F] | [slot F slot [F]] | store.  The tile never leaves the registers between the
 // two passes: one load, one store, one prologue and one launch less per pair; results are bit-identical.
 template <typename T, int N, int E, int LINES, int TILES, int AXIS, int BR, int BC, bool SPLIT,
           int KPRE, int KMID, int NFFT, int STORE = 0, int TAB = 0, int LONG = 0>
@@ -713,9 +713,10 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   constexpr int kTwIt = (kTwiddleLds + kThreads - 1) / kThreads;
   constexpr int kClIt = sizeof(T) == 8 ? (kCircleLds + kThreads - 1) / kThreads : 1;
   // (LONG builds: what is written, and what becomes of dead tiles, is the second pass's business)
-  const FrugalItem& it2 = *(const FrugalItem*)((ConstItemPtr)a.items + item + (LONG != 0 ? gridDim.y : 0));
-  const double h_active = it.active, h_line_lo = it.line_lo, h_line_hi = it.line_hi, h_line_fill = it2.line_fill,
-               h_pos_lo = it.pos_lo, h_pos_hi = it.pos_hi, h_spos_lo = it2.spos_lo, h_spos_hi = it2.spos_hi;
+  constexpr int kExtra = (LONG + 1) / 2;  // passes behind the first one that this launch runs too
+  const FrugalItem& it_last = *(const FrugalItem*)((ConstItemPtr)a.items + item + kExtra * gridDim.y);
+  const double h_active = it.active, h_line_lo = it.line_lo, h_line_hi = it.line_hi, h_line_fill = it_last.line_fill,
+               h_pos_lo = it.pos_lo, h_pos_hi = it.pos_hi, h_spos_lo = it_last.spos_lo, h_spos_hi = it_last.spos_hi;
   // (shapes that fetch their aperture line records in front of the tile: the switch and the pointer ride along
   // instead of costing two more dependent scalar loads behind the header)
   const double h_mask_on = it.mid.mask_on;
@@ -961,21 +962,33 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
     }
   }
   if constexpr (LONG != 0) {
-    const bool ran3 = it2.fft1_on != 0.0;
-    const bool ran4 = LONG == 2 && it2.fft2_on != 0.0;
-    const bool inv3 = ran3 && it2.fft1_inv != 0.0;
-    frugal_slot<T, N, E, 1, decltype(m), 0, false, 0, TAB>(v, it2.pre, it2.pre_ph, m, circle, false, inv3, m.t, lds, false);
-    if (ran3) {
-      if (ran1 || ran2) __syncthreads();  // the exchange area may still be read by the transform in front
-      frugal_fft<T, N, E, SPLIT, false>(v, lds, m.t, tw, circle, it2.fft1_inv);
-    }
-    frugal_slot<T, N, E, 1, decltype(m), 0, false, 0, TAB>(v, it2.mid, it2.mid_ph, m, circle, inv3, ran4 && it2.fft2_inv != 0.0, m.t, lds, ran3);
-    if constexpr (LONG == 2) {
-      if (ran4) {
-        if (ran1 || ran2 || ran3) __syncthreads();
-        frugal_fft<T, N, E, SPLIT>(v, lds, m.t, tw, circle, it2.fft2_inv);
+    bool busy = ran1 || ran2;  // the exchange area may still be read by the transform in front
+    auto extra_pass = [&](const FrugalItem& ix, auto two) __attribute__((always_inline)) {
+      constexpr bool kTwo = decltype(two)::value;
+      const bool ran3 = ix.fft1_on != 0.0;
+      const bool ran4 = kTwo && ix.fft2_on != 0.0;
+      const bool inv3 = ran3 && ix.fft1_inv != 0.0;
+      frugal_slot<T, N, E, 1, decltype(m), 0, false, 0, TAB>(v, ix.pre, ix.pre_ph, m, circle, false, inv3, m.t, lds, false);
+      if (ran3) {
+        if (busy) __syncthreads();
+        frugal_fft<T, N, E, SPLIT, false>(v, lds, m.t, tw, circle, ix.fft1_inv);
+        busy = true;
       }
-    }
+      frugal_slot<T, N, E, 1, decltype(m), 0, false, 0, TAB>(v, ix.mid, ix.mid_ph, m, circle, inv3, ran4 && ix.fft2_inv != 0.0, m.t, lds, ran3);
+      if constexpr (kTwo) {
+        if (ran4) {
+          if (busy) __syncthreads();
+          frugal_fft<T, N, E, SPLIT>(v, lds, m.t, tw, circle, ix.fft2_inv);
+          busy = true;
+        }
+      }
+    };
+    // LONG = extra transforms: 1 -> [1], 2 -> [2], 3 -> [2][1], 4 -> [2][2]
+    const FrugalItem& it2 = *(const FrugalItem*)((ConstItemPtr)a.items + item + gridDim.y);
+    if constexpr (LONG == 1) extra_pass(it2, std::false_type{});
+    else extra_pass(it2, std::true_type{});
+    if constexpr (LONG == 3) extra_pass(it_last, std::false_type{});
+    if constexpr (LONG == 4) extra_pass(it_last, std::true_type{});
   }
   PAOS_STAMP(5);
   if constexpr (STORE == 1) {

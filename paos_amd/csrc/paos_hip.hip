@@ -22,6 +22,7 @@
 #include <set>
 #include <string>
 #include <utility>
+#include <type_traits>
 #include <vector>
 
 #include "frugal_pass.h"
@@ -686,12 +687,22 @@ template <typename T, int N, int AXIS, int KPRE, int KMID>
 int frugal_nfft(paos_ctx* c, const FrugalArgs& a, int nfft) {
   // (the digit-swapped two-transform variant NFFT = 3 of frugal_pass.h is built by tools/fftbench.hip only:
   // measured in round 2 with parity unchanged and no gain, profiles/r02_fftbench_digit_swapped_experiment.txt)
-  if (a.tab && a.fuse) {  // ... and the launch runs the next pass of the program as well (LONG builds)
+  if (a.tab && a.fuse) {  // ... and the launch runs the next pass -- or the next two -- of the program as well (LONG builds)
     if constexpr (sizeof(T) == 8 && KPRE == 1 && KMID == 1) {
-      if (nfft < 2) return fail(c, PAOS_EINVAL, "a fused pair starts with a two-transform pass");
-      if (a.psf) return a.fuse >= 2 ? frugal_launch<T, N, AXIS, 1, 1, 2, 1, 1, 2>(c, a) : frugal_launch<T, N, AXIS, 1, 1, 2, 1, 1, 1>(c, a);
-      if (a.pow_partial) return a.fuse >= 2 ? frugal_launch<T, N, AXIS, 1, 1, 2, 2, 1, 2>(c, a) : frugal_launch<T, N, AXIS, 1, 1, 2, 2, 1, 1>(c, a);
-      return a.fuse >= 2 ? frugal_launch<T, N, AXIS, 1, 1, 2, 0, 1, 2>(c, a) : frugal_launch<T, N, AXIS, 1, 1, 2, 0, 1, 1>(c, a);
+      if (nfft < 2) return fail(c, PAOS_EINVAL, "a fused chain starts with a two-transform pass");
+#define PAOS_LONG_CASE(L)                                                           \
+  case L:                                                                           \
+    if (a.psf) return frugal_launch<T, N, AXIS, 1, 1, 2, 1, 1, L>(c, a);            \
+    if (a.pow_partial) return frugal_launch<T, N, AXIS, 1, 1, 2, 2, 1, L>(c, a);    \
+    return frugal_launch<T, N, AXIS, 1, 1, 2, 0, 1, L>(c, a);
+      switch (a.fuse) {
+        PAOS_LONG_CASE(1)
+        PAOS_LONG_CASE(2)
+        PAOS_LONG_CASE(3)
+        PAOS_LONG_CASE(4)
+      }
+#undef PAOS_LONG_CASE
+      return fail(c, PAOS_EINVAL, "a launch runs at most three passes");
     } else {
       return fail(c, PAOS_EINVAL, "no fused build of this pass shape");
     }
@@ -935,7 +946,8 @@ bool can_fuse_pair(const paos_ctx* c, const paos_pass& p, const LoweredPass& lp,
 
 // launch a pass that lower_frugal accepted -- and, with `next`, the pass behind it in the same launch (can_fuse_pair)
 int launch_lowered(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const double* dblocks, bool store_psf = false,
-                   bool sum_power = false, LoweredPass* next = nullptr) {
+                   bool sum_power = false, LoweredPass* next = nullptr, LoweredPass* next2 = nullptr) {
+  LoweredPass* const last = next2 ? next2 : next;  // the pass whose stores leave the launch (nullptr: this one)
   // PAOS_DUMP_PASSES=1: one line per pass launch on stderr (shape and what item 0's two slots carry)
   static const bool dump = [] { const char* e = getenv("PAOS_DUMP_PASSES"); return e && e[0] == '1'; }();
   if (dump && !lp.items.empty()) {
@@ -945,7 +957,7 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const doubl
                  f.pre.scale, f.pre.mask_on, f.fft1_on, f.fft1_inv, f.mid.sign_on, f.mid.scale, f.mid.mask_on, f.fft2_on, f.fft2_inv,
                  f.line_lo, f.line_hi, f.line_fill, f.pos_lo, f.pos_hi, f.spos_lo, f.spos_hi);
   }
-  for (LoweredPass* l : {&lp, next}) {  // render the records along the pass axis, right before the pass (both passes of a pair)
+  for (LoweredPass* l : {&lp, next, next2}) {  // render the records along the pass axis, right before the pass (every pass of a chain)
     if (!l || l->mask_block < 0 || !l->mask_render) continue;
     const double* ap = dblocks + (size_t)l->mask_block * c->batch * FP_STRIDE;
     const double* dshared = nullptr;
@@ -967,14 +979,16 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const doubl
           (k == 0 ? l.items[it].pre : l.items[it].mid).table =
               tables && (counts[k] > 0 || next) ? c->ptab + ((size_t)(first + k) * c->batch + it) * c->n : nullptr;
     };
-    if (tables && !c->ptab) HIPCHK(c, hipMalloc(&c->ptab, (size_t)4 * c->batch * c->n * sizeof(cx<double>)));
+    if (tables && !c->ptab) HIPCHK(c, hipMalloc(&c->ptab, (size_t)6 * c->batch * c->n * sizeof(cx<double>)));
     point(lp, 0);
     if (next) point(*next, 2);
+    if (next2) point(*next2, 4);
   }
   std::vector<FrugalItem> both;
-  if (next) {  // the second pass's records follow the first's
+  if (next) {  // the later passes' records follow the first's
     both = lp.items;
     both.insert(both.end(), next->items.begin(), next->items.end());
+    if (next2) both.insert(both.end(), next2->items.begin(), next2->items.end());
   }
   const std::vector<FrugalItem>& launch_items = next ? both : lp.items;
   const double* ditems = nullptr;
@@ -984,8 +998,8 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const doubl
   if (rc) return rc;
   if (tables) {
     const PhaseTableArgs ta{reinterpret_cast<const FrugalItem*>(ditems), reinterpret_cast<const cx<double>*>(c->tw), c->n, p.axis,
-                            lp.kpre, lp.kmid, next ? next->kpre : 0, next ? next->kmid : 0};
-    hipLaunchKernelGGL(phase_table_kernel<0>, dim3(c->n / 256, c->batch, next ? 4 : 2), dim3(256), 0, c->stream, ta);
+                            {lp.kpre, lp.kmid, next ? next->kpre : 0, next ? next->kmid : 0, next2 ? next2->kpre : 0, next2 ? next2->kmid : 0}};
+    hipLaunchKernelGGL(phase_table_kernel<0>, dim3(c->n / 256, c->batch, next2 ? 6 : (next ? 4 : 2)), dim3(256), 0, c->stream, ta);
     HIPCHK(c, hipGetLastError());
   }
   FrugalArgs a{c->field, c->tw, reinterpret_cast<const FrugalItem*>(ditems), c->pitch, c->item_stride, nullptr, nullptr, nullptr};
@@ -998,7 +1012,7 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const doubl
     double lo = (double)c->n, hi = 0.0;
     bool fill = false;
     // (a fused pair: the lines are the same for both passes, what is stored and filled is the second pass's business)
-    const std::vector<FrugalItem>& out_items = next ? next->items : lp.items;
+    const std::vector<FrugalItem>& out_items = last ? last->items : lp.items;
     for (const FrugalItem& fi : out_items) {
       if (fi.active == 0.0) continue;
       lo = fi.line_lo < lo ? fi.line_lo : lo;
@@ -1021,10 +1035,10 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const doubl
   // positions, bit 2: stores nobody reads, bit 3: it stores the PSF instead of the field
   c->prof_next_tag = store_psf ? 8 : 0;
   c->prof_next_bytes = 0.0;
-  if (next) c->prof_next_tag |= 16;  // bit 4: the launch ran two passes of the program
+  if (next) c->prof_next_tag |= next2 ? 32 : 16;  // bit 4: the launch ran two passes of the program, bit 5: three
   for (int it = 0; it < c->batch; ++it) {
     const FrugalItem& fi = lp.items[it];
-    const FrugalItem& fo = next ? next->items[it] : fi;  // the pass whose stores leave the launch
+    const FrugalItem& fo = last ? last->items[it] : fi;  // the pass whose stores leave the launch
     if (fi.active == 0.0) continue;
     if (fi.line_lo > 0.0 || fi.line_hi < (double)c->n) c->prof_next_tag |= 1;
     if (fi.pos_lo > 0.0 || fi.pos_hi < (double)c->n) c->prof_next_tag |= 2;
@@ -1035,7 +1049,7 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const doubl
   }
   if (c->precision == PAOS_F64) {
     a.tab = tables ? 1 : 0;  // (the TAB builds take "has phases" for the number of phases: their slots read one factor)
-    a.fuse = next ? next->nfft : 0;
+    a.fuse = next2 ? 2 + next2->nfft : (next ? next->nfft : 0);  // LONG: the transforms of the passes that ride along
     // (a fused pair runs on the one build whose four slots all read tables)
     const int kpre = next ? 1 : (tables && lp.kpre > 1 ? 1 : lp.kpre), kmid = next ? 1 : (tables && lp.kmid > 1 ? 1 : lp.kmid);
     switch (c->n) {
@@ -1371,11 +1385,14 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
     for (int q = i; q < j; ++q) {
       if (low[q].ok) {
         // two passes of one row / column chain in ONE launch (frugal_pass.h: LONG builds) where the pair allows it
+        // (and a third: the five-transform chains -- ptp, stw, ptp -- that end a SYN20-like prescription)
         const bool pair = pruned && q + 1 < j && can_fuse_pair(c, passes[q], low[q], passes[q + 1], low[q + 1]);
-        const int last = pair ? q + 1 : q;
+        const bool triple = pair && q + 2 < j && can_fuse_pair(c, passes[q + 1], low[q + 1], passes[q + 2], low[q + 2]) &&
+                            !(low[q].mask_block >= 0 && low[q + 2].mask_block >= 0 && low[q].mask_set == low[q + 2].mask_set);
+        const int last = triple ? q + 2 : (pair ? q + 1 : q);
         if ((rc = launch_lowered(c, passes[q], low[q], dblocks, fused_store && last == n_passes - 1, fused_power && last == n_passes - 1,
-                                 pair ? &low[q + 1] : nullptr))) return rc;
-        if (pair) ++q;
+                                 pair ? &low[q + 1] : nullptr, triple ? &low[q + 2] : nullptr))) return rc;
+        q = last;
         if (c->dyn_pending) {  // (first launch of the program) the stop's factor has gone into the field: ones again for the next
           hipLaunchKernelGGL(dyn_scale_reset_kernel, dim3((c->batch + 255) / 256), dim3(256), 0, c->stream, c->dyn_scale, c->batch);
           HIPCHK(c, hipGetLastError());
