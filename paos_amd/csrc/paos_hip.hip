@@ -896,6 +896,10 @@ MaskJob mask_job(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const d
 // one launch per shape that occurs for `count` renderings (blockIdx.z), the grid sized for the widest line window
 int launch_mask_jobs(paos_ctx* c, MaskJobs& jobs, int count) {
   jobs.batch_stride = c->batch * (int)FP_STRIDE; jobs.param_stride = (int)FP_STRIDE; jobs.n = c->n; jobs.overflow = c->mask_overflow;
+  {
+    const char* e = getenv("PAOS_MASK_SCAN");  // (read per launch: tests switch it)
+    jobs.windows = (e && e[0] == '1') ? 0 : 1;
+  }
   int widest = 0, shapes = 0;
   for (int j = 0; j < count; ++j) {
     widest = std::max(widest, jobs.job[j].line_end - jobs.job[j].line0);

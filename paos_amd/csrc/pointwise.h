@@ -626,6 +626,7 @@ constexpr int kMaskJobs = 8;
 // step as five launches of a latency-bound kernel were 1.3 ms of a 62 ms step.
 struct MaskJobs {
   MaskJob job[kMaskJobs];
+  int windows;       // 1: lines whose two boundary runs fit two 32-pixel windows take the one-evaluation path (PAOS_MASK_SCAN=1: 0)
   int batch_stride;  // doubles between the two parameter block sets of a job (= batch * param_stride)
   int param_stride, n;
   int* overflow;
@@ -673,6 +674,70 @@ __global__ void __launch_bounds__(kMaskWaves * 64) mask_lines_kernel(MaskJobs jo
   const bool line_in_box = axis == 0 ? (line >= box.iymin && line < box.iymax) : (line >= box.ixmin && line < box.ixmax);
   const int scan_lo = line_in_box ? max(0, (axis == 0 ? box.ixmin : box.iymin)) & ~63 : 0;
   const int scan_hi = line_in_box ? min(n, axis == 0 ? box.ixmax : box.iymax) : 0;
+  // Round 4: the two boundary windows of the chord at once.  The partially covered pixels of a line lie where the
+  // ellipse crosses the strip of the line: between the chord at the strip's edge nearer the centre and the chord at its
+  // far edge, on either side.  When both of these runs fit 32 pixels (with a margin of 3; every line but the few near
+  // the tips of the ellipse), lanes 0-31 evaluate the exact overlap of the left window and lanes 32-63 of the right one
+  // -- ONE evaluation of ellipse_pixel per line instead of one per 64-pixel chunk that touches the boundary (2-4) --
+  // and the rest of the line is classified by the same two rectangle tests the chunks use (see below: exactly
+  // consistent with the per-pixel rule), applied to the span between the windows (inside) and to the two spans
+  // outside them (outside).  Whatever fails -- a window too wide, a test that does not hold -- takes the scan below.
+  // Records are identical to the scan's bit for bit (tests/test_gpu_r4.py, PAOS_MASK_SCAN=1 forces the scan).
+  if (SHAPE == 0 && line_in_box && jobs.windows != 0) {
+    const double sa = axis == 0 ? a : b, sc = axis == 0 ? b : a;          // semi-axes along / across the line
+    const double ca = axis == 0 ? xc : yc, cc = axis == 0 ? yc : xc;      // centre along / across
+    const double lo_c = __dsub_rn((double)line - 0.5, cc), hi_c = __dsub_rn((double)line + 0.5, cc);
+    const double near_c = (lo_c > 0.0 ? lo_c : (hi_c < 0.0 ? -hi_c : 0.0)) / sc;   // strip edge nearer the centre
+    const double far_c = fmax(fabs(lo_c), fabs(hi_c)) / sc;
+    const double half_long = near_c < 1.0 ? sa * sqrt(1.0 - near_c * near_c) : 0.0;
+    const double half_short = far_c < 1.0 ? sa * sqrt(1.0 - far_c * far_c) : 0.0;
+    const int box_lo = max(0, axis == 0 ? box.ixmin : box.iymin), box_hi = min(n, axis == 0 ? box.ixmax : box.iymax);
+    const int wl0 = max(box_lo, (int)floor(ca - half_long) - 3), wl1 = (int)ceil(ca - half_short) + 3;   // [wl0, wl1]
+    const int wr1 = min(box_hi - 1, (int)ceil(ca + half_long) + 3), wr0 = wr1 - 31;                       // [wr0, wr1]
+    const int wr_need = (int)floor(ca + half_short) - 3;
+    auto sum2 = [&](double al, double ac) { const double u = al / sa, v = ac / sc; return axis == 0 ? __dadd_rn(__dmul_rn(u, u), __dmul_rn(v, v)) : __dadd_rn(__dmul_rn(v, v), __dmul_rn(u, u)); };
+    bool ok = wl1 - wl0 < 32 && wr_need >= wr0 && wl0 + 32 <= wr0 && half_long > 0.0;
+    if (ok) {
+      // between the windows: the four outer corners of the span inside the ellipse => every pixel of it is (monotone)
+      const double ia = __dsub_rn((double)(wl0 + 32) - 0.5, ca), ib = __dsub_rn((double)(wr0 - 1) + 0.5, ca);
+      ok = sum2(ia, lo_c) <= 1.0 && sum2(ib, lo_c) <= 1.0 && sum2(ia, hi_c) <= 1.0 && sum2(ib, hi_c) <= 1.0;
+      // left of the left window and right of the right one: the nearest point of each span outside by a margin
+      const double nc = lo_c > 0.0 ? lo_c : (hi_c < 0.0 ? hi_c : 0.0);
+      if (ok && wl0 > box_lo) {
+        const double hi_a = __dsub_rn((double)(wl0 - 1) + 0.5, ca);
+        ok = hi_a < 0.0 && sum2(hi_a, nc) > 1.0 + 1.0e-9;
+      }
+      if (ok && wr1 + 1 < box_hi) {
+        const double lo_a = __dsub_rn((double)(wr1 + 1) - 0.5, ca);
+        ok = lo_a > 0.0 && sum2(lo_a, nc) > 1.0 + 1.0e-9;
+      }
+    }
+    if (ok) {  // wave-uniform
+      const int pos = lane < 32 ? wl0 + lane : wr0 + (lane - 32);
+      const int c = axis == 0 ? pos : line, r = axis == 0 ? line : pos;
+      double mask = 0.0;
+      if (c >= box.ixmin && c < box.ixmax && r >= box.iymin && r < box.iymax) mask = ellipse_pixel(c, r, xc, yc, a, b, 1.0, 0.0, full_disk);
+      const double w = obsc ? __dsub_rn(1.0, mask) : mask;
+      const unsigned long long not_out = __ballot(w != w_out), is_in = __ballot(w == w_in);
+      const unsigned no_l = (unsigned)not_out, no_r = (unsigned)(not_out >> 32), in_l = (unsigned)is_in, in_r = (unsigned)(is_in >> 32);
+      const int i0 = wl0 + 32, i1 = wr0;  // the span between the windows: w_in throughout (i0 <= i1; empty when equal)
+      // the scan's four extents over: left window | span | right window
+      p0 = no_l ? wl0 + (__ffs((int)no_l) - 1) : (i0 < i1 ? i0 : (no_r ? wr0 + (__ffs((int)no_r) - 1) : n));
+      p3 = no_r ? wr0 + 32 - __clz((int)no_r) : (i0 < i1 ? i1 : (no_l ? wl0 + 32 - __clz((int)no_l) : 0));
+      p1 = in_l ? wl0 + (__ffs((int)in_l) - 1) : (i0 < i1 ? i0 : (in_r ? wr0 + (__ffs((int)in_r) - 1) : -1));
+      p2i = in_r ? wr0 + 32 - __clz((int)in_r) : (i0 < i1 ? i1 : (in_l ? wl0 + 32 - __clz((int)in_l) : -1));
+      if (p3 <= p0) { p0 = p1 = p2i = p3 = 0; }
+      else if (p1 < 0) { p1 = p2i = p3; }
+      if (p1 - p0 > kMaskW || p3 - p2i > kMaskW) {
+        if (lane == 0) atomicAdd(overflow, 1);
+        p0 = p1 = p2i = p3 = 0;
+      }
+      if (pos >= p0 && pos < p1) vout[pos - p0] = w;
+      if (pos >= p2i && pos < p3) vout[kMaskW + pos - p2i] = w;
+      if (lane == 0) *out = {p0, p1, p2i, p3, lm, 0.0};
+      return;
+    }
+  }
   // pass 1: extents.  Chunks of 64 pixels that hold partially covered pixels keep their weights in
   // a small per-wave LDS cache, so that pass 2 does not evaluate the exact overlap a second time.
   constexpr int kCache = 6;                           // chunks per line (two edge zones, a few chunks each)

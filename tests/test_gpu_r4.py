@@ -190,3 +190,54 @@ def test_two_passes_in_one_launch_change_no_bit(n):
         assert power == power0
     finally:
         dev.close()
+
+
+@pytest.mark.parametrize("n", [1024, 4096])
+def test_two_window_aperture_records_equal_the_scan(n):
+    """The aperture line records of an ellipse are rendered with one exact-overlap evaluation per line where the two
+    boundary runs of the line fit two 32-pixel windows (pointwise.h: mask_lines_kernel), and by the chunk scan of rounds
+    2-3 elsewhere; PAOS_MASK_SCAN=1 forces the scan.  Random ellipses -- round and flat, centred and near the edge of
+    the grid, apertures and obscurations -- riding on a row pass and on a column pass over a random field: the two
+    renderings give the same field bit for bit."""
+    import os
+
+    from paos_amd import _lib
+
+    rng = np.random.default_rng(7 * n)
+    u = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    dev = _lib.DeviceFields(n, 1, "fp64")
+    try:
+        for trial in range(10):
+            a, b = rng.uniform(4.0, 0.45 * n, 2)
+            if trial % 3 == 0:
+                b = a  # round
+            xc, yc = (n / 2 + rng.uniform(-3, 3, 2)) if trial % 2 == 0 else rng.uniform(0.1 * n, 0.9 * n, 2)
+            obsc = 1.0 if trial in (4, 7) else 0.0
+            if 2.0 * max(a, b) * np.sqrt(3.0 / min(a, b)) + 8.0 > 192:  # (the bound of lower_frugal: records must fit)
+                a = b = max(a, b)
+            blocks = np.array([[[1.0, xc, yc, a, b]], [[0.0, obsc, 1.0, float(_lib.SHAPE_ELLIPSE), 0.0]], [[1.0, 0.0, 0.0, 0.0, 0.0]]])
+            got = {}
+            for mode in ("windows", "scan"):
+                if mode == "scan":
+                    os.environ["PAOS_MASK_SCAN"] = "1"
+                try:
+                    out = []
+                    for axis in (0, 1):
+                        dev.upload(0, u)
+                        dev.run_passes([{"axis": axis, "fft1": 2, "fft2": -1, "pre": [(_lib.PW_MASK, 0, 0)], "mid": [], "post": []}], blocks)
+                        out.append(dev.download(0))
+                    got[mode] = out
+                finally:
+                    os.environ.pop("PAOS_MASK_SCAN", None)
+            for x, y in zip(got["windows"], got["scan"]):
+                assert np.array_equal(x, y), (trial, a, b, xc, yc, obsc)
+            # ... and the mask is what the stand-alone aperture kernel applies: |F^-1| of the row pass is the masked field
+            if obsc == 0.0:
+                back = np.fft.ifft(got["windows"][0], axis=1)
+                dark = np.abs(back) < 1e-9
+                yy, xx = np.mgrid[0:n, 0:n]
+                outside = ((xx - xc) / (a + 1.5)) ** 2 + ((yy - yc) / (b + 1.5)) ** 2 > 1.0
+                inside = ((xx - xc) / max(a - 1.5, 0.1)) ** 2 + ((yy - yc) / max(b - 1.5, 0.1)) ** 2 < 1.0
+                assert dark[outside].all() and np.allclose(back[inside], u[inside], rtol=0, atol=1e-9)
+    finally:
+        dev.close()
