@@ -521,14 +521,18 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
   }
 }
 
-// The factors of the slots of one pass whose phases vary along the line only (FrugalSlot::table), for every item and
-// position: blockIdx = (position / 256, item, slot), complex128 passes.  The unit circle of sincos_tab is rebuilt from
+// The factors of the slots whose phases vary along the line only (FrugalSlot::table), for every item and position:
+// blockIdx = (position / 256, item, table) -- the tables of every launch of a pass program in one go --, complex128 passes.  The unit circle of sincos_tab is rebuilt from
 // the context's twiddle table exactly as frugal_pass_kernel builds it, the arguments are formed by slot_factor: an entry
 // is bit for bit what the slot would have evaluated at that position on any line.
+// One table: the slot (`mid` = 0: in front of the first transform, 1: behind it) of the pass whose item records start at
+// items[item_base], with `k` phases, along `axis`.
+struct PhaseSlotDesc { int item_base, mid, k, axis; };
 struct PhaseTableArgs {
-  const FrugalItem* items;  // [batch], as handed to the pass ([2 or 3][batch] for a LONG launch: gridDim.z = 4 or 6)
-  const cx<double>* tw;     // the context's twiddle table for n
-  int n, axis, k[6];  // phases per slot: pre, mid of the first pass, of the second, of the third
+  const FrugalItem* items;     // the staged records of every launch the tables are for (paos_hip.hip: stage_groups)
+  const cx<double>* tw;        // the context's twiddle table for n
+  const PhaseSlotDesc* desc;   // [gridDim.z]
+  int n;
 };
 template <int UNIT = 0>  // (a template: the header is compiled into several translation units)
 __global__ void __launch_bounds__(256) phase_table_kernel(PhaseTableArgs a) {
@@ -538,12 +542,13 @@ __global__ void __launch_bounds__(256) phase_table_kernel(PhaseTableArgs a) {
     circle[threadIdx.x] = {w.x, -w.y};
   }
   __syncthreads();
-  const FrugalItem& it = a.items[blockIdx.y + (blockIdx.z >> 1) * gridDim.y];
-  const bool mid = (blockIdx.z & 1) != 0;
+  const PhaseSlotDesc d = a.desc[blockIdx.z];
+  const FrugalItem& it = a.items[d.item_base + blockIdx.y];
+  const bool mid = d.mid != 0;
   const FrugalSlot& sl = mid ? it.mid : it.pre;
   if (it.active == 0.0 || sl.table == nullptr) return;
   const FrugalPhase* ph = mid ? it.mid_ph : it.pre_ph;
-  const int K = a.k[blockIdx.z];
+  const int K = d.k;
   // behind a conjugated transform the slot runs its phases with -q (frugal_slot: qflip)
   const int qflip = (mid && it.fft1_on != 0.0 && it.fft1_inv != 0.0) ? (int)0x80000000 : 0;
   const int pos = blockIdx.x * blockDim.x + threadIdx.x;
@@ -552,7 +557,7 @@ __global__ void __launch_bounds__(256) phase_table_kernel(PhaseTableArgs a) {
   for (int j = 0; j < kFrugalMaxMid; ++j) {
     const FrugalPhase& q = ph[j < K ? j : 0];
     g[j] = (double)(q.natural != 0.0 ? (pos < a.n / 2 ? pos : pos - a.n) : pos - a.n / 2);
-    step[j] = a.axis == 0 ? q.sx : q.sy;
+    step[j] = d.axis == 0 ? q.sx : q.sy;
     across2[j] = 0.0;
     coefq[j] = __hiloint2double(__double2hiint(q.coef) ^ qflip, __double2loint(q.coef));
     m2[j] = q.m2;

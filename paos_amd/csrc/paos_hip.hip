@@ -92,7 +92,8 @@ struct paos_ctx {
   int pow_nparts = 0;
   // [batch] factors every frugal pass multiplies into the scale of its middle slot (FrugalArgs::dyn_scale): ones, except
   // between paos_stop_defer_last_power and the pass (or settle_scale) that applies the stop's 1 / sqrt(power)
-  cx<double>* ptab = nullptr;  // [2 slots][batch][n] phase factors by position of the pass about to run (FrugalSlot::table)
+  cx<double>* ptab = nullptr;  // [ptab_slots][batch][n] phase factors by position: a table per operator slot of the launches of the
+  int ptab_slots = 0;          // program about to run (FrugalSlot::table; stage_groups)
   double* dyn_scale = nullptr;
   bool dyn_pending = false;
   // What the PSF buffer (and psf_partial) is known to hold after a pass stored it: for item i the lines along
@@ -949,8 +950,71 @@ bool can_fuse_pair(const paos_ctx* c, const paos_pass& p, const LoweredPass& lp,
 }
 
 // launch a pass that lower_frugal accepted -- and, with `next`, the pass behind it in the same launch (can_fuse_pair)
+// One launch of a pass program: a pass and the one or two behind it that ride along (can_fuse_pair).
+struct FusedGroup {
+  LoweredPass* lp[3] = {nullptr, nullptr, nullptr};
+  int q = 0, count = 1, axis = 0;
+  bool tables = false;   // its slots read their phase factors from tables
+  size_t item_base = 0;  // index of its first item record in the staged array
+};
+
+// Stage the launches `groups`: decide which of them run on table slots (all phases of all their passes along the lines;
+// a fused group always does), point their slots at tables of the context's store, copy the item records of all of them to
+// the device in ONE transfer and build all tables with ONE launch -- in front of the program's first launch, so that
+// nothing but the pass kernels themselves stands between two passes (round 4: a copy and a table launch in front of
+// every pass cost ~50 us of an 1.3 ms launch).  *ditems: the device array; groups[g].item_base indexes it.
+int stage_groups(paos_ctx* c, std::vector<FusedGroup>& groups, const FrugalItem** ditems) {
+  std::vector<FrugalItem> blob;
+  std::vector<PhaseSlotDesc> descs;
+  int slots = 0;
+  for (FusedGroup& g : groups) {
+    paos_pass axis_only{};
+    axis_only.axis = g.axis;
+    g.tables = g.count > 1 || phases_along_lines(c, axis_only, *g.lp[0]);
+    if (g.tables) slots += 2 * g.count;
+  }
+  if (slots > c->ptab_slots) {
+    if (c->ptab) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->ptab); c->ptab = nullptr; c->ptab_slots = 0; }
+    HIPCHK(c, hipMalloc(&c->ptab, (size_t)slots * c->batch * c->n * sizeof(cx<double>)));
+    c->ptab_slots = slots;
+  }
+  int slot = 0;
+  for (FusedGroup& g : groups) {
+    g.item_base = blob.size();
+    for (int k = 0; k < g.count; ++k) {
+      LoweredPass& l = *g.lp[k];
+      const int counts[2] = {l.kpre, l.kmid};
+      for (int s = 0; s < 2; ++s) {
+        // (in a fused group a slot without phases rides with a table of ones)
+        const bool has = g.tables && (counts[s] > 0 || g.count > 1);
+        for (int it = 0; it < c->batch; ++it)
+          (s == 0 ? l.items[it].pre : l.items[it].mid).table = has ? c->ptab + ((size_t)slot * c->batch + it) * c->n : nullptr;
+        if (has) descs.push_back(PhaseSlotDesc{(int)blob.size(), s, counts[s], g.axis});
+        if (g.tables) ++slot;
+      }
+      blob.insert(blob.end(), l.items.begin(), l.items.end());
+    }
+  }
+  static_assert(sizeof(FrugalItem) % sizeof(double) == 0 && sizeof(PhaseSlotDesc) == 2 * sizeof(double), "records of doubles");
+  const size_t item_doubles = blob.size() * sizeof(FrugalItem) / sizeof(double);
+  std::vector<double> flat(item_doubles + 2 * descs.size());
+  std::memcpy(flat.data(), blob.data(), item_doubles * sizeof(double));
+  if (!descs.empty()) std::memcpy(flat.data() + item_doubles, descs.data(), descs.size() * sizeof(PhaseSlotDesc));
+  const double* dflat = nullptr;
+  int rc = arena_push(c, flat.data(), flat.size(), &dflat);
+  if (rc) return rc;
+  *ditems = reinterpret_cast<const FrugalItem*>(dflat);
+  if (!descs.empty()) {
+    const PhaseTableArgs ta{*ditems, reinterpret_cast<const cx<double>*>(c->tw), reinterpret_cast<const PhaseSlotDesc*>(dflat + item_doubles), c->n};
+    hipLaunchKernelGGL(phase_table_kernel<0>, dim3(c->n / 256, c->batch, (unsigned)descs.size()), dim3(256), 0, c->stream, ta);
+    HIPCHK(c, hipGetLastError());
+  }
+  return PAOS_OK;
+}
+
 int launch_lowered(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const double* dblocks, bool store_psf = false,
-                   bool sum_power = false, LoweredPass* next = nullptr, LoweredPass* next2 = nullptr) {
+                   bool sum_power = false, LoweredPass* next = nullptr, LoweredPass* next2 = nullptr,
+                   const FrugalItem* staged = nullptr, bool staged_tables = false) {
   LoweredPass* const last = next2 ? next2 : next;  // the pass whose stores leave the launch (nullptr: this one)
   // PAOS_DUMP_PASSES=1: one line per pass launch on stderr (shape and what item 0's two slots carry)
   static const bool dump = [] { const char* e = getenv("PAOS_DUMP_PASSES"); return e && e[0] == '1'; }();
@@ -972,40 +1036,21 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const doubl
     if ((rcs = launch_mask_jobs(c, jobs, 1))) return rcs;
     l->mask_render = false;
   }
-  // Slots whose phases vary along the line only: their factors come from a table by position, built once per pass
-  // instead of on each of its lines (phases_along_lines).  All slots of the pass that have phases, or none.
-  const bool tables = next != nullptr || phases_along_lines(c, p, lp);
-  {
-    auto point = [&](LoweredPass& l, int first) {
-      const int counts[2] = {l.kpre, l.kmid};
-      for (int it = 0; it < c->batch; ++it)
-        for (int k = 0; k < 2; ++k)
-          (k == 0 ? l.items[it].pre : l.items[it].mid).table =
-              tables && (counts[k] > 0 || next) ? c->ptab + ((size_t)(first + k) * c->batch + it) * c->n : nullptr;
-    };
-    if (tables && !c->ptab) HIPCHK(c, hipMalloc(&c->ptab, (size_t)6 * c->batch * c->n * sizeof(cx<double>)));
-    point(lp, 0);
-    if (next) point(*next, 2);
-    if (next2) point(*next2, 4);
+  // The item records (with the pointers to their slots' phase tables) and the tables themselves: staged for the whole
+  // program in front of its first launch (stage_groups: one copy, one table launch), or here for this launch alone.
+  bool tables = staged_tables;
+  const FrugalItem* ditems_f = staged;
+  if (!ditems_f) {
+    FusedGroup g;
+    g.lp[0] = &lp; g.lp[1] = next; g.lp[2] = next2; g.count = next2 ? 3 : (next ? 2 : 1);
+    g.axis = p.axis;
+    std::vector<FusedGroup> one{g};
+    int rcg = stage_groups(c, one, &ditems_f);
+    if (rcg) return rcg;
+    tables = one[0].tables;
+    ditems_f += one[0].item_base;
   }
-  std::vector<FrugalItem> both;
-  if (next) {  // the later passes' records follow the first's
-    both = lp.items;
-    both.insert(both.end(), next->items.begin(), next->items.end());
-    if (next2) both.insert(both.end(), next2->items.begin(), next2->items.end());
-  }
-  const std::vector<FrugalItem>& launch_items = next ? both : lp.items;
-  const double* ditems = nullptr;
-  static_assert(sizeof(FrugalItem) % sizeof(double) == 0, "record of doubles");
-  int rc = arena_push(c, reinterpret_cast<const double*>(launch_items.data()),
-                      launch_items.size() * sizeof(FrugalItem) / sizeof(double), &ditems);
-  if (rc) return rc;
-  if (tables) {
-    const PhaseTableArgs ta{reinterpret_cast<const FrugalItem*>(ditems), reinterpret_cast<const cx<double>*>(c->tw), c->n, p.axis,
-                            {lp.kpre, lp.kmid, next ? next->kpre : 0, next ? next->kmid : 0, next2 ? next2->kpre : 0, next2 ? next2->kmid : 0}};
-    hipLaunchKernelGGL(phase_table_kernel<0>, dim3(c->n / 256, c->batch, next2 ? 6 : (next ? 4 : 2)), dim3(256), 0, c->stream, ta);
-    HIPCHK(c, hipGetLastError());
-  }
+  const double* ditems = reinterpret_cast<const double*>(ditems_f);
   FrugalArgs a{c->field, c->tw, reinterpret_cast<const FrugalItem*>(ditems), c->pitch, c->item_stride, nullptr, nullptr, nullptr};
   if (store_psf) { a.psf = c->psf; a.psf_partial = c->psf_partial; }
   if (sum_power) a.pow_partial = c->pow_partial;
@@ -1183,8 +1228,9 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
   // everything this program pushes stays live until its last pass has run: the block table and,
   // per pass, one FrugalItem record per batch item (each push is rounded up to 16 doubles)
   // plus, for a pass that carries an aperture, the [batch] "shares its line records" vector (launch_lowered)
+  // ... and two table descriptors (stage_groups)
   const size_t per_pass = (((size_t)c->batch * sizeof(FrugalItem) / sizeof(double) + 15) & ~size_t(15)) +
-                          (((size_t)c->batch + 15) & ~size_t(15));
+                          (((size_t)c->batch + 15) & ~size_t(15)) + 16;
   int rc = arena_reserve(c, (size_t)n_blocks * c->batch * FP_STRIDE + 16 + (size_t)n_passes * per_pass);
   if (rc) return rc;
   rc = arena_push(c, blocks, (size_t)n_blocks * c->batch * FP_STRIDE, &dblocks);
@@ -1345,6 +1391,32 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
       }
     }
   }
+  // The launches of the program: a pass, or two / three consecutive passes of one row / column chain (can_fuse_pair).
+  // When every pass runs on the frugal kernels their item records and phase tables are staged here, once, for all of
+  // them (stage_groups); otherwise each launch stages its own.  PAOS_STAGE_PROGRAM=0: each launch stages its own.
+  std::vector<FusedGroup> groups;
+  std::vector<int> group_of(n_passes, -1);
+  const FrugalItem* staged_items = nullptr;
+  {
+    for (int q = 0; q < n_passes;) {
+      FusedGroup g;
+      g.q = q; g.axis = passes[q].axis; g.lp[0] = &low[q];
+      if (low[q].ok && all_frugal && pruned) {
+        const bool pair = q + 1 < n_passes && can_fuse_pair(c, passes[q], low[q], passes[q + 1], low[q + 1]);
+        // (and a third: the five-transform chains -- ptp, stw, ptp -- that end a SYN20-like prescription)
+        const bool triple = pair && q + 2 < n_passes && can_fuse_pair(c, passes[q + 1], low[q + 1], passes[q + 2], low[q + 2]) &&
+                            !(low[q].mask_block >= 0 && low[q + 2].mask_block >= 0 && low[q].mask_set == low[q + 2].mask_set);
+        g.count = triple ? 3 : (pair ? 2 : 1);
+        for (int k = 1; k < g.count; ++k) g.lp[k] = &low[q + k];
+      }
+      group_of[q] = (int)groups.size();
+      groups.push_back(g);
+      q += g.count;
+    }
+    const char* e = getenv("PAOS_STAGE_PROGRAM");
+    if (all_frugal && !(e && e[0] == '0'))
+      if ((rc = stage_groups(c, groups, &staged_items))) return rc;
+  }
   // Walk the program in chunks whose phase operators fit the table store: fill the tables of
   // a chunk with one small launch, then run its passes.
   int i = 0;
@@ -1388,14 +1460,12 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
     }
     for (int q = i; q < j; ++q) {
       if (low[q].ok) {
-        // two passes of one row / column chain in ONE launch (frugal_pass.h: LONG builds) where the pair allows it
-        // (and a third: the five-transform chains -- ptp, stw, ptp -- that end a SYN20-like prescription)
-        const bool pair = pruned && q + 1 < j && can_fuse_pair(c, passes[q], low[q], passes[q + 1], low[q + 1]);
-        const bool triple = pair && q + 2 < j && can_fuse_pair(c, passes[q + 1], low[q + 1], passes[q + 2], low[q + 2]) &&
-                            !(low[q].mask_block >= 0 && low[q + 2].mask_block >= 0 && low[q].mask_set == low[q + 2].mask_set);
-        const int last = triple ? q + 2 : (pair ? q + 1 : q);
+        // (a group of up to three passes of one row / column chain runs in ONE launch: frugal_pass.h, LONG builds)
+        const FusedGroup& g = groups[group_of[q]];
+        const int last = q + g.count - 1;
+        if (last >= j) return fail(c, PAOS_EINVAL, "a fused group crosses a table chunk");
         if ((rc = launch_lowered(c, passes[q], low[q], dblocks, fused_store && last == n_passes - 1, fused_power && last == n_passes - 1,
-                                 pair ? &low[q + 1] : nullptr, triple ? &low[q + 2] : nullptr))) return rc;
+                                 g.lp[1], g.lp[2], staged_items ? staged_items + g.item_base : nullptr, g.tables))) return rc;
         q = last;
         if (c->dyn_pending) {  // (first launch of the program) the stop's factor has gone into the field: ones again for the next
           hipLaunchKernelGGL(dyn_scale_reset_kernel, dim3((c->batch + 255) / 256), dim3(256), 0, c->stream, c->dyn_scale, c->batch);
