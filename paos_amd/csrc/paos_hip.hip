@@ -1414,7 +1414,10 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
       q += g.count;
     }
     const char* e = getenv("PAOS_STAGE_PROGRAM");
-    if (all_frugal && !(e && e[0] == '0'))
+    // (a table per operator slot of every pass: 2 MiB each at 4096^2 x 32; a program that would need more than 1 GiB of
+    // them -- hundreds of passes -- stages launch by launch, on six tables)
+    const size_t table_bytes = (size_t)2 * n_passes * c->batch * c->n * sizeof(cx<double>);
+    if (all_frugal && !(e && e[0] == '0') && table_bytes <= (size_t(1) << 30))
       if ((rc = stage_groups(c, groups, &staged_items))) return rc;
   }
   // Walk the program in chunks whose phase operators fit the table store: fill the tables of
