@@ -719,7 +719,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   constexpr int kClIt = sizeof(T) == 8 ? (kCircleLds + kThreads - 1) / kThreads : 1;
   // (LONG builds: what is written, and what becomes of dead tiles, is the second pass's business)
   constexpr int kExtra = (LONG + 1) / 2;  // passes behind the first one that this launch runs too
-  const FrugalItem& it_last = *(const FrugalItem*)((ConstItemPtr)a.items + item + kExtra * gridDim.y);
+  const FrugalItem& it_last = LONG == 0 ? it : *(const FrugalItem*)((ConstItemPtr)a.items + item + kExtra * gridDim.y);
   const double h_active = it.active, h_line_lo = it.line_lo, h_line_hi = it.line_hi, h_line_fill = it_last.line_fill,
                h_pos_lo = it.pos_lo, h_pos_hi = it.pos_hi, h_spos_lo = it_last.spos_lo, h_spos_hi = it_last.spos_hi;
   // (shapes that fetch their aperture line records in front of the tile: the switch and the pointer ride along
@@ -967,33 +967,37 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
     }
   }
   if constexpr (LONG != 0) {
+    // (a macro, not a lambda: a generic lambda that captures the tile by reference -- even inside a discarded
+    // `if constexpr` branch -- cost EVERY shape of the family its register allocation: 52-72 B of scratch, make spillcheck)
     bool busy = ran1 || ran2;  // the exchange area may still be read by the transform in front
-    auto extra_pass = [&](const FrugalItem& ix, auto two) __attribute__((always_inline)) {
-      constexpr bool kTwo = decltype(two)::value;
-      const bool ran3 = ix.fft1_on != 0.0;
-      const bool ran4 = kTwo && ix.fft2_on != 0.0;
-      const bool inv3 = ran3 && ix.fft1_inv != 0.0;
-      frugal_slot<T, N, E, 1, decltype(m), 0, false, 0, TAB>(v, ix.pre, ix.pre_ph, m, circle, false, inv3, m.t, lds, false);
-      if (ran3) {
-        if (busy) __syncthreads();
-        frugal_fft<T, N, E, SPLIT, false>(v, lds, m.t, tw, circle, ix.fft1_inv);
-        busy = true;
-      }
-      frugal_slot<T, N, E, 1, decltype(m), 0, false, 0, TAB>(v, ix.mid, ix.mid_ph, m, circle, inv3, ran4 && ix.fft2_inv != 0.0, m.t, lds, ran3);
-      if constexpr (kTwo) {
-        if (ran4) {
-          if (busy) __syncthreads();
-          frugal_fft<T, N, E, SPLIT>(v, lds, m.t, tw, circle, ix.fft2_inv);
-          busy = true;
-        }
-      }
-    };
+#define PAOS_EXTRA_PASS(ix, kTwo)                                                                                                    \
+  {                                                                                                                                  \
+    const bool ran3 = (ix).fft1_on != 0.0;                                                                                           \
+    const bool ran4 = (kTwo) && (ix).fft2_on != 0.0;                                                                                 \
+    const bool inv3 = ran3 && (ix).fft1_inv != 0.0;                                                                                  \
+    frugal_slot<T, N, E, 1, decltype(m), 0, false, 0, TAB>(v, (ix).pre, (ix).pre_ph, m, circle, false, inv3, m.t, lds, false);       \
+    if (ran3) {                                                                                                                      \
+      if (busy) __syncthreads();                                                                                                     \
+      frugal_fft<T, N, E, SPLIT, false>(v, lds, m.t, tw, circle, (ix).fft1_inv);                                                     \
+      busy = true;                                                                                                                   \
+    }                                                                                                                                \
+    frugal_slot<T, N, E, 1, decltype(m), 0, false, 0, TAB>(v, (ix).mid, (ix).mid_ph, m, circle, inv3, ran4 && (ix).fft2_inv != 0.0,  \
+                                                           m.t, lds, ran3);                                                          \
+    if constexpr (kTwo) {                                                                                                            \
+      if (ran4) {                                                                                                                    \
+        if (busy) __syncthreads();                                                                                                   \
+        frugal_fft<T, N, E, SPLIT>(v, lds, m.t, tw, circle, (ix).fft2_inv);                                                          \
+        busy = true;                                                                                                                 \
+      }                                                                                                                              \
+    }                                                                                                                                \
+  }
     // LONG = extra transforms: 1 -> [1], 2 -> [2], 3 -> [2][1], 4 -> [2][2]
     const FrugalItem& it2 = *(const FrugalItem*)((ConstItemPtr)a.items + item + gridDim.y);
-    if constexpr (LONG == 1) extra_pass(it2, std::false_type{});
-    else extra_pass(it2, std::true_type{});
-    if constexpr (LONG == 3) extra_pass(it_last, std::false_type{});
-    if constexpr (LONG == 4) extra_pass(it_last, std::true_type{});
+    if constexpr (LONG == 1) PAOS_EXTRA_PASS(it2, false)
+    else PAOS_EXTRA_PASS(it2, true)
+    if constexpr (LONG == 3) PAOS_EXTRA_PASS(it_last, false)
+    if constexpr (LONG == 4) PAOS_EXTRA_PASS(it_last, true)
+#undef PAOS_EXTRA_PASS
   }
   PAOS_STAMP(5);
   if constexpr (STORE == 1) {
