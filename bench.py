@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Headline benchmark: wavefronts/s through the 20-surface SYN20 chain.
 
-    python bench.py --gpus 1 --steps 5 --warmup 1            # 4096^2 complex128 (default)
+    python bench.py --gpus 1 --steps 20 --warmup 3           # 4096^2 complex128 (default)
     python bench.py --gpus N --steps K --warmup W            # starts its own N ranks (one process per GPU, no torch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W   # ... or joins the ranks a launcher started
@@ -20,17 +20,23 @@ seen and every rank's bring-up note).  Rank 0 prints one JSON line (contract in 
 
   roofline           the dominant kernel (the fused FFT pass): every pass launch of the timed region is bracketed by
                      HIP events on the context's stream (paos_profile_end_launches: time and class of each launch);
-                     `achieved` = 32 B/px x N^2 x batch (one read and one write of every element) / mean duration of
-                     the launches that skip nothing; `classes` lists every class of launch (full, skipping tiles of
-                     dead lines / loads of dead positions / stores nobody reads, storing the PSF) with its mean time
-                     and -- from the counters -- the bytes it really moved; `all_launches` sums both over one step;
-                     `copy_yardstick` is measured in this run (paos_copy_yardstick); `traffic` = HBM bytes per full
-                     launch from FETCH_SIZE / WRITE_SIZE, collected by two child runs of this script under
-                     rocprofv3 --pmc (measure_traffic; N = 1 only, --no-traffic skips it).
+                     `achieved` = the bytes the library's pruning plan has those launches load + store (live lines x
+                     (loaded + stored positions) x element size: paos_profile_planned_bytes -- for a launch that skips
+                     nothing: one read and one write of every element of the batch) / their summed duration; `dense` =
+                     the same kernel with the pruning off for one step (every launch moves the whole batch: what rounds
+                     1-3 reported as `achieved`); `classes` lists every class of launch (skipping tiles of dead lines /
+                     loads of dead positions / stores nobody reads, storing the PSF, running two or three passes of a
+                     row / column chain) with its mean time, planned bytes and -- from the counters -- the bytes it
+                     really moved; `all_launches` sums them over one step; `copy_yardstick` is measured in this run
+                     (paos_copy_yardstick); `traffic` = HBM bytes per launch from FETCH_SIZE / WRITE_SIZE, collected
+                     by two child runs of this script under rocprofv3 --pmc (measure_traffic; N = 1 only,
+                     --no-traffic skips it).
   chain_vs_survey_model / ptp_step   the whole chain and one ptp priced with SURVEY 8d's UNFUSED byte model next to
                      the bytes the launches of one step really moved under the counters.
   without_ptp_algebra  the rate over the SAME number of steps with the pass compiler's ptp identities switched off
                      (PAOS_PTP_ALGEBRA=0: 44 passes per wavefront instead of 24).
+  operator_by_operator  the rate over the same steps with the pass compiler of rounds 2-3 (PAOS_SEPARABLE=0: every operator's
+                     transforms glued to its neighbours' instead of row factors first, column factors second).
   same_wavelengths_every_step  the rate when every step repeats the first block of the sweep (how rounds 1-3 quoted
                      the headline; the walked sweep costs ~3 %: records rendered, PSF zeros rewritten).
   extra              2048^2 / 1024^2 (the north star's sweep); fp32_4096 (SYN20 in fp32 mode with its roofline);
