@@ -254,7 +254,9 @@ def measure_traffic(grid, batch, precision):
     if exe is None:
         return None, "rocprofv3 not found"
     series, trace_ms = {}, {}
-    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    # (round 4: a third child counts the vector instructions of every dispatch -- the pass launches of the separable
+    # programs are bound by their issue rate, not by bytes: roofline.issue)
+    for counter in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
         tmp = tempfile.mkdtemp(prefix="paos_pmc_", dir="/tmp")
         try:
             cmd = [exe, "--kernel-trace", "--pmc", counter, "-d", tmp, "-o", "pmc", "--output-format", "csv", "--",
@@ -265,6 +267,8 @@ def measure_traffic(grid, batch, precision):
                                  stderr=subprocess.PIPE, timeout=600)
             files = glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True)
             if run.returncode != 0 or not files:
+                if counter == "SQ_INSTS_VALU":
+                    continue  # (the byte counters stand on their own)
                 return None, f"rocprofv3 --pmc {counter} failed (exit {run.returncode})"
             per_dispatch = {}
             with open(files[0]) as fh:
@@ -300,7 +304,10 @@ def measure_traffic(grid, batch, precision):
     f, w = series["FETCH_SIZE"], series["WRITE_SIZE"]
     if not f or len(f) != len(w) or any(a[0] != b[0] for a, b in zip(f, w)):
         return None, f"dispatches seen: {len(f)} (FETCH_SIZE run) vs {len(w)} (WRITE_SIZE run), or in another order"
-    out = {"pass": [], "other": {}}
+    out = {"pass": [], "other": {}, "pass_valu": None}
+    v = series.get("SQ_INSTS_VALU")
+    if v and len(v) == len(f) and all(a[0] == b[0] for a, b in zip(f, v)):
+        out["pass_valu"] = [val for name, val in v if "_pass_kernel" in name]
     for (name, fetch), (_, write) in zip(f, w):
         rd, wr = 2.0 * fetch * 1024.0, write * 1024.0
         if "_pass_kernel" in name:
@@ -315,9 +322,9 @@ def measure_traffic(grid, batch, precision):
         short = name.split("<")[0].split("(")[0]
         if short in out["other"]:
             out["other"][short]["ms"] += ms
-    note = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE on one chain step of this workload (global step 1 of the "
-            "walked sweep) behind a warm-up step (two child runs, counters in KiB, FETCH_SIZE x2 per MI355X_MICROARCH.md), "
-            "every dispatch of that step kept")
+    note = ("rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU on one chain step of this workload (global "
+            "step 1 of the walked sweep) behind a warm-up step (three child runs, one counter each; byte counters in KiB, "
+            "FETCH_SIZE x2 per MI355X_MICROARCH.md), every dispatch of that step kept")
     return out, note
 
 
@@ -413,6 +420,22 @@ def roofline_block(m, n, nb, esz, dev, kernel_name, steps, traffic=None, traffic
             block["traffic_over_algorithmic"] = total / (float(planned[bounds[s]:bounds[s + 1]].sum()) or 1.0)
         block["traffic_note"] = (f"mean over the {len(step_tags)} pass launches of one step: read {reads / len(step_tags) / 1e9:.3f} GB "
                                  f"+ written {(total - reads) / len(step_tags) / 1e9:.3f} GB per launch")
+        valu = traffic.get("pass_valu")
+        if valu and len(valu) == len(step_tags):
+            # vector instructions of the counted step's launches against the issue rate of the chip: a wave64 fp64
+            # instruction holds its SIMD for 4 cycles (MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, 2.4 GHz peak clock)
+            insts = float(sum(valu))
+            step_ms = float(ms.sum()) / steps  # (the counted step is another run's: the mean pass time of a timed step of this one)
+            cycles = insts * 4.0 / (256 * 4)
+            block["issue"] = {
+                "valu_instructions_per_step": insts, "valu_instructions_per_launch": insts / len(step_tags),
+                "pass_launch_ms_per_step": step_ms,
+                "frac_of_issue_peak": cycles / (step_ms * 1e-3 * 2.4e9),
+                "what": "SQ_INSTS_VALU of the pass launches of the counted step (a third rocprofv3 --pmc child) x 4 cycles per "
+                        "wave instruction / 1024 SIMDs, over the mean HIP-event time of a step's pass launches in this run at the 2.4 GHz "
+                        "peak clock: the fraction of the vector issue slots the launches fill.  About three quarters of the "
+                        "instructions are fp64 (4 cycles); the chip holds ~1.7 GHz under this load (profiles/"
+                        "r03_timeline_workgroup_phases.txt), so the fraction of the slots it really has is ~1.4x this figure"}
     return block
 
 
