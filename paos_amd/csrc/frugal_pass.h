@@ -258,6 +258,33 @@ __device__ __forceinline__ cx<double> slot_factor(const double* g, const double*
   return p;
 }
 
+// The same factor in fp32 mode (complex64 fields): the argument in TURNS, still formed in fp64 (it reaches 1e5 turns), one
+// fraction, then the hardware sin / cos (inputs in revolutions).  turn_coef[j] = m2 coef / 2 pi (the sign rides on coef).
+// Shared by frugal_slot and phase_table_kernel like slot_factor.
+template <int K>
+__device__ __forceinline__ cx<float> slot_factor32(const double* g, const double* step, const double* across2,
+                                                   const double* turn_coef) {
+  cx<float> p = {1.0f, 0.0f};
+  if constexpr (K == 2 && PAOS_MERGE_PHASES != 0) {
+    // two phases of one slot: their turns add in fp64 (1e5 turns to 1e-11, the field carries 1e-7), then ONE
+    // fraction and ONE hardware sin / cos instead of two of each and a rotation
+    const double x0 = g[0] * step[0];
+    const double x1 = g[1] * step[1];
+    const double turns = fma(fma(x0, x0, across2[0]), turn_coef[0], fma(x1, x1, across2[1]) * turn_coef[1]);
+    const float frac = (float)(turns - floor(turns));
+    return cx<float>{__builtin_amdgcn_cosf(frac), __builtin_amdgcn_sinf(frac)};
+  }
+#pragma unroll
+  for (int j = 0; j < K; ++j) {
+    const double x = g[j] * step[j];
+    const double turns = fma(x, x, across2[j]) * turn_coef[j];
+    const float frac = (float)(turns - floor(turns));
+    const float snf = __builtin_amdgcn_sinf(frac), csf = __builtin_amdgcn_cosf(frac);
+    p = j == 0 ? cx<float>{csf, snf} : cmul_after_trans(p, cx<float>{csf, snf});
+  }
+  return p;
+}
+
 // RECS > 0: the aperture line records of the workgroup's RECS lines (first line ``lbase``) were fetched by the kernel
 // before the tile's loads (wave-uniform: scalar registers); RECS < 0: the kernel staged them in LDS (``recs``);
 // RECS = 0: the slot loads its line's record itself.
@@ -401,26 +428,22 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
     for (int j = 0; j < K; ++j) turn_coef[j] = ph[j].m2 * coefq[j] * 0.15915494309189535;  // / 2 pi; coef carries the sign
     const float ff = (float)f, ffy = (float)fy;
     auto factor32 = [&](int k) __attribute__((always_inline)) {
-      cx<float> p = {1.0f, 0.0f};
-      if constexpr (K == 2 && PAOS_MERGE_PHASES != 0) {
-        // two phases of one slot: their turns add in fp64 (1e5 turns to 1e-11, the field carries 1e-7), then ONE
-        // fraction and ONE hardware sin / cos instead of two of each and a rotation
-        const double x0 = ((k < E / 2 ? g_lo[0] : g_hi[0]) + (double)(k * TL)) * step[0];
-        const double x1 = ((k < E / 2 ? g_lo[KK - 1] : g_hi[KK - 1]) + (double)(k * TL)) * step[KK - 1];
-        const double turns = fma(fma(x0, x0, across2[0]), turn_coef[0], fma(x1, x1, across2[KK - 1]) * turn_coef[KK - 1]);
-        const float frac = (float)(turns - floor(turns));
-        return cx<float>{__builtin_amdgcn_cosf(frac), __builtin_amdgcn_sinf(frac)};
-      }
+      double gk[KK];
 #pragma unroll
-      for (int j = 0; j < K; ++j) {
-        const double x = ((k < E / 2 ? g_lo[j] : g_hi[j]) + (double)(k * TL)) * step[j];
-        const double turns = fma(x, x, across2[j]) * turn_coef[j];
-        const float frac = (float)(turns - floor(turns));
-        const float snf = __builtin_amdgcn_sinf(frac), csf = __builtin_amdgcn_cosf(frac);
-        p = j == 0 ? cx<float>{csf, snf} : cmul_after_trans(p, cx<float>{csf, snf});
-      }
-      return p;
+      for (int j = 0; j < K; ++j) gk[j] = (k < E / 2 ? g_lo[j] : g_hi[j]) + (double)(k * TL);
+      return slot_factor32<K>(gk, step, across2, turn_coef);
     };
+    if constexpr (K > 0 && TAB != 0) {  // TAB builds: the factors by position, from phase_table_kernel's table (cx<float> entries)
+      static_assert(!SHARE, "a table slot does not stand for a barrier");
+      const cx<float>* tb = reinterpret_cast<const cx<float>*>(sl.table) + tpos;
+#pragma unroll
+      for (int k = 0; k < E; ++k) {
+        const cx<float> zs = scale2(cmul(cx<float>{(float)v[k].x, (float)v[k].y}, tb[k * TL]), ff, ffy);
+        v[k] = {(T)zs.x, (T)zs.y};
+        if ((k + 1) % PAOS_TABLE_FENCE == 0) __builtin_amdgcn_sched_barrier(0);
+      }
+      return;
+    }
     if constexpr (SHARE && K > 0) {
       cx<float>* fac = reinterpret_cast<cx<float>*>(area);
       if (area_busy) lds_barrier();
@@ -533,11 +556,12 @@ struct PhaseTableArgs {
   const cx<double>* tw;        // the context's twiddle table for n
   const PhaseSlotDesc* desc;   // [gridDim.z]
   int n;
+  int f32;                     // complex64 fields: cx<float> entries from slot_factor32, no circle table
 };
 template <int UNIT = 0>  // (a template: the header is compiled into several translation units)
 __global__ void __launch_bounds__(256) phase_table_kernel(PhaseTableArgs a) {
   __shared__ cx<double> circle[kCircleLds];
-  {
+  if (!a.f32) {
     const cx<double> w = a.tw[threadIdx.x * (a.n / kCircleLds)];
     circle[threadIdx.x] = {w.x, -w.y};
   }
@@ -561,6 +585,18 @@ __global__ void __launch_bounds__(256) phase_table_kernel(PhaseTableArgs a) {
     across2[j] = 0.0;
     coefq[j] = __hiloint2double(__double2hiint(q.coef) ^ qflip, __double2loint(q.coef));
     m2[j] = q.m2;
+  }
+  if (a.f32) {
+    double turn_coef[kFrugalMaxMid];
+#pragma unroll
+    for (int j = 0; j < kFrugalMaxMid; ++j) turn_coef[j] = m2[j] * coefq[j] * 0.15915494309189535;
+    cx<float> pf = {1.0f, 0.0f};
+    if (K <= 0) {}
+    else if (K == 1) pf = slot_factor32<1>(g, step, across2, turn_coef);
+    else if (K == 2) pf = slot_factor32<2>(g, step, across2, turn_coef);
+    else pf = slot_factor32<3>(g, step, across2, turn_coef);
+    reinterpret_cast<cx<float>*>(const_cast<cx<double>*>(sl.table))[pos] = pf;
+    return;
   }
   cx<double> p = {1.0, 0.0};  // (K = 0: a slot without phases that rides in a fused pair)
   if (K <= 0) {}
@@ -695,7 +731,7 @@ template <typename T, int N, int E, int LINES, int TILES, int AXIS, int BR, int 
           int KPRE, int KMID, int NFFT, int STORE = 0, int TAB = 0, int LONG = 0>
 __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, TILES * LINES * N / E>()))
     frugal_pass_kernel(PAOS_FRUGAL_PARAMS) {
-  static_assert(LONG == 0 || (TAB != 0 && NFFT == 2 && KPRE == 1 && KMID == 1 && sizeof(T) == 8), "LONG builds: see above");
+  static_assert(LONG == 0 || (TAB != 0 && NFFT == 2 && KPRE == 1 && KMID == 1), "LONG builds: see above");
   FrugalArgs a;
   a.items = k_items; a.field = k_field; a.pitch = k_pitch; a.item_stride = k_item_stride; a.wg0 = k_wg0;
   a.tw = k_tw; a.psf = k_psf; a.psf_partial = k_psf_partial; a.pow_partial = k_pow_partial; a.dyn_scale = k_dyn_scale; a.live_lo = a.live_hi = 0;

@@ -689,7 +689,7 @@ int frugal_nfft(paos_ctx* c, const FrugalArgs& a, int nfft) {
   // (the digit-swapped two-transform variant NFFT = 3 of frugal_pass.h is built by tools/fftbench.hip only:
   // measured in round 2 with parity unchanged and no gain, profiles/r02_fftbench_digit_swapped_experiment.txt)
   if (a.tab && a.fuse) {  // ... and the launch runs the next pass -- or the next two -- of the program as well (LONG builds)
-    if constexpr (sizeof(T) == 8 && KPRE == 1 && KMID == 1) {
+    if constexpr (KPRE == 1 && KMID == 1) {
       if (nfft < 2) return fail(c, PAOS_EINVAL, "a fused chain starts with a two-transform pass");
 #define PAOS_LONG_CASE(L)                                                           \
   case L:                                                                           \
@@ -709,7 +709,7 @@ int frugal_nfft(paos_ctx* c, const FrugalArgs& a, int nfft) {
     }
   }
   if (a.tab) {  // the slots read their factors from tables: one build for any number of phases per slot
-    if constexpr (sizeof(T) == 8 && KPRE <= 1 && KMID <= 1 && KPRE + KMID > 0) {
+    if constexpr (KPRE <= 1 && KMID <= 1 && KPRE + KMID > 0) {
       if (a.psf) return nfft >= 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2, 1, 1>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1, 1, 1>(c, a);
       if (a.pow_partial) return nfft >= 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2, 2, 1>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1, 2, 1>(c, a);
       return nfft >= 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2, 0, 1>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1, 0, 1>(c, a);
@@ -918,7 +918,7 @@ int launch_mask_jobs(paos_ctx* c, MaskJobs& jobs, int count) {
 // hardware sin / cos).  PAOS_LINE_TABLES=0: every slot evaluates.
 bool phases_along_lines(const paos_ctx* c, const paos_pass& p, const LoweredPass& lp, bool or_none = false) {
   static const bool want = [] { const char* e = getenv("PAOS_LINE_TABLES"); return !(e && e[0] == '0'); }();
-  if (!want || c->precision != PAOS_F64 || (lp.kpre + lp.kmid == 0 && !or_none)) return false;
+  if (!want || (lp.kpre + lp.kmid == 0 && !or_none)) return false;
   const int counts[2] = {lp.kpre, lp.kmid};
   for (int l = 0; l < 2; ++l)
     for (const FrugalItem& fi : lp.items) {
@@ -970,7 +970,9 @@ int stage_groups(paos_ctx* c, std::vector<FusedGroup>& groups, const FrugalItem*
   for (FusedGroup& g : groups) {
     paos_pass axis_only{};
     axis_only.axis = g.axis;
-    g.tables = g.count > 1 || phases_along_lines(c, axis_only, *g.lp[0]);
+    // (complex64: a slot evaluates its factors with the hardware sin / cos for less than the table's loads cost -- measured: dense
+    // launches 2.03 -> 2.41 ms with tables -- so only the fused groups, whose one build reads tables, use them)
+    g.tables = g.count > 1 || (c->precision == PAOS_F64 && phases_along_lines(c, axis_only, *g.lp[0]));
     if (g.tables) slots += 2 * g.count;
   }
   if (slots > c->ptab_slots) {
@@ -1005,7 +1007,8 @@ int stage_groups(paos_ctx* c, std::vector<FusedGroup>& groups, const FrugalItem*
   if (rc) return rc;
   *ditems = reinterpret_cast<const FrugalItem*>(dflat);
   if (!descs.empty()) {
-    const PhaseTableArgs ta{*ditems, reinterpret_cast<const cx<double>*>(c->tw), reinterpret_cast<const PhaseSlotDesc*>(dflat + item_doubles), c->n};
+    const PhaseTableArgs ta{*ditems, reinterpret_cast<const cx<double>*>(c->tw), reinterpret_cast<const PhaseSlotDesc*>(dflat + item_doubles), c->n,
+                            c->precision == PAOS_F64 ? 0 : 1};
     hipLaunchKernelGGL(phase_table_kernel<0>, dim3(c->n / 256, c->batch, (unsigned)descs.size()), dim3(256), 0, c->stream, ta);
     HIPCHK(c, hipGetLastError());
   }
@@ -1096,11 +1099,11 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const doubl
     c->prof_next_bytes += (fi.line_hi - fi.line_lo) * ((fi.pos_hi - fi.pos_lo) * (double)elem_bytes(c) +
                                                         (store_psf ? (double)c->n * 8.0 : (fo.spos_hi - fo.spos_lo) * (double)elem_bytes(c)));
   }
+  a.tab = tables ? 1 : 0;  // (the TAB builds take "has phases" for the number of phases: their slots read one factor)
+  a.fuse = next2 ? 2 + next2->nfft : (next ? next->nfft : 0);  // LONG: the transforms of the passes that ride along
+  // (a fused pair runs on the one build whose four slots all read tables)
+  const int kpre = next ? 1 : (tables && lp.kpre > 1 ? 1 : lp.kpre), kmid = next ? 1 : (tables && lp.kmid > 1 ? 1 : lp.kmid);
   if (c->precision == PAOS_F64) {
-    a.tab = tables ? 1 : 0;  // (the TAB builds take "has phases" for the number of phases: their slots read one factor)
-    a.fuse = next2 ? 2 + next2->nfft : (next ? next->nfft : 0);  // LONG: the transforms of the passes that ride along
-    // (a fused pair runs on the one build whose four slots all read tables)
-    const int kpre = next ? 1 : (tables && lp.kpre > 1 ? 1 : lp.kpre), kmid = next ? 1 : (tables && lp.kmid > 1 ? 1 : lp.kmid);
     switch (c->n) {
       case 1024: return paos_frugal_d1024(c, a, p.axis, kpre, kmid, nfft);
       case 2048: return paos_frugal_d2048(c, a, p.axis, kpre, kmid, nfft);
@@ -1108,8 +1111,8 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const doubl
     }
   }
   switch (c->n) {
-    case 2048: return paos_frugal_f2048(c, a, p.axis, lp.kpre, lp.kmid, nfft);
-    default: return paos_frugal_f4096(c, a, p.axis, lp.kpre, lp.kmid, nfft);
+    case 2048: return paos_frugal_f2048(c, a, p.axis, kpre, kmid, nfft);
+    default: return paos_frugal_f4096(c, a, p.axis, kpre, kmid, nfft);
   }
 }
 

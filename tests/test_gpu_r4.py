@@ -155,11 +155,11 @@ def test_half_checkerboards_through_the_c_abi(n):
         dev.close()
 
 
-@pytest.mark.parametrize("n", [1024, 4096])
-def test_two_passes_in_one_launch_change_no_bit(n):
+@pytest.mark.parametrize("n,precision", [(1024, "fp64"), (4096, "fp64"), (2048, "fp32"), (4096, "fp32")])
+def test_two_passes_in_one_launch_change_no_bit(n, precision):
     """Where two (or three) consecutive passes of a row / column chain allow it the library runs them in one launch (frugal_pass.h:
     LONG builds; PAOS_FUSE_PAIRS=0 switches it off): the tile stays in registers between them -- the same arithmetic in
-    the same order, so the PSFs are equal bit for bit, in fewer launches."""
+    the same order, so the complex128 PSFs are equal bit for bit, in fewer launches (complex64: to fp32 rounding, see below)."""
     import os
 
     from paos_amd import _lib
@@ -168,11 +168,11 @@ def test_two_passes_in_one_launch_change_no_bit(n):
 
     wls = [syn20_wavelength(k) for k in (1, 255)]
     chains = [syn20_chain() for _ in wls]
-    dev = _lib.DeviceFields(n, len(wls), "fp64")
+    dev = _lib.DeviceFields(n, len(wls), precision)
     try:
         def step():
             dev.profile_begin(_lib.KERNEL_PASS_ANY, max_launches=256)
-            res = run_batch(1.0, wls, n, 4, ON_AXIS, chains, outputs=(), dev=dev, keep_psf=True)
+            res = run_batch(1.0, wls, n, 4, ON_AXIS, chains, outputs=(), dev=dev, keep_psf=True, precision=precision)
             _, tags = dev.profile_end_launches()
             return tags, [dev.psf_fetch(i) for i in range(len(wls))], [r[20]["power"] for r in res]
 
@@ -186,8 +186,17 @@ def test_two_passes_in_one_launch_change_no_bit(n):
         assert tags0.size == 24 and not np.any(tags0 & 48)
         assert tags.size < 24 and tags.size + int(np.sum((tags & 16) != 0)) + 2 * int(np.sum((tags & 32) != 0)) == 24
         for a, b in zip(psf, psf0):
-            assert np.array_equal(a, b)
-        assert power == power0
+            if precision == "fp64":
+                assert np.array_equal(a, b)
+            else:
+                # complex64: a fused launch reads its factors from tables (one product per slot), a single pass evaluates
+                # them with the hardware sin / cos -- two phases of a slot as two rotations where the table holds one: the
+                # same numbers to fp32 rounding, not to the bit
+                assert rel_err(a, b) < 2e-6
+        if precision == "fp64":
+            assert power == power0
+        else:
+            assert np.allclose(power, power0, rtol=1e-5)
     finally:
         dev.close()
 
