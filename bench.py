@@ -718,7 +718,11 @@ def main(argv=None):
                                    f"wavelength; the pass compiler runs a step as {passes_seen} fused passes: at each of the "
                                    f"chain's five foci the reference steps ptp(+d), ptp(-d) with d = 1.6 nm, which cancel "
                                    f"algebraically (H(-d) H(d) = 1, fft2(ifft2(X)) = X; same results to 1e-15, "
-                                   f"`without_ptp_algebra` gives the rate with every ptp run on its own); the final |u|^2 of "
+                                   f"`without_ptp_algebra` gives the rate with every ptp run on its own); since round 4 the row factors of every "
+                                   f"operator between two apertures run first, on the live rows, then the column factors, on the "
+                                   f"wanted columns, two or three consecutive passes of a chain per launch "
+                                   f"(`roofline.launches_per_step`; `operator_by_operator` gives the rate of rounds 2-3's "
+                                   f"order); the final |u|^2 of "
                                    f"every wavefront is written to HBM (8 B/px) and stays there, powers of the saved surfaces "
                                    f"are reduced on the GPU; aperture line records are kept per context and found again "
                                    f"where the next batch samples an aperture alike (`sweep`)",
