@@ -973,6 +973,14 @@ int stage_groups(paos_ctx* c, std::vector<FusedGroup>& groups, const FrugalItem*
     // (complex64: a slot evaluates its factors with the hardware sin / cos for less than the table's loads cost -- measured: dense
     // launches 2.03 -> 2.41 ms with tables -- so only the fused groups, whose one build reads tables, use them)
     g.tables = g.count > 1 || (c->precision == PAOS_F64 && phases_along_lines(c, axis_only, *g.lp[0]));
+    if (g.tables && g.count == 1) {
+      // (a single pass over most of the grid is bound by HBM, and the table's reads are traffic too: dense launches
+      // 3.75 ms evaluated, 3.85-4.0 with tables -- tables where the pass works on at most half of the lines)
+      double lines = 0.0, active = 0.0;
+      for (const FrugalItem& fi : g.lp[0]->items)
+        if (fi.active != 0.0) { lines += fi.line_hi - fi.line_lo; active += 1.0; }
+      if (active > 0.0 && lines > 0.5 * active * c->n) g.tables = false;
+    }
     if (g.tables) slots += 2 * g.count;
   }
   if (slots > c->ptab_slots) {
