@@ -8,6 +8,9 @@ behind them (csrc/paos_hip.hip: plan_pruning).
   are an eighth of the dense ones, and with the pruning off every launch is a full pass again with the same PSF.
 * A field buffer poisoned with NaN wherever the programs are not supposed to look (every stretch, not only the start).
 * The half checkerboards (PAOS_PWF_X_ONLY / PAOS_PWF_Y_ONLY) through the C ABI on the frugal AND the generic kernels.
+* Two or three consecutive passes of a row / column chain in one launch (LONG builds) against one launch per pass: bit-identical
+  in complex128, to fp32 rounding in complex64 (whose fused launches read tables where single passes evaluate).
+* Aperture line records through two boundary windows against the chunk scan: bit-identical fields for random ellipses.
 """
 import numpy as np
 import pytest
