@@ -468,17 +468,13 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
       lds_barrier();  // the transform behind the slot writes the area next
       return;
     }
+    // (round 4: the slot's ONE factor per element -- two phases through one sin / cos of their summed turns, as the sharing
+    // loop above and the tables of the fused launches have it -- instead of one rotation per phase: every path that puts a
+    // slot's phases on an element now multiplies by the same number, bit for bit)
 #pragma unroll
     for (int k = 0; k < E; ++k) {
       cx<float> z = {(float)v[k].x, (float)v[k].y};
-#pragma unroll
-      for (int j = 0; j < K; ++j) {
-        const double x = ((k < E / 2 ? g_lo[j] : g_hi[j]) + (double)(k * TL)) * step[j];
-        const double turns = fma(x, x, across2[j]) * turn_coef[j];
-        const float frac = (float)(turns - floor(turns));
-        const float snf = __builtin_amdgcn_sinf(frac), csf = __builtin_amdgcn_cosf(frac);
-        z = cmul_after_trans(z, cx<float>{csf, snf});  // two packed instructions (fft_core.h)
-      }
+      if constexpr (K > 0) z = cmul_after_trans(z, factor32(k));  // two packed instructions (fft_core.h)
       const cx<float> zs = scale2(z, ff, ffy);
       v[k] = {(T)zs.x, (T)zs.y};
       if ((k + 1) % PAOS_FENCE_EVERY == 0) __builtin_amdgcn_sched_barrier(0);

@@ -219,15 +219,8 @@ def test_dead_line_pruning_changes_nothing(n):
         for a, b in zip(*out):
             assert sorted(a) == sorted(b)
             for k in a:
-                if precision == "fp64":
-                    assert np.array_equal(a[k]["wfo"], b[k]["wfo"]), k
-                    assert a[k]["power"] == b[k]["power"]
-                else:
-                    # complex64 since round 4: with the pruning on, consecutive passes of a row / column chain run in one
-                    # launch that reads its phase factors from tables (one product per slot); with it off every pass
-                    # evaluates them (two phases of a slot as two rotations): equal to fp32 rounding, not to the bit
-                    assert rel_err(a[k]["wfo"], b[k]["wfo"]) < 2e-6, k
-                    assert abs(a[k]["power"] / b[k]["power"] - 1.0) < 1e-5
+                assert np.array_equal(a[k]["wfo"], b[k]["wfo"]), k
+                assert a[k]["power"] == b[k]["power"]
         return out[0]
 
     on_axis = {"us": 0.0, "ut": 0.0}

@@ -8,8 +8,8 @@ behind them (csrc/paos_hip.hip: plan_pruning).
   are an eighth of the dense ones, and with the pruning off every launch is a full pass again with the same PSF.
 * A field buffer poisoned with NaN wherever the programs are not supposed to look (every stretch, not only the start).
 * The half checkerboards (PAOS_PWF_X_ONLY / PAOS_PWF_Y_ONLY) through the C ABI on the frugal AND the generic kernels.
-* Two or three consecutive passes of a row / column chain in one launch (LONG builds) against one launch per pass: bit-identical
-  in complex128, to fp32 rounding in complex64 (whose fused launches read tables where single passes evaluate).
+* Two or three consecutive passes of a row / column chain in one launch (LONG builds) against one launch per pass: bit-identical,
+  complex128 and complex64 (whose fused launches read from tables the factors single passes evaluate).
 * Aperture line records through two boundary windows against the chunk scan: bit-identical fields for random ellipses.
 """
 import numpy as np
@@ -162,7 +162,7 @@ def test_half_checkerboards_through_the_c_abi(n):
 def test_two_passes_in_one_launch_change_no_bit(n, precision):
     """Where two (or three) consecutive passes of a row / column chain allow it the library runs them in one launch (frugal_pass.h:
     LONG builds; PAOS_FUSE_PAIRS=0 switches it off): the tile stays in registers between them -- the same arithmetic in
-    the same order, so the complex128 PSFs are equal bit for bit, in fewer launches (complex64: to fp32 rounding, see below)."""
+    the same order, so the PSFs are equal bit for bit, in fewer launches."""
     import os
 
     from paos_amd import _lib
@@ -188,18 +188,10 @@ def test_two_passes_in_one_launch_change_no_bit(n, precision):
             del os.environ["PAOS_FUSE_PAIRS"]
         assert tags0.size == 24 and not np.any(tags0 & 48)
         assert tags.size < 24 and tags.size + int(np.sum((tags & 16) != 0)) + 2 * int(np.sum((tags & 32) != 0)) == 24
+        # (complex64 too: a fused launch reads from tables the very factors a single pass evaluates -- slot_factor32)
         for a, b in zip(psf, psf0):
-            if precision == "fp64":
-                assert np.array_equal(a, b)
-            else:
-                # complex64: a fused launch reads its factors from tables (one product per slot), a single pass evaluates
-                # them with the hardware sin / cos -- two phases of a slot as two rotations where the table holds one: the
-                # same numbers to fp32 rounding, not to the bit
-                assert rel_err(a, b) < 2e-6
-        if precision == "fp64":
-            assert power == power0
-        else:
-            assert np.allclose(power, power0, rtol=1e-5)
+            assert np.array_equal(a, b)
+        assert power == power0
     finally:
         dev.close()
 
