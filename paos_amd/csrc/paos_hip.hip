@@ -1029,13 +1029,15 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const doubl
   LoweredPass* const last = next2 ? next2 : next;  // the pass whose stores leave the launch (nullptr: this one)
   // PAOS_DUMP_PASSES=1: one line per pass launch on stderr (shape and what item 0's two slots carry)
   static const bool dump = [] { const char* e = getenv("PAOS_DUMP_PASSES"); return e && e[0] == '1'; }();
-  if (dump && !lp.items.empty()) {
-    const FrugalItem& f = lp.items[0];
-    std::fprintf(stderr, "pass axis %d kpre %d kmid %d nfft %d | pre: sign %g scale %g mask %g | fft1 on %g inv %g | mid: sign %g scale %g mask %g | "
-                 "fft2 on %g inv %g | lines [%g, %g) fill %g loads [%g, %g) stores [%g, %g)\n", p.axis, lp.kpre, lp.kmid, lp.nfft, f.pre.sign_on,
-                 f.pre.scale, f.pre.mask_on, f.fft1_on, f.fft1_inv, f.mid.sign_on, f.mid.scale, f.mid.mask_on, f.fft2_on, f.fft2_inv,
-                 f.line_lo, f.line_hi, f.line_fill, f.pos_lo, f.pos_hi, f.spos_lo, f.spos_hi);
-  }
+  if (dump)
+    for (const LoweredPass* l : {(const LoweredPass*)&lp, (const LoweredPass*)next, (const LoweredPass*)next2}) {
+      if (!l || l->items.empty()) continue;
+      const FrugalItem& f = l->items[0];  // ("+pass": rides in the launch of the pass above it)
+      std::fprintf(stderr, "%spass axis %d kpre %d kmid %d nfft %d | pre: sign %g scale %g mask %g | fft1 on %g inv %g | mid: sign %g scale %g mask %g | "
+                   "fft2 on %g inv %g | lines [%g, %g) fill %g loads [%g, %g) stores [%g, %g)\n", l == &lp ? "" : "+", p.axis, l->kpre, l->kmid, l->nfft,
+                   f.pre.sign_on, f.pre.scale, f.pre.mask_on, f.fft1_on, f.fft1_inv, f.mid.sign_on, f.mid.scale, f.mid.mask_on, f.fft2_on, f.fft2_inv,
+                   f.line_lo, f.line_hi, f.line_fill, f.pos_lo, f.pos_hi, f.spos_lo, f.spos_hi);
+    }
   for (LoweredPass* l : {&lp, next, next2}) {  // render the records along the pass axis, right before the pass (every pass of a chain)
     if (!l || l->mask_block < 0 || !l->mask_render) continue;
     const double* ap = dblocks + (size_t)l->mask_block * c->batch * FP_STRIDE;
