@@ -8,7 +8,11 @@ ORDER = ["full", T, "skips loads of dead positions", "skips stores nobody reads"
          "skips loads of dead positions + skips stores nobody reads", T + " + stores the PSF instead of the field",
          # the separable programs of round 4: every launch skips the tiles of dead / unwanted lines
          T + " + skips loads of dead positions", T + " + skips stores nobody reads",
-         T + " + skips loads of dead positions + skips stores nobody reads"]
+         T + " + skips loads of dead positions + skips stores nobody reads",
+         # ... and a launch may run two or three consecutive passes of a row / column chain
+         T + " + skips loads of dead positions + skips stores nobody reads + runs two passes of a row / column chain",
+         T + " + skips loads of dead positions + skips stores nobody reads + runs three passes of a row / column chain",
+         T + " + skips loads of dead positions + stores the PSF instead of the field + runs three passes of a row / column chain"]
 for path in sys.argv[1:]:
     d = json.load(open(path))
     cl = d["roofline"].get("classes", {})
