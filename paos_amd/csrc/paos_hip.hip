@@ -863,8 +863,14 @@ int assign_mask_set(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const doub
   const int k = hit >= 0 ? hit : victim;
   paos_ctx::MaskSet& ms = c->mask_sets[k];
   if (!ms.lines) {
-    HIPCHK(c, hipMalloc(&ms.lines, (size_t)c->batch * c->n * sizeof(MaskLine)));
-    HIPCHK(c, hipMalloc(&ms.vals, (size_t)c->batch * c->n * 2 * kMaskW * sizeof(double)));
+    // (every set of the context at the first use of any: a sweep walks through all of them within two or three programs, and an
+    // allocation of this size in the middle of a later program stalls the stream -- a five-step bench run behind ONE warm-up step
+    // measured 7 % low for it)
+    for (paos_ctx::MaskSet& m2 : c->mask_sets) {
+      if (m2.lines) continue;
+      HIPCHK(c, hipMalloc(&m2.lines, (size_t)c->batch * c->n * sizeof(MaskLine)));
+      HIPCHK(c, hipMalloc(&m2.vals, (size_t)c->batch * c->n * 2 * kMaskW * sizeof(double)));
+    }
   }
   ms.used = ++c->mask_clock;
   lp.mask_set = k;
