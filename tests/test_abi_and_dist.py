@@ -440,3 +440,42 @@ def test_bench_self_launch_starts_ranks_relays_rank0_and_propagates_failure(capf
         del os.environ["PAOS_BENCH_REHEARSAL"]
     line = json.loads(capfd.readouterr().out.strip().splitlines()[-1])
     assert rc == 0 and line["devices_seen"] == [0, 0]
+
+
+def test_bench_roofline_block_accounting():
+    """bench.py's roofline block from synthetic launch records: `achieved` over every launch on the plan's bytes, `dense`
+    from the un-pruned leg, classes cut into steps by the launches timed per step (a launch may run two or three passes),
+    counter bytes and vector instructions matched by launch order.  Pure host logic: no GPU, no library."""
+    import numpy as np
+
+    import bench
+
+    class Dev:
+        def copy_yardstick(self, reps):
+            return 3.0, 2 * 16 * 4096 * 4096 * 32
+
+    steps, per_step = 2, 3
+    ms = np.array([1.0, 2.0, 0.5, 1.0, 2.0, 0.5])
+    tags = np.array([1 | 2, 1 | 2 | 4 | 16, 1 | 8 | 32] * steps, dtype=np.int32)
+    planned = np.array([2.0e9, 1.0e9, 1.0e9] * steps)
+    m = {"launch_ms": ms, "launch_tags": tags, "launch_bytes": planned, "fused_passes": 6, "per_step_passes": [6, 6],
+         "per_step_launches": [per_step, per_step], "first_timed_step": 3}
+    dense = {"launch_ms": np.array([4.0, 4.0, 1.0]), "launch_tags": np.array([0, 0, 8], dtype=np.int32)}
+    traffic = {"pass": [(1.2e9, 1.0e9), (0.6e9, 0.6e9), (0.5e9, 0.7e9)], "other": {}, "pass_valu": [4.0e8, 8.0e8, 2.0e8]}
+    n, nb, esz = 4096, 32, 16
+    r = bench.roofline_block(m, n, nb, esz, Dev(), "k", steps, traffic, dense=dense)
+    full = 2 * esz * n * n * nb
+    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and r["unit"] == "GB/s"
+    assert abs(r["achieved"] - planned.sum() / (ms.sum() * 1e-3) / 1e9) < 1e-9
+    assert abs(r["frac"] - r["achieved"] / 8000.0) < 1e-12
+    assert r["launches"] == 6 and r["launches_per_step"] == 3.0 and r["full_pass_bytes"] == full
+    assert abs(r["dense"]["achieved"] - full / 4.0e-3 / 1e9) < 1e-6 and r["dense"]["launches"] == 2
+    assert len(r["classes"]) == 3
+    two = [v for k, v in r["classes"].items() if "two passes" in k][0]
+    assert two["launches_per_step"] == 1.0 and two["avg_launch_ms"] == 2.0 and two["bytes_planned"] == 1.0e9 and two["bytes_measured"] == 1.2e9
+    assert abs(r["traffic"] - (2.2e9 + 1.2e9 + 1.2e9) / 3) < 1.0
+    assert abs(r["traffic_over_algorithmic"] - 4.6e9 / 4.0e9) < 1e-12
+    assert abs(r["issue"]["frac_of_issue_peak"] - (1.4e9 * 4 / 1024) / (3.5e-3 * 2.4e9)) < 1e-12
+    # without counters and without a dense leg the block still stands
+    r2 = bench.roofline_block(m, n, nb, esz, Dev(), "k", steps)
+    assert r2["traffic"] is None and "dense" not in r2 and "issue" not in r2 and len(r2["classes"]) == 3
