@@ -16,7 +16,9 @@ block of each step's wavelengths (weak scaling) after ONE broadcast of the packe
 WORLD_SIZE in the environment `--gpus N` starts the N ranks itself, BEFORE anything touches a GPU in the parent, which
 only relays rank 0's line and the exit codes.  With N > 1 the run FAILS (exit 3) when the ranks could not agree on
 RCCL, unless --allow-tcp is given -- and still prints a JSON line then (`"value": null`, the transport, the ranks
-seen and every rank's bring-up note).  Rank 0 prints one JSON line (contract in the task statement) with these extras:
+seen and every rank's bring-up note).  Rank 0 prints ONE JSON line of at most 4 KB as the last line of stdout
+(`contract_line`: the contract's keys, `roofline` for the dominant class of pass launch on the roofline that binds it,
+`cpu_baseline`) and writes everything else to bench_detail.json (`--detail`), where the record holds these entries:
 
   roofline           the dominant kernel (the fused FFT pass): every pass launch of the timed region is bracketed by
                      HIP events on the context's stream (paos_profile_end_launches: time and class of each launch);
@@ -220,16 +222,20 @@ def measure(dev, n, precision, wavelengths_of, chains, steps, warmup, comm=None,
 
     if timer:
         planned = dev.profile_planned_bytes() if hasattr(dev, "profile_planned_bytes") else None
+        lines = dev.profile_line_transforms() if hasattr(dev, "profile_line_transforms") else None
         ms, tags = dev.profile_end_launches()
         if planned is None or planned.size != ms.size:
             planned = np.zeros(ms.size)
+        if lines is None or lines.size != ms.size:
+            lines = np.zeros(ms.size)
     else:
-        ms, tags, planned = np.zeros(0), np.zeros(0, dtype=np.int32), np.zeros(0)
+        ms, tags, planned, lines = np.zeros(0), np.zeros(0, dtype=np.int32), np.zeros(0), np.zeros(0)
     if comm is not None:
         elapsed = comm.max(elapsed)
     full = tags == 0
     return {"elapsed": elapsed, "launches": int(ms.size), "kern_ms": float(ms.sum()), "pruned": int((~full).sum()),
             "pruned_ms": float(ms[~full].sum()), "launch_ms": ms, "launch_tags": tags, "launch_bytes": planned,
+            "launch_lines": lines,
             "fused_passes": stats.get("fused_passes"), "per_step_passes": per_step_passes,
             "per_step_launches": per_step_launches,
             "per_step_sets": per_step_sets, "first_timed_step": first_step + warmup, "res": res}
@@ -439,6 +445,179 @@ def roofline_block(m, n, nb, esz, dev, kernel_name, steps, traffic=None, traffic
     return block
 
 
+FP64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X: 256 CUs x 4 SIMDs x 16 fp64 FMA lanes x 2 flop x 2.4 GHz (half the fp32 vector peak of MI355X_MICROARCH.md)
+FP32_VECTOR_PEAK_TFLOPS = 157.3
+CONTRACT_LINE_MAX = 4096         # bytes: the driver keeps an 8 KB tail of stdout; round 4's 25 KB line did not parse
+
+
+def dominant_launch(m, n, precision, steps, traffic=None, traffic_step=1):
+    """The class of pass launch the timed region spends most of its time in, priced on BOTH of its candidate rooflines:
+    `hbm_frac` = the bytes the pruning plan has one such launch load + store / its mean HIP-event time / 8 TB/s;
+    `flop_frac` = its 1-D line transforms (paos_profile_line_transforms) x 5 N log2 N nominal flops / the same time / the
+    fp64 (fp32 mode: fp32) vector peak; `issue_frac` = SQ_INSTS_VALU of the class's launches in the counted step x 4 cycles
+    / 1024 SIMDs / time at the 2.4 GHz peak clock; `traffic` = FETCH_SIZE x 2 + WRITE_SIZE per launch of the class.  The
+    bound named is the resource with the larger fraction.  Returns None when nothing was timed."""
+    import math
+
+    import numpy as np
+
+    ms, tags, planned = m["launch_ms"], m["launch_tags"], m["launch_bytes"]
+    lines = m.get("launch_lines")
+    if not ms.size:
+        return None
+    by_time = {}
+    for t in set(int(x) for x in tags):
+        by_time[t] = float(ms[tags == t].sum())
+    tag = max(by_time, key=by_time.get)
+    sel = tags == tag
+    avg_ms = float(ms[sel].mean())
+    alg_bytes = float(planned[sel].mean()) if planned.size == ms.size else 0.0
+    peak_tf = FP64_VECTOR_PEAK_TFLOPS if precision == "fp64" else FP32_VECTOR_PEAK_TFLOPS
+    flops = float(lines[sel].mean()) * 5.0 * n * math.log2(n) if lines is not None and lines.size == ms.size else 0.0
+    out = {"tag": tag, "class": class_name(tag), "launches": int(sel.sum()), "avg_launch_ms": avg_ms,
+           "share_of_pass_time": by_time[tag] / float(ms.sum()),
+           "algorithmic_bytes_per_launch": alg_bytes or None,
+           "line_transforms_per_launch": float(lines[sel].mean()) if flops else None,
+           "hbm_GBps": alg_bytes / (avg_ms * 1e-3) / 1e9 if alg_bytes else None,
+           "hbm_frac": alg_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if alg_bytes else None,
+           "TFLOPs": flops / (avg_ms * 1e-3) / 1e12 if flops else None,
+           "flop_frac": flops / (avg_ms * 1e-3) / 1e12 / peak_tf if flops else None,
+           "flop_peak_TFLOPs": peak_tf, "traffic": None, "traffic_over_planned": None, "issue_frac": None,
+           "valu_instructions_per_launch": None}
+    counts = m.get("per_step_launches") or []
+    if traffic is not None and len(counts) == steps and sum(counts) == ms.size:
+        bounds = np.concatenate([[0], np.cumsum(counts)])
+        sidx = traffic_step - m["first_timed_step"]
+        sidx = sidx if 0 <= sidx < steps else 0
+        step_tags = tags[bounds[sidx]:bounds[sidx + 1]]
+        if len(traffic["pass"]) == len(step_tags):
+            moved = [r + w for t, (r, w) in zip(step_tags, traffic["pass"]) if int(t) == tag]
+            if moved:
+                out["traffic"] = sum(moved) / len(moved)
+                if alg_bytes:
+                    out["traffic_over_planned"] = out["traffic"] / alg_bytes
+            valu = traffic.get("pass_valu")
+            if valu and len(valu) == len(step_tags):
+                v = [x for t, x in zip(step_tags, valu) if int(t) == tag]
+                if v:
+                    out["valu_instructions_per_launch"] = sum(v) / len(v)
+                    out["issue_frac"] = (out["valu_instructions_per_launch"] * 4.0 / 1024.0) / (avg_ms * 1e-3 * 2.4e9)
+    cands = {"hbm": max(out["hbm_frac"] or 0.0, (out["traffic"] or 0.0) / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS),
+             "valu": max(out["flop_frac"] or 0.0, out["issue_frac"] or 0.0)}
+    out["bound"] = "hbm" if cands["hbm"] >= cands["valu"] else ("valu_fp64" if precision == "fp64" else "valu_fp32")
+    return out
+
+
+def _r(x, digits=4):
+    """A float rounded to ``digits`` significant digits (the contract line is read by people and a parser: 17 digits of a
+    time help neither); None and non-finite values become None -- the line is strict JSON."""
+    import math
+
+    if x is None:
+        return None
+    if isinstance(x, (int, str, bool)):
+        return x
+    x = float(x)
+    if not math.isfinite(x):
+        return None
+    if x == 0.0:
+        return 0.0
+    return round(x, digits - 1 - int(math.floor(math.log10(abs(x)))))
+
+
+def contract_line(full):
+    """The ONE line rank 0 prints last: the contract's keys and nothing else, <= CONTRACT_LINE_MAX bytes, strict JSON
+    (``full`` is the detailed record that goes to bench_detail.json).  `roofline` describes the dominant class of pass
+    launch on the roofline that binds it (`bound`; achieved / peak / unit / frac follow it) and carries the other
+    figures a reader needs beside it: the same launch's fraction of the HBM roofline, its issue-slot fraction, counter
+    traffic over planned bytes, the HBM fraction of all pass launches, of the dense (un-pruned) launches measured in the
+    same run, of one dense `ptp` over the batch (the north star's "FFT-propagate step") and of the copy yardstick."""
+    roof, dom = full.get("roofline") or {}, full.get("dominant_launch") or {}
+    cfg = full.get("config") or {}
+    hbm_bound = dom.get("bound", "hbm") == "hbm"
+    if dom:
+        achieved = dom.get("hbm_GBps") if hbm_bound else dom.get("TFLOPs")
+        peak = HBM_PEAK_GBS if hbm_bound else dom.get("flop_peak_TFLOPs")
+        unit = "GB/s" if hbm_bound else "TFLOP/s"
+        frac = dom.get("hbm_frac") if hbm_bound else dom.get("flop_frac")
+    else:  # (nothing was timed launch by launch: a generic-kernel grid)
+        achieved, peak, unit, frac = roof.get("achieved"), HBM_PEAK_GBS, "GB/s", roof.get("frac")
+    ptp = full.get("ptp_step") or {}
+    yard = (roof.get("copy_yardstick") or {}).get("GBps")
+    cpu = full.get("cpu_baseline")
+    line = {
+        "metric": full.get("metric"), "value": _r(full.get("value"), 6), "unit": full.get("unit"),
+        "n_gpus": full.get("n_gpus"), "steps": full.get("steps"), "warmup": full.get("warmup"),
+        "ms_per_step": _r(full.get("ms_per_step"), 6), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": full.get("dtype"), "data": "synthetic",
+        "config": {"workload": str(cfg.get("workload", ""))[:300], "grid": cfg.get("grid"),
+                   "batch_per_gpu": cfg.get("batch_per_gpu"), "parallelism": cfg.get("parallelism"),
+                   "transport": cfg.get("transport"), "ranks_seen": cfg.get("ranks_seen"),
+                   "devices_seen": cfg.get("devices_seen"), "launcher": cfg.get("launcher")},
+        "roofline": {
+            "bound": dom.get("bound", roof.get("bound", "hbm")),
+            "kernel": (str(roof.get("kernel", "")).split(" (")[0] + ": " + str(dom.get("class", "every pass launch")))[:160],
+            "achieved": _r(achieved), "peak": peak, "unit": unit, "frac": _r(frac),
+            "traffic": _r(dom.get("traffic") if dom else roof.get("traffic")),
+            "algorithmic_bytes_per_launch": _r(dom.get("algorithmic_bytes_per_launch") if dom else roof.get("algorithmic_bytes_per_launch")),
+            "avg_launch_ms": _r(dom.get("avg_launch_ms") if dom else roof.get("avg_launch_ms")),
+            "launches": dom.get("launches") if dom else roof.get("launches"),
+            "share_of_pass_time": _r(dom.get("share_of_pass_time")),
+            "hbm_frac": _r(dom.get("hbm_frac")), "flop_frac": _r(dom.get("flop_frac")), "issue_frac": _r(dom.get("issue_frac")),
+            "traffic_over_planned": _r(dom.get("traffic_over_planned")),
+            "all_launches_hbm_frac": _r(roof.get("frac")),
+            "dense_frac": _r((roof.get("dense") or {}).get("frac")),
+            "ptp_step_frac": _r(ptp.get("frac_bytes_moved")),
+            "copy_yardstick_frac": _r(yard / HBM_PEAK_GBS if yard else None),
+            "launches_per_step": _r(roof.get("launches_per_step")),
+        },
+        "cpu_baseline": ({"value": _r(cpu.get("value")), "unit": cpu.get("unit"), "cores": cpu.get("cores"),
+                          "kind": cpu.get("kind"), "sample": str(cpu.get("sample", ""))[:260]} if cpu else None),
+        "detail": full.get("detail_file"),
+    }
+    if full.get("error"):
+        line["error"] = str(full["error"])[:300]
+    text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    if len(text) > CONTRACT_LINE_MAX:  # cannot happen with the caps above; never print an unparseable line
+        line["config"]["workload"] = line["config"]["workload"][:80]
+        if line["cpu_baseline"]:
+            line["cpu_baseline"]["sample"] = line["cpu_baseline"]["sample"][:80]
+        text = json.dumps(line, allow_nan=False, separators=(",", ":"))
+    assert len(text) <= CONTRACT_LINE_MAX, len(text)
+    return text
+
+
+def _jsonable(x):
+    """The detailed record as strict JSON: NumPy scalars / arrays to Python, non-finite floats to None."""
+    import math
+
+    import numpy as np
+
+    if isinstance(x, dict):
+        return {str(k): _jsonable(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_jsonable(v) for v in x]
+    if isinstance(x, np.ndarray):
+        return _jsonable(x.tolist())
+    if isinstance(x, (np.floating, float)):
+        return float(x) if math.isfinite(float(x)) else None
+    if isinstance(x, (np.integer,)):
+        return int(x)
+    return x
+
+
+def write_detail(full, path):
+    """Everything beyond the contract line (classes, sweep, other kernels, side measurements, `extra`) as one JSON file;
+    returns the path written, or None (the line must come out whatever the file system says)."""
+    try:
+        with open(path, "w") as fh:
+            json.dump(_jsonable(full), fh, allow_nan=False, indent=1)
+        return path
+    except Exception as exc:  # noqa: BLE001
+        print(f"bench.py: could not write {path}: {exc}", file=sys.stderr)
+        return None
+
+
 def sweep_report(m):
     """What the walked sweep did to the context's kept aperture line records, per timed step."""
     sets = m["per_step_sets"]
@@ -518,15 +697,15 @@ def no_rccl_line(args, comm, world, local_rank):
     seen = [int(p[0]) for p in comm.allgather_scalars([float(local_rank)])]
     if comm.rank != 0:
         return
-    print(json.dumps({
+    print(contract_line({
         "metric": f"wavefronts/sec ({args.grid}^2 {'c128' if args.precision == 'fp64' else 'c64'}, 20-surface chain) + achieved HBM GB/s",
         "value": None, "unit": "wavefronts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "data": "synthetic",
+        "dtype": "c128 (f64)" if args.precision == "fp64" else "c64 (f32, f64 phase arguments)",
         "error": "RCCL did not come up on every rank: the ranks agreed on the TCP transport and --allow-tcp was not given "
-                 "(exit 3, nothing was measured)",
-        "config": {"workload": "not run", "grid": args.grid, "transport": comm.transport, "transport_requested": "rccl",
-                   "ranks_seen": len(seen), "devices_seen": seen,
-                   "bringup_notes": {str(r): t for r, t in enumerate(notes)}}}), flush=True)
+                 "(exit 3, nothing was measured); bring-up notes per rank: " +
+                 "; ".join(f"{r}: {t}" for r, t in enumerate(notes) if t),
+        "config": {"workload": "not run", "grid": args.grid, "batch_per_gpu": args.batch, "parallelism": f"wavefront-sharded x{world}",
+                   "transport": f"{comm.transport} (rccl requested)", "ranks_seen": len(seen), "devices_seen": seen}}), flush=True)
 
 
 def main(argv=None):
@@ -546,6 +725,9 @@ def main(argv=None):
                     help="with --gpus N > 1: accept the TCP transport when RCCL does not come up on every rank (default: exit 3)")
     ap.add_argument("--launch-timeout", type=float, default=3000.0, help="self-launch: seconds the ranks may take")
     ap.add_argument("--traffic-child", action="store_true", help=argparse.SUPPRESS)  # one chain step and nothing else (measure_traffic)
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="where the detailed record goes (classes of launch, sweep, other kernels, side measurements, extras); "
+                         "stdout carries the contract line only")
     args = ap.parse_args(argv)
     if args.batch <= 0:
         # 8 -> 32 wavefronts per step is +3 % (launch tails and host work amortised; 64: +0.3 % more): 217 -> 224 at 4096^2
@@ -712,7 +894,10 @@ def main(argv=None):
             "vs_baseline": None,
             "dtype": dtype,
             "data": "synthetic",
-            "config": {"workload": f"SYN20 20-surface chain, {n}x{n} {args.precision}, WALKED wavelength sweep 1um*(1+k/512): step g "
+            "config": {"workload": f"SYN20 20-surface chain (SURVEY 8d: {ffts} 2-D FFTs per wavefront as the reference runs it), {n}x{n} "
+                                   f"{args.precision}, walked 512-wavelength sweep, {nb} wavefronts/GPU/step, PSFs stay in HBM; "
+                                   f"separable pass programs + ptp identities ({passes_seen} passes/wavefront, parity 1e-15..2e-14 vs oracle)",
+                       "workload_notes": f"SYN20 20-surface chain, {n}x{n} {args.precision}, WALKED wavelength sweep 1um*(1+k/512): step g "
                                    f"runs k = g*{total} ... (mod 512), {nb} wavefronts/GPU/step, {ffts} 2-D FFTs per wavefront "
                                    f"({n_ptp} ptp, {n_stw} stw, {n_wts} wts as the reference executes them at the first "
                                    f"wavelength; the pass compiler runs a step as {passes_seen} fused passes: at each of the "
@@ -734,6 +919,7 @@ def main(argv=None):
                        "bringup_notes": {str(r): t for r, t in enumerate(notes) if t}},
             "sweep": sweep_report(m),
             "roofline": roofline_block(m, n, nb, esz, dev, kernel_name, args.steps, traffic, dense=dense),
+            "dominant_launch": dominant_launch(m, n, args.precision, args.steps, traffic),
             "chain_vs_survey_model": {
                 "survey_model_bytes_per_wavefront": survey_bytes,
                 "frac_of_hbm_peak_vs_survey_model": survey_bytes * per_gpu / 1e9 / HBM_PEAK_GBS,
@@ -768,7 +954,9 @@ def main(argv=None):
             out["cpu_baseline_parallel"] = cpu_parallel
         elif cpu_single is not None:
             out["cpu_baseline"] = cpu_single
-        print(json.dumps(out), flush=True)
+        # the detailed record to a file (and nothing but the contract line to stdout: <= 4 KB, strict JSON, last line)
+        out["detail_file"] = os.path.basename(args.detail) if write_detail(out, args.detail) else None
+        print(contract_line(out), flush=True)
     else:
         dev.close()
     if comm is not None:

@@ -115,6 +115,11 @@ int paos_profile_end_launches(paos_ctx* ctx, int capacity, double* ms_out, int* 
 /* round 4: the bytes the pruning plan had each launch timed so far load + store (live lines x (loaded + stored positions)
  * x element size, summed over the batch items): the launch's algorithmic bytes.  Call before paos_profile_end_*. */
 int paos_profile_planned_bytes(paos_ctx* ctx, int capacity, double* bytes_out, int* count);
+/* round 5: the 1-D line transforms each launch timed so far ran (live lines x the transforms switched on for the item,
+ * over every pass the launch carries and every batch item): x 5 N log2 N = the launch's nominal flops, what bench.py
+ * prices the fused launches with -- they move a sixteenth of the grid and are bound by fp64 issue, not by bytes.
+ * Call before paos_profile_end_*. */
+int paos_profile_line_transforms(paos_ctx* ctx, int capacity, double* lines_out, int* count);
 
 /* ---- field I/O ---------------------------------------------------------------------- */
 /* u[:] = re + i im for every batch item -- np.ones(..., complex128), wfo.py:118 */

@@ -62,6 +62,7 @@ SYMBOLS = {
     "paos_profile_end": (ctypes.c_int, [_c_ctx, ctypes.POINTER(ctypes.c_int), _dbl_p]),
     "paos_profile_end_split": (ctypes.c_int, [_c_ctx, ctypes.POINTER(ctypes.c_int), _dbl_p, ctypes.POINTER(ctypes.c_int), _dbl_p]),
     "paos_profile_planned_bytes": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p, ctypes.POINTER(ctypes.c_int)]),
+    "paos_profile_line_transforms": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p, ctypes.POINTER(ctypes.c_int)]),
     "paos_profile_end_launches": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p, ctypes.POINTER(ctypes.c_int),
                                                  ctypes.POINTER(ctypes.c_int)]),
     "paos_fill": (ctypes.c_int, [_c_ctx, ctypes.c_double, ctypes.c_double]),
@@ -292,6 +293,14 @@ class DeviceFields:
         n = ctypes.c_int(0)
         self._check(self._lib.paos_profile_planned_bytes(self._ctx, int(capacity), _dptr(out), ctypes.byref(n)),
                     "paos_profile_planned_bytes")
+        return out[:n.value].copy()
+
+    def profile_line_transforms(self, capacity=1 << 16):
+        """1-D line transforms every launch timed so far ran (call before profile_end_launches)."""
+        out = np.empty(capacity, dtype=np.float64)
+        n = ctypes.c_int(0)
+        self._check(self._lib.paos_profile_line_transforms(self._ctx, int(capacity), _dptr(out), ctypes.byref(n)),
+                    "paos_profile_line_transforms")
         return out[:n.value].copy()
 
     def profile_end_launches(self, capacity=1 << 16):

@@ -148,6 +148,8 @@ struct paos_ctx {
   int prof_next_tag = 0;
   double prof_next_bytes = 0.0;         // bytes the planner has the next timed launch load + store (its algorithmic bytes)
   std::vector<double> prof_bytes;       // per pair, like prof_tags
+  double prof_next_lines = 0.0;         // 1-D line transforms the next timed launch runs (live lines x transforms that are on, over the batch)
+  std::vector<double> prof_lines;       // per pair, like prof_tags
   size_t prof_used = 0;
 };
 
@@ -299,6 +301,8 @@ hipError_t timed_launch_end(paos_ctx* c, int tag) {
   c->prof_tags.push_back(tag);
   c->prof_bytes.resize(c->prof_tags.size() - 1, 0.0);
   c->prof_bytes.push_back(c->prof_next_bytes);
+  c->prof_lines.resize(c->prof_tags.size() - 1, 0.0);
+  c->prof_lines.push_back(c->prof_next_lines);
   c->prof_used += 2;
   return hipSuccess;
 }
@@ -1103,6 +1107,7 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const doubl
   // positions, bit 2: stores nobody reads, bit 3: it stores the PSF instead of the field
   c->prof_next_tag = store_psf ? 8 : 0;
   c->prof_next_bytes = 0.0;
+  c->prof_next_lines = 0.0;
   if (next) c->prof_next_tag |= next2 ? 32 : 16;  // bit 4: the launch ran two passes of the program, bit 5: three
   for (int it = 0; it < c->batch; ++it) {
     const FrugalItem& fi = lp.items[it];
@@ -1114,6 +1119,12 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const doubl
     // what the plan has this launch move: its live lines' loaded and stored positions (the PSF store: doubles, every position)
     c->prof_next_bytes += (fi.line_hi - fi.line_lo) * ((fi.pos_hi - fi.pos_lo) * (double)elem_bytes(c) +
                                                         (store_psf ? (double)c->n * 8.0 : (fo.spos_hi - fo.spos_lo) * (double)elem_bytes(c)));
+    // ... and compute: every live line goes through the transforms that are switched on for this item, in every pass of the launch
+    for (const LoweredPass* l : {(const LoweredPass*)&lp, (const LoweredPass*)next, (const LoweredPass*)next2}) {
+      if (!l) continue;
+      const FrugalItem& fk = l->items[it];
+      c->prof_next_lines += (fi.line_hi - fi.line_lo) * ((fk.fft1_on != 0.0 ? 1.0 : 0.0) + (l->nfft >= 2 && fk.fft2_on != 0.0 ? 1.0 : 0.0));
+    }
   }
   a.tab = tables ? 1 : 0;  // (the TAB builds take "has phases" for the number of phases: their slots read one factor)
   a.fuse = next2 ? 2 + next2->nfft : (next ? next->nfft : 0);  // LONG: the transforms of the passes that ride along
@@ -1666,6 +1677,7 @@ int paos_profile_begin(paos_ctx* c, int kernel_kind, int max_launches) {
   c->prof_used = 0;
   c->prof_tags.clear();
   c->prof_bytes.clear();
+  c->prof_lines.clear();
   return PAOS_OK;
 }
 
@@ -1714,6 +1726,16 @@ int paos_profile_planned_bytes(paos_ctx* c, int capacity, double* bytes_out, int
   const int n = (int)(c->prof_used / 2);
   if (n > capacity) return fail(c, PAOS_EINVAL, "more launches were timed than the caller's array holds");
   for (int i = 0; i < n; ++i) bytes_out[i] = (size_t)i < c->prof_bytes.size() ? c->prof_bytes[i] : 0.0;
+  *count = n;
+  return PAOS_OK;
+}
+
+// 1-D line transforms each timed launch so far ran (call BEFORE paos_profile_end_launches, which resets)
+int paos_profile_line_transforms(paos_ctx* c, int capacity, double* lines_out, int* count) {
+  if (!c || !lines_out || !count || capacity < 0) return fail(c, PAOS_EINVAL, "bad profile request");
+  const int n = (int)(c->prof_used / 2);
+  if (n > capacity) return fail(c, PAOS_EINVAL, "profile buffer too small");
+  for (int i = 0; i < n; ++i) lines_out[i] = (size_t)i < c->prof_lines.size() ? c->prof_lines[i] : 0.0;
   *count = n;
   return PAOS_OK;
 }

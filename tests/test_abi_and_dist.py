@@ -479,3 +479,85 @@ def test_bench_roofline_block_accounting():
     # without counters and without a dense leg the block still stands
     r2 = bench.roofline_block(m, n, nb, esz, Dev(), "k", steps)
     assert r2["traffic"] is None and "dense" not in r2 and "issue" not in r2 and len(r2["classes"]) == 3
+
+
+def test_bench_contract_line_is_small_strict_json():
+    """The ONE line bench.py prints (a 25 KB line did not parse): built from a synthetic measure() result with the
+    worst-case texts, it stays under 4 KB, round-trips as strict JSON (no NaN / Infinity), carries `roofline` and
+    `cpu_baseline` with the contract's keys, names the bound by the larger of the two roofline fractions of the dominant
+    class of launch, and the detail record is strict JSON too.  Pure host logic."""
+    import json
+
+    import numpy as np
+
+    import bench
+
+    class Dev:
+        def copy_yardstick(self, reps):
+            return 3.0, 2 * 16 * 4096 * 4096 * 32
+
+    steps, n, nb, esz = 2, 4096, 32, 16
+    ms = np.array([0.8, 1.3, 1.3, 0.9] * steps)
+    tags = np.array([1 | 4, 1 | 2 | 4 | 16, 1 | 2 | 4 | 16, 1 | 8 | 32] * steps, dtype=np.int32)
+    planned = np.array([2.7e9, 1.09e9, 1.09e9, 0.89e9] * steps)
+    lines = np.array([2 * 33024.0, 4 * 33024.0, 4 * 33024.0, 5 * 33024.0] * steps)
+    m = {"launch_ms": ms, "launch_tags": tags, "launch_bytes": planned, "launch_lines": lines, "fused_passes": 24,
+         "per_step_passes": [24, 24], "per_step_launches": [4, 4], "first_timed_step": 1}
+    traffic = {"pass": [(1.4e9, 1.4e9), (0.8e9, 0.62e9), (0.8e9, 0.62e9), (0.9e9, 0.66e9)], "other": {},
+               "pass_valu": [2.2e8, 4.7e8, 4.7e8, 4.2e8]}
+    dense = {"launch_ms": np.array([3.8, 3.9]), "launch_tags": np.array([0, 0], dtype=np.int32)}
+    dom = bench.dominant_launch(m, n, "fp64", steps, traffic)
+    assert dom["tag"] == (1 | 2 | 4 | 16) and dom["launches"] == 4 and abs(dom["avg_launch_ms"] - 1.3) < 1e-12
+    flops = 4 * 33024.0 * 5 * 4096 * 12
+    assert abs(dom["TFLOPs"] - flops / 1.3e-3 / 1e12) < 1e-9 and abs(dom["flop_frac"] - dom["TFLOPs"] / 78.6) < 1e-12
+    assert abs(dom["hbm_frac"] - 1.09e9 / 1.3e-3 / 1e9 / 8000.0) < 1e-12
+    assert abs(dom["issue_frac"] - (4.7e8 * 4 / 1024) / (1.3e-3 * 2.4e9)) < 1e-12
+    assert abs(dom["traffic"] - 1.42e9) < 1.0 and abs(dom["traffic_over_planned"] - 1.42e9 / 1.09e9) < 1e-12
+    assert dom["bound"] == "valu_fp64"  # 0.57 of the issue slots against 0.10 (0.14 on counted bytes) of 8 TB/s
+    full = {
+        "metric": "wavefronts/sec (4096^2 c128, 20-surface chain) + achieved HBM GB/s", "value": 1987.123456789, "unit": "wavefronts/s",
+        "n_gpus": 1, "steps": steps, "warmup": 3, "ms_per_step": 16.1234567, "dtype": "c128 (f64)",
+        "config": {"workload": "w" * 2000, "workload_notes": "x" * 5000, "grid": n, "batch_per_gpu": nb,
+                   "parallelism": "wavefront-sharded x1", "transport": "none (single process)", "launcher": "none",
+                   "ranks_seen": 1, "devices_seen": [0], "bringup_notes": {"0": "y" * 3000}},
+        "roofline": bench.roofline_block(m, n, nb, esz, Dev(), "frugal_pass_kernel (every FFT pass launch, rows and columns)", steps,
+                                         traffic, dense=dense),
+        "dominant_launch": dom,
+        "ptp_step": {"frac_bytes_moved": 0.636, "ms_per_wavefront": float("nan")},
+        "extra": {"big": ["z" * 100] * 300, "inf": float("inf"), "arr": np.arange(4), "np": np.float64(1.5)},
+        "cpu_baseline": {"value": 0.0213, "unit": "wavefronts/s", "cores": 1, "kind": "port", "sample": "s" * 1000},
+        "detail_file": "bench_detail.json",
+    }
+    text = bench.contract_line(full)
+    assert len(text) < 4096 and "\n" not in text
+    line = json.loads(text, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))  # NaN / Infinity would raise
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    assert line["value"] == 1987.12 and line["higher_is_better"] is True and line["vs_baseline"] is None
+    r = line["roofline"]
+    for key in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch",
+                "avg_launch_ms", "launches", "hbm_frac", "flop_frac", "issue_frac", "traffic_over_planned", "dense_frac",
+                "ptp_step_frac", "all_launches_hbm_frac", "copy_yardstick_frac"):
+        assert key in r, key
+    assert r["bound"] == "valu_fp64" and r["unit"] == "TFLOP/s" and r["peak"] == 78.6
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 2e-3 and r["ptp_step_frac"] == 0.636
+    assert abs(r["dense_frac"] - 2 * esz * n * n * nb / 3.85e-3 / 1e9 / 8000.0) < 1e-3
+    assert len(line["config"]["workload"]) <= 300 and set(line["cpu_baseline"]) == {"value", "unit", "cores", "kind", "sample"}
+    # an hbm-bound dominant class names hbm and reports GB/s
+    m2 = dict(m, launch_bytes=planned * 8.0)
+    full2 = dict(full, dominant_launch=bench.dominant_launch(m2, n, "fp64", steps, None))
+    l2 = json.loads(bench.contract_line(full2))
+    assert l2["roofline"]["bound"] == "hbm" and l2["roofline"]["unit"] == "GB/s" and l2["roofline"]["peak"] == 8000.0
+    # the exit-3 record of a scaling run without RCCL: same function, value null
+    l3 = json.loads(bench.contract_line({"metric": "m", "value": None, "unit": "wavefronts/s", "n_gpus": 8, "steps": 5, "warmup": 1,
+                                         "ms_per_step": None, "dtype": "c128 (f64)", "error": "e" * 1000,
+                                         "config": {"workload": "not run", "ranks_seen": 8, "devices_seen": list(range(8))}}))
+    assert l3["value"] is None and l3["config"]["ranks_seen"] == 8 and len(l3["error"]) <= 300
+    # the detail record: strict JSON whatever the measurements held
+    import tempfile
+
+    with tempfile.TemporaryDirectory() as tmp:
+        path = bench.write_detail(full, os.path.join(tmp, "d.json"))
+        back = json.load(open(path), parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
+        assert back["extra"]["inf"] is None and back["extra"]["arr"] == [0, 1, 2, 3] and back["ptp_step"]["ms_per_wavefront"] is None
