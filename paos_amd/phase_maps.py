@@ -12,7 +12,9 @@ same NumPy build:
   odd size difference or a different pixel scale, ``resize`` for a final shape mismatch; wfo.py:702-716, 739-750,
   786-800, 845-859) run on :func:`_ski_resize`, a restatement of ``skimage.transform.resize`` 0.24.0
   (poetry.lock:3268; the package is neither under /root/reference nor in this image) from its published
-  algorithm on ``scipy.ndimage`` -- **parity unpinned**: nothing here can be compared with scikit-image itself.
+  algorithm on ``scipy.ndimage`` -- pinned by the reference's own recorded run of these branches
+  (``notebook/ComputeGridSag.ipynb`` cells 10, 12, 15, 17-19: the sums of an anti-aliased rescale to 1e-14 / bit-exact,
+  the refine -> crop -> rescale shape trail, RMS / PV to the printed digits: ``tests/test_grid_sag_known_answers.py``).
 * :func:`psd_map` -- paos/classes/psd.py:100-160: a white-noise field from NumPy's legacy global
   generator (``np.random.randn`` exactly like the reference, so ``np.random.seed`` makes a run
   reproducible -- and comparable with the reference), filtered by the power-law PSD, plus surface

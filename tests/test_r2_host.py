@@ -124,11 +124,12 @@ def test_grid_sag_maps_match_reference():
         grid_sag_map(np.ones((64, 64)), 32, 64, b.dx, b.dy, 0.0, 0.0, (64, 64), b.dx, b.dy)
 
 
-def test_grid_sag_resampling_is_sane_but_unpinned():
+def test_grid_sag_resampling_is_sane():
     """The branches of WFO.grid_sag that call scikit-image (wfo.py:786-800, 845-859): a sag at another pixel scale, an
     odd size difference, a final shape nudge.  scikit-image 0.24.0 is not available, so `_ski_resize` restates its
-    published algorithm on scipy.ndimage and NOTHING here pins it to the real package: the checks are about sanity
-    (shapes, masks, a smooth surface reproduced to the accuracy of cubic interpolation, value range kept)."""
+    published algorithm on scipy.ndimage; it is PINNED by the reference's recorded notebook run in
+    tests/test_grid_sag_known_answers.py -- the checks here are about sanity on more shapes (masks, a smooth surface
+    reproduced to the accuracy of cubic interpolation, value range kept)."""
     from paos_amd.phase_maps import _ski_rescale, _ski_resize, grid_sag_map
 
     n, dx = 64, 1.0 / 16
