@@ -576,7 +576,7 @@ def contract_line(full):
         "detail": full.get("detail_file"),
     }
     if full.get("error"):
-        line["error"] = str(full["error"])[:300]
+        line["error"] = str(full["error"])[:800]
     text = json.dumps(line, allow_nan=False, separators=(",", ":"))
     if len(text) > CONTRACT_LINE_MAX:  # cannot happen with the caps above; never print an unparseable line
         line["config"]["workload"] = line["config"]["workload"][:80]
@@ -701,11 +701,10 @@ def no_rccl_line(args, comm, world, local_rank):
         "metric": f"wavefronts/sec ({args.grid}^2 {'c128' if args.precision == 'fp64' else 'c64'}, 20-surface chain) + achieved HBM GB/s",
         "value": None, "unit": "wavefronts/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None,
         "dtype": "c128 (f64)" if args.precision == "fp64" else "c64 (f32, f64 phase arguments)",
-        "error": "RCCL did not come up on every rank: the ranks agreed on the TCP transport and --allow-tcp was not given "
-                 "(exit 3, nothing was measured); bring-up notes per rank: " +
-                 "; ".join(f"{r}: {t}" for r, t in enumerate(notes) if t),
+        "error": "RCCL did not come up on every rank (exit 3, nothing measured; --allow-tcp accepts the TCP transport); "
+                 "bring-up notes per rank: " + "; ".join(f"{r}: {t[:120]}" for r, t in enumerate(notes) if t),
         "config": {"workload": "not run", "grid": args.grid, "batch_per_gpu": args.batch, "parallelism": f"wavefront-sharded x{world}",
-                   "transport": f"{comm.transport} (rccl requested)", "ranks_seen": len(seen), "devices_seen": seen}}), flush=True)
+                   "transport": comm.transport, "ranks_seen": len(seen), "devices_seen": seen}}), flush=True)
 
 
 def main(argv=None):
@@ -761,7 +760,7 @@ def main(argv=None):
 
     comm = None
     if world > 1 or os.environ.get("PAOS_BENCH_FORCE_COMM") == "1":
-        from paos_amd.comm import Comm  # (exports HSA_ENABLE_IPC_MODE_LEGACY=0 unless set: before the first HIP call)
+        from paos_amd.comm import Comm  # (an RCCL Comm exports HSA_ENABLE_IPC_MODE_LEGACY=0 unless set: before the first HIP call)
 
         if os.environ.get("PAOS_BENCH_REHEARSAL") == "1":
             # several ranks sharing ONE GPU over the TCP transport: rehearses the N > 1 control flow (launch, broadcast,

@@ -176,7 +176,10 @@ int paos_make_stop(paos_ctx* ctx, const double* enable);
 /* make_stop (wfo.py:195-201) for a field whose power the context has JUST reduced: the pass program that stored the
  * field ended with final_intensity = 2 (paos_run_program) and nothing has run on the context since.  Only the scaling
  * sweep u *= 1/sqrt(power) is launched -- the reduction that would read the field back has already been done by the
- * pass that stored it.  The caller vouches for the precondition (paos_amd/run.py: _walk is the one caller). */
+ * pass that stored it.  Round 5: the context checks the precondition itself -- a flag set by such a program and cleared by
+ * every entry point that reads or rewrites the field or reduces a power (including this one and the next: behind a stop
+ * the reduced power no longer is the field's); when it is clear, both functions run paos_make_stop (same result, one
+ * reduction more). */
 int paos_stop_scale_last_power(paos_ctx* ctx, const double* enable);
 /* The same stop, with even the scaling sweep left out: 1 / sqrt(power) is kept per item on the device and the NEXT pass
  * program's first pass multiplies it into its middle slot (one more factor in a multiplication it performs anyway), so

@@ -226,11 +226,20 @@ def release_pinned_pool():
         load().paos_host_free(ctypes.c_void_p(address))
 
 
+_HIP_TOUCHED = [False]
+
+
+def hip_initialised():
+    """Has this process asked the library for a device context yet (the first HIP call of the process)?"""
+    return _HIP_TOUCHED[0]
+
+
 class DeviceFields:
     """``batch`` n x n complex fields in HBM plus the stream that owns them."""
 
     def __init__(self, n, batch=1, precision="fp64", device=0):
         self._lib = load()
+        _HIP_TOUCHED[0] = True
         self._ctx = _c_ctx()
         self.n, self.batch = int(n), int(batch)
         if precision not in ("fp64", "fp32"):
@@ -413,11 +422,15 @@ class DeviceFields:
         self._check(self._lib.paos_zero_outside_rows(self._ctx, _dptr(self._rows(live_rows))), "paos_zero_outside_rows")
 
     def norm2_fetch(self, ticket):
+        if hasattr(ticket, "fetch"):  # a run.PowerTicket: fetched once, however many records share it
+            return ticket.fetch()
         out = np.empty(self.batch, dtype=np.float64)
         self._check(self._lib.paos_norm2_fetch(self._ctx, int(ticket), _dptr(out)), "paos_norm2_fetch")
         return out
 
     def norm2_release(self, ticket):
+        if hasattr(ticket, "release"):
+            return ticket.release()
         self._check(self._lib.paos_norm2_release(self._ctx, int(ticket)), "paos_norm2_release")
 
     def psf_metrics(self, radii_px=(), centre=None):

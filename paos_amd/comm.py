@@ -12,10 +12,26 @@ import numpy as np
 
 from . import _lib
 
-# RCCL's buffer exchange between processes needs dmabuf IPC on these hosts; the variable is read when the HSA runtime
-# starts, i.e. it must be in the environment before the FIRST HIP call of the process -- so it is set when this module
-# is imported (paos_comm_init_rank sets it too, for callers of the C ABI).  A value the user exported is kept.
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def _want_dmabuf_ipc():
+    """RCCL's buffer exchange between processes needs dmabuf IPC on these hosts (HSA_ENABLE_IPC_MODE_LEGACY=0); the
+    variable is read when the HSA runtime starts, i.e. it must be in the environment before the FIRST HIP call of the
+    process.  Set only when an RCCL communicator is asked for (importing this module used to export it for
+    every process, single-GPU and TCP-only ones included); a value the user exported is kept; a process that has already
+    created a device context is told that the setting comes too late (paos_comm_init_rank sets it too, for callers of
+    the C ABI)."""
+    if "HSA_ENABLE_IPC_MODE_LEGACY" in os.environ:
+        return
+    if _lib.hip_initialised():
+        import warnings
+
+        warnings.warn("an RCCL communicator is being created after this process has already used the GPU: "
+                      "HSA_ENABLE_IPC_MODE_LEGACY=0 was not in the environment when HIP started, so RCCL may fail with "
+                      "'hipIpcGetMemHandle: invalid argument' -- create the Comm before the first DeviceFields, or export "
+                      "the variable", RuntimeWarning, stacklevel=3)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+
 
 SOCKET, RCCL = 0, 1
 _c_comm = ctypes.c_void_p
@@ -62,6 +78,8 @@ class Comm:
     def __init__(self, nranks=1, rank=0, device=0, transport="socket", key=None, rendezvous_dir=None, timeout=120.0):
         self._lib = _load()
         code = {"socket": SOCKET, "rccl": RCCL}[transport]
+        if code == RCCL:
+            _want_dmabuf_ipc()
         self._h = _c_comm()
         rc = self._lib.paos_comm_init_rank(int(nranks), int(rank), int(device), code,
                                            key.encode() if key else None,

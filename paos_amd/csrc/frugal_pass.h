@@ -964,7 +964,8 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
       __builtin_amdgcn_sched_barrier(0);
     }
     PAOS_STAMP(3);
-    frugal_slot<T, N, E, KMID>(v, it.mid, it.mid_ph, m, circle, false, it.fft2_inv != 0.0, swap_nibbles(m.t));
+    // (h_dyn: a deferred stop's 1 / sqrt(power) rides on this slot like on the NFFT <= 2 shapes' -- ADVICE r04)
+    frugal_slot<T, N, E, KMID>(v, it.mid, it.mid_ph, m, circle, false, it.fft2_inv != 0.0, swap_nibbles(m.t), nullptr, false, nullptr, 0, h_dyn);
     PAOS_STAMP(4);
     fft4096_swapped_to_nat<T>(v, area, m.t, tw, circle);
     {

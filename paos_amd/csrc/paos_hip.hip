@@ -96,6 +96,11 @@ struct paos_ctx {
   int ptab_slots = 0;          // program about to run (FrugalSlot::table; stage_groups)
   double* dyn_scale = nullptr;
   bool dyn_pending = false;
+  // c->norm2 holds sum |u|^2 of the field exactly as it is stored: set by a pass program whose last pass summed it on the
+  // way out (paos_run_program, final_intensity = 2), cleared by every entry point that reads or rewrites the field or
+  // reduces into c->norm2 (SETTLE_SCALE / DROP_SCALE sit at the top of all of them).  paos_stop_scale_last_power and
+  // paos_stop_defer_last_power trust c->norm2 only while it is set and run paos_make_stop otherwise.
+  bool norm2_of_field = false;
   // What the PSF buffer (and psf_partial) is known to hold after a pass stored it: for item i the lines along
   // psf_zero_axis outside [psf_zero_lo[i], psf_zero_hi[i]) are zero (their per-workgroup sums too).  The next
   // PSF-storing pass with the same live lines need not write those zeros again; -1 = nothing known.
@@ -830,8 +835,8 @@ int settle_scale(paos_ctx* c, bool field_is_overwritten = false) {
   c->dyn_pending = false;
   return PAOS_OK;
 }
-#define SETTLE_SCALE(c) do { if ((c) && (c)->dyn_pending) { int rc_ = settle_scale(c); if (rc_) return rc_; } } while (0)
-#define DROP_SCALE(c) do { if ((c) && (c)->dyn_pending) { int rc_ = settle_scale(c, true); if (rc_) return rc_; } } while (0)
+#define SETTLE_SCALE(c) do { if (c) { (c)->norm2_of_field = false; if ((c)->dyn_pending) { int rc_ = settle_scale(c); if (rc_) return rc_; } } } while (0)
+#define DROP_SCALE(c) do { if (c) { (c)->norm2_of_field = false; if ((c)->dyn_pending) { int rc_ = settle_scale(c, true); if (rc_) return rc_; } } } while (0)
 
 
 bool frugal_sizes(const paos_ctx* c) {
@@ -1230,6 +1235,7 @@ int run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double*
 int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks, int n_blocks,
                     const double* entry_rows, bool entry_stale, int* final_ticket, int final_mode) {
   if (!c || !passes || !blocks || n_passes < 0 || n_blocks < 1) return fail(c, PAOS_EINVAL, "bad pass program");
+  c->norm2_of_field = false;  // (set again at the end when the last pass sums the power of what it stores)
   // A program that ends on the PSF gives the field up for it: the free power-ticket slot it will need is checked
   // BEFORE anything is launched (found full afterwards, the context held neither field nor ticket).
   if (final_ticket && c->norm_busy[next_norm_slot(c)])
@@ -1512,8 +1518,10 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
     i = j;
   }
   if (final_ticket && final_mode == 2) {
-    if (fused_power) return psf_power_ticket(c, c->pow_partial, power_groups, final_ticket);
-    return paos_norm2_enqueue(c, final_ticket);  // (a generic-kernel pass, or an item that sat the last pass out)
+    // (the fallback: a generic-kernel pass, or an item that sat the last pass out)
+    const int rcp = fused_power ? psf_power_ticket(c, c->pow_partial, power_groups, final_ticket) : paos_norm2_enqueue(c, final_ticket);
+    if (rcp == PAOS_OK) c->norm2_of_field = true;  // c->norm2 = the power of every item's field as stored
+    return rcp;
   }
   if (final_ticket) {
     if (fused_store) {
@@ -2108,9 +2116,11 @@ int paos_make_stop(paos_ctx* c, const double* enable) {
 }
 
 int paos_stop_scale_last_power(paos_ctx* c, const double* enable) {
-  SETTLE_SCALE(c);
-  if (c) (void)hipSetDevice(c->device);
   if (!c) return fail(c, PAOS_EINVAL, "null context");
+  // something has touched the field or c->norm2 since the program summed the power (or no program did): reduce now
+  if (!c->norm2_of_field) return paos_make_stop(c, enable);
+  SETTLE_SCALE(c);  // (clears norm2_of_field: behind the stop c->norm2 no longer is the field's power)
+  (void)hipSetDevice(c->device);
   const double* den = nullptr;
   if (enable) {
     int rc = arena_push(c, enable, (size_t)c->batch, &den);
@@ -2126,9 +2136,12 @@ int paos_stop_scale_last_power(paos_ctx* c, const double* enable) {
 }
 
 int paos_stop_defer_last_power(paos_ctx* c, const double* enable) {
-  if (c) (void)hipSetDevice(c->device);
   if (!c) return fail(c, PAOS_EINVAL, "null context");
-  SETTLE_SCALE(c);  // (a second stop with nothing in between: the first one's factor goes into the field first)
+  // (a second stop with nothing in between lands here too: the first one consumed the flag, so this one reduces the
+  // field as it then is -- make_stop settles the first one's factor first)
+  if (!c->norm2_of_field) return paos_make_stop(c, enable);
+  (void)hipSetDevice(c->device);
+  SETTLE_SCALE(c);  // (clears norm2_of_field)
   const double* den = nullptr;
   if (enable) {
     int rc = arena_push(c, enable, (size_t)c->batch, &den);

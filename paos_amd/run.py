@@ -71,6 +71,58 @@ _OFF_PHASE = [0.0] * _lib.PHASE_STRIDE
 _OFF_APERTURE = [0.0] * _lib.APERTURE_STRIDE
 
 
+class _Reduction:
+    """One reduction of sum |u|^2 per item that is outstanding on the device (a ticket slot of paos_norm2_enqueue* /
+    paos_run_program).  The library frees the slot on the first fetch and hands it out again, so the values are fetched
+    at most once and kept here; every record that the reduction answers for shares this object."""
+
+    __slots__ = ("dev", "slot", "raw", "released")
+
+    def __init__(self, dev, slot):
+        self.dev, self.slot, self.raw, self.released = dev, int(slot), None, False
+
+    def values(self):
+        if self.raw is None:
+            if self.released:
+                raise RuntimeError("this power was given back unread (PowerTicket.release)")
+            self.raw = self.dev.norm2_fetch(self.slot)  # synchronises the stream
+        return self.raw
+
+    def release(self):
+        if self.raw is None and not self.released:
+            self.dev.norm2_release(self.slot)
+            self.released = True
+
+
+class PowerTicket:
+    """What ``run_batch(..., sync=False)`` leaves under ``'power_ticket'``: a handle to the powers (one per batch item)
+    of a saved surface that are still being reduced on the GPU.  ``fetch()`` waits for them and returns the array --
+    any number of times, from any of the records that share the reduction (several saved surfaces can be answered by
+    one reduction: a saved slit and the image plane right behind it); ``release()`` gives the slot back unread.
+    ``dev.norm2_fetch(ticket)`` / ``dev.norm2_release(ticket)`` accept the handle as well.  A power that is derived
+    from the reduced one (the power BEHIND a stop that scales by it) is derived at fetch time: nothing synchronises
+    before the caller asks."""
+
+    __slots__ = ("_red", "_post")
+
+    def __init__(self, reduction, post=None):
+        self._red, self._post = reduction, post
+
+    def fetch(self):
+        v = self._red.values()
+        return self._post(v) if self._post is not None else v
+
+    def release(self):
+        self._red.release()
+
+    def __int__(self):  # the slot, for diagnostics
+        return self._red.slot
+
+    def __repr__(self):
+        state = "fetched" if self._red.raw is not None else ("released" if self._red.released else "outstanding")
+        return f"PowerTicket(slot {self._red.slot}, {state}{', derived' if self._post is not None else ''})"
+
+
 class _Item:
     """Host state of one wavefront while it walks the chain: the two paraxial rays of the field
     point and the ray-transfer factors met so far.  (The pilot beams of all wavefronts live together
@@ -659,8 +711,9 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
     ``wavelengths[i]`` / ``opt_chains[i]`` describe wavefront ``i`` (chains must
     contain the same surfaces).  Returns a list of ``B`` dicts
     ``{num: {scalars..., 'power': sum|u|^2, ['psf'], ['wfo'], ['amplitude'], ['phase']}}``
-    for saved surfaces (with ``sync=False`` the power is left as ``'power_ticket'`` for
-    ``dev.norm2_fetch``).  ``outputs`` picks which N x N arrays are copied back to the
+    for saved surfaces (with ``sync=False`` the power is left as ``'power_ticket'``, a :class:`PowerTicket`:
+    ``ticket.fetch()[i]`` -- or ``dev.norm2_fetch(ticket)[i]`` -- is item i's power; records whose powers come from one
+    reduction share one handle state, so every record may be fetched, in any order, any number of times).  ``outputs`` picks which N x N arrays are copied back to the
     host per saved surface and item ('psf' = |u|^2, plot.py:125-130); ``()`` keeps
     every array on the GPU and returns scalars and the power only -- the mode the
     throughput benchmark uses.  ``metrics_radii_px`` (up to 16 radii, pixels) adds
@@ -695,28 +748,37 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
     # nobody reads an array at a saved surface: the walk may skip writing dead rows at the start and store the PSF
     # straight from the last pass (csrc/frugal_pass.h: STORE)
     lean = _WalkState() if (not outputs and metrics_radii_px is None) else None
-    tickets = []  # (ticket, [(item index, record)]): powers are fetched after the walk, so the
+    tickets = []  # (_Reduction, [(item index, record)], post): powers are fetched after the walk, so the
     # host keeps planning while the GPU works (no mid-chain synchronisation) -- except when a chain
     # saves more surfaces than the library has ticket slots: then the oldest are fetched early
     drained = [0]
+    # The reduction a pass program left behind when it stored the PSF for good answers for every saved surface from
+    # there on (lean.final_ticket): those entries share ONE _Reduction, fetched once -- also when a mid-walk drain has
+    # already read it.  Every other ticket is a reduction of its own (a slot number alone does not say which: the
+    # library hands a slot out again as soon as it was fetched or released).
+    final_reduction = {}
 
-    fetched, released = {}, set()  # (one ticket may answer for several surfaces: fetched / given back once)
+    def reduction_of(ticket, final=False):
+        if not final:
+            return _Reduction(dev, ticket)
+        if ticket not in final_reduction:
+            final_reduction[ticket] = _Reduction(dev, ticket)
+        return final_reduction[ticket]
+
+    def outstanding():
+        return sum(1 for e in tickets[drained[0]:] if e[0].raw is None and not e[0].released)
 
     def drain():
-        for entry in tickets[drained[0]:]:
-            ticket, pending = entry[0], entry[1]
-            if ticket not in fetched:
-                fetched.clear()  # (slots are handed out again once fetched: only the latest value is worth keeping)
-                fetched[ticket] = dev.norm2_fetch(ticket)
-            values = fetched[ticket]
-            if len(entry) > 2 and entry[2] is not None:
-                values = entry[2](values)
+        for red, pending, post in tickets[drained[0]:]:
+            values = red.values()
+            if post is not None:
+                values = post(values)
             for i, rec in pending:
                 rec["power"] = float(values[i])
         drained[0] = len(tickets)
 
     def room_in_the_ring():
-        if len(tickets) - drained[0] >= _lib.NORM_SLOTS - 2:
+        if outstanding() >= _lib.NORM_SLOTS - 2:
             drain()
 
     # the power of a saved surface summed by the pass that stores its field (csrc/frugal_pass.h: pow_partial): _walk
@@ -745,29 +807,28 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
         fused = (lean.psf_ticket if lean.psf_ticket is not None else lean.final_ticket) if lean is not None else None
         rows = lean.rows if lean is not None else None
         if power:
-            if len(tickets) - drained[0] >= _lib.NORM_SLOTS - 1 and fused is None:
+            if outstanding() >= _lib.NORM_SLOTS - 1 and fused is None:
                 drain()  # the ticket ring of the library is about to fill: fetch what is pending
             # the saved last surface of a run that keeps its PSFs: |u|^2 written and summed in one sweep
             if fused is not None:
-                tickets.append((fused, pending))
+                tickets.append((reduction_of(fused, final=True), pending, None))
             elif power_state is not None and power_state["ticket"] is not None and not keep:
-                tickets.append((power_state["ticket"], pending, power_state.get("post")))
+                tickets.append((reduction_of(power_state["ticket"]), pending, power_state.get("post")))
                 power_state["used"] = True
             elif keep:
                 if power_state is not None and power_state["ticket"] is not None:  # (the kept PSF brings its own sum)
                     dev.norm2_release(power_state["ticket"])
                     power_state["used"] = True
-                tickets.append((dev.psf_keep_power(), pending))
+                tickets.append((reduction_of(dev.psf_keep_power()), pending, None))
             else:
                 like = lean.same_as if lean is not None else None
                 if rows is not None and like is not None:
-                    tickets.append((dev.norm2_enqueue(rows, same_as=like), pending))
+                    tickets.append((reduction_of(dev.norm2_enqueue(rows, same_as=like)), pending, None))
                 else:
-                    tickets.append((dev.norm2_enqueue(rows) if rows is not None else dev.norm2_enqueue(), pending))
+                    tickets.append((reduction_of(dev.norm2_enqueue(rows) if rows is not None else dev.norm2_enqueue()),
+                                    pending, None))
         elif fused is not None:
-            if fused not in released:
-                released.add(fused)
-                dev.norm2_release(fused)
+            reduction_of(fused, final=True).release()  # (once, however many surfaces it stands for)
         elif keep:
             dev.psf_keep()
 
@@ -776,15 +837,11 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
               psf_at=last_key if (keep_psf and lean is not None) else None, power_state=power_state)
         if sync or own:
             drain()
-        else:  # caller synchronises later: hand out the tickets still outstanding
-            for entry in tickets[drained[0]:]:
-                if len(entry) > 2 and entry[2] is not None:  # (a derived value: it cannot be handed out as a bare ticket)
-                    values = entry[2](dev.norm2_fetch(entry[0]))
-                    for i, rec in entry[1]:
-                        rec["power"] = float(values[i])
-                    continue
-                for i, rec in entry[1]:
-                    rec["power_ticket"] = entry[0]
+        else:  # caller synchronises later: hand out handles to the reductions still outstanding (nothing waits here)
+            for red, pending, post in tickets[drained[0]:]:
+                handle = PowerTicket(red, post)
+                for i, rec in pending:
+                    rec["power_ticket"] = handle
     finally:
         if own:
             dev.close()

@@ -62,19 +62,35 @@ class ModelDevice:
         return out
 
     def norm2_enqueue(self, live_rows=None, same_as=None):
-        self._tickets = getattr(self, "_tickets", [])
         if same_as is not None:  # the caller claims copies: hold it to that
             for i, j in enumerate(same_as):
                 lo, hi = (int(x) for x in live_rows[i])
                 assert int(same_as[int(j)]) == int(j) and np.array_equal(self.u[i][lo:hi], self.u[int(j)][lo:hi]), (i, j)
         if live_rows is None:
-            self._tickets.append(self.norm2())
-        else:  # rows outside [lo, hi) are not read (they may hold stale data: NaN in this model)
-            self._tickets.append(np.array([np.sum(np.abs(u[int(lo):int(hi)]) ** 2) for u, (lo, hi) in zip(self.u, live_rows)]))
-        return len(self._tickets) - 1
+            return self._new_ticket(self.norm2())
+        # rows outside [lo, hi) are not read (they may hold stale data: NaN in this model)
+        return self._new_ticket(np.array([np.sum(np.abs(u[int(lo):int(hi)]) ** 2) for u, (lo, hi) in zip(self.u, live_rows)]))
+
+    # The library's ticket ring (paos_hip.hip: next_norm_slot): NORM_SLOTS slots, the next FREE one is handed out, a slot
+    # is free again as soon as it was fetched or released -- so a slot NUMBER does not identify a reduction, and
+    # fetching one twice is an error (or, worse, somebody else's value).  The model is as strict.
+    def _new_ticket(self, values):
+        ring = self.__dict__.setdefault("_ring", {})
+        start = self.__dict__.get("_ring_next", 0)
+        for k in range(_lib.NORM_SLOTS):
+            slot = (start + k) % _lib.NORM_SLOTS
+            if slot not in ring:
+                ring[slot] = np.array(values, dtype=np.float64)
+                self._ring_next = (slot + 1) % _lib.NORM_SLOTS
+                return slot
+        raise RuntimeError(f"{_lib.NORM_SLOTS} tickets outstanding")
 
     def norm2_release(self, ticket):
-        pass
+        if hasattr(ticket, "release"):
+            return ticket.release()
+        if int(ticket) not in self.__dict__.get("_ring", {}):
+            raise RuntimeError("ticket is not outstanding")
+        del self._ring[int(ticket)]
 
     def zero_outside_rows(self, live_rows):
         self.log.append(("zero_outside_rows", None))
@@ -83,7 +99,11 @@ class ModelDevice:
             u[int(hi):] = 0.0
 
     def norm2_fetch(self, ticket):
-        return self._tickets[ticket]
+        if hasattr(ticket, "fetch"):
+            return ticket.fetch()
+        if int(ticket) not in self.__dict__.get("_ring", {}):
+            raise RuntimeError("ticket is not outstanding")
+        return self._ring.pop(int(ticket))
 
     def make_stop(self, enable=None, power_known=False, defer=False):
         # (defer: the real device leaves the scaling to the next pass; the model has no such thing as a cost and scales now)
@@ -295,16 +315,13 @@ class ModelDevice:
                 self.u[i] = u
         if final_intensity == 2:  # the field is kept; its power comes back as a ticket (the last pass sums it on the way)
             self.log.append(("power_on_store", None))
-            self._tickets = getattr(self, "_tickets", [])
-            self._tickets.append(self.norm2())
-            return len(self._tickets) - 1
+            return self._new_ticket(self.norm2())
         if final_intensity:  # the PSF and its sum instead of the field, which is given up
             self.log.append(("psf_store", None))
             self.psf = self.u.real**2 + self.u.imag**2
-            self._tickets = getattr(self, "_tickets", [])
-            self._tickets.append(self.psf.sum(axis=(1, 2)))
+            ticket = self._new_ticket(self.psf.sum(axis=(1, 2)))
             self.u[:] = np.nan
-            return len(self._tickets) - 1
+            return ticket
         return None
 
     # one-operator programs, as csrc/paos_hip.hip builds them

@@ -810,3 +810,76 @@ def test_the_image_plane_right_behind_a_saved_slit_shares_its_pass():
             assert abs(got[i][k]["power"] - want[i][k]["power"]) <= 1e-12 * want[i][k]["power"], (i, k)
             assert abs(old[i][k]["power"] - want[i][k]["power"]) <= 1e-12 * want[i][k]["power"], (i, k)
         assert got[i][slit]["power"] == got[i][last]["power"]
+
+
+def test_power_tickets_of_an_unsynchronised_run_can_be_fetched_per_record():
+    """with ``sync=False`` a saved slit and the image plane behind it are answered by ONE reduction (the
+    pass that stored the PSF), and a surface whose stop scales by its program's power reports a DERIVED power.  Every
+    record gets a ``PowerTicket``: each may be fetched (through the handle or through ``dev.norm2_fetch``), in any
+    order, more than once; the library's slot is read exactly once (the model device, like the library, refuses a
+    second fetch of a slot); a derived power is formed at fetch time -- run_batch itself never waits."""
+    import paos_amd.run as prun
+    from paos_amd.run import PowerTicket, run_batch
+
+    spec = _spec("Excite_TEL")
+    wls = [spec["wl"], 1.2 * spec["wl"]]
+    chain = {k: dict(v, save=True) for k, v in spec["chain"].items()}  # every surface saved: the stop's power is derived
+    args = (spec["pup"], wls, 64, spec["zoom"], spec["field"], [chain] * 2)
+    prun.FUSE_APERTURES = True
+    try:
+        want = run_batch(*args, outputs=(), dev=ModelDevice(64, 2), keep_psf=True)
+        dev = ModelDevice(64, 2)
+        fetches = []
+        real_fetch = dev.norm2_fetch
+        dev.norm2_fetch = lambda t: (fetches.append(t) if not hasattr(t, "fetch") else None, real_fetch(t))[1]
+        got = run_batch(*args, outputs=(), dev=dev, keep_psf=True, sync=False)
+    finally:
+        prun.FUSE_APERTURES = "auto"
+    assert fetches == [], "run_batch(sync=False) fetched a power itself"
+    last, slit = max(want[0]), sorted(want[0])[-2]
+    assert got[0][slit]["power_ticket"]._red is got[0][last]["power_ticket"]._red  # two handles on ONE reduction
+    derived = [k for k in got[0] if isinstance(got[0][k].get("power_ticket"), PowerTicket) and got[0][k]["power_ticket"]._post]
+    assert derived, "no surface reported a power derived from its program's reduction"
+    for order in (sorted(got[0]), sorted(got[0], reverse=True)):  # any order, twice over
+        for k in order:
+            for i in range(2):
+                rec = got[i][k]
+                assert "power" not in rec and isinstance(rec["power_ticket"], PowerTicket)
+                a, b = rec["power_ticket"].fetch()[i], dev.norm2_fetch(rec["power_ticket"])[i]
+                assert a == b and abs(a - want[i][k]["power"]) <= 1e-12 * want[i][k]["power"], (i, k, a, want[i][k]["power"])
+    assert len(fetches) == len(set(fetches)), "a slot was read twice"
+    assert not dev._ring, "a slot leaked"
+    # given back unread: release is idempotent across the records that share a reduction, and a later fetch says so
+    dev2 = ModelDevice(64, 2)
+    prun.FUSE_APERTURES = True
+    try:
+        res = run_batch(*args, outputs=(), dev=dev2, keep_psf=True, sync=False)
+    finally:
+        prun.FUSE_APERTURES = "auto"
+    for t in {rec["power_ticket"] for r in res for rec in r.values()}:
+        dev2.norm2_release(t)
+        t.release()
+    assert not dev2._ring
+    with pytest.raises(RuntimeError):
+        res[0][last]["power_ticket"].fetch()
+
+
+def test_many_saved_surfaces_wrap_the_ticket_ring_without_stale_powers():
+    """a mid-walk drain must not serve a later surface the cached value of a slot that has been handed
+    out again.  A chain with more saved surfaces than ticket slots, on the model's ring (64 slots, reissued as soon as
+    they are free): every power equals the directly summed one."""
+    from paos_amd.abcd import ABCD
+    from paos_amd.run import run_batch
+
+    chain = {}
+    base = syn20_chain()
+    first = base[min(base)]
+    chain[1] = dict(first, num=1, save=True)
+    for k in range(2, 2 + 2 * _lib.NORM_SLOTS + 5):  # flat, saved surfaces a short hop apart: each is one reduction
+        chain[k] = {"num": k, "type": "Standard", "name": f"P{k}", "is_stop": False, "save": True,
+                    "ABCDt": ABCD(thickness=1.0e-3 * (1 + k % 3), curvature=0.0), "ABCDs": ABCD(thickness=1.0e-3 * (1 + k % 3), curvature=0.0)}
+    got = run_batch(1.0, [1.0e-6, 1.3e-6], 64, 4, FIELD, [chain, chain], outputs=("wfo",), dev=ModelDevice(64, 2))
+    for i in range(2):
+        for k, rec in got[i].items():
+            direct = float(np.sum(np.abs(rec["wfo"]) ** 2))
+            assert abs(rec["power"] - direct) <= 1e-12 * direct, (i, k)
