@@ -192,8 +192,9 @@ static __global__ void phase_table_kernel(TableArgs a) {  // static: the header 
 // while line s is transformed).
 // COLSIB > 1 (complex64: a block is 64 B, so two column tiles share every 128-byte line): column tiles
 // are renumbered like the half-block row tiles, siblings 8 workgroups apart = on one XCD.
-template <int N, int E, int LINES, int TILES, int AXIS, int BR, int BC, int SEQ = 1, int COLSIB = 1>
+template <int N, int E, int LINES, int TILES, int AXIS, int BR, int BC, int SEQ = 1, int COLSIB = 1, int SWZ = 0>
 struct TileMap {
+  static constexpr int kLinesPerWorkgroup = LINES * TILES;
   static constexpr int kAxis = AXIS;
   static constexpr int TL = N / E;
   static constexpr int PAR = LINES / SEQ;            // lines processed concurrently
@@ -223,7 +224,19 @@ struct TileMap {
           tile = (grp * 8 + in % 8) * SUB + in / 8;
         }
         row0 = tile * LINES;
-        const int bc = tid % BC, br = (tid / BC) % PAR, q = tid / (BC * PAR);
+        const int bc = tid % BC, br = (tid / BC) % PAR;
+        int q = tid / (BC * PAR);
+        // SWZ (round 5): the lanes of a wave alternate between the PAR lines of the tile, so the 16 lanes of one
+        // ds_write_b64 group hold 16 / PAR consecutive positions of every line -- and the scatter slots 17 t + r of two lines
+        // (whose areas start a multiple of 128 B apart, as the gathers need) fall on the same banks: a 2-way conflict on every
+        // exchange write, all of SQ_LDS_BANK_CONFLICT (profiles/r04_sq_counters.txt: 1.458e8 = 32 writes x 4 array cycles x
+        // 8 exchanges x 139 300 waves).  Odd lines therefore take their positions 8 further on (t ^ 8: the other half of the
+        // 16 slot residues); the set of addresses a wave touches in HBM is the same, only which lane holds which changes.
+        // Measured (profiles/r05_fftbench_fused_variants.txt, r05_ab_variants_bench.txt): stand-alone dense two-transform passes
+        // -1 ... -2.5 %, the fused launches of the separable programs 0 ... +4 % (bound by the latency of their chain, not by
+        // LDS cycles), and in the chain the launches that load / store a quarter of their positions +2 ... +13 % -- the lane
+        // pairs of a quad then come from two 128-byte blocks.  Off in the library (frugal_pass.h: PAOS_LDS_SWIZZLE).
+        if constexpr (SWZ != 0 && PAR == 2 && BC == 2) q ^= (br & 1) ? 4 : 0;
         line = br; t = q * BC + bc;
       }
       base = (unsigned)layout_index<BR, BC>(row0 + line, t, pitch);
@@ -238,9 +251,11 @@ struct TileMap {
       if constexpr (BR == 1) {
         line = tid % LINES; t = tid / LINES;
       } else {
-        static_assert(LINES == BC, "column tiles span exactly one block column");
+        static_assert(BC % LINES == 0, "column tiles span one block column, or one column of it (COLSIB siblings share its lines)");
         static_assert((N / E) % BR == 0, "threads per line must cover whole blocks");
-        const int bc = tid % PAR, br = (tid / PAR) % BR, q = tid / (PAR * BR);
+        const int bc = tid % PAR, br = (tid / PAR) % BR;
+        int q = tid / (PAR * BR);
+        if constexpr (SWZ != 0 && PAR == 2 && BR == 4) q ^= (bc & 1) ? 2 : 0;  // (t ^ 8 for the odd column, as above)
         line = bc; t = q * BR + br;
       }
       base = (unsigned)layout_index<BR, BC>(t, col0 + line, pitch);

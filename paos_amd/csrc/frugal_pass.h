@@ -93,7 +93,7 @@ struct FrugalItem {
 // k < NS, i.e. an index below N / R <= N / 4; with 16 points per thread every supported N stays below 256,
 // with 32 points per thread (complex64) below 1024
 template <int N, int E>
-constexpr int twiddle_lds_entries() { return E <= 16 ? 256 : (N / 4 < 1024 ? N / 4 : 1024); }
+constexpr int twiddle_lds_entries() { return E == 8 ? N / 8 : (E <= 16 ? 256 : (N / 4 < 1024 ? N / 4 : 1024)); }  // (E = 8: round-5 experiment)
 
 // PAOS_STAMPS (tools/fftbench.hip timeline builds only): wave 0 of every workgroup records
 // s_memtime at the phase boundaries plus where it ran (HW_ID, XCC_ID) into FrugalArgs::stamps.
@@ -207,6 +207,12 @@ __device__ __forceinline__ T flip_sign(T x, unsigned mask_hi) {
 #endif
 #ifndef PAOS_MERGE_PHASES
 #define PAOS_MERGE_PHASES 1  // two phases of one slot through one sincos of their exactly summed arguments
+#endif
+#ifndef PAOS_LDS_SWIZZLE
+#define PAOS_LDS_SWIZZLE 0   // 1: the single-pass shapes of the pass kernel take the bank swizzle of fft_kernels.h (TileMap: SWZ).  Measured and
+                             // left OFF (profiles/r05_ab_variants_bench.txt): it removes every LDS bank conflict of the exchanges and buys dense
+                             // launches +0.8 %, but a lane pair of an odd line then sits in another 128-byte block than its even neighbour,
+                             // and the launches that load or store a quarter of their positions take 2-13 % longer
 #endif
 #ifndef PAOS_TABLE_FENCE
 #define PAOS_TABLE_FENCE 8   // table slots (TAB builds): factors fetched and applied in groups of this many elements.  Measured
@@ -493,7 +499,11 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
   };
   auto apply = [&](int k, cx<double> p) __attribute__((always_inline)) {
     const cx<double> vd = {(double)v[k].x, (double)v[k].y};
+#if defined(PAOS_DIAG_NOSCALE)  // (timing diagnostic: what folding sign and scale into the table would save -- results wrong)
+    v[k] = {(T)(fma(vd.x, p.x, -(vd.y * p.y))), (T)(fma(vd.x, p.y, vd.y * p.x))};
+#else
     v[k] = {(T)(fma(vd.x, p.x, -(vd.y * p.y)) * f), (T)(fma(vd.x, p.y, vd.y * p.x) * fy)};
+#endif
   };
   if constexpr (K > 0 && TAB != 0) {
     // TAB builds (round 4): the factors of this item's slot by position, from phase_table_kernel's table -- a compile-time
@@ -501,6 +511,9 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
     // register allocation (60-100 bytes of scratch; both variants 15 % slower, profiles/r04_ab_variants_bench.txt)
     static_assert(!SHARE, "a table slot does not stand for a barrier");
     const cx<double>* tb = sl.table + tpos;
+    // (one-line workgroups -- four per CU, one wave each per SIMD -- do best with groups of 4: -2 ... -3 % against 8, which
+    // the two-line workgroups keep; 16: +14 %.  profiles/r05_fftbench_fused_variants.txt)
+    constexpr int kFence = Map::kLinesPerWorkgroup == 1 ? 4 : PAOS_TABLE_FENCE;
 #pragma unroll
     for (int k = 0; k < E; ++k) {
 #if defined(PAOS_DIAG_NOTABLE)  // (timing diagnostic: what the table loads cost -- results wrong)
@@ -508,7 +521,7 @@ __device__ __forceinline__ void frugal_slot(cx<T>* v, const FrugalSlot& sl, cons
 #else
       apply(k, tb[k * TL]);
 #endif
-      if ((k + 1) % PAOS_TABLE_FENCE == 0) __builtin_amdgcn_sched_barrier(0);
+      if ((k + 1) % kFence == 0) __builtin_amdgcn_sched_barrier(0);
     }
     return;
   }
@@ -631,8 +644,8 @@ __device__ __forceinline__ void stream_store(cx<T>* p, cx<T> v) {
 // FLIP = false: the conjugation behind the transform is left to the slot that follows (frugal_slot: conj_in)
 template <typename T, int N, int E, bool SPLIT, bool FLIP = true>
 __device__ __forceinline__ void frugal_fft(cx<T>* v, void* lds, int t, const cx<T>* tw, const cx<double>* circle,
-                                           double inv) {
-  fft_stages<T, N, E, +1, SPLIT, 1, 1>(v, lds, t, tw, circle);
+                                           double inv, const cx<T>* w1_last = nullptr) {
+  fft_stages<T, N, E, +1, SPLIT, 1, 1>(v, lds, t, tw, circle, w1_last);
   unpermute_slots<N, E>(v);
   if constexpr (FLIP) {
     const unsigned mask = inv != 0.0 ? 0x80000000u : 0u;
@@ -655,9 +668,15 @@ template <int LINES, int TILES, int KPRE>
 constexpr int frugal_record_mode() {
   return PAOS_HOIST_RECORDS == 0 ? 0 : ((TILES * LINES == 2 && KPRE == 0) ? 2 : (TILES * LINES <= 16 ? 1 : 0));
 }
+// One-line workgroups (round 5: 4096-point complex128 lines, 256 threads): the only stage twiddle that is not a 256th root of
+// unity is the last stage's tw[t] -- one value per thread for the whole kernel, kept in registers -- so the 4 KiB stage table
+// stays out of LDS and FOUR workgroups (4 x 38.2 KiB) fit a CU.
+template <typename T, int N, int E, int LINES, int TILES>
+constexpr bool frugal_tw_in_regs() { return sizeof(T) == 8 && N == 4096 && E == 16 && TILES * LINES == 1; }
 template <typename T, int N, int LINES, int TILES, bool SPLIT, int KPRE, int KMID, int E = 16, int STORE = 0>
 constexpr size_t frugal_lds_bytes() {
-  return (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT, LINES>() + twiddle_lds_entries<N, E>() * sizeof(cx<T>) +
+  return (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT, LINES>() +
+         (frugal_tw_in_regs<T, N, E, LINES, TILES>() ? 0 : twiddle_lds_entries<N, E>() * sizeof(cx<T>)) +
          (sizeof(T) == 8 ? kCircleLds * sizeof(cx<double>) : 0) + kStoreScratch +
          (frugal_record_mode<LINES, TILES, KPRE>() == 1 ? (size_t)TILES * LINES * sizeof(MaskLine) : 0);
 }
@@ -685,6 +704,10 @@ template <typename T, int N, int THREADS>
 constexpr int frugal_min_waves() {
   if (sizeof(T) == 4 && THREADS >= 1024) return 8;  // 4-row tiles of complex64: two 1024-thread workgroups per CU
   if (sizeof(T) == 4 && THREADS >= 512) return PAOS_F32_MINW;
+  if (sizeof(T) == 8 && N == 4096 && THREADS == 256) return 4;  // one-line workgroups: four per CU, one wave each per SIMD
+#ifdef PAOS_E8_MINW
+  if (sizeof(T) == 8 && N == 4096 && THREADS == 512) return PAOS_E8_MINW;  // (experiment: 8 points per thread, one line per workgroup)
+#endif
   return THREADS >= 512 ? 4 : PAOS_MINW_SMALL;
 }
 
@@ -727,7 +750,7 @@ template <typename T, int N, int E, int LINES, int TILES, int AXIS, int BR, int 
           int KPRE, int KMID, int NFFT, int STORE = 0, int TAB = 0, int LONG = 0>
 __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, TILES * LINES * N / E>()))
     frugal_pass_kernel(PAOS_FRUGAL_PARAMS) {
-  static_assert(LONG == 0 || (TAB != 0 && NFFT == 2 && KPRE == 1 && KMID == 1), "LONG builds: see above");
+  static_assert(LONG == 0 || (TAB != 0 && (NFFT == 2 || NFFT == 3) && KPRE == 1 && KMID == 1), "LONG builds: see above");
   FrugalArgs a;
   a.items = k_items; a.field = k_field; a.pitch = k_pitch; a.item_stride = k_item_stride; a.wg0 = k_wg0;
   a.tw = k_tw; a.psf = k_psf; a.psf_partial = k_psf_partial; a.pow_partial = k_pow_partial; a.dyn_scale = k_dyn_scale; a.live_lo = a.live_hi = 0;
@@ -775,13 +798,15 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   // a block of BR x BC elements is a whole 128-byte line for complex128, half of one for complex64
   constexpr bool kBlockIsLine = BR * BC * sizeof(cx<T>) >= 128;
-  constexpr int COLSIB = kBlockIsLine ? 1 : (int)(128 / (BR * BC * sizeof(cx<T>)));
+  // (column tiles of fewer columns than a block has share the block's lines with BC / LINES - 1 siblings too)
+  constexpr int COLSIB = (kBlockIsLine ? 1 : (int)(128 / (BR * BC * sizeof(cx<T>)))) * (AXIS == 1 && LINES < BC ? BC / LINES : 1);
   const unsigned wg = blockIdx.x + a.wg0;  // compact grids (FrugalArgs::wg0)
-  const TileMap<N, E, LINES, TILES, AXIS, BR, BC, 1, COLSIB> m(wg, threadIdx.x, a.pitch);
+  constexpr int kSwz = (PAOS_LDS_SWIZZLE != 0 && LONG == 0 && sizeof(T) == 8) ? 1 : 0;
+  const TileMap<N, E, LINES, TILES, AXIS, BR, BC, 1, COLSIB, kSwz> m(wg, threadIdx.x, a.pitch);
   cx<T>* f = reinterpret_cast<cx<T>*>(a.field) + (size_t)item * a.item_stride;
   // tiles that own whole 128-byte lines (c128 column tiles; row tiles that span a full block row) stream
   // around the caches; tiles that share lines with a sibling need the L2 to merge the halves
-  constexpr bool NT = kBlockIsLine && (PAOS_NT_FULL_LINES ? (AXIS == 1 || LINES == BR) : (AXIS == 1));
+  constexpr bool NT = kBlockIsLine && (PAOS_NT_FULL_LINES ? ((AXIS == 1 && LINES >= BC) || (AXIS == 0 && LINES == BR)) : (AXIS == 1 && LINES >= BC));
   // experiment knob (tools/build_variant.sh): nontemporal LOADS for tiles that share their lines with a sibling
   // (stores stay ordinary so that the L2 can merge the halves)
   constexpr bool NTL = NT || (PAOS_SHARED_NT_LOADS != 0);
@@ -812,10 +837,11 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   // exchange areas: the load that follows each exchange barrier is then a ~100-cycle ds_read
   // instead of a dependent global load.  Published by the barrier behind the tile's loads.
   cx<T>* tw_lds = reinterpret_cast<cx<T>*>(smem + (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT, LINES>());
-  const cx<T>* tw = tw_lds;
+  constexpr bool kTwRegs = frugal_tw_in_regs<T, N, E, LINES, TILES>();  // no stage table in LDS: tw[t] in registers (below)
+  const cx<T>* tw = kTwRegs ? reinterpret_cast<const cx<T>*>(a.tw) : tw_lds;
   // the unit circle in 256 steps for the phase factors (sincos_tab) and the twiddles of the second
   // stage: conj of every (N/256)-th entry of the twiddle table
-  cx<double>* cl = reinterpret_cast<cx<double>*>(tw_lds + kTwiddleLds);
+  cx<double>* cl = reinterpret_cast<cx<double>*>(tw_lds + (kTwRegs ? 0 : kTwiddleLds));
   const cx<double>* circle = sizeof(T) == 8 ? cl : nullptr;
 #if PAOS_STAMPS
   if (threadIdx.x == 0) {
@@ -875,7 +901,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   if constexpr (PAOS_PREFETCH > 0) {
     const unsigned wgp = wg + (unsigned)PAOS_PREFETCH;
     if (wgp < a.wg0 + gridDim.x) {
-      const TileMap<N, E, LINES, TILES, AXIS, BR, BC, 1, COLSIB> mp(wgp, threadIdx.x & ~3u, a.pitch);
+      const TileMap<N, E, LINES, TILES, AXIS, BR, BC, 1, COLSIB, kSwz> mp(wgp, threadIdx.x & ~3u, a.pitch);
       // threads 4 q .. 4 q + 3 own one 64-byte piece per element index k: lane (tid & 3) touches the pieces k = 4 j + (tid & 3)
       typedef const __attribute__((address_space(1))) char* GlobalBytes;
       const GlobalBytes pbase = (GlobalBytes)fb;
@@ -910,11 +936,15 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   if constexpr (kRecMode == 1) {
     if (stage_recs && (int)threadIdx.x < kRecDwords) rec_fetch = reinterpret_cast<const unsigned*>(h_lines + lbase)[threadIdx.x];
   }
+  // (one-line workgroups: the thread's one stage twiddle rides behind the tile's loads like the table fetches do)
+  cx<T> w1_keep = cx<T>{(T)1, (T)0};
+  if constexpr (kTwRegs) w1_keep = reinterpret_cast<const cx<T>*>(a.tw)[m.t];
+  const cx<T>* const w1_last = kTwRegs ? &w1_keep : nullptr;
 #pragma unroll
   for (int j = 0; j < kTwIt; ++j) {
     const int i = (int)threadIdx.x + j * kThreads;
     tw_fetch[j] = cx<T>{(T)0, (T)0};
-    if (i < kTwiddleLds) tw_fetch[j] = reinterpret_cast<const cx<T>*>(a.tw)[i];
+    if (!kTwRegs && i < kTwiddleLds) tw_fetch[j] = reinterpret_cast<const cx<T>*>(a.tw)[i];
   }
   if constexpr (sizeof(T) == 8) {
 #pragma unroll
@@ -927,7 +957,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
 #pragma unroll
   for (int j = 0; j < kTwIt; ++j) {
     const int i = (int)threadIdx.x + j * kThreads;
-    if (i < kTwiddleLds) tw_lds[i] = tw_fetch[j];
+    if (!kTwRegs && i < kTwiddleLds) tw_lds[i] = tw_fetch[j];
   }
   if constexpr (sizeof(T) == 8) {
 #pragma unroll
@@ -954,29 +984,48 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
     // launches this shape only when both transforms run for every active item of the batch
     static_assert(N == 4096 && E == 16 && sizeof(T) == 8 && SPLIT, "digit-swapped passes: 4096-point complex128 lines");
     T* area = reinterpret_cast<T*>(lds);
-    frugal_slot<T, N, E, KPRE, decltype(m), kPlainPre>(v, it.pre, it.pre_ph, m, circle, false, it.fft1_inv != 0.0, m.t);
-    PAOS_STAMP(2);
-    fft4096_nat_to_swapped<T>(v, area, m.t, tw, circle, true);
-    {
-      const unsigned mask = it.fft1_inv != 0.0 ? 0x80000000u : 0u;
-#pragma unroll
-      for (int k = 0; k < E; ++k) v[k].y = flip_sign(v[k].y, mask);
-      __builtin_amdgcn_sched_barrier(0);
+    // (round 5 experiment: LONG = 2 runs the next pass of the program the same way -- two digit-swapped pairs per launch, three
+    // workgroup barriers per transform instead of seven; every transform of both passes must be on for every item)
+#define PAOS_SWAPPED_PASS(ix, kpre, plain, idle, dyn)                                                                                        \
+  {                                                                                                                                          \
+    frugal_slot<T, N, E, kpre, decltype(m), plain, false, 0, TAB>(v, (ix).pre, (ix).pre_ph, m, circle, false, (ix).fft1_inv != 0.0, m.t);    \
+    fft4096_nat_to_swapped<T>(v, area, m.t, tw, circle, idle);                                                                               \
+    {                                                                                                                                        \
+      const unsigned mask = (ix).fft1_inv != 0.0 ? 0x80000000u : 0u;                                                                         \
+      _Pragma("unroll") for (int k = 0; k < E; ++k) v[k].y = flip_sign(v[k].y, mask);                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                                                     \
+    }                                                                                                                                        \
+    /* (dyn: a deferred stop's 1 / sqrt(power) rides on this slot like on the NFFT <= 2 shapes' -- ADVICE r04) */                            \
+    frugal_slot<T, N, E, KMID, decltype(m), 0, false, 0, TAB>(v, (ix).mid, (ix).mid_ph, m, circle, false, (ix).fft2_inv != 0.0,              \
+                                                              swap_nibbles(m.t), nullptr, false, nullptr, 0, dyn);                           \
+    fft4096_swapped_to_nat<T>(v, area, m.t, tw, circle);                                                                                     \
+    {                                                                                                                                        \
+      const unsigned mask = (ix).fft2_inv != 0.0 ? 0x80000000u : 0u;                                                                         \
+      _Pragma("unroll") for (int k = 0; k < E; ++k) v[k].y = flip_sign(v[k].y, mask);                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                                                                     \
+    }                                                                                                                                        \
+  }
+    PAOS_SWAPPED_PASS(it, KPRE, kPlainPre, true, h_dyn)
+    if constexpr (LONG == 2) {
+      const FrugalItem& it2 = *(const FrugalItem*)((ConstItemPtr)a.items + item + gridDim.y);
+      __syncthreads();  // the exchange area is still being read by the transform in front
+      PAOS_SWAPPED_PASS(it2, 1, 0, true, 1.0)
     }
-    PAOS_STAMP(3);
-    // (h_dyn: a deferred stop's 1 / sqrt(power) rides on this slot like on the NFFT <= 2 shapes' -- ADVICE r04)
-    frugal_slot<T, N, E, KMID>(v, it.mid, it.mid_ph, m, circle, false, it.fft2_inv != 0.0, swap_nibbles(m.t), nullptr, false, nullptr, 0, h_dyn);
-    PAOS_STAMP(4);
-    fft4096_swapped_to_nat<T>(v, area, m.t, tw, circle);
-    {
-      const unsigned mask = it.fft2_inv != 0.0 ? 0x80000000u : 0u;
-#pragma unroll
-      for (int k = 0; k < E; ++k) v[k].y = flip_sign(v[k].y, mask);
-      __builtin_amdgcn_sched_barrier(0);
-    }
+#undef PAOS_SWAPPED_PASS
     PAOS_STAMP(5);
+    {
+      const int slo3 = (int)h_spos_lo, shi3 = (int)h_spos_hi;
+      if (slo3 <= 0 && shi3 >= N) {
 #pragma unroll
-    for (int k = 0; k < E; ++k) stream_store<NT>(at(k), v[k]);
+        for (int k = 0; k < E; ++k) stream_store<NT>(at(k), v[k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < E; ++k) {
+          const int pos = m.t + k * (N / E);
+          if (pos >= slo3 && pos < shi3) stream_store<NT>(at(k), v[k]);
+        }
+      }
+    }
     return;
   }
   const bool ran1 = it.fft1_on != 0.0;
@@ -987,7 +1036,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   // only the slot between the transforms shares)
   frugal_slot<T, N, E, KPRE, decltype(m), kPlainPre, kShare && KMID == 0, 0, TAB>(v, it.pre, it.pre_ph, m, circle, false, inv1, m.t, lds, false);
   PAOS_STAMP(2);
-  if (ran1) frugal_fft<T, N, E, SPLIT, false>(v, lds, m.t, tw, circle, it.fft1_inv);
+  if (ran1) frugal_fft<T, N, E, SPLIT, false>(v, lds, m.t, tw, circle, it.fft1_inv, w1_last);
   PAOS_STAMP(3);
   constexpr bool kShareMid = kShare && KPRE == 0 && KMID < 3;
   frugal_slot<T, N, E, KMID, decltype(m), 0, kShareMid, (kRecMode == 1 ? -1 : kRecs), TAB>(
@@ -996,7 +1045,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   if constexpr (NFFT == 2) {
     if (ran2) {
       if (ran1 && !(kShareMid && KMID > 0)) __syncthreads();  // (a sharing slot ends on a barrier of its own)
-      frugal_fft<T, N, E, SPLIT>(v, lds, m.t, tw, circle, it.fft2_inv);
+      frugal_fft<T, N, E, SPLIT>(v, lds, m.t, tw, circle, it.fft2_inv, w1_last);
     }
   }
   if constexpr (LONG != 0) {
@@ -1011,7 +1060,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
     frugal_slot<T, N, E, 1, decltype(m), 0, false, 0, TAB>(v, (ix).pre, (ix).pre_ph, m, circle, false, inv3, m.t, lds, false);       \
     if (ran3) {                                                                                                                      \
       if (busy) __syncthreads();                                                                                                     \
-      frugal_fft<T, N, E, SPLIT, false>(v, lds, m.t, tw, circle, (ix).fft1_inv);                                                     \
+      frugal_fft<T, N, E, SPLIT, false>(v, lds, m.t, tw, circle, (ix).fft1_inv, w1_last);                                            \
       busy = true;                                                                                                                   \
     }                                                                                                                                \
     frugal_slot<T, N, E, 1, decltype(m), 0, false, 0, TAB>(v, (ix).mid, (ix).mid_ph, m, circle, inv3, ran4 && (ix).fft2_inv != 0.0,  \
@@ -1019,7 +1068,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
     if constexpr (kTwo) {                                                                                                            \
       if (ran4) {                                                                                                                    \
         if (busy) __syncthreads();                                                                                                   \
-        frugal_fft<T, N, E, SPLIT>(v, lds, m.t, tw, circle, (ix).fft2_inv);                                                          \
+        frugal_fft<T, N, E, SPLIT>(v, lds, m.t, tw, circle, (ix).fft2_inv, w1_last);                                                 \
         busy = true;                                                                                                                 \
       }                                                                                                                              \
     }                                                                                                                                \

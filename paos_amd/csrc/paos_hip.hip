@@ -651,10 +651,20 @@ void plan_pruning(const paos_ctx* c, const paos_pass* passes, int n_passes, cons
   }
 }
 
+#ifndef PAOS_LONG_ONE_LINE
+#define PAOS_LONG_ONE_LINE 1
+#endif
 template <typename T, int N, int AXIS, int KPRE, int KMID, int NFFT, int STORE = 0, int TAB = 0, int LONG = 0>
 int frugal_launch(paos_ctx* c, const FrugalArgs& args) {
   using C = FftCfg<T, N>;
-  constexpr int LINES = AXIS == 0 ? C::FR_ROW_LINES : C::COL_LINES;
+  // Round 5: the launches that run two or three passes of a chain (LONG builds) and store the field are bound by the latency
+  // chain of a workgroup -- exchanges, barriers, table reads -- not by bytes (they move a sixteenth of the grid): at 4096^2
+  // complex128 they run on ONE-line workgroups of 256 threads, four per CU with one wave each per SIMD instead of two of
+  // 512 threads (-6 ... -8 % rows, -2 ... -3 % columns, bit-identical: profiles/r05_fftbench_fused_variants.txt).  The 16- /
+  // 32-byte pieces such tiles take out of every 128-byte block, which rule them out for byte-bound passes, cost nothing
+  // here.  (The PSF- / power-summing builds keep the two-line tiles: their partial sums are laid out per two-line tile.)
+  constexpr bool kOneLine = PAOS_LONG_ONE_LINE != 0 && LONG != 0 && STORE == 0 && sizeof(T) == 8 && N == 4096;
+  constexpr int LINES = kOneLine ? 1 : (AXIS == 0 ? C::FR_ROW_LINES : C::COL_LINES);
   constexpr int TILES = AXIS == 0 ? C::ROW_TILES : C::COL_TILES;
   // several workgroups share the 160 KiB of LDS: c128 exchanges re and im in turn; a c64 line
   // fits whole (the same 35 KiB) and so needs half the barriers -- except in the 4-line row tiles
@@ -662,11 +672,14 @@ int frugal_launch(paos_ctx* c, const FrugalArgs& args) {
   FrugalArgs a = args;
   unsigned groups = N / LINES / TILES;
   a.wg0 = 0;
-  static_assert((N / LINES / TILES) % 16 == 0, "TileMap renumbers tiles inside aligned groups of 16 workgroups");
-  if (a.live_hi > a.live_lo) {  // launch the workgroups of live lines only, in whole groups of 16
+  // TileMap renumbers the tiles that share 128-byte lines inside aligned groups of workgroups (siblings 8 apart: one XCD):
+  // 16 for half-block row tiles and whole-block column tiles, 32 for the quarter-block row tiles of the one-line builds
+  constexpr unsigned kAlign = (kOneLine && AXIS == 0) ? 32 : 16;
+  static_assert((N / LINES / TILES) % kAlign == 0, "TileMap renumbers tiles inside aligned groups of workgroups");
+  if (a.live_hi > a.live_lo) {  // launch the workgroups of live lines only, in whole groups
     const unsigned per = LINES * TILES;
-    a.wg0 = (a.live_lo / per) / 16 * 16;
-    unsigned end = ((a.live_hi + per - 1) / per + 15) / 16 * 16;
+    a.wg0 = (a.live_lo / per) / kAlign * kAlign;
+    unsigned end = ((a.live_hi + per - 1) / per + kAlign - 1) / kAlign * kAlign;
     if (end > groups) end = groups;
     groups = end - a.wg0;
   }

@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <algorithm>
 
 #include "frugal_pass.h"
 
@@ -226,6 +227,114 @@ void bench_frugal(const char* name, int batch, int reps, int pad_blocks) {
   CK(hipFree(d)); CK(hipFree(dtw)); CK(hipFree(ditems));
 }
 
+// Round 5: the fused launches of the separable pass programs -- load | slot F slot F | slot F slot F | store on a quarter of the
+// lines, a quarter of the positions loaded and stored, every slot reading a phase table (TAB = 1, LONG = 2) -- with the
+// library's two-line workgroups (512 threads, two per CU) against one-line workgroups (256 threads, four per CU).
+template <int AXIS, int LINES, int LONG = 2, int NFFT = 2, int E = 16>
+void bench_fused(const char* name, int batch, int reps, int pad_blocks) {
+  using T = double;
+  constexpr int N = 4096, BR = 4, BC = 2, TILES = 1;
+  if (getenv("PAOS_BENCH_BATCH")) batch = atoi(getenv("PAOS_BENCH_BATCH"));
+  const unsigned pitch = (unsigned)N * BR + (unsigned)pad_blocks * BR * BC;
+  const unsigned item_stride = pitch * (N / BR);
+  cx<T>* d;
+  CK(hipMalloc(&d, (size_t)item_stride * batch * sizeof(cx<T>)));
+  std::vector<std::complex<T>> h((size_t)N * N);
+  srand(1);
+  for (auto& z : h) z = std::complex<T>((T)(rand() / (double)RAND_MAX - 0.5), (T)(rand() / (double)RAND_MAX - 0.5));
+  for (int b = 0; b < batch; ++b)
+    for (int r = 0; r < N / BR; ++r)
+      CK(hipMemcpy(d + (size_t)b * item_stride + (size_t)r * pitch, h.data() + (size_t)r * N * BR,
+                   (size_t)N * BR * sizeof(cx<T>), hipMemcpyHostToDevice));
+  auto tw = make_twiddles<T, N>();
+  cx<T>* dtw;
+  CK(hipMalloc(&dtw, N * sizeof(cx<T>)));
+  CK(hipMemcpy(dtw, tw.data(), N * sizeof(cx<T>), hipMemcpyHostToDevice));
+  // one table of unit factors per slot and item (2 MiB per slot of a 32-item launch, like the library's)
+  constexpr int kPasses = 1 + (LONG + 1) / 2;
+  std::vector<std::complex<double>> tab((size_t)2 * kPasses * batch * N);
+  for (size_t i = 0; i < tab.size(); ++i) { const double a = 0.001 * (double)(i % 6283); tab[i] = {cos(a), sin(a)}; }
+  cx<double>* dtab;
+  CK(hipMalloc(&dtab, tab.size() * sizeof(cx<double>)));
+  CK(hipMemcpy(dtab, tab.data(), tab.size() * sizeof(cx<double>), hipMemcpyHostToDevice));
+  const int lo = 1536, hi = 2560;  // the live quarter (whole groups of 32 workgroups either way)
+  std::vector<FrugalItem> items((size_t)kPasses * batch);
+  for (int p = 0; p < kPasses; ++p)
+    for (int b = 0; b < batch; ++b) {
+      FrugalItem& it = items[(size_t)p * batch + b];
+      std::memset(&it, 0, sizeof(it));
+      it.active = 1; it.fft1_on = 1; it.fft1_inv = 0; it.fft2_on = 1; it.fft2_inv = 1;
+      it.pre.scale = 1.0; it.mid.scale = 1.0 / N;
+      it.line_lo = lo; it.line_hi = hi; it.pos_lo = lo; it.pos_hi = hi; it.spos_lo = lo; it.spos_hi = hi;
+      it.pre.table = dtab + ((size_t)(2 * p) * batch + b) * N;
+      it.mid.table = dtab + ((size_t)(2 * p + 1) * batch + b) * N;
+      for (int j = 0; j < kFrugalMaxPre; ++j) it.pre_ph[j] = {0.01, 0.01, 0.21, 1.0, 1.0, 0.0};
+      for (int j = 0; j < kFrugalMaxMid; ++j) it.mid_ph[j] = {0.01, 0.01, 0.37, -1.0, 1.0, 1.0};
+    }
+  FrugalItem* ditems;
+  CK(hipMalloc(&ditems, items.size() * sizeof(FrugalItem)));
+  CK(hipMemcpy(ditems, items.data(), items.size() * sizeof(FrugalItem), hipMemcpyHostToDevice));
+  std::vector<double> ones((size_t)batch, 1.0);
+  double* dones;
+  CK(hipMalloc(&dones, ones.size() * sizeof(double)));
+  CK(hipMemcpy(dones, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice));
+  FrugalArgs a{d, dtw, ditems, pitch, item_stride};
+  a.dyn_scale = dones;
+  a.wg0 = lo / (LINES * TILES);
+  const dim3 grid((hi - lo) / (LINES * TILES), batch), block(TILES * LINES * N / E);
+#if PAOS_STAMPS
+  unsigned long long* dstamps;
+  const size_t nstamps = (size_t)grid.x * grid.y * kStampSlots;
+  CK(hipMalloc(&dstamps, nstamps * sizeof(unsigned long long)));
+  CK(hipMemset(dstamps, 0, nstamps * sizeof(unsigned long long)));
+  a.stamps = dstamps;
+#endif
+  constexpr bool SPLIT = true;
+  const size_t lds = frugal_lds_bytes<T, N, LINES, TILES, SPLIT, 1, 1, E>();
+  auto kf = frugal_pass_kernel<T, N, E, LINES, TILES, AXIS, BR, BC, SPLIT, 1, 1, NFFT, 0, 1, LONG>;
+  CK(hipFuncSetAttribute((const void*)kf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  // checksum of one launch on a fresh copy (the variants must agree bit for bit)
+  hipLaunchKernelGGL(kf, grid, block, lds, 0, PAOS_FRUGAL_PASS(a));
+  CK(hipDeviceSynchronize());
+  std::vector<std::complex<T>> row(N);
+  double sum = 0.0;
+  for (int r = lo; r < hi; r += 97) {
+    for (int c0 = 0; c0 < N; c0 += 2) {
+      std::complex<T> two[2];
+      CK(hipMemcpy(two, d + layout_index<BR, BC>(r, c0, pitch), sizeof(two), hipMemcpyDeviceToHost));
+      sum += two[0].real() * (1 + (c0 % 7)) + two[1].imag() * (1 + (r % 5));
+    }
+  }
+  Timer tm;
+  float ms = tm.run([&] { hipLaunchKernelGGL(kf, grid, block, lds, 0, PAOS_FRUGAL_PASS(a)); }, reps);
+  int nb = 0;
+  CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)kf, block.x, lds));
+  const double lines = (double)(hi - lo) * batch, transforms = lines * 2 * kPasses;
+  printf("%-40s ax=%d lines/wg=%d thr=%d lds=%zuK occ=%d  %8.3f ms  %6.2f TFLOP/s (5 N log2 N)  checksum %.17g\n", name, AXIS, LINES, block.x,
+         lds / 1024, nb, ms, transforms * 5.0 * N * 12.0 / (ms * 1e-3) / 1e12, sum);
+  fflush(stdout);
+#if PAOS_STAMPS
+  {  // the clock the chip held in the last launch, and where a workgroup's time went (wave 0 of every workgroup)
+    std::vector<unsigned long long> st(nstamps);
+    CK(hipMemcpy(st.data(), dstamps, nstamps * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    std::vector<double> clk, seg[7], life;
+    for (size_t w = 0; w < (size_t)grid.x * grid.y; ++w) {
+      const unsigned long long* q = &st[w * kStampSlots];
+      if (!q[7] || q[10] <= q[8]) continue;
+      const double cyc = (double)(q[7] - q[0]), real = (double)(q[10] - q[8]);  // s_memrealtime: 100 MHz
+      clk.push_back(cyc / real * 0.1);
+      life.push_back(cyc);
+      for (int k = 0; k < 7; ++k) seg[k].push_back((double)(q[k + 1] - q[k]));
+    }
+    auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+    printf("   stamps: %zu workgroups, shader clock (median) %.3f GHz, workgroup life %.0f cyc; load wait %.0f | pre slot %.0f | fft1 %.0f | mid slot %.0f | fft2 + later passes %.0f | store issue %.0f | drain %.0f\n",
+           clk.size(), med(clk), med(life), med(seg[0]), med(seg[1]), med(seg[2]), med(seg[3]), med(seg[4]), med(seg[5]), med(seg[6]));
+    CK(hipFree(dstamps));
+  }
+#endif
+  CK(hipFree(d)); CK(hipFree(dtw)); CK(hipFree(ditems)); CK(hipFree(dtab)); CK(hipFree(dones));
+}
+
 template <typename T>
 void bench_copy(int n, int batch, int reps) {
   const size_t elems = (size_t)n * n * batch;
@@ -246,6 +355,19 @@ int main(int argc, char** argv) {
   // NOTE: only instantiate 512-or-fewer-thread shapes: a 1024-thread instantiation in the same translation unit
   // changes the register allocation of the others (measured in round 2).
   bench_copy<double>(4096, b4, reps);
+  if (getenv("PAOS_BENCH_FUSED")) {  // the fused launches of the separable programs: two-line against one-line workgroups
+    for (int round = 0; round < 2; ++round) {
+      bench_fused<0, 2>("fused rows, 2 lines per workgroup", 32, reps, pad);
+      bench_fused<0, 1>("fused rows, 1 line per workgroup", 32, reps, pad);
+      bench_fused<1, 2>("fused cols, 2 lines per workgroup", 32, reps, pad);
+      bench_fused<1, 1>("fused cols, 1 line per workgroup", 32, reps, pad);
+#ifdef PAOS_E8_MINW
+      bench_fused<0, 1, 2, 2, 8>("fused rows, 1 line, 8 points per thread", 32, reps, pad);
+      bench_fused<1, 1, 2, 2, 8>("fused cols, 1 line, 8 points per thread", 32, reps, pad);
+#endif
+    }
+    return 0;
+  }
   bench_frugal<double, 4096, 0, 0, 0, 1>("rows single", b4, reps, pad);
   bench_frugal<double, 4096, 1, 0, 0, 1>("cols single", b4, reps, pad);
   bench_frugal<double, 4096, 0, 0, 1, 2>("rows double 1 phase", b4, reps, pad);
