@@ -10,6 +10,12 @@ from it (reference paos/core/run.py:181-190); no GPU kernel is involved.
 import numpy as np
 
 
+# Bumped by every in-place change of a matrix or a direction flag (the ``ABCD`` / ``cin`` / ``cout`` setters): callers that
+# keep derived values of MANY matrices (run.py: the per-surface gate arrays of a batch) compare it instead of asking
+# each object again.
+EPOCH = [0]
+
+
 def _compose(thickness, curvature, n1, n2, mag):
     """[[1,t],[0,1]] @ D @ diag(M, 1/M) with D a thin lens when n1 == n2 and a
     dioptre/mirror otherwise (abcd.py:79-90).  Plain matmul keeps the
@@ -45,6 +51,7 @@ class ABCD:
     def ABCD(self, value):
         self._mat = value.copy()
         self._cache = {}
+        EPOCH[0] += 1
 
     # direction of travel (+1 left-to-right, -1 right-to-left) ---------------
     @property
@@ -54,6 +61,7 @@ class ABCD:
     @cin.setter
     def cin(self, value):
         self._cin = value
+        EPOCH[0] += 1
 
     @property
     def cout(self):
@@ -63,6 +71,7 @@ class ABCD:
     def cout(self, value):
         self._cout = value
         self._cache.pop("gates", None)
+        EPOCH[0] += 1
 
     def gates(self):
         """(M, fl, T, n1n2) the way the propagation loop derives them from a surface's matrix

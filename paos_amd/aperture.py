@@ -30,13 +30,32 @@ class _MaskImage:
             dev.close()
 
 
-class EllipticalAperture:
+class _Centred:
+    """``positions`` (the centre, pixels) as the ndarray photutils' apertures carry, made when somebody reads it: a batch
+    of 256 wavefronts builds ~2000 handles per walk and reads the attribute of a handful (round 5)."""
+
+    __slots__ = ()
+
+    @property
+    def positions(self):
+        return np.array(self._xy, dtype=np.float64)
+
+    @positions.setter
+    def positions(self, value):
+        x, y = np.asarray(value, dtype=np.float64)
+        self._xy = (float(x), float(y))
+
+
+class EllipticalAperture(_Centred):
+    __slots__ = ("_xy", "a", "b", "theta")
+
     def __init__(self, positions, a, b, theta=0.0):
-        self.positions = np.asarray(positions, dtype=np.float64)
+        x, y = positions
+        self._xy = (float(x), float(y))
         self.a, self.b, self.theta = float(a), float(b), float(theta)
 
     def block(self, obscuration=False, enable=True):
-        xc, yc = self.positions
+        xc, yc = self._xy
         return [1.0 if enable else 0.0, xc, yc, self.a, self.b, self.theta,
                 1.0 if obscuration else 0.0, 0.0]
 
@@ -49,13 +68,16 @@ class EllipticalAperture:
         return f"<EllipticalAperture({list(self.positions)}, a={self.a}, b={self.b}, theta={self.theta})>"
 
 
-class RectangularAperture:
+class RectangularAperture(_Centred):
+    __slots__ = ("_xy", "w", "h", "theta")
+
     def __init__(self, positions, w, h, theta=0.0):
-        self.positions = np.asarray(positions, dtype=np.float64)
+        x, y = positions
+        self._xy = (float(x), float(y))
         self.w, self.h, self.theta = float(w), float(h), float(theta)
 
     def block(self, obscuration=False, enable=True, subpixels=32):
-        xc, yc = self.positions
+        xc, yc = self._xy
         return [1.0 if enable else 0.0, xc, yc, self.w, self.h, self.theta,
                 1.0 if obscuration else 0.0, float(subpixels)]
 
@@ -104,7 +126,7 @@ def bbox_misses_grid(ap, n):
         hw, hh = ap.w / 2.0, ap.h / 2.0
         xe = max(abs(hw * ct - hh * st), abs(hw * ct + hh * st))
         ye = max(abs(hw * st + hh * ct), abs(hw * st - hh * ct))
-    xc, yc = float(ap.positions[0]), float(ap.positions[1])
+    xc, yc = ap._xy
     if not (math.isfinite(xc) and math.isfinite(yc) and math.isfinite(xe) and math.isfinite(ye)):
         return True
     x0, x1 = math.floor(xc - xe + 0.5), math.ceil(xc + xe + 0.5)

@@ -60,6 +60,31 @@ def _rows(rows, batch):
     return np.array([r if r is not None else _OFF for r in rows], dtype=np.float64).reshape(batch, 5)
 
 
+def _aperture_rows(records, batch):
+    """The two [batch][5] block sets of an aperture operator from per-item records (None, or the 8-double block of
+    paos_aperture plus the shape code) -- or, for a batch planned with array arithmetic (run.py: _BatchApertures), from
+    the ([batch][8] blocks, [batch] shape codes) pair itself.  None when no item carries an aperture."""
+    if isinstance(records, tuple) and len(records) == 2 and isinstance(records[0], np.ndarray):
+        blocks, codes = records
+        if blocks.shape != (batch, 8):
+            raise ValueError("aperture blocks must be [batch][8]")
+        on = blocks[:, 0] != 0.0
+        if not on.any():
+            return None
+        first = np.ascontiguousarray(blocks[:, :5])
+        second = np.zeros((batch, 5), dtype=np.float64)
+        second[:, :3] = blocks[:, 5:8]
+        second[:, 3] = codes
+        first[~on] = 0.0
+        second[~on] = 0.0
+        return first, second
+    if all(r is None for r in records):
+        return None
+    first = [list(r[0][:5]) if r is not None else None for r in records]
+    second = [[r[0][5], r[0][6], r[0][7], float(r[1]), 0.0] if r is not None else None for r in records]
+    return _rows(first, batch), _rows(second, batch)
+
+
 class PassCompiler:
     def __init__(self, batch, n):
         self.batch, self.n = int(batch), int(n)
@@ -133,14 +158,14 @@ class PassCompiler:
         """records: per item None or the 8-double aperture block of paos_aperture
         [enable, xc, yc, a|w, b|h, theta, obscuration, subpixels] plus the shape code.  The
         mask rides on the next pass (its weight map is rendered right before it)."""
-        if all(r is None for r in records):
+        rows = _aperture_rows(records, self.batch)
+        if rows is None:
             return
         if any(op[0] == _lib.PW_MASK for op in self.tail) or (
                 self.open is not None and any(op[0] == _lib.PW_MASK for op in self.open["mid"])):
             self._close_open()  # one aperture per pass
-        first = self._block([list(r[0][:5]) if r is not None else None for r in records])
-        self._block([[r[0][5], r[0][6], r[0][7], float(r[1]), 0.0] if r is not None else None
-                     for r in records])
+        first = self._block(rows[0])
+        self._block(rows[1])
         self.tail.append((_lib.PW_MASK, 0, first))
 
     def lens(self, rows):
@@ -381,11 +406,10 @@ class SeparableCompiler(PassCompiler):
 
     # ---- operators -----------------------------------------------------------------------
     def aperture(self, records):
-        if all(r is None for r in records):
+        rows = _aperture_rows(records, self.batch)
+        if rows is None:
             return
-        first = [list(r[0][:5]) if r is not None else None for r in records]
-        second = [[r[0][5], r[0][6], r[0][7], float(r[1]), 0.0] if r is not None else None for r in records]
-        self.ops.append({"k": "mask", "first": _rows(first, self.batch), "second": _rows(second, self.batch)})
+        self.ops.append({"k": "mask", "first": rows[0], "second": rows[1]})
 
     def lens(self, rows):
         arr = _rows(rows, self.batch)

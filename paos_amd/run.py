@@ -16,6 +16,7 @@ planners disagree (a ptp skipped for one wavelength, II vs OI) still share
 launches.
 """
 import atexit
+import gc
 import math
 import threading
 from copy import deepcopy
@@ -23,8 +24,9 @@ from copy import deepcopy
 import numpy as np
 
 from . import _lib
+from . import abcd as _abcd
 from .abcd import ABCD
-from .aperture import EllipticalAperture, bbox_misses_grid, make_aperture
+from .aperture import EllipticalAperture, RectangularAperture, bbox_misses_grid, make_aperture
 from .coordinate_break import coordinate_break
 from . import passes as _passes
 from .passes import PassCompiler, SeparableCompiler
@@ -123,6 +125,97 @@ class PowerTicket:
         return f"PowerTicket(slot {self._red.slot}, {state}{', derived' if self._post is not None else ''})"
 
 
+class _BatchApertures:
+    """The apertures of one surface for every wavefront of a batch as arrays (round 5: ``_plan_batch``): pixel-unit centres
+    and sizes, shape, obscuration flag -- what the library's parameter blocks, the line-record test and the live-row
+    bookkeeping need, without a Python object per wavefront.  ``handle(i)`` makes the photutils-like object of item i
+    when somebody wants to see it (a saved surface's record, an orthonormal Zernike pupil)."""
+
+    def __init__(self, ixc, iyc, ea, eb, rect, obsc):
+        self.ixc, self.iyc, self.ea, self.eb, self.rect, self.obsc = ixc, iyc, ea, eb, rect, obsc
+        self.batch = len(ixc)
+        self._handles = {}
+
+    def handle(self, i):
+        h = self._handles.get(i)
+        if h is None:
+            cls = RectangularAperture if self.rect[i] else EllipticalAperture
+            h = self._handles[i] = cls((float(self.ixc[i]), float(self.iyc[i])), float(self.ea[i]), float(self.eb[i]), 0.0)
+        return h
+
+    def blocks(self):
+        """[batch][8] parameter blocks of paos_aperture / paos_start (aperture.py: block) and the shape code per item."""
+        b = np.zeros((self.batch, _lib.APERTURE_STRIDE), dtype=np.float64)
+        b[:, 0] = 1.0
+        b[:, 1], b[:, 2], b[:, 3], b[:, 4] = self.ixc, self.iyc, self.ea, self.eb
+        b[:, 6] = self.obsc
+        b[:, 7] = np.where(self.rect, 32.0, 0.0)
+        return b, np.where(self.rect, float(_lib.SHAPE_RECT), float(_lib.SHAPE_ELLIPSE))
+
+    def fits_line_records(self, n, precision):
+        """``_aperture_fits_line_records`` for every item."""
+        if n < (1024 if precision == "fp64" else 2048):
+            return False
+        a, b = self.ea, self.eb
+        with np.errstate(all="ignore"):
+            ell = (a >= 2.0) & (b >= 2.0) & (2.0 * a * np.sqrt(3.0 / b) + 8.0 <= _MASK_RUN) & (2.0 * b * np.sqrt(3.0 / a) + 8.0 <= _MASK_RUN)
+        rec = ~self.obsc & (a > 0.0) & (b > 0.0)
+        return bool(np.all(np.where(self.rect, rec, ell)))
+
+    def narrow_rows(self, live, n):
+        """``_live_rows_after`` for every item: rows outside a clear aperture's bounding box (widened by a pixel) are zero."""
+        ext = np.where(self.rect, self.eb / 2.0, self.eb)
+        ok = ~self.obsc & np.isfinite(self.iyc) & np.isfinite(ext) & (ext > 0.0)
+        with np.errstate(all="ignore"):
+            lo = np.maximum(0, np.floor(self.iyc - ext + 0.5) - 1)
+            hi = np.minimum(n, np.ceil(self.iyc + ext + 0.5) + 1)
+        for i in np.nonzero(ok & (lo < hi))[0].tolist():
+            r = live[i]
+            r[0], r[1] = max(r[0], int(lo[i])), min(r[1], int(hi[i]))
+            if r[0] >= r[1]:
+                r[0], r[1] = 0, 0
+
+
+class _LazyAperture:
+    """``plan["aperture"]`` of an item of a ``_BatchApertures`` surface: behaves like the (handle, obscuration) pair
+    ``_plan_host`` makes; the handle is built when it is looked at."""
+
+    __slots__ = ("src", "i")
+
+    def __init__(self, src, i):
+        self.src, self.i = src, i
+
+    def __getitem__(self, k):
+        if k == 0:
+            return self.src.handle(self.i)
+        if k == 1:
+            return bool(self.src.obsc[self.i])
+        raise IndexError(k)
+
+    def __iter__(self):
+        yield self.src.handle(self.i)
+        yield bool(self.src.obsc[self.i])
+
+    def __len__(self):
+        return 2
+
+
+class _Plans(list):
+    """The per-item plans of one surface; ``ap`` is the surface's ``_BatchApertures`` when ``_plan_batch`` planned the
+    apertures of ALL items with array arithmetic (None otherwise: the consumers then read the per-item entries).
+    ``summary()``: (any stop, any Zernike, any phase map, any aperture) over the items -- looked at a dozen times per
+    surface by the walk, scanned once."""
+
+    ap = None
+    _summary = None
+
+    def summary(self):
+        if self._summary is None:
+            self._summary = (any(p["stop"] for p in self), any(p["zernike"] is not None for p in self),
+                             any(p["phase_map"] is not None for p in self), any(p["aperture"] is not None for p in self))
+        return self._summary
+
+
 class _Item:
     """Host state of one wavefront while it walks the chain: the two paraxial rays of the field
     point and the ray-transfer factors met so far.  (The pilot beams of all wavefronts live together
@@ -160,7 +253,7 @@ class ABCDProduct(ABCD):
         raise AttributeError(name)
 
 
-def _plan_host(st, item, n, dx, dy, wl, wz_of):
+def _plan_host(st, item, n, dx, dy, wl, wz_of, aperture_plan=False):
     """Host half of one loop iteration of run.py:77-178 for one wavefront -- everything but the
     pilot-beam scalars (those are advanced for the whole batch in one C call, planner.BeamBatch).
     ``dx, dy, wl`` are the wavefront's current sampling and wavelength, ``wz_of()`` its beam radius."""
@@ -173,7 +266,9 @@ def _plan_host(st, item, n, dx, dy, wl, wz_of):
         st.still = not (np.any(st.vt) or np.any(st.vs))
 
     ap = item.get("aperture")
-    if ap is not None:
+    if aperture_plan is not False:  # (_plan_batch has done the aperture)
+        plan["aperture"] = aperture_plan
+    elif ap is not None:
         xdec = ap["xc"] if math.isfinite(ap["xc"]) else st.vs[0]
         ydec = ap["yc"] if math.isfinite(ap["yc"]) else st.vt[0]
         xrad = ap["xrad"]
@@ -216,16 +311,124 @@ def _plan_host(st, item, n, dx, dy, wl, wz_of):
     return plan
 
 
+def _plan_batch(states, items, n, dxs, dys, wls, wz_of, all_still=None):
+    """``_plan_host`` for every wavefront of a batch.  The common case -- every item on axis (both paraxial rays zero:
+    no coordinate break has moved them), the same kind of surface for all, no Grid Sag / PSD map to build -- is planned
+    with array arithmetic (round 5: at 1024^2 x 256 wavefronts the per-item Python of this function was 40 % of a
+    step that the GPU finishes in half the time the host needed to describe it).  The numbers are the ones
+    ``_plan_host`` forms: with the rays at zero its ``xrad *= sqrt(1 / (0**2 + 1))`` and ``xdec - 0.0`` are exact
+    identities, the pixel quantities are the same IEEE divisions and sums.  Anything else takes the per-item path."""
+    kind = items[0]["type"]
+    if all_still is None:
+        all_still = all(st.still for st in states)
+    fast = kind not in ("Coordinate Break", "Grid Sag", "PSD") and all_still and all(it["type"] == kind for it in items)
+    if not fast:
+        return _Plans(_plan_host(st, it, n, dxs[i], dys[i], wls[i], lambda i=i: wz_of(i))
+                      for i, (st, it) in enumerate(zip(states, items)))
+    plans = _Plans({"aperture": None, "stop": bool(it["is_stop"]), "zernike": None, "phase_map": None} for it in items)
+    aps = [it.get("aperture") for it in items]
+    have = [i for i, a in enumerate(aps) if a is not None]
+    if have:
+        sel = aps if len(have) == len(aps) else [aps[i] for i in have]
+        geo = np.array([(a["xc"], a["yc"], a["xrad"], a["yrad"]) for a in sel], dtype=np.float64)
+        xc, yc, xrad, yrad = geo[:, 0], geo[:, 1], geo[:, 2], geo[:, 3]
+        if len(have) == len(aps):
+            dx, dy = np.asarray(dxs, dtype=np.float64), np.asarray(dys, dtype=np.float64)
+        else:
+            dx, dy = np.array([dxs[i] for i in have], dtype=np.float64), np.array([dys[i] for i in have], dtype=np.float64)
+        shapes = [a["shape"] for a in sel]
+        rect = np.array([sh == "rectangular" for sh in shapes])
+        known = all(sh in ("elliptical", "rectangular") for sh in shapes)
+        xaper = np.where(np.isfinite(xc), xc, 0.0)  # (a missing centre falls back on the chief ray: zero here)
+        yaper = np.where(np.isfinite(yc), yc, 0.0)
+        with np.errstate(all="ignore"):
+            ixc, iyc = xaper / dx + n / 2, yaper / dy + n / 2
+            ea, eb = xrad / dx, yrad / dy   # semi-axes of an ellipse, FULL widths of a rectangle (wfo.py:224,261-264)
+            xe, ye = np.where(rect, np.abs(ea / 2.0), np.abs(ea)), np.where(rect, np.abs(eb / 2.0), np.abs(eb))
+            x0, x1 = np.floor(ixc - xe + 0.5), np.ceil(ixc + xe + 0.5)
+            y0, y1 = np.floor(iyc - ye + 0.5), np.ceil(iyc + ye + 0.5)
+            miss = ~(np.isfinite(ixc) & np.isfinite(iyc) & np.isfinite(xe) & np.isfinite(ye))
+            miss |= (np.maximum(x0, 0) >= np.minimum(x1, n)) | (np.maximum(y0, 0) >= np.minimum(y1, n))
+        finite = np.isfinite(xrad) & np.isfinite(yrad)
+        obsc = np.array([a["type"] != "aperture" for a in sel])
+        if known and len(have) == len(aps) and bool(finite.all()):
+            # every item carries an aperture of a shape the kernels render: no per-item objects at all
+            if bool(miss.any()):
+                raise TypeError("aperture does not overlap the grid (mask is None in the reference)")
+            plans.ap = _BatchApertures(ixc, iyc, ea, eb, rect, obsc)
+            for i, p in enumerate(plans):
+                p["aperture"] = _LazyAperture(plans.ap, i)
+        else:
+            ixc, iyc, ea, eb = ixc.tolist(), iyc.tolist(), ea.tolist(), eb.tolist()
+            for k, i in enumerate(have):
+                if not finite[k]:
+                    continue  # run.py:112: skipped unless both radii are finite
+                shape = shapes[k]
+                if shape == "elliptical":
+                    handle = EllipticalAperture((ixc[k], iyc[k]), ea[k], eb[k], 0.0)
+                elif shape == "rectangular":
+                    handle = RectangularAperture((ixc[k], iyc[k]), ea[k], eb[k], 0.0)
+                else:  # ("circular" needs r, which run() never passes: make_aperture raises as the reference does)
+                    handle = make_aperture(n, dxs[i], dys[i], float(xaper[k]), float(yaper[k]), hx=float(xrad[k]),
+                                           hy=float(yrad[k]), shape=shape)
+                if miss[k]:
+                    raise TypeError("aperture does not overlap the grid (mask is None in the reference)")
+                plans[i]["aperture"] = (handle, bool(obsc[k]))
+    plans._summary = (any(it["is_stop"] for it in items), kind == "Zernike", False,
+                      plans.ap is not None or any(p["aperture"] is not None for p in plans) if have else False)
+    if kind == "Zernike":
+        # (run.py:124-152 per item; what depends only on the index array / ordering / normalisation -- the continuity
+        # check, the (m, n, norm) tables -- is looked up once per distinct index array of the batch)
+        tables = {}
+        for i, it in enumerate(items):
+            radius = it["Zradius"] if math.isfinite(it["Zradius"]) else wz_of(i)
+            pupil = None
+            if it["Zorthonorm"]:
+                assert "aperture" in it, "Zorthonorm requires aperture"
+                if plans[i]["aperture"] is None:
+                    raise KeyError("aperture")  # the reference finds no _retval_["aperture"]
+                pupil = plans[i]["aperture"][0]
+            index = np.asarray(it["Zindex"])
+            key = (index.tobytes(), index.dtype.str, it["Zordering"], bool(it["Znormalize"]))
+            hit = tables.get(key)
+            if hit is None:
+                assert not np.any(np.diff(index) - 1), "Zernike sequence should be continuous"
+                if it["Zordering"] not in ("ansi", "noll", "fringe", "standard"):
+                    raise AssertionError("Unrecognised ordering scheme.")
+                hit = tables[key] = zernike_tables(len(index), it["Zordering"], bool(it["Znormalize"]))
+            m, nn, norm = hit
+            plans[i]["zernike"] = dict(m=m, n=nn, norm=norm, Z=np.asarray(it["Z"], dtype=np.float64), dx=dxs[i], dy=dys[i],
+                                       radius=radius, wl=wls[i], origin=it["Zorigin"], pupil=pupil)
+    return plans
+
+
 def _surface_gates(items):
     """Mt, Ms, fl, T, n1n2 of one surface for every item -- the quantities run.py:181-190 reads off the
     surface's ABCD matrices (fl = cout / power, inf for a powerless surface; T = cout * thickness)."""
-    gt = [it["ABCDt"].gates() for it in items]
-    Mt = [g[0] for g in gt]
+    Mt, fl, T, n1n2 = zip(*[it["ABCDt"].gates() for it in items])
     Ms = [it["ABCDs"].M for it in items]
-    fl = [g[1] for g in gt]
-    T = [g[2] for g in gt]
-    n1n2 = [g[3] for g in gt]
     return Mt, Ms, fl, T, n1n2
+
+
+# The same for the columns of ABCD objects the walk has gathered anyway, as arrays, remembered per column: the batches of a
+# sweep or of a Monte-Carlo study meet the SAME matrix objects at every step (parse_config's, shared by the shallow copies
+# inject_wfe makes), and asking 2 x 256 objects per surface again was a tenth of the host's time per step at 256 wavefronts.
+# An entry is valid while the column holds the very same objects (list equality on objects without __eq__ is identity, at C
+# speed) and no matrix has been edited in place since (abcd.EPOCH).
+_GATE_COLUMNS = {}
+
+
+def _gate_arrays(col_t, col_s):
+    key = (id(col_t[0]), id(col_s[0]), len(col_t))
+    hit = _GATE_COLUMNS.get(key)
+    if hit is not None and hit[0] == _abcd.EPOCH[0] and hit[1] == col_t and hit[2] == col_s:
+        return hit[3]
+    Mt, fl, T, n1n2 = zip(*[a.gates() for a in col_t])
+    arrays = tuple(np.array(v, dtype=np.float64) for v in (Mt, [a.M for a in col_s], fl, T, n1n2))
+    if len(_GATE_COLUMNS) >= 1024:
+        _GATE_COLUMNS.clear()
+    _GATE_COLUMNS[key] = (_abcd.EPOCH[0], list(col_t), list(col_s), arrays)
+    return arrays
 
 
 def _inert(item):
@@ -234,21 +437,24 @@ def _inert(item):
     a coordinate break.  (What run.py:181-207 would gate on: Mt = Ms = 1, fl = inf, T = 0, n1n2 = 1.)"""
     if item.get("aperture") is not None or item.get("is_stop") or item["type"] in ("Zernike", "Grid Sag", "PSD"):
         return False
-    (Mt,), (Ms,), (fl,), (T,), (n1n2,) = _surface_gates([item])
-    return Mt == 1.0 and Ms == 1.0 and math.isinf(fl) and T == 0.0 and n1n2 == 1.0
+    Mt, fl, T, n1n2 = item["ABCDt"].gates()
+    return Mt == 1.0 and item["ABCDs"].M == 1.0 and math.isinf(fl) and T == 0.0 and n1n2 == 1.0
 
 
 def _live_rows_after(plans, live, n):
     """Rows that may be non-zero after the stand-alone apertures of ``plans`` were applied: a clear
     aperture (not an obscuration) leaves exact zeros outside its bounding box (photutils' box,
     widened by a pixel here).  ``live`` is updated in place, one [lo, hi) per item."""
+    if getattr(plans, "ap", None) is not None:
+        plans.ap.narrow_rows(live, n)
+        return
     for i, p in enumerate(plans):
         ap = p["aperture"]
         if ap is None or ap[1] or ap[0].theta != 0.0:
             continue
         h = ap[0]
         ext = h.b if isinstance(h, EllipticalAperture) else h.h / 2.0
-        yc = float(h.positions[1])
+        yc = h._xy[1]
         if not (math.isfinite(yc) and math.isfinite(ext) and ext > 0.0):
             continue
         lo = max(0, int(math.floor(yc - ext + 0.5)) - 1)
@@ -262,6 +468,15 @@ def _live_rows_after(plans, live, n):
 
 
 def _launch_apertures(dev, plans):
+    if getattr(plans, "ap", None) is not None:
+        blocks, codes = plans.ap.blocks()
+        for code in (_lib.SHAPE_ELLIPSE, _lib.SHAPE_RECT):
+            mine = codes == float(code)
+            if mine.any():
+                b = blocks.copy()
+                b[~mine] = 0.0
+                dev.aperture(code, b)
+        return
     for code, cls_is_ellipse in ((_lib.SHAPE_ELLIPSE, True), (_lib.SHAPE_RECT, False)):
         blocks, any_on = [], False
         for p in plans:
@@ -276,6 +491,8 @@ def _launch_apertures(dev, plans):
 
 
 def _launch_zernike(dev, plans, want_wfe=False):
+    if isinstance(plans, _Plans) and not plans.summary()[1]:
+        return None
     zs = [p["zernike"] for p in plans]
     if not any(z is not None for z in zs):
         return None
@@ -287,10 +504,20 @@ def _launch_zernike(dev, plans, want_wfe=False):
 
     def build(coeffs):
         blocks = np.zeros((len(plans), stride), dtype=np.float64)
+        # (items of a sweep share polynomial tables and coefficients and differ in the header only -- sampling, radius,
+        # wavelength: the coefficient planes are formed once per distinct (tables, coefficients) and copied)
+        planes = {}
         for i, z in enumerate(zs):
-            if z is not None:
-                blocks[i], _, _ = zernike_block(z["m"], z["n"], z["norm"], coeffs[i], z["dx"], z["dy"],
-                                                z["radius"], z["wl"], origin=z["origin"], nmax=nmax)
+            if z is None:
+                continue
+            c = np.asarray(coeffs[i], dtype=np.float64)
+            key = (id(z["m"]), id(z["n"]), id(z["norm"]), c.tobytes(), z["origin"])
+            hit = planes.get(key)
+            if hit is None:
+                hit = planes[key] = zernike_block(z["m"], z["n"], z["norm"], c, 1.0, 1.0, 1.0, 1.0, origin=z["origin"], nmax=nmax)[0]
+            row = blocks[i]
+            row[:] = hit
+            row[1], row[2], row[3], row[7] = z["dx"], z["dy"], z["radius"], 1.0 / z["wl"]
         return blocks
 
     coeffs = [z["Z"] if z is not None else None for z in zs]
@@ -325,6 +552,8 @@ def _launch_phase_maps(dev, plans, wfe):
     """Grid Sag / PSD surfaces (run.py:154-177): each item's host-built WFE map multiplies its field
     (paos_phase_map).  Returns what the surface's ``wfe`` entry holds for a single wavefront: the map
     of the LAST of Zernike / Grid Sag / PSD (each assignment at run.py:143,156,168 overwrites)."""
+    if isinstance(plans, _Plans) and not plans.summary()[2]:
+        return wfe
     for i, p in enumerate(plans):
         if p["phase_map"] is not None:
             m, wl = p["phase_map"]
@@ -337,6 +566,9 @@ def _launch_phase_maps(dev, plans, wfe):
 def _queue_apertures(comp, plans):
     """Apertures as pass operators (their weight maps are rendered right before the pass
     they ride on, csrc/paos_hip.hip: launch_one_pass)."""
+    if getattr(plans, "ap", None) is not None:
+        comp.aperture(plans.ap.blocks())
+        return
     recs = []
     for p in plans:
         ap = p["aperture"]
@@ -365,12 +597,20 @@ def _start_field(dev, plans, value, write_rows=None):
     field (paos_start); otherwise fill and let the surface run as usual.  Returns False, or -- when the
     first surface's aperture and stop are done -- per item the index of the first item with the same field.  ``write_rows`` ([lo, hi) per item): only these rows are
     written, the others are left standing for zeros (paos_start_rows)."""
-    aps = [p["aperture"] for p in plans]
-    if any(a is None for a in aps) or len({isinstance(a[0], EllipticalAperture) for a in aps}) != 1:
-        dev.fill(value)
-        return None
-    code = _lib.SHAPE_ELLIPSE if isinstance(aps[0][0], EllipticalAperture) else _lib.SHAPE_RECT
-    blocks = [a[0].block(obscuration=a[1]) for a in aps]
+    batch_ap = getattr(plans, "ap", None)
+    if batch_ap is not None:
+        if bool(batch_ap.rect.any()) and not bool(batch_ap.rect.all()):
+            dev.fill(value)
+            return None
+        code = _lib.SHAPE_RECT if bool(batch_ap.rect.all()) else _lib.SHAPE_ELLIPSE
+        blocks = batch_ap.blocks()[0].tolist()
+    else:
+        aps = [p["aperture"] for p in plans]
+        if any(a is None for a in aps) or len({isinstance(a[0], EllipticalAperture) for a in aps}) != 1:
+            dev.fill(value)
+            return None
+        code = _lib.SHAPE_ELLIPSE if isinstance(aps[0][0], EllipticalAperture) else _lib.SHAPE_RECT
+        blocks = [a[0].block(obscuration=a[1]) for a in aps]
     stops = [1.0 if p["stop"] else 0.0 for p in plans]
     if write_rows is None:
         dev.start(value, code, blocks, stops)
@@ -423,6 +663,8 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
     dead = [False]   # the field has been given up for its PSF (lean end): nothing may run on it any more
 
     prog_power = [None]  # ticket of the power of the field a program has just stored (flush(final_power=True))
+    factor_cols_t, factor_cols_s = [], []  # [surface][item] ABCD factors met so far (run.py:215-219)
+    all_still = [all(st.still for st in states)]  # every item on axis: nothing moves the rays (refreshed behind a coordinate break)
 
     def known_rows():
         return [list(r) for r in live] if any(r[0] > 0 or r[1] < dev.n for r in live) else None
@@ -487,8 +729,9 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
                 readout.extend(beams.readout())
             return readout
 
-        plans = [_plan_host(st, it, n, dxs[i], dys[i], wls[i], lambda i=i: wz_dtf()[0][i])
-                 for i, (st, it) in enumerate(zip(states, items))]
+        plans = _plan_batch(states, items, n, dxs, dys, wls, lambda i: wz_dtf()[0][i], all_still[0])
+        if not all_still[0] or items[0]["type"] == "Coordinate Break" or any(it["type"] == "Coordinate Break" for it in items):
+            all_still[0] = all(st.still for st in states)
         saved = any(it["save"] for it in items)
         if saved:  # push_results scalars (run.py:12-27) are those BEFORE magnification / lens / propagate
             wz, dtf = wz_dtf()
@@ -500,16 +743,21 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
                                     "propagator": props[i]}
         # the pilot beams of the whole batch through this surface (one C call), the rays and the
         # accumulated ABCD factors of each item
-        lens, stw, ptp, wts, inv_stw, inv_wts = beams.surface(*_surface_gates(items))
-        for st, it, p in zip(states, items, plans):
-            if not st.still:
-                st.vt = it["ABCDt"]() @ st.vt
-                st.vs = it["ABCDs"]() @ st.vs
-            st.factors_t.append(it["ABCDt"])
-            st.factors_s.append(it["ABCDs"])
-            if it["save"]:
-                p["ABCDt"] = ABCDProduct(tuple(st.factors_t))
-                p["ABCDs"] = ABCDProduct(tuple(st.factors_s))
+        # (the ray-transfer factors met so far, one column per surface; a saved surface gets its product -- lazily)
+        col_t, col_s = [it["ABCDt"] for it in items], [it["ABCDs"] for it in items]
+        factor_cols_t.append(col_t)
+        factor_cols_s.append(col_s)
+        lens, stw, ptp, wts, inv_stw, inv_wts = beams.surface(*_gate_arrays(col_t, col_s))
+        if not all_still[0]:
+            for i, st in enumerate(states):
+                if not st.still:
+                    st.vt = col_t[i]() @ st.vt
+                    st.vs = col_s[i]() @ st.vs
+        if saved:
+            for i, (it, p) in enumerate(zip(items, plans)):
+                if it["save"]:
+                    p["ABCDt"] = ABCDProduct(tuple(col[i] for col in factor_cols_t))
+                    p["ABCDs"] = ABCDProduct(tuple(col[i] for col in factor_cols_s))
 
         if fresh is not None and not saved and all(_inert(it) for it in items):
             # (coordinate breaks in front of the first mirror: the field is still the constant it will be filled with;
@@ -544,27 +792,28 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
                 _queue_steps(comp, lens, stw, ptp, wts, inv_stw, inv_wts)
                 continue
         fuse_ap = FUSE_APERTURES
-        own_breaker = saved or any(p["stop"] or p["zernike"] is not None or p["phase_map"] is not None
-                                   for p in plans)
+        any_stop, any_zern, any_map, any_ap = plans.summary()
+        own_breaker = saved or any_stop or any_zern or any_map
         if fuse_ap == "auto":
             # an aperture followed on its own surface by a stop / Zernike / save could only ride
             # on a transform-free pass: the stand-alone aperture kernel is cheaper there
             # -- unless the previous propagation left a pass open: then the aperture becomes the
             # last operator of that pass (applied while the tile is stored) at no extra traffic
-            aps = [p["aperture"] for p in plans if p["aperture"] is not None]
-            fuse_ap = (bool(aps) and (not own_breaker or comp.open_takes_mask()) and
-                       all(_aperture_fits_line_records(h, o, dev.n, dev.precision) for h, o in aps))
+            if plans.ap is not None:
+                fuse_ap = (not own_breaker or comp.open_takes_mask()) and plans.ap.fits_line_records(dev.n, dev.precision)
+            else:
+                aps = [p["aperture"] for p in plans if p["aperture"] is not None]
+                fuse_ap = (bool(aps) and (not own_breaker or comp.open_takes_mask()) and
+                           all(_aperture_fits_line_records(h, o, dev.n, dev.precision) for h, o in aps))
         if fuse_ap:
             _queue_apertures(comp, plans)
-        breaker = saved or any(p["stop"] or p["zernike"] is not None or p["phase_map"] is not None or
-                               (p["aperture"] is not None and not fuse_ap) for p in plans)
+        breaker = own_breaker or (any_ap and not fuse_ap)
         if breaker:
             # the field must be current before a non-fusable operator -- unless all this surface wants of it is the
             # PSF of every item (a lean walk's last, saved surface with nothing else on it): then the last pass
             # stores |u|^2 instead
-            only_saved = saved and all(it["save"] for it in items) and not any(
-                p["stop"] or p["zernike"] is not None or p["phase_map"] is not None or
-                (p["aperture"] is not None and not fuse_ap) for p in plans)
+            only_saved = (saved and all(it["save"] for it in items) and
+                          not (any_stop or any_zern or any_map or (any_ap and not fuse_ap)))
             # ... the last surface -- or a surface behind which only inert ones follow (the image plane right behind a
             # saved slit): what the program stores here is what the chain ends with
             ends_here = key == psf_at or (INERT_TAIL and pos + 1 >= inert_from and psf_at == order[-1])
@@ -572,16 +821,16 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
                       and not dead[0])
             # a stop right behind the program needs the power of what the program stores; a saved surface whose
             # field IS what the program stores reports it
-            stop_rides = (STOP_FROM_PROGRAM and any(p["stop"] for p in plans) and comp.pending() and not dead[0] and
-                          not any(p["aperture"] is not None and not fuse_ap for p in plans))
+            stop_rides = (STOP_FROM_PROGRAM and any_stop and comp.pending() and not dead[0] and
+                          not (any_ap and not fuse_ap))
             npass += flush(final_intensity=as_psf,
                            final_power=(not as_psf and comp.pending() and not dead[0] and
                                         (stop_rides or (power_state is not None and only_saved))))
-        if not fuse_ap:
+        if not fuse_ap and any_ap:
             _launch_apertures(dev, plans)
             if not comp.pending():
                 _live_rows_after(plans, live, dev.n)
-        if any(p["stop"] for p in plans):
+        if any_stop:
             settle()
             flags = [1.0 if p["stop"] else 0.0 for p in plans]
             if prog_power[0] is not None:  # the program's last pass has summed the power on its way out
@@ -832,6 +1081,12 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
         elif keep:
             dev.psf_keep()
 
+    # The walk allocates a few thousand small containers per surface of a large batch (plans, blocks, handles); a
+    # generation-2 pass of the cycle collector in the middle of it costs as much as planning several surfaces (round 5:
+    # 10 ms of a 29 ms walk at 256 wavefronts).  Nothing the walk builds is cyclic garbage worth collecting before it
+    # ends, so the collector is paused for its duration (and left as it was found).
+    gc_was_on = gc.isenabled()
+    gc.disable()
     try:
         _walk(dev, states, list(opt_chains), on_saved, stats=stats, fresh=1.0 + 0.0j, lean=lean,
               psf_at=last_key if (keep_psf and lean is not None) else None, power_state=power_state)
@@ -843,6 +1098,8 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
                 for i, rec in pending:
                     rec["power_ticket"] = handle
     finally:
+        if gc_was_on:
+            gc.enable()
         if own:
             dev.close()
     for res in results:
