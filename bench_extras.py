@@ -25,8 +25,13 @@ def _syn20(n2, nb2, precision, steps, warmup, esz, measure, roofline_block, swee
         m = measure(dev, n2, precision, wavelengths_of, chains, steps, warmup)
         frugal = n2 >= (1024 if precision == "fp64" else 2048)
         name = ("frugal_pass_kernel" if frugal else "fused_pass_kernel") + " (every FFT pass launch)"
+        ms_step = 1e3 * m["elapsed"] / steps
+        pass_ms = float(m["launch_ms"].sum()) / steps if m["launch_ms"].size else None
         return {"value": nb2 * steps / m["elapsed"], "unit": "wavefronts/s", "batch": nb2, "steps": steps,
-                "ms_per_step": 1e3 * m["elapsed"] / steps, "workload": label or f"SYN20, walked sweep, {n2}^2 {precision}",
+                "ms_per_step": ms_step, "workload": label or f"SYN20, walked sweep, {n2}^2 {precision}",
+                # (round 5: how much of a step's wall time the GPU spends in pass launches -- the host's share of a step at
+                # 256 wavefronts was the bound at 1024^2 in round 4)
+                "pass_launch_ms_per_step": pass_ms, "pass_share_of_step": pass_ms / ms_step if pass_ms else None,
                 "sweep": sweep_report(m), "roofline": roofline_block(m, n2, nb2, esz, dev, name, steps)}
     finally:
         dev.close()

@@ -72,10 +72,22 @@ namespace {
 
 thread_local std::string g_err;
 
+// Parameter arena: kArenaSlabs slabs of `cap` doubles each (pinned host mirror + device), filled one after the other.
+// Round 5: a slab is reused only after the work that read it has run -- told by an EVENT recorded one slab switch after it
+// was left (by then every launch that reads it has been enqueued: a call's pushes and its launches never span more than
+// two slabs) -- instead of by a hipStreamSynchronize at every wrap of one ring: at 512 wavefronts per step the ring
+// wrapped every second step, and each wrap made the host wait for the GPU to drain (1024^2: 33 ms per step where the GPU
+// needs 25 and the host 18).  With four slabs the host may run two to three steps ahead and no further.
+constexpr int kArenaSlabs = 4;
 struct Arena {
-  double* host = nullptr;  // pinned
+  double* host = nullptr;  // pinned, kArenaSlabs * cap doubles
   double* dev = nullptr;
-  size_t cap = 0, head = 0;  // in doubles
+  size_t cap = 0, head = 0;  // doubles per slab / fill of the current slab
+  int cur = 0;               // slab being filled
+  int left = -1;             // the slab left at the last switch: its fence is recorded at the NEXT switch
+  hipEvent_t fence[kArenaSlabs] = {};
+  bool fenced[kArenaSlabs] = {};  // fence[k] has been recorded since slab k was last filled
+  bool used[kArenaSlabs] = {};
 };
 
 }  // namespace
@@ -181,28 +193,47 @@ size_t elem_bytes(const paos_ctx* c) { return c->precision == PAOS_F64 ? 16 : 8;
 // them has run (a pass program: its block table plus one record set per pass).  A ring wrap in the
 // middle of such a sequence would overwrite parameters that later launches still read, so the
 // wrap (one stream synchronisation) or a growth of the arena happens here, before the first push.
+// next slab: record the fence of the slab left one switch ago, wait for the readers of the slab about to be refilled
+int arena_switch(paos_ctx* c) {
+  Arena& a = c->arena;
+  if (a.left >= 0) {
+    HIPCHK(c, hipEventRecord(a.fence[a.left], c->stream));
+    a.fenced[a.left] = true;
+  }
+  a.left = a.cur;
+  const int next = (a.cur + 1) % kArenaSlabs;
+  if (a.used[next]) {
+    if (a.fenced[next]) HIPCHK(c, hipEventSynchronize(a.fence[next]));  // (recorded two switches ago: normally long done)
+    else HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  a.fenced[next] = false;
+  a.used[next] = true;
+  a.cur = next;
+  a.head = 0;
+  return PAOS_OK;
+}
+
 int arena_reserve(paos_ctx* c, size_t total) {
   Arena& a = c->arena;
   total += 64;  // rounding of the individual pushes
-  if (total > a.cap) {
+  if (total > a.cap) {  // (grow every slab: one synchronisation, once)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     size_t cap = a.cap;
     while (cap < total) cap *= 2;
     double *h = nullptr, *d = nullptr;
-    HIPCHK(c, hipHostMalloc(&h, cap * sizeof(double)));
-    if (hipMalloc(&d, cap * sizeof(double)) != hipSuccess) {
+    HIPCHK(c, hipHostMalloc(&h, kArenaSlabs * cap * sizeof(double)));
+    if (hipMalloc(&d, kArenaSlabs * cap * sizeof(double)) != hipSuccess) {
       (void)hipHostFree(h);
       return fail(c, PAOS_EHIP, "hipMalloc(arena growth)");
     }
     (void)hipHostFree(a.host);
     (void)hipFree(a.dev);
-    a.host = h; a.dev = d; a.cap = cap; a.head = 0;
+    a.host = h; a.dev = d; a.cap = cap; a.head = 0; a.cur = 0; a.left = -1;
+    for (int k = 0; k < kArenaSlabs; ++k) a.fenced[k] = a.used[k] = false;
+    a.used[0] = true;
     return PAOS_OK;
   }
-  if (a.head + total > a.cap) {
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    a.head = 0;
-  }
+  if (a.head + total > a.cap) return arena_switch(c);
   return PAOS_OK;
 }
 
@@ -211,13 +242,14 @@ int arena_push(paos_ctx* c, const double* src, size_t count, const double** dev)
   Arena& a = c->arena;
   if (count > a.cap) return fail(c, PAOS_EINVAL, "parameter block larger than the arena");
   if (a.head + count > a.cap) {
-    HIPCHK(c, hipStreamSynchronize(c->stream));  // ring wrap: earlier copies must have landed
-    a.head = 0;
+    int rc = arena_switch(c);
+    if (rc) return rc;
   }
-  std::memcpy(a.host + a.head, src, count * sizeof(double));
-  HIPCHK(c, hipMemcpyAsync(a.dev + a.head, a.host + a.head, count * sizeof(double),
-                           hipMemcpyHostToDevice, c->stream));
-  *dev = a.dev + a.head;
+  double* h = a.host + (size_t)a.cur * a.cap + a.head;
+  double* d = a.dev + (size_t)a.cur * a.cap + a.head;
+  std::memcpy(h, src, count * sizeof(double));
+  HIPCHK(c, hipMemcpyAsync(d, h, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  *dev = d;
   a.head += (count + 15) & ~size_t(15);
   return PAOS_OK;
 }
@@ -1669,10 +1701,13 @@ int paos_ctx_create(int device, int n, int batch, int precision, paos_ctx** out)
   if ((e = hipMalloc(&c->partial, (size_t)batch * c->nparts * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(partial)");
   if ((e = hipMalloc(&c->norm2, (size_t)batch * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(norm2)");
   if ((e = hipHostMalloc(&c->norm2_host, (size_t)kNormSlots * batch * sizeof(double))) != hipSuccess) return bail(e, "hipHostMalloc(norm2)");
-  c->arena.cap = (size_t)1 << 20;  // 8 MiB of doubles
-  if (c->arena.cap < (size_t)batch * 4096) c->arena.cap = (size_t)batch * 4096;
-  if ((e = hipHostMalloc(&c->arena.host, c->arena.cap * sizeof(double))) != hipSuccess) return bail(e, "hipHostMalloc(arena)");
-  if ((e = hipMalloc(&c->arena.dev, c->arena.cap * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(arena)");
+  c->arena.cap = (size_t)1 << 18;  // four slabs of 2 MiB of doubles; a large batch starts with room for one of its programs per slab
+  if (c->arena.cap < (size_t)batch * 2048) c->arena.cap = (size_t)batch * 2048;
+  if ((e = hipHostMalloc(&c->arena.host, kArenaSlabs * c->arena.cap * sizeof(double))) != hipSuccess) return bail(e, "hipHostMalloc(arena)");
+  if ((e = hipMalloc(&c->arena.dev, kArenaSlabs * c->arena.cap * sizeof(double))) != hipSuccess) return bail(e, "hipMalloc(arena)");
+  for (int k = 0; k < kArenaSlabs; ++k)
+    if ((e = hipEventCreateWithFlags(&c->arena.fence[k], hipEventDisableTiming)) != hipSuccess) return bail(e, "hipEventCreate(arena fence)");
+  c->arena.used[0] = true;
   if (precision == PAOS_F64) {
     auto tw = twiddles<double>(n);
     e = hipMemcpy(c->tw, tw.data(), (size_t)n * eb, hipMemcpyHostToDevice);
@@ -1802,6 +1837,8 @@ int paos_ctx_destroy(paos_ctx* c) {
   }
   if (c->arena.host) (void)hipHostFree(c->arena.host);
   if (c->arena.dev) (void)hipFree(c->arena.dev);
+  for (int k = 0; k < kArenaSlabs; ++k)
+    if (c->arena.fence[k]) (void)hipEventDestroy(c->arena.fence[k]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return PAOS_OK;
