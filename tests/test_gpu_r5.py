@@ -1,0 +1,97 @@
+"""Round-5 GPU tests: state carried between the steps of a walked sweep at the headline shape, and the round's library
+change of the parameter arena (fenced slabs) bit for bit.  (The one-line workgroups of the fused launches are covered by
+tests/test_gpu_r4.py::test_two_passes_in_one_launch_change_no_bit[4096-fp64]: fused against single launches, bit for bit.)
+Everything goes through the C ABI of libpaoship.so."""
+import numpy as np
+import pytest
+
+from conftest import l2_rel_err, rel_err
+
+pytestmark = pytest.mark.gpu
+
+ON_AXIS = {"us": 0.0, "ut": 0.0}
+PSF_TOL = 1.0e-10  # north star: |PSF_gpu - PSF_ref| / |PSF_ref| < 1e-10 (max-norm and L2-relative)
+
+
+def test_second_walked_step_at_the_headline_shape_vs_oracle():
+    """the timed region of bench.py is a WALKED sweep on one long-lived context -- aperture record
+    sets kept between batches, PSF zeros known from the previous storing pass, rows that merely stand for zeros, the
+    parameter arena's slabs reused.  Two consecutive steps issued exactly as ``bench.measure`` issues them (one
+    ``DeviceFields(4096, 32)``, ``outputs=()``, ``keep_psf=True``, ``sync=False``, the next block of the 512-wavelength
+    sweep each step), then items 0 and 31 of the SECOND step against the oracle: PSF max-norm and L2-relative < 1e-10,
+    the power of the saved last surface against the oracle's sum."""
+    from oracle.run_np import run as oracle_run
+    from paos_amd import _lib
+    from paos_amd.chains import syn20_chain, syn20_wavelength
+    from paos_amd.run import run_batch
+
+    n, nb = 4096, 32
+    dev = _lib.DeviceFields(n, nb)
+    try:
+        chains = [syn20_chain() for _ in range(nb)]
+        res = None
+        sets0 = dev.record_set_stats()
+        for g in (0, 1):
+            if res is not None:  # bench.measure: the tickets of a step nobody reads are given back unsynchronised
+                for t in {rec["power_ticket"] for r in res for rec in r.values() if "power_ticket" in rec}:
+                    dev.norm2_release(t)
+            wls = [syn20_wavelength((g * nb + i) % 512) for i in range(nb)]
+            res = run_batch(1.0, wls, n, 4, ON_AXIS, chains, outputs=(), dev=dev, sync=False, keep_psf=True)
+        found, rendered = (b - a for a, b in zip(sets0, dev.record_set_stats()))
+        assert rendered >= 6  # (the second step renders its own aperture records: the walk changes the sampling)
+        last = max(res[0])
+        powers = dev.norm2_fetch(res[0][last]["power_ticket"])  # one reduction answers for every item
+        worst = 0.0
+        for i in (0, nb - 1):
+            psf = dev.psf_fetch(i)
+            ref = oracle_run(1.0, wls[i], n, 4, ON_AXIS, syn20_chain(), light=True)[last]
+            want = ref["amplitude"] ** 2
+            e, e2 = rel_err(psf, want), l2_rel_err(psf, want)
+            assert e < PSF_TOL and e2 < PSF_TOL, (i, e, e2)
+            assert abs(powers[i] - want.sum()) <= 1e-12 * want.sum(), (i, powers[i], want.sum())
+            for key in ("dx", "dy", "wl", "fratio", "wz", "distancetofocus", "propagator"):
+                assert res[i][last][key] == ref[key], (i, key)
+            worst = max(worst, e)
+        print(f"second walked step at 4096^2 x 32 (items 0, 31) PSF error vs oracle: {worst:.2e}; record sets found {found} rendered {rendered}")
+    finally:
+        dev.close()
+
+
+def test_many_steps_run_ahead_of_the_gpu_without_corrupting_parameters():
+    """The parameter arena is four slabs fenced by events (round 5): the host enqueues several steps before the GPU has
+    run the first -- every step's parameter blocks must still be intact when its launches run.  Twelve unsynchronised
+    steps of a 256-wavefront batch at 1024^2 (each needs most of a slab, so every slab is refilled three times), every
+    step with its own wavelengths; afterwards the LAST step's PSFs equal those of the same step run alone on a fresh
+    context, bit for bit, and the powers of an early step fetched late are that step's."""
+    from paos_amd import _lib
+    from paos_amd.chains import syn20_chain, syn20_wavelength
+    from paos_amd.run import run_batch
+
+    n, nb, steps = 1024, 256, 12
+    chains = [syn20_chain() for _ in range(nb)]
+    wl_of = lambda g: [syn20_wavelength((g * nb + 7 * i) % 512) for i in range(nb)]  # noqa: E731
+    dev = _lib.DeviceFields(n, nb)
+    try:
+        kept = None
+        for g in range(steps):
+            res = run_batch(1.0, wl_of(g), n, 4, ON_AXIS, chains, outputs=(), dev=dev, sync=False, keep_psf=True)
+            tickets = {rec["power_ticket"] for r in res for rec in r.values() if "power_ticket" in rec}
+            if g == 1:
+                kept = (res, tickets)  # fetched after the run
+            else:
+                for t in tickets:
+                    dev.norm2_release(t)
+        last = max(kept[0][0])
+        early_powers = dev.norm2_fetch(kept[0][0][last]["power_ticket"]).copy()
+        got = [dev.psf_fetch(i) for i in (0, 100, nb - 1)]
+    finally:
+        dev.close()
+    fresh = _lib.DeviceFields(n, nb)
+    try:
+        run_batch(1.0, wl_of(steps - 1), n, 4, ON_AXIS, chains, outputs=(), dev=fresh, sync=True, keep_psf=True)
+        for k, i in enumerate((0, 100, nb - 1)):
+            assert np.array_equal(got[k], fresh.psf_fetch(i)), i
+        alone = run_batch(1.0, wl_of(1), n, 4, ON_AXIS, chains, outputs=(), dev=fresh, sync=True, keep_psf=True)
+        assert np.array_equal(early_powers, np.array([alone[i][last]["power"] for i in range(nb)]))
+    finally:
+        fresh.close()
