@@ -85,6 +85,9 @@ typedef struct {
   int rows_stale;
   int final_intensity;
   int* power_ticket;
+  /* round 5: [batch][2] or NULL -- with rows_stale, columns outside [lo, hi) of the live rows hold old data that stands
+   * for zeros as well (what paos_start_box leaves: the first field is written inside the aperture's box only). */
+  const double* live_cols;
 } paos_program_opts;
 
 /* ---- lifetime -------------------------------------------------------------------- */
@@ -139,6 +142,15 @@ int paos_start_rows(paos_ctx* ctx, double re, double im, int shape, const double
                     const double* write_rows);
 /* make such rows real zeros (whole blocks of rows outside [lo, hi) of every item are cleared) */
 int paos_zero_outside_rows(paos_ctx* ctx, const double* live_rows);
+/* Round 5: paos_start_rows that also leaves the COLUMNS outside [write_cols[2 i], write_cols[2 i + 1]) (rounded outward to
+ * whole blocks) of the written rows alone -- the field is stored inside the aperture's bounding box only, a sixteenth of the
+ * grid at zoom 4 instead of a quarter (wfo.py:118 -> :236-276 -> :195-201).  Until a pass program has consumed the box
+ * (paos_run_program with rows_stale and live_cols) only paos_zernike, paos_norm2_enqueue_box and paos_zero_outside_box may
+ * touch the field. */
+int paos_start_box(paos_ctx* ctx, double re, double im, int shape, const double* aperture, const double* stop,
+                   const double* write_rows, const double* write_cols);
+/* make everything outside the box rows x cols of every item real zeros (live_cols may be NULL: whole rows) */
+int paos_zero_outside_box(paos_ctx* ctx, const double* live_rows, const double* live_cols);
 /* host row-major complex128 -> batch item (WFO._wfo assignment in notebooks/tests) */
 int paos_import(paos_ctx* ctx, int item, const void* host_c128);
 /* batch item -> host.  what = FIELD: complex128 copy (wfo.py:162-164); AMPLITUDE: |u|
@@ -203,6 +215,9 @@ int paos_norm2_enqueue_rows(paos_ctx* ctx, const double* live_rows, int* ticket)
  * the wavelengths of a sweep right behind paos_start_rows, whose aperture records agree (wfo.py:195-201 at the
  * entrance pupil does not depend on the wavelength).  Every item gets its leader's sum. */
 int paos_norm2_enqueue_rows_like(paos_ctx* ctx, const double* live_rows, const double* same_as, int* ticket);
+/* round 5: the same sum over the box rows x cols (live_cols: [batch][2]; same_as may be NULL) -- elements outside are zero
+ * or stand for zeros and are not read; bit-identical to the full sum of the zero-filled field. */
+int paos_norm2_enqueue_box(paos_ctx* ctx, const double* live_rows, const double* live_cols, const double* same_as, int* ticket);
 int paos_norm2_fetch(paos_ctx* ctx, int ticket, double* host_out);
 /* give a ticket back without reading it (no synchronisation) */
 int paos_norm2_release(paos_ctx* ctx, int ticket);

@@ -35,7 +35,8 @@ class PwOp(ctypes.Structure):
 class ProgramOpts(ctypes.Structure):
     """paos_program_opts of include/paos_hip.h"""
     _fields_ = [("live_rows", ctypes.POINTER(ctypes.c_double)), ("rows_stale", ctypes.c_int),
-                ("final_intensity", ctypes.c_int), ("power_ticket", ctypes.POINTER(ctypes.c_int))]
+                ("final_intensity", ctypes.c_int), ("power_ticket", ctypes.POINTER(ctypes.c_int)),
+                ("live_cols", ctypes.POINTER(ctypes.c_double))]
 
 
 class Pass(ctypes.Structure):
@@ -103,6 +104,9 @@ SYMBOLS = {
     "paos_zernike_pupil": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, _dbl_p, _dbl_p, ctypes.c_int, _dbl_p]),
     "paos_start_rows": (ctypes.c_int, [_c_ctx, ctypes.c_double, ctypes.c_double, ctypes.c_int, _dbl_p, _dbl_p, _dbl_p]),
     "paos_zero_outside_rows": (ctypes.c_int, [_c_ctx, _dbl_p]),
+    "paos_start_box": (ctypes.c_int, [_c_ctx, ctypes.c_double, ctypes.c_double, ctypes.c_int, _dbl_p, _dbl_p, _dbl_p, _dbl_p]),
+    "paos_zero_outside_box": (ctypes.c_int, [_c_ctx, _dbl_p, _dbl_p]),
+    "paos_norm2_enqueue_box": (ctypes.c_int, [_c_ctx, _dbl_p, _dbl_p, _dbl_p, ctypes.POINTER(ctypes.c_int)]),
     "paos_norm2_enqueue_rows": (ctypes.c_int, [_c_ctx, _dbl_p, ctypes.POINTER(ctypes.c_int)]),
     "paos_norm2_enqueue_rows_like": (ctypes.c_int, [_c_ctx, _dbl_p, _dbl_p, ctypes.POINTER(ctypes.c_int)]),
     "paos_run_program": (ctypes.c_int, [_c_ctx, ctypes.POINTER(Pass), ctypes.c_int, _dbl_p, ctypes.c_int,
@@ -399,10 +403,21 @@ class DeviceFields:
             raise ValueError("row ranges must be [batch][2]")
         return lr
 
-    def norm2_enqueue(self, live_rows=None, same_as=None):
+    def norm2_enqueue(self, live_rows=None, same_as=None, live_cols=None):
         """``live_rows`` ([batch][2], optional): rows outside [lo, hi) are zero (or stand for zeros) and are not read.
-        ``same_as`` ([batch] indices, with ``live_rows``): item i's field is a copy of item same_as[i]'s -- summed once."""
+        ``same_as`` ([batch] indices, with ``live_rows``): item i's field is a copy of item same_as[i]'s -- summed once.
+        ``live_cols`` ([batch][2], with ``live_rows``): ... and neither are the columns outside [lo, hi) of those rows."""
         t = ctypes.c_int(-1)
+        if live_rows is not None and live_cols is not None:
+            like = None
+            if same_as is not None:
+                like = np.ascontiguousarray(same_as, dtype=np.float64)
+                if like.shape != (self.batch,):
+                    raise ValueError("same_as must be [batch]")
+            self._check(self._lib.paos_norm2_enqueue_box(self._ctx, _dptr(self._rows(live_rows)), _dptr(self._rows(live_cols)),
+                                                         _dptr(like) if like is not None else None, ctypes.byref(t)),
+                        "paos_norm2_enqueue_box")
+            return t.value
         if live_rows is not None and same_as is not None:
             like = np.ascontiguousarray(same_as, dtype=np.float64)
             if like.shape != (self.batch,):
@@ -417,8 +432,13 @@ class DeviceFields:
         self._check(self._lib.paos_norm2_enqueue(self._ctx, ctypes.byref(t)), "paos_norm2_enqueue")
         return t.value
 
-    def zero_outside_rows(self, live_rows):
-        """Rows that merely stand for zeros (``start(..., write_rows=...)``) become zeros."""
+    def zero_outside_rows(self, live_rows, live_cols=None):
+        """Rows (and, with ``live_cols``, columns of the rows in between) that merely stand for zeros
+        (``start(..., write_rows=..., write_cols=...)``) become zeros."""
+        if live_cols is not None:
+            self._check(self._lib.paos_zero_outside_box(self._ctx, _dptr(self._rows(live_rows)), _dptr(self._rows(live_cols))),
+                        "paos_zero_outside_box")
+            return
         self._check(self._lib.paos_zero_outside_rows(self._ctx, _dptr(self._rows(live_rows))), "paos_zero_outside_rows")
 
     def norm2_fetch(self, ticket):
@@ -489,14 +509,15 @@ class DeviceFields:
         """Dead-line pruning of the pass programs on (default) / off -- results are identical."""
         self._check(self._lib.paos_ctx_set_pruning(self._ctx, 1 if on else 0), "paos_ctx_set_pruning")
 
-    def run_passes(self, passes, blocks, live_rows=None, rows_stale=False, final_intensity=False):
+    def run_passes(self, passes, blocks, live_rows=None, rows_stale=False, final_intensity=False, live_cols=None):
         """passes: list of dicts {axis, fft1, fft2, pre, mid, post} with operator tuples
         (kind, flags, block); blocks: array [n_blocks][batch][PHASE_STRIDE].  ``live_rows``
         ([batch][2], optional): rows outside [lo, hi) of item i are exactly zero in memory -- or, with
         ``rows_stale``, hold old data that stands for zeros.  ``final_intensity``: True / 1 -- the last pass writes |u|^2 to
         the PSF buffer instead of the field (which is undefined afterwards); 2 -- the field is stored as usual and its
         sum |u|^2 is reduced by the last pass on the way (the power of a saved surface without reading the field
-        back); either way the power ticket is returned."""
+        back); either way the power ticket is returned.  ``live_cols`` (with ``rows_stale``): the columns outside stand
+        for zeros as well (``start(..., write_cols=...)``)."""
         b = np.ascontiguousarray(blocks, dtype=np.float64)
         if b.ndim != 3 or b.shape[1:] != (self.batch, PHASE_STRIDE):
             raise ValueError("blocks must be [n_blocks][batch][5]")
@@ -513,9 +534,10 @@ class DeviceFields:
                     lst[i].kind, lst[i].flags, lst[i].block = kind, flags, block
         if rows_stale or final_intensity:
             lr = self._rows(live_rows) if live_rows is not None else None
+            lc = self._rows(live_cols) if (live_cols is not None and rows_stale and lr is not None) else None
             ticket = ctypes.c_int(-1)
             opts = ProgramOpts(_dptr(lr) if lr is not None else None, 1 if (rows_stale and lr is not None) else 0,
-                               int(final_intensity), ctypes.pointer(ticket))
+                               int(final_intensity), ctypes.pointer(ticket), _dptr(lc) if lc is not None else None)
             self._check(self._lib.paos_run_program(self._ctx, arr, len(passes), _dptr(b), b.shape[0], ctypes.byref(opts)),
                         "paos_run_program")
             return ticket.value if final_intensity else None
@@ -541,9 +563,10 @@ class DeviceFields:
                     "paos_zernike_pupil" if pupil else "paos_zernike")
         return out
 
-    def start(self, value, shape, blocks, stop=None, write_rows=None):
+    def start(self, value, shape, blocks, stop=None, write_rows=None, write_cols=None):
         """fill(value) + aperture(shape, blocks) + make_stop(stop) in one write of the field.  ``write_rows``
-        ([batch][2]): only these rows are written, the others stand for zeros (see paos_start_rows)."""
+        ([batch][2]): only these rows are written, the others stand for zeros (see paos_start_rows); ``write_cols``
+        (with ``write_rows``): ... and only these columns of them (paos_start_box)."""
         b = np.ascontiguousarray(blocks, dtype=np.float64)
         if b.shape != (self.batch, APERTURE_STRIDE):
             raise ValueError("aperture blocks must be [batch][8]")
@@ -551,6 +574,11 @@ class DeviceFields:
         if st is not None and st.shape != (self.batch,):
             raise ValueError("stop flags must be [batch]")
         v = complex(value)
+        if write_rows is not None and write_cols is not None:
+            self._check(self._lib.paos_start_box(self._ctx, v.real, v.imag, int(shape), _dptr(b),
+                                                 _dptr(st) if st is not None else None, _dptr(self._rows(write_rows)),
+                                                 _dptr(self._rows(write_cols))), "paos_start_box")
+            return
         if write_rows is not None:
             self._check(self._lib.paos_start_rows(self._ctx, v.real, v.imag, int(shape), _dptr(b),
                                                   _dptr(st) if st is not None else None, _dptr(self._rows(write_rows))),

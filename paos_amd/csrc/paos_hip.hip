@@ -608,7 +608,7 @@ bool mask_live_range(const paos_ctx* c, const double* q, const double* q2, int a
 // operator-by-operator programs it yields the ranges of round 2's one-axis planner and round 3's "stores nobody reads".
 struct LineRange { int lo, hi; };
 void plan_pruning(const paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks,
-                  std::vector<LoweredPass>& low, const double* entry_rows, bool entry_stale) {
+                  std::vector<LoweredPass>& low, const double* entry_rows, bool entry_stale, const double* entry_cols = nullptr) {
   const int n = c->n, br = c->br;
   // never empty, always inside `a`: an aperture off the live range keeps one block row of `a` (which it then zeroes)
   auto meet = [br](LineRange a, LineRange b) {
@@ -633,6 +633,15 @@ void plan_pruning(const paos_ctx* c, const paos_pass* passes, int n_passes, cons
       if (h > n) h = n;
       if (l < h && (l > 0 || h < n)) { box[0] = {l, h}; clean = !entry_stale; }
       rows0 = box[0];
+    }
+    if (entry_cols && entry_stale) {
+      // (round 5: paos_start_box) the columns outside stand for zeros too, inside the live rows: the first pass loads the box
+      // only, and every later pass reads what its predecessor stored -- nobody ever looks at them
+      int l = (int)entry_cols[2 * it], h = (int)entry_cols[2 * it + 1];
+      l = l < 0 ? 0 : (l / br) * br;
+      h = h > n ? n : ((h + br - 1) / br) * br;
+      if (h > n) h = n;
+      if (l < h && (l > 0 || h < n)) box[1] = {l, h};
     }
     // forwards
     lines.assign(act.size(), LineRange{0, n});
@@ -1261,24 +1270,26 @@ bool use_pruning() {
 }
 
 int zero_outside_rows(paos_ctx* c, const double* live_rows);
+int zero_outside_box(paos_ctx* c, const double* live_rows, const double* live_cols);
 int psf_power_ticket(paos_ctx* c, const double* partial, int nparts, int* ticket, const double* source = nullptr);
 int psf_keep_power_impl(paos_ctx* c, int* ticket);
 
 // entry_rows / entry_stale: see paos_program_opts.  final_ticket != nullptr: the caller wants |u|^2 and its sum of
 // the field the program ends with, not the field.
 int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks, int n_blocks,
-                    const double* entry_rows, bool entry_stale, int* final_ticket, int final_mode);
+                    const double* entry_rows, bool entry_stale, int* final_ticket, int final_mode, const double* entry_cols);
 
 // final_mode (with final_ticket): 1 = the PSF instead of the field, 2 = the field as usual plus the ticket of its power
 int run_passes(paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks, int n_blocks,
-               const double* entry_rows = nullptr, bool entry_stale = false, int* final_ticket = nullptr, int final_mode = 1) {
-  const int rc = run_passes_impl(c, passes, n_passes, blocks, n_blocks, entry_rows, entry_stale, final_ticket, final_mode);
+               const double* entry_rows = nullptr, bool entry_stale = false, int* final_ticket = nullptr, int final_mode = 1,
+               const double* entry_cols = nullptr) {
+  const int rc = run_passes_impl(c, passes, n_passes, blocks, n_blocks, entry_rows, entry_stale, final_ticket, final_mode, entry_cols);
   if (rc != PAOS_OK && c) forget_mask_sets(c);  // a program that stopped half way: which records were rendered is moot
   return rc;
 }
 
 int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const double* blocks, int n_blocks,
-                    const double* entry_rows, bool entry_stale, int* final_ticket, int final_mode) {
+                    const double* entry_rows, bool entry_stale, int* final_ticket, int final_mode, const double* entry_cols) {
   if (!c || !passes || !blocks || n_passes < 0 || n_blocks < 1) return fail(c, PAOS_EINVAL, "bad pass program");
   c->norm2_of_field = false;  // (set again at the end when the last pass sums the power of what it stores)
   // A program that ends on the PSF gives the field up for it: the free power-ticket slot it will need is checked
@@ -1339,7 +1350,7 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
     if (!ride && (rc = settle_scale(c))) return rc;
   }
   const bool pruned = all_frugal && use_pruning() && c->prune;
-  if (pruned) plan_pruning(c, passes, n_passes, blocks, low, entry_rows, entry_stale);
+  if (pruned) plan_pruning(c, passes, n_passes, blocks, low, entry_rows, entry_stale, entry_cols);
   // Which lines' aperture records does each pass read?  Those of its live tiles only: a workgroup whose lines are dead
   // for its item (frugal_pass_kernel: outside [line_lo, line_hi), bounds that are multiples of the tile height)
   // leaves before it looks at a record.  Only these lines are rendered (a quarter of them behind a clear aperture at
@@ -1377,7 +1388,7 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
     if (need) {
       // (all items at once: the ones the planner handles lose nothing but a little time, and the planner was told
       // "stale", which is also right for zeros)
-      if ((rc = zero_outside_rows(c, entry_rows))) return rc;
+      if ((rc = entry_cols ? zero_outside_box(c, entry_rows, entry_cols) : zero_outside_rows(c, entry_rows))) return rc;
     }
   }
   // The PSF instead of the field: the last pass stores |u|^2 and its per-workgroup sums (frugal_pass.h: STORE) when
@@ -1887,8 +1898,24 @@ static int check_rows(paos_ctx* c, const double* rows) {
   return PAOS_OK;
 }
 
+// Column windows as every consumer uses them: rounded outward to whole multiples of the block height c->br -- the
+// granularity at which plan_pruning lets a pass load positions -- so that what paos_start_box writes, what
+// paos_norm2_enqueue_box sums, what paos_zero_outside_box keeps and what the first pass of a program loads are ONE window
+// (round 5: written to whole blocks of two columns only, the first pass read up to two stale columns at either edge).
+static std::vector<double> rounded_cols(const paos_ctx* c, const double* cols) {
+  std::vector<double> out((size_t)2 * c->batch);
+  for (int i = 0; i < c->batch; ++i) {
+    int l = (int)cols[2 * i], h = (int)cols[2 * i + 1];
+    l = l < 0 ? 0 : (l / c->br) * c->br;
+    h = ((h + c->br - 1) / c->br) * c->br;
+    if (h > c->n) h = c->n;
+    out[2 * i] = l; out[2 * i + 1] = h;
+  }
+  return out;
+}
+
 static int start_impl(paos_ctx* c, double re, double im, int shape, const double* aperture, const double* stop,
-                      const double* write_rows) {
+                      const double* write_rows, const double* write_cols = nullptr) {
   if (c) (void)hipSetDevice(c->device);
   if (!c || !aperture) return fail(c, PAOS_EINVAL, "null argument");
   if (shape != PAOS_SHAPE_ELLIPSE && shape != PAOS_SHAPE_RECT) return fail(c, PAOS_EINVAL, "unknown aperture shape");
@@ -1917,6 +1944,13 @@ static int start_impl(paos_ctx* c, double re, double im, int shape, const double
     if ((rc = check_rows(c, write_rows))) return rc;
     if ((rc = arena_push(c, write_rows, (size_t)2 * c->batch, &drows))) return rc;
   }
+  const double* dcols = nullptr;
+  if (write_cols) {
+    if (!write_rows) return fail(c, PAOS_EINVAL, "a column window needs a row window");
+    if ((rc = check_rows(c, write_cols))) return rc;
+    const std::vector<double> wc = rounded_cols(c, write_cols);
+    if ((rc = arena_push(c, wc.data(), wc.size(), &dcols))) return rc;
+  }
   // groups of items that start from the same field (start_write_kernel)
   static const bool share_start = [] { const char* e = getenv("PAOS_SHARE_START"); return !(e && e[0] == '0'); }();
   std::vector<double> goff(c->batch, 0.0), glen(c->batch, 0.0), members;
@@ -1928,7 +1962,8 @@ static int start_impl(paos_ctx* c, double re, double im, int shape, const double
       for (int j = 0; j < i; ++j)
         if (lead[j] == j && flags[j] == flags[i] &&
             !std::memcmp(aperture + (size_t)j * AP_STRIDE, aperture + (size_t)i * AP_STRIDE, AP_STRIDE * sizeof(double)) &&
-            (!write_rows || !std::memcmp(write_rows + 2 * j, write_rows + 2 * i, 2 * sizeof(double)))) { lead[i] = j; break; }
+            (!write_rows || !std::memcmp(write_rows + 2 * j, write_rows + 2 * i, 2 * sizeof(double))) &&
+            (!write_cols || !std::memcmp(write_cols + 2 * j, write_cols + 2 * i, 2 * sizeof(double)))) { lead[i] = j; break; }
     }
     for (int i = 0; i < c->batch; ++i) {
       if (lead[i] != i) continue;
@@ -1953,7 +1988,7 @@ static int start_impl(paos_ctx* c, double re, double im, int shape, const double
     }                                                                                                   \
     hipLaunchKernelGGL((start_write_kernel<T, BRV, Lay<T>::BC, S>), dim3(pw_blocks(c), c->batch), block, 0, \
                        c->stream, (cx<T>*)c->field, dp, c->n, c->pitch, c->item_stride, re, im,          \
-                       (const double*)c->norm2, ds, drows, dgoff, dglen, dmembers);                     \
+                       (const double*)c->norm2, ds, drows, dgoff, dglen, dmembers, dcols);              \
   } while (0)
   if (c->precision == PAOS_F64) {
     if (shape == PAOS_SHAPE_ELLIPSE) START_LAUNCH(double, BR, 0); else START_LAUNCH(double, BR, 1);
@@ -1974,6 +2009,22 @@ int paos_start_rows(paos_ctx* c, double re, double im, int shape, const double* 
                     const double* write_rows) {
   DROP_SCALE(c);
   return start_impl(c, re, im, shape, aperture, stop, write_rows);
+}
+
+int paos_start_box(paos_ctx* c, double re, double im, int shape, const double* aperture, const double* stop,
+                   const double* write_rows, const double* write_cols) {
+  DROP_SCALE(c);
+  return start_impl(c, re, im, shape, aperture, stop, write_rows, write_cols);
+}
+
+int paos_zero_outside_box(paos_ctx* c, const double* live_rows, const double* live_cols) {
+  SETTLE_SCALE(c);
+  if (c) (void)hipSetDevice(c->device);
+  if (!c || !live_rows) return fail(c, PAOS_EINVAL, "null argument");
+  int rc = check_rows(c, live_rows);
+  if (rc) return rc;
+  if (live_cols && (rc = check_rows(c, live_cols))) return rc;
+  return zero_outside_box(c, live_rows, live_cols);
 }
 
 int paos_zero_outside_rows(paos_ctx* c, const double* live_rows) {
@@ -2298,6 +2349,26 @@ int zero_outside_rows(paos_ctx* c, const double* live_rows) {
   return PAOS_OK;
 }
 
+// ... and outside the columns [lo, hi) of the rows in between (round 5: a sweep over the field; this is the rare path --
+// something wants to read a field that was started inside its aperture's box only)
+int zero_outside_box(paos_ctx* c, const double* live_rows, const double* live_cols) {
+  if (!live_cols) return zero_outside_rows(c, live_rows);
+  const double *drows = nullptr, *dcols = nullptr;
+  int rc;
+  if ((rc = arena_push(c, live_rows, (size_t)2 * c->batch, &drows))) return rc;
+  const std::vector<double> lc = rounded_cols(c, live_cols);
+  if ((rc = arena_push(c, lc.data(), lc.size(), &dcols))) return rc;
+  const dim3 grid(pw_blocks(c), c->batch), block(kPwThreads);
+  if (c->precision == PAOS_F64)
+    hipLaunchKernelGGL((zero_outside_box_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream, (cx<double>*)c->field, c->n,
+                       c->pitch, c->item_stride, drows, dcols);
+  else
+    F32_BR_SWITCH(c, hipLaunchKernelGGL((zero_outside_box_kernel<float, FBR, Lay<float>::BC>), grid, block, 0, c->stream,
+                                        (cx<float>*)c->field, c->n, c->pitch, c->item_stride, drows, dcols));
+  HIPCHK(c, hipGetLastError());
+  return PAOS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2319,11 +2390,18 @@ int paos_run_program(paos_ctx* c, const paos_pass* passes, int n_passes, const d
   }
   if (opts->final_intensity && !opts->power_ticket) return fail(c, PAOS_EINVAL, "final_intensity needs a place for the power ticket");
   if (opts->final_intensity < 0 || opts->final_intensity > 2) return fail(c, PAOS_EINVAL, "final_intensity: 0, 1 (PSF instead of the field) or 2 (field + its power)");
-  return run_passes(c, passes, n_passes, blocks, n_blocks, opts->live_rows, opts->live_rows && opts->rows_stale != 0,
-                    opts->final_intensity ? opts->power_ticket : nullptr, opts->final_intensity == 2 ? 2 : 1);
+  const bool stale = opts->live_rows && opts->rows_stale != 0;
+  if (c && opts->live_cols && stale) {
+    int rc = check_rows(c, opts->live_cols);
+    if (rc) return rc;
+  }
+  return run_passes(c, passes, n_passes, blocks, n_blocks, opts->live_rows, stale,
+                    opts->final_intensity ? opts->power_ticket : nullptr, opts->final_intensity == 2 ? 2 : 1,
+                    stale ? opts->live_cols : nullptr);
 }
 
-static int norm2_enqueue_rows_impl(paos_ctx* c, const double* live_rows, const double* same_as, int* ticket) {
+static int norm2_enqueue_rows_impl(paos_ctx* c, const double* live_rows, const double* same_as, int* ticket,
+                                   const double* live_cols = nullptr) {
   if (c) (void)hipSetDevice(c->device);
   if (!c || !ticket || !live_rows) return fail(c, PAOS_EINVAL, "null argument");
   int rc = check_rows(c, live_rows);
@@ -2331,16 +2409,21 @@ static int norm2_enqueue_rows_impl(paos_ctx* c, const double* live_rows, const d
   const int slot = next_norm_slot(c);
   if (c->norm_busy[slot])
     return fail(c, PAOS_EINVAL, "64 power reductions outstanding: fetch earlier tickets (paos_norm2_fetch) first");
-  const double *drows = nullptr, *dlead = nullptr, *dsame = nullptr;
+  const double *drows = nullptr, *dlead = nullptr, *dsame = nullptr, *dcols = nullptr;
   if ((rc = arena_push(c, live_rows, (size_t)2 * c->batch, &drows))) return rc;
+  if (live_cols) {
+    const std::vector<double> lc = rounded_cols(c, live_cols);
+    if ((rc = arena_push(c, lc.data(), lc.size(), &dcols))) return rc;
+  }
   if (same_as) {  // items whose fields the caller knows to be copies of another item's: summed once
     std::vector<double> lead(c->batch);
     for (int i = 0; i < c->batch; ++i) {
       const int j = (int)same_as[i];
       if (!(same_as[i] >= 0.0) || j >= c->batch || (double)j != same_as[i] || (int)same_as[j] != j)
         return fail(c, PAOS_EINVAL, "same_as must name an item that stands for itself");
-      if (live_rows[2 * i] != live_rows[2 * j] || live_rows[2 * i + 1] != live_rows[2 * j + 1])
-        return fail(c, PAOS_EINVAL, "items that share a sum must share their row window");
+      if (live_rows[2 * i] != live_rows[2 * j] || live_rows[2 * i + 1] != live_rows[2 * j + 1] ||
+          (live_cols && (live_cols[2 * i] != live_cols[2 * j] || live_cols[2 * i + 1] != live_cols[2 * j + 1])))
+        return fail(c, PAOS_EINVAL, "items that share a sum must share their row (and column) window");
       lead[i] = j == i ? 1.0 : 0.0;
     }
     if ((rc = arena_push(c, lead.data(), lead.size(), &dlead))) return rc;
@@ -2349,12 +2432,21 @@ static int norm2_enqueue_rows_impl(paos_ctx* c, const double* live_rows, const d
   const dim3 grid(c->nparts, c->batch), block(kPwThreads);
   if (c->precision == PAOS_F64)
     hipLaunchKernelGGL((norm2_partial_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream,
-                       (const cx<double>*)c->field, c->partial, c->n, c->pitch, c->item_stride, dlead, 1, drows);
+                       (const cx<double>*)c->field, c->partial, c->n, c->pitch, c->item_stride, dlead, 1, drows, dcols);
   else
     F32_BR_SWITCH(c, hipLaunchKernelGGL((norm2_partial_kernel<float, FBR, Lay<float>::BC>), grid, block, 0, c->stream,
-                       (const cx<float>*)c->field, c->partial, c->n, c->pitch, c->item_stride, dlead, 1, drows));
+                       (const cx<float>*)c->field, c->partial, c->n, c->pitch, c->item_stride, dlead, 1, drows, dcols));
   HIPCHK(c, hipGetLastError());
   return psf_power_ticket(c, c->partial, c->nparts, ticket, dsame);
+}
+
+int paos_norm2_enqueue_box(paos_ctx* c, const double* live_rows, const double* live_cols, const double* same_as, int* ticket) {
+  SETTLE_SCALE(c);
+  if (c && live_cols) {
+    int rc = check_rows(c, live_cols);
+    if (rc) return rc;
+  }
+  return norm2_enqueue_rows_impl(c, live_rows, same_as, ticket, live_cols);
 }
 
 int paos_norm2_enqueue_rows(paos_ctx* c, const double* live_rows, int* ticket) {

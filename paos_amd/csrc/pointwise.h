@@ -177,7 +177,7 @@ __device__ __forceinline__ double block_sum(double v, double* sh) {
 template <typename T, int BR, int BC>
 __global__ void norm2_partial_kernel(const cx<T>* field, double* partial, int n, unsigned pitch,
                                      unsigned item_stride, const double* enable, int enable_stride,
-                                     const double* rows = nullptr) {
+                                     const double* rows = nullptr, const double* cols = nullptr) {
   const int item = blockIdx.y;
   if (enable && enable[(size_t)item * enable_stride] == 0.0) return;
   __shared__ double sh[kPwThreads / 64];
@@ -192,8 +192,16 @@ __global__ void norm2_partial_kernel(const cx<T>* field, double* partial, int n,
   const size_t step = (size_t)gridDim.x * blockDim.x;
   size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (m < first) m += (first - m + step - 1) / step * step;
+  // (round 5) ``cols``: columns outside [lo, hi) -- rounded outward to blocks -- are zero or stand for zeros: not read
+  unsigned in_lo = 0, in_hi = (unsigned)n * BR;  // element offsets inside a block row
+  if (cols) {
+    in_lo = (unsigned)((int)cols[2 * item] / BC) * (BR * BC);
+    const unsigned h = (unsigned)(((int)cols[2 * item + 1] + BC - 1) / BC) * (BR * BC);
+    in_hi = h < in_hi ? h : in_hi;
+  }
   for (; m < total; m += step) {
-    if ((unsigned)(m % pitch) >= (unsigned)n * BR) continue;  // pitch padding
+    const unsigned off = (unsigned)(m % pitch);
+    if (off >= in_hi || off < in_lo) continue;  // pitch padding / outside the column window
     const double x = (double)f[m].x, y = (double)f[m].y;
     acc += __dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y));
   }
@@ -561,7 +569,7 @@ template <typename T, int BR, int BC, int SHAPE>
 __global__ void start_write_kernel(cx<T>* field, const double* params, int n, unsigned pitch,
                                    unsigned item_stride, double vre, double vim, const double* norm2,
                                    const double* stop, const double* rows, const double* grp_off,
-                                   const double* grp_len, const double* grp_members) {
+                                   const double* grp_len, const double* grp_members, const double* cols = nullptr) {
   // Items with the same aperture record, stop flag and row window (a wavelength sweep at the entrance pupil, a
   // Monte-Carlo batch) start from the same field: the first of them evaluates the weights once per pixel and writes
   // every member of its group (grp_members[grp_off[item] ...], grp_len[item] of them; 0 = somebody else's member).
@@ -584,8 +592,19 @@ __global__ void start_write_kernel(cx<T>* field, const double* params, int n, un
     total = (size_t)(((int)rows[2 * item + 1] + BR - 1) / BR) * pitch;
     if (total > item_stride) total = item_stride;
   }
-  size_t m = first + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
+  // (round 5) ``cols``: only the columns [lo, hi) -- whole blocks -- of those rows are written: the walk covers the
+  // in-window part of every block row, `span` elements starting `in_lo` elements into it
+  unsigned in_lo = 0, span = pitch;
+  if (cols) {
+    in_lo = (unsigned)((int)cols[2 * item] / BC) * (BR * BC);
+    unsigned h = (unsigned)(((int)cols[2 * item + 1] + BC - 1) / BC) * (BR * BC);
+    if (h > (unsigned)n * BR) h = (unsigned)n * BR;
+    span = h > in_lo ? h - in_lo : 0;
+  }
+  const size_t nbr = (total - first) / pitch;  // block rows to write
+  const size_t work = cols ? nbr * span : total - first;
+  for (size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x; j < work; j += (size_t)gridDim.x * blockDim.x) {
+    const size_t m = cols ? first + (j / span) * pitch + in_lo + (j % span) : first + j;
     int r, c;
     double x = 0.0, y = 0.0;
     if (layout_unmap<BR, BC>(m, n, pitch, r, c)) {
@@ -596,6 +615,22 @@ __global__ void start_write_kernel(cx<T>* field, const double* params, int n, un
       if (scaled) { x = __dmul_rn(x, s); y = __dmul_rn(y, s); }
     }
     for (int g = 0; g < glen; ++g) field[(size_t)(int)members[g] * item_stride + m] = {(T)x, (T)y};
+  }
+}
+
+// everything outside rows [lo, hi) x columns [lo, hi) of every item := 0 (round 5: what makes a box that merely stands for
+// zeros around it -- paos_start_box -- a field anybody may read; bounds rounded outward to whole blocks)
+template <typename T, int BR, int BC>
+__global__ void zero_outside_box_kernel(cx<T>* field, int n, unsigned pitch, unsigned item_stride, const double* rows,
+                                        const double* cols) {
+  const int item = blockIdx.y;
+  const int rlo = ((int)rows[2 * item] / BR) * BR, rhi = (((int)rows[2 * item + 1] + BR - 1) / BR) * BR;
+  const int clo = cols ? ((int)cols[2 * item] / BC) * BC : 0, chi = cols ? (((int)cols[2 * item + 1] + BC - 1) / BC) * BC : n;
+  cx<T>* f = field + (size_t)item * item_stride;
+  for (size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x; m < item_stride; m += (size_t)gridDim.x * blockDim.x) {
+    int r, c;
+    if (!layout_unmap<BR, BC>(m, n, pitch, r, c)) continue;
+    if (r < rlo || r >= rhi || c < clo || c >= chi) f[m] = {(T)0, (T)0};
   }
 }
 

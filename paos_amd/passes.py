@@ -348,7 +348,7 @@ class PassCompiler:
         self._reset()
         return passes, blocks
 
-    def flush(self, dev, live_rows=None, rows_stale=False, final_intensity=False):
+    def flush(self, dev, live_rows=None, rows_stale=False, final_intensity=False, live_cols=None):
         """``live_rows`` ([batch][2], optional): rows of each item outside [lo, hi) are exactly zero in
         memory on entry (a stand-alone aperture has just been applied) -- the library then skips them;
         ``rows_stale``: they hold old data standing for zeros instead.  ``final_intensity``: the last pass
@@ -359,7 +359,10 @@ class PassCompiler:
         passes, blocks = self.program()
         ticket = None
         if passes:
-            if rows_stale or final_intensity:
+            if rows_stale and live_cols is not None:  # (the start field was written inside its aperture's box only)
+                ticket = dev.run_passes(passes, blocks, live_rows=live_rows, rows_stale=True, final_intensity=final_intensity,
+                                        live_cols=live_cols)
+            elif rows_stale or final_intensity:
                 ticket = dev.run_passes(passes, blocks, live_rows=live_rows, rows_stale=rows_stale,
                                         final_intensity=final_intensity)
             elif live_rows is None:

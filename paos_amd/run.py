@@ -55,6 +55,9 @@ INERT_TAIL = _os.environ.get("PAOS_INERT_TAIL", "1") != "0"
 # ... and such a stop leaves even its scaling to the next pass program's first pass (paos_stop_defer_last_power);
 # PAOS_STOP_DEFERRED=0 runs the scaling sweep at the stop.
 STOP_DEFERRED = _os.environ.get("PAOS_STOP_DEFERRED", "1") != "0"
+# ... and a lean walk's first field is written inside the aperture's bounding BOX only (rows and columns: paos_start_box,
+# round 5; rounds 3-4 wrote whole rows); PAOS_START_BOX=0 writes whole rows again.
+START_BOX = _os.environ.get("PAOS_START_BOX", "1") != "0"
 _MASK_RUN = 192  # kMaskW of csrc/frugal_pass.h
 
 
@@ -174,6 +177,27 @@ class _BatchApertures:
             r[0], r[1] = max(r[0], int(lo[i])), min(r[1], int(hi[i]))
             if r[0] >= r[1]:
                 r[0], r[1] = 0, 0
+
+
+def _live_cols_of(plans, n):
+    """Per item the columns [lo, hi) outside which a clear aperture leaves exact zeros (photutils' bounding box widened by
+    a pixel, like ``_live_rows_after`` for the rows), or None when some item has no such aperture."""
+    out = []
+    for i, p in enumerate(plans):
+        ap = p["aperture"]
+        if ap is None or ap[1] or ap[0].theta != 0.0:
+            return None
+        h = ap[0]
+        ext = h.a if isinstance(h, EllipticalAperture) else h.w / 2.0
+        xc = h._xy[0]
+        if not (math.isfinite(xc) and math.isfinite(ext) and ext > 0.0):
+            return None
+        lo = max(0, int(math.floor(xc - ext + 0.5)) - 1)
+        hi = min(n, int(math.ceil(xc + ext + 0.5)) + 1)
+        if lo >= hi:
+            return None
+        out.append([lo, hi])
+    return out
 
 
 class _LazyAperture:
@@ -591,7 +615,7 @@ def _queue_steps(comp, lens, stw, ptp, wts, inv_stw, inv_wts):
     comp.wts(wts, inv_wts != 0.0)
 
 
-def _start_field(dev, plans, value, write_rows=None):
+def _start_field(dev, plans, value, write_rows=None, write_cols=None):
     """The wavefront is still the constant ``value`` (wfo.py:118).  When every item opens with a
     stand-alone aperture of one shape, ones -> aperture -> [make_stop] is a single write of the
     field (paos_start); otherwise fill and let the surface run as usual.  Returns False, or -- when the
@@ -614,12 +638,15 @@ def _start_field(dev, plans, value, write_rows=None):
     stops = [1.0 if p["stop"] else 0.0 for p in plans]
     if write_rows is None:
         dev.start(value, code, blocks, stops)
-    else:
+    elif write_cols is None:
         dev.start(value, code, blocks, stops, write_rows=write_rows)
+    else:
+        dev.start(value, code, blocks, stops, write_rows=write_rows, write_cols=write_cols)
     # which items now hold the same field: same aperture record, stop flag and row window
     seen, same_as = {}, []
     for i, (b, st) in enumerate(zip(blocks, stops)):
-        key = (tuple(float(x) for x in b), st, tuple(write_rows[i]) if write_rows is not None else None)
+        key = (tuple(float(x) for x in b), st, tuple(write_rows[i]) if write_rows is not None else None,
+               tuple(write_cols[i]) if write_cols is not None else None)
         same_as.append(seen.setdefault(key, i))
     return same_as
 
@@ -634,6 +661,7 @@ class _WalkState:
 
     def __init__(self):
         self.rows, self.psf_ticket, self.same_as = None, None, None
+        self.cols = None  # with ``rows``: the columns outside which those rows stand for zeros as well (the start box)
         # set once a pass program has stored the PSF for good (nothing but inert surfaces follows): the saved surfaces
         # still to come report this ticket's power, and the PSF is already where keep_psf wants it
         self.final_ticket = None
@@ -660,6 +688,7 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
     # program (which skips them) and forgotten once that program has run
     live = [[0, dev.n] for _ in states]
     stale = [False]  # rows outside ``live`` hold old data that stands for zeros (lean start)
+    stale_cols = [None]  # ... and, while ``stale``, so do the columns outside these [lo, hi) per item (paos_start_box)
     dead = [False]   # the field has been given up for its PSF (lean end): nothing may run on it any more
 
     prog_power = [None]  # ticket of the power of the field a program has just stored (flush(final_power=True))
@@ -672,8 +701,11 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
     def settle():
         """Before anything reads whole fields: rows that stand for zeros become zeros."""
         if stale[0]:
-            dev.zero_outside_rows(live)
-            stale[0] = False
+            if stale_cols[0] is not None:
+                dev.zero_outside_rows(live, stale_cols[0])
+            else:
+                dev.zero_outside_rows(live)
+            stale[0], stale_cols[0] = False, None
 
     def keep_reads_field():
         """The saved LAST surface of a lean walk that keeps its PSFs, reached without a pass program having stored
@@ -690,8 +722,10 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
         rows = known_rows()
         if not comp.pending():
             return 0
+        cols = stale_cols[0] if (stale[0] and rows is not None) else None
         if final_intensity:
-            done, ticket = comp.flush(dev, live_rows=rows, rows_stale=stale[0] and rows is not None, final_intensity=True)
+            done, ticket = comp.flush(dev, live_rows=rows, rows_stale=stale[0] and rows is not None, final_intensity=True,
+                                      live_cols=cols)
             lean.psf_ticket = lean.final_ticket = ticket
             dead[0] = True
         elif final_power:
@@ -700,12 +734,13 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
             # reads the field back
             if power_state is not None:
                 power_state["before"]()  # (the ticket is taken inside: room in the ring first)
-            done, ticket = comp.flush(dev, live_rows=rows, rows_stale=stale[0] and rows is not None, final_intensity=2)
+            done, ticket = comp.flush(dev, live_rows=rows, rows_stale=stale[0] and rows is not None, final_intensity=2,
+                                      live_cols=cols)
             prog_power[0] = ticket if done else None
         else:
-            done = comp.flush(dev, live_rows=rows, rows_stale=stale[0] and rows is not None)
+            done = comp.flush(dev, live_rows=rows, rows_stale=stale[0] and rows is not None, live_cols=cols)
         if done:
-            stale[0] = False
+            stale[0], stale_cols[0] = False, None
             for r in live:
                 r[0], r[1] = 0, dev.n
         return done
@@ -765,17 +800,20 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
             continue
         if fresh is not None:
             value, fresh = fresh, None
-            rows0 = None
+            rows0 = cols0 = None
             if lean is not None and hasattr(dev, "zero_outside_rows"):
                 trial = [[0, dev.n] for _ in states]
                 _live_rows_after(plans, trial, dev.n)
                 # worth it only when every item's aperture leaves whole rows dark
                 if all(r[0] > 0 or r[1] < dev.n for r in trial) and all(r[0] < r[1] for r in trial):
                     rows0 = trial
-            same_as = _start_field(dev, plans, value, write_rows=rows0)
+                    if START_BOX:  # ... and whole columns: the field is written inside the aperture's box only
+                        cols0 = _live_cols_of(plans, dev.n)
+            same_as = _start_field(dev, plans, value, write_rows=rows0, write_cols=cols0)
             if same_as is not None:
                 _live_rows_after(plans, live, dev.n)
                 stale[0] = rows0 is not None
+                stale_cols[0] = cols0 if stale[0] else None
                 want_wfe = len(plans) == 1 and bool(items[0]["save"])
                 wfe = _launch_zernike(dev, plans, want_wfe=want_wfe)
                 wfe = _launch_phase_maps(dev, plans, wfe)
@@ -783,12 +821,13 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
                     if lean is not None:
                         keep_reads_field()
                         lean.rows = known_rows()
+                        lean.cols = stale_cols[0] if (stale[0] and lean.rows is not None) else None
                         # still copies of each other unless this surface put a wavefront error on them
                         untouched = not any(p["zernike"] is not None or p["phase_map"] is not None for p in plans)
                         lean.same_as = same_as if untouched and len(set(same_as)) < len(same_as) else None
                     on_saved(key, items, plans, wfe)
                     if lean is not None:
-                        lean.same_as = None
+                        lean.same_as, lean.cols = None, None
                 _queue_steps(comp, lens, stw, ptp, wts, inv_stw, inv_wts)
                 continue
         fuse_ap = FUSE_APERTURES
@@ -857,11 +896,12 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
             if lean is not None:
                 keep_reads_field()
                 lean.rows = known_rows() if not comp.pending() else None
+                lean.cols = stale_cols[0] if (stale[0] and lean.rows is not None) else None
             else:
                 settle()
             on_saved(key, items, plans, wfe)
             if lean is not None:
-                lean.rows, lean.psf_ticket = None, None
+                lean.rows, lean.psf_ticket, lean.cols = None, None, None
         _queue_steps(comp, lens, stw, ptp, wts, inv_stw, inv_wts)
     if power_state is not None and power_state["ticket"] is not None and not power_state.get("used"):
         dev.norm2_release(power_state["ticket"])  # (taken for a stop on the last surface, which nobody saved)
@@ -1071,7 +1111,10 @@ def run_batch(pupil_diameter, wavelengths, gridsize, zoom, field, opt_chains, pr
                 tickets.append((reduction_of(dev.psf_keep_power()), pending, None))
             else:
                 like = lean.same_as if lean is not None else None
-                if rows is not None and like is not None:
+                cols = lean.cols if lean is not None else None
+                if rows is not None and cols is not None:
+                    tickets.append((reduction_of(dev.norm2_enqueue(rows, same_as=like, live_cols=cols)), pending, None))
+                elif rows is not None and like is not None:
                     tickets.append((reduction_of(dev.norm2_enqueue(rows, same_as=like)), pending, None))
                 else:
                     tickets.append((reduction_of(dev.norm2_enqueue(rows) if rows is not None else dev.norm2_enqueue()),

@@ -61,7 +61,11 @@ class ModelDevice:
                         "encircled": np.array([I[d2 <= r * r].sum() for r in radii_px])})
         return out
 
-    def norm2_enqueue(self, live_rows=None, same_as=None):
+    def norm2_enqueue(self, live_rows=None, same_as=None, live_cols=None):
+        if live_cols is not None:  # the columns outside are not read either (they may hold NaN in this model)
+            assert live_rows is not None
+            return self._new_ticket(np.array([np.sum(np.abs(u[int(lo):int(hi), (int(cl) // 4) * 4:-(-int(ch) // 4) * 4]) ** 2)
+                                              for u, (lo, hi), (cl, ch) in zip(self.u, live_rows, live_cols)]))
         if same_as is not None:  # the caller claims copies: hold it to that
             for i, j in enumerate(same_as):
                 lo, hi = (int(x) for x in live_rows[i])
@@ -92,11 +96,15 @@ class ModelDevice:
             raise RuntimeError("ticket is not outstanding")
         del self._ring[int(ticket)]
 
-    def zero_outside_rows(self, live_rows):
+    def zero_outside_rows(self, live_rows, live_cols=None):
         self.log.append(("zero_outside_rows", None))
-        for u, (lo, hi) in zip(self.u, live_rows):
+        for i, (u, (lo, hi)) in enumerate(zip(self.u, live_rows)):
             u[:int(lo)] = 0.0
             u[int(hi):] = 0.0
+            if live_cols is not None:
+                cl, ch = (int(live_cols[i][0]) // 4) * 4, -(-int(live_cols[i][1]) // 4) * 4
+                u[:, :cl] = 0.0
+                u[:, ch:] = 0.0
 
     def norm2_fetch(self, ticket):
         if hasattr(ticket, "fetch"):
@@ -125,7 +133,7 @@ class ModelDevice:
     def psf_fetch(self, item=0):
         return self.psf[item].copy()
 
-    def start(self, value, shape, blocks, stop=None, write_rows=None):
+    def start(self, value, shape, blocks, stop=None, write_rows=None, write_cols=None):
         """paos_start: fill -> aperture -> make_stop on the flagged items.  ``write_rows``: the rows outside
         are NOT written and merely stand for zeros -- the model poisons them so that any read shows."""
         self.log.append(("start", shape))
@@ -141,6 +149,13 @@ class ModelDevice:
                 assert not u[:lo].any() and not u[hi:].any(), "write_rows must contain every non-zero row"
                 u[:lo] = np.nan
                 u[hi:] = np.nan
+            if write_cols is not None:
+                for u, (lo, hi) in zip(self.u, write_cols):
+                    lo, hi = (int(lo) // 4) * 4, min(self.n, -(-int(hi) // 4) * 4)
+                    live = np.nan_to_num(u, nan=0.0)
+                    assert not live[:, :lo].any() and not live[:, hi:].any(), "write_cols must contain every non-zero column"
+                    u[:, :lo] = np.nan
+                    u[:, hi:] = np.nan
 
     def aperture(self, shape, blocks):
         self.log.append(("aperture", shape))
@@ -275,18 +290,22 @@ class ModelDevice:
             q = 6.283185307179586 * q
         return u * (np.cos(q) + 1j * p[4] * np.sin(q))
 
-    def run_passes(self, passes, blocks, live_rows=None, rows_stale=False, final_intensity=False):
+    def run_passes(self, passes, blocks, live_rows=None, rows_stale=False, final_intensity=False, live_cols=None):
         # live_rows: a traffic hint, results are the same -- unless rows_stale: then the rows outside hold garbage
         # that stands for zeros and the program must behave as if they were zeros
         blocks = np.asarray(blocks, dtype=np.float64)
         assert blocks.ndim == 3 and blocks.shape[1:] == (self.batch, 5)
         n_ = self.n
         if live_rows is not None:
-            for u, (lo, hi) in zip(self.u, live_rows):
+            for k, (u, (lo, hi)) in enumerate(zip(self.u, live_rows)):
                 lo, hi = (int(lo) // 4) * 4, min(self.n, -(-int(hi) // 4) * 4)
                 if rows_stale:
                     u[:lo] = 0.0
                     u[hi:] = 0.0
+                    if live_cols is not None:
+                        cl, ch = (int(live_cols[k][0]) // 4) * 4, min(self.n, -(-int(live_cols[k][1]) // 4) * 4)
+                        u[:, :cl] = 0.0
+                        u[:, ch:] = 0.0
                 else:
                     assert not u[:lo].any() and not u[hi:].any(), "live_rows promised zeros"
         else:

@@ -95,3 +95,52 @@ def test_many_steps_run_ahead_of_the_gpu_without_corrupting_parameters():
         assert np.array_equal(early_powers, np.array([alone[i][last]["power"] for i in range(nb)]))
     finally:
         fresh.close()
+
+
+@pytest.mark.parametrize("n", [1024, 4096])
+def test_start_box_on_a_poisoned_buffer(n):
+    """Round 5: the lean start writes the first field inside its aperture's bounding box only -- rows AND
+    columns (paos_start_box) -- the first surface's power is summed over that box (paos_norm2_enqueue_box) and the first pass
+    loads nothing else.  On a buffer poisoned with NaN everywhere: PSFs and the powers of both saved surfaces equal those of
+    whole-row starts (PAOS_START_BOX=0) on a clean context bit for bit, and a run that needs the whole field first (a
+    stop on the second surface: paos_zero_outside_box) agrees with the ordinary walk."""
+    import paos_amd.run as prun
+    from paos_amd import _lib
+    from paos_amd.chains import syn20_chain, syn20_wavelength
+    from paos_amd.run import run_batch
+
+    wls = [syn20_wavelength(k) for k in (7, 333)]
+    chains = [syn20_chain() for _ in wls]
+    assert prun.START_BOX is True
+    prun.START_BOX = False
+    try:
+        ref_dev = _lib.DeviceFields(n, len(wls))
+        try:
+            whole = run_batch(1.0, wls, n, 4, ON_AXIS, chains, outputs=(), dev=ref_dev, keep_psf=True)
+            ref_psf = [ref_dev.psf_fetch(i) for i in range(len(wls))]
+        finally:
+            ref_dev.close()
+    finally:
+        prun.START_BOX = True
+    dev = _lib.DeviceFields(n, len(wls))
+    try:
+        for i in range(len(wls)):
+            dev.upload(i, np.full((n, n), complex(np.nan, np.nan)))
+        box = run_batch(1.0, wls, n, 4, ON_AXIS, chains, outputs=(), dev=dev, keep_psf=True)
+        for i in range(len(wls)):
+            assert np.array_equal(dev.psf_fetch(i), ref_psf[i]), i
+            for k in whole[i]:
+                assert box[i][k]["power"] == whole[i][k]["power"], (i, k)  # zeros add nothing: the same sum bit for bit
+        # something needs the whole field before any program runs: the box is made real zeros first
+        chain = syn20_chain()
+        chain[2] = dict(chain[2], is_stop=True)
+        for i in range(len(wls)):
+            dev.upload(i, np.full((n, n), complex(np.nan, np.nan)))
+        got = run_batch(1.0, wls, n, 4, ON_AXIS, [chain, chain], outputs=(), dev=dev, keep_psf=True)
+        psf = [dev.psf_fetch(i) for i in range(len(wls))]
+        want = run_batch(1.0, wls, n, 4, ON_AXIS, [chain, chain], outputs=("psf",), dev=dev, keep_psf=True)
+        for i in range(len(wls)):
+            assert np.isfinite(psf[i]).all() and rel_err(psf[i], want[i][20]["psf"]) < 1e-13, i
+            assert abs(got[i][20]["power"] - want[i][20]["power"]) <= 1e-13 * want[i][20]["power"]
+    finally:
+        dev.close()

@@ -883,3 +883,73 @@ def test_many_saved_surfaces_wrap_the_ticket_ring_without_stale_powers():
         for k, rec in got[i].items():
             direct = float(np.sum(np.abs(rec["wfo"]) ** 2))
             assert abs(rec["power"] - direct) <= 1e-12 * direct, (i, k)
+
+
+def test_lean_walk_writes_the_first_field_inside_its_aperture_box_only():
+    """Round 5: the lean start writes only the rows AND the columns inside the first aperture's bounding
+    box (paos_start_box); the model device poisons everything else with NaN.  The power of the saved first surface is
+    summed over the box, the first pass program is told the columns stand for zeros, a second saved surface in front of any
+    program still reports the right power, a stop in front of any program makes the box real zeros first -- and the results
+    equal those of whole-row starts (PAOS_START_BOX=0) and of the ordinary walk."""
+    from fakes import ModelDevice
+    import paos_amd.run as prun
+    from paos_amd.chains import syn20_chain, syn20_wavelength
+    from paos_amd.run import run_batch
+
+    wls = [syn20_wavelength(0), syn20_wavelength(300)]
+    field = {"us": 0.0, "ut": 0.0}
+
+    class Spy(ModelDevice):
+        def start(self, value, shape, blocks, stop=None, write_rows=None, write_cols=None):
+            self.log.append(("start_windows", (write_rows, write_cols)))
+            super().start(value, shape, blocks, stop, write_rows=write_rows, write_cols=write_cols)
+            if write_cols is not None:  # the poison is really there
+                lo, hi = (int(write_cols[0][0]) // 4) * 4, -(-int(write_cols[0][1]) // 4) * 4
+                assert np.isnan(self.u[0][:, :lo]).all() and np.isnan(self.u[0][:, hi:]).all() and lo > 0 and hi < self.n
+
+        def run_passes(self, passes, blocks, live_rows=None, rows_stale=False, final_intensity=False, live_cols=None):
+            self.log.append(("program_windows", (rows_stale, live_cols is not None)))
+            return super().run_passes(passes, blocks, live_rows=live_rows, rows_stale=rows_stale, final_intensity=final_intensity,
+                                      live_cols=live_cols)
+
+    prun.FUSE_APERTURES = True
+    try:
+        chains = [syn20_chain(), syn20_chain()]
+        plain = run_batch(1.0, wls, 128, 4, field, chains, outputs=("psf",), dev=ModelDevice(128, 2), keep_psf=True)
+        dev = Spy(128, 2)
+        box = run_batch(1.0, wls, 128, 4, field, chains, outputs=(), dev=dev, keep_psf=True)
+        rows, cols = [d for k, d in dev.log if k == "start_windows"][0]
+        assert rows is not None and cols is not None and all(0 < lo < hi < 128 for lo, hi in cols)
+        assert [d for k, d in dev.log if k == "program_windows"][0] == (True, True)
+        prun.START_BOX = False
+        try:
+            dev_rows = Spy(128, 2)
+            whole = run_batch(1.0, wls, 128, 4, field, chains, outputs=(), dev=dev_rows, keep_psf=True)
+        finally:
+            prun.START_BOX = True
+        assert [d for k, d in dev_rows.log if k == "start_windows"][0][1] is None
+        for i in range(2):
+            for k in (1, 20):
+                # (on the GPU the two sums are the same bit for bit -- tests/test_gpu_r5.py; NumPy's pairwise sum over
+                # another window rounds differently)
+                assert abs(box[i][k]["power"] - whole[i][k]["power"]) <= 4e-16 * whole[i][k]["power"]
+                assert abs(box[i][k]["power"] - plain[i][k]["power"]) <= 1e-13 * plain[i][k]["power"]
+            assert np.allclose(dev.psf_fetch(i), dev_rows.psf_fetch(i), rtol=0, atol=1e-15 * dev_rows.psf_fetch(i).max())
+        # a second saved surface before any program runs (S02, the Zernike surface, saved): summed over the box as well
+        chain2 = syn20_chain()
+        chain2[2] = dict(chain2[2], save=True)
+        dev2 = Spy(128, 1)
+        got = run_batch(1.0, wls[:1], 128, 4, field, [chain2], outputs=(), dev=dev2, keep_psf=True)
+        want = run_batch(1.0, wls[:1], 128, 4, field, [chain2], outputs=("psf",), dev=ModelDevice(128, 1), keep_psf=True)
+        for k in want[0]:
+            assert np.isfinite(got[0][k]["power"]) and abs(got[0][k]["power"] - want[0][k]["power"]) <= 1e-13 * want[0][k]["power"], k
+        # a stop on the second surface: the box becomes real zeros (rows and columns) before the sum reads the field
+        chain3 = syn20_chain()
+        chain3[2] = dict(chain3[2], is_stop=True)
+        dev3 = Spy(128, 1)
+        got = run_batch(1.0, wls[:1], 128, 4, field, [chain3], outputs=(), dev=dev3, keep_psf=True)
+        assert [k for k, _ in dev3.log].count("zero_outside_rows") == 1
+        want = run_batch(1.0, wls[:1], 128, 4, field, [chain3], outputs=("psf",), dev=ModelDevice(128, 1), keep_psf=True)
+        assert abs(got[0][20]["power"] - want[0][20]["power"]) <= 1e-13 * want[0][20]["power"]
+    finally:
+        prun.FUSE_APERTURES = "auto"
