@@ -61,13 +61,13 @@ def dense_chain(n, rms_m=40.0e-9, seed=20260101):
 
 
 def _dense(args, esz, measure, roofline_block):
-    """SYN20 behind the screen at the headline grid, small batch (the screen crosses PCIe per item and step:
-    128 MiB at 4096^2 -- the whole-step rate is host- and PCIe-bound and says so; the pass launches are event-timed
-    on the device and are what this entry is for)."""
+    """SYN20 behind the screen at the headline grid, batch 8.  Round 5: the screen -- one array for every item, as a measured
+    surface map is -- is turned into its map once (run.py: _sag_map_once) and crosses PCIe once (paos_phase_map_items keeps
+    it on the device); rounds 2-4 rebuilt and uploaded 128 MiB per item and step (30 wavefronts/s end to end)."""
     from paos_amd import _lib
     from paos_amd.chains import syn20_wavelength
 
-    n, nb, steps = args.grid, 8, 2
+    n, nb, steps = args.grid, 8, 10
     chain = dense_chain(n)
     chains = [chain] * nb
     dev = _lib.DeviceFields(n, nb, args.precision)
@@ -75,7 +75,7 @@ def _dense(args, esz, measure, roofline_block):
         def wavelengths_of(g):
             return [syn20_wavelength((g * nb + i) % 512) for i in range(nb)]
 
-        m = measure(dev, n, args.precision, wavelengths_of, chains, steps, 1)
+        m = measure(dev, n, args.precision, wavelengths_of, chains, steps, 2)
         block = roofline_block(m, n, nb, esz, dev, "frugal_pass_kernel (every FFT pass launch)", steps)
         ms = m["launch_ms"]
         return {"value": nb * steps / m["elapsed"], "unit": "wavefronts/s", "batch": nb, "steps": steps,
@@ -83,9 +83,9 @@ def _dense(args, esz, measure, roofline_block):
                 "pass_launch_ms_per_step": float(ms.sum()) / steps,
                 "wavefronts_per_s_of_pass_time": nb * steps / (float(ms.sum()) * 1e-3) if ms.size else None,
                 "workload": f"SYN20 + a white-noise grid-sag screen (40 nm rms) behind S02, {n}^2 {args.precision}, batch {nb}: "
-                            f"`value` includes building and uploading the screen for every item of every step "
-                            f"(host + PCIe, 128 MiB per item); `pass_launch_ms_per_step` / `roofline.classes` are "
-                            f"the device times of the pass launches on these rough fields",
+                            f"the screen is one array shared by all items, built and uploaded once (round 5); "
+                            f"`pass_launch_ms_per_step` / `roofline.classes` are the device times of the pass launches on "
+                            f"these rough fields",
                 "roofline": block}
     finally:
         dev.close()

@@ -236,6 +236,13 @@ int paos_phase(paos_ctx* ctx, const double* params, int mul2pi);
  * n x n doubles, finite: masked pixels filled with 0 as the reference does).  The resampling of a
  * sag map and the random draw of a PSD screen stay on the host (paos_amd/wfo.py).  Synchronises. */
 int paos_phase_map(paos_ctx* ctx, int item, const double* host_wfe, double wl);
+/* Round 5: the same for `n_items` items that share ONE map (a measured surface map is the same for every wavelength of a
+ * sweep and every draw of a Monte-Carlo study): items[k] (indices, as doubles) get u *= exp(2 pi i wfe / wl[k]).  The map
+ * crosses PCIe once and stays on the device; `key` != 0 names its content: a later call with the same key skips the
+ * validation and the upload (the caller vouches that the host buffer still holds what was uploaded under that key;
+ * 0 = always upload).  Does not synchronise when the key matches. */
+int paos_phase_map_items(paos_ctx* ctx, const double* host_wfe, unsigned long long key, int n_items, const double* items,
+                         const double* wl);
 /* WFO.ptp (wfo.py:462-472): ifft2(exp(-i coef (fx^2+fy^2)) fft2(u)), ortho norms, shifts
  * cancelled; sx, sy = 1/(n dx), 1/(n dy) (np.fft.fftfreq spacing), coef = pi wl dz. */
 int paos_ptp(paos_ctx* ctx, const double* params);

@@ -104,6 +104,7 @@ SYMBOLS = {
     "paos_zernike_pupil": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, _dbl_p, _dbl_p, ctypes.c_int, _dbl_p]),
     "paos_start_rows": (ctypes.c_int, [_c_ctx, ctypes.c_double, ctypes.c_double, ctypes.c_int, _dbl_p, _dbl_p, _dbl_p]),
     "paos_zero_outside_rows": (ctypes.c_int, [_c_ctx, _dbl_p]),
+    "paos_phase_map_items": (ctypes.c_int, [_c_ctx, _dbl_p, ctypes.c_ulonglong, ctypes.c_int, _dbl_p, _dbl_p]),
     "paos_start_box": (ctypes.c_int, [_c_ctx, ctypes.c_double, ctypes.c_double, ctypes.c_int, _dbl_p, _dbl_p, _dbl_p, _dbl_p]),
     "paos_zero_outside_box": (ctypes.c_int, [_c_ctx, _dbl_p, _dbl_p]),
     "paos_norm2_enqueue_box": (ctypes.c_int, [_c_ctx, _dbl_p, _dbl_p, _dbl_p, ctypes.POINTER(ctypes.c_int)]),
@@ -478,6 +479,19 @@ class DeviceFields:
         if w.shape != (self.n, self.n):
             raise ValueError(f"phase map must have shape {(self.n, self.n)}")
         self._check(self._lib.paos_phase_map(self._ctx, int(item), _dptr(w), float(wl)), "paos_phase_map")
+
+    def phase_map_items(self, wfe, items, wls, key=0):
+        """u[i] *= exp(2 pi i wfe / wl_i) for the listed items, which share the host map ``wfe`` (metres): one upload.
+        ``key`` != 0 names the map's content: the same key again re-uses the copy already on the device."""
+        w = np.ascontiguousarray(wfe, dtype=np.float64)
+        if w.shape != (self.n, self.n):
+            raise ValueError(f"phase map must have shape {(self.n, self.n)}")
+        it = np.ascontiguousarray(items, dtype=np.float64).reshape(-1)
+        wl = np.ascontiguousarray(wls, dtype=np.float64).reshape(-1)
+        if it.size != wl.size or it.size < 1:
+            raise ValueError("one wavelength per listed item is required")
+        self._check(self._lib.paos_phase_map_items(self._ctx, _dptr(w), int(key) & 0xFFFFFFFFFFFFFFFF, int(it.size), _dptr(it), _dptr(wl)),
+                    "paos_phase_map_items")
 
     def ptp(self, blocks):
         b = as_blocks(blocks, self.batch, PHASE_STRIDE)

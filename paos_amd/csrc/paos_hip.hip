@@ -98,6 +98,8 @@ struct paos_ctx {
   unsigned pitch = 0, item_stride = 0;
   hipStream_t stream = nullptr;
   double* psf = nullptr;  // batch x item_stride intensities kept on the device, blocked like the field (paos_psf_keep)
+  double* map_dev = nullptr;      // one n x n phase map kept on the device (paos_phase_map_items) and the key it was uploaded under
+  unsigned long long map_key = 0;
   double* psf_partial = nullptr;  // per-workgroup sums of a pass that stores the PSF (paos_run_program: final_intensity)
   int psf_nparts = 0;
   double* pow_partial = nullptr;  // per-workgroup sums of |u|^2 of a pass that stores the FIELD (final_intensity = 2)
@@ -1407,7 +1409,8 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
       const int lines = passes[n_passes - 1].axis == 0 ? (c->n >= 2048 ? c->br / 2 : c->br) : 2;  // FftCfg: FR_ROW_LINES / COL_LINES
       power_groups = c->n / lines;
       if (c->pow_nparts < c->n / 2) {  // (sized for the finest tiling of either axis)
-        if (c->pow_partial) (void)hipFree(c->pow_partial);
+        if (c->map_dev) (void)hipFree(c->map_dev);
+  if (c->pow_partial) (void)hipFree(c->pow_partial);
         c->pow_partial = nullptr; c->pow_nparts = 0;
         HIPCHK(c, hipMalloc(&c->pow_partial, (size_t)c->batch * (c->n / 2) * sizeof(double)));
         c->pow_nparts = c->n / 2;
@@ -2516,6 +2519,40 @@ int paos_phase_map(paos_ctx* c, int item, const double* host_wfe, double wl) {
                        (cx<float>*)c->field + (size_t)item * c->item_stride, (const double*)c->staging, c->n, c->pitch, wl));
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(c->stream));  // the host buffer is only borrowed
+  return PAOS_OK;
+}
+
+int paos_phase_map_items(paos_ctx* c, const double* host_wfe, unsigned long long key, int n_items, const double* items,
+                         const double* wl) {
+  SETTLE_SCALE(c);
+  if (c) (void)hipSetDevice(c->device);
+  if (!c || !host_wfe || !items || !wl || n_items < 1 || n_items > c->batch) return fail(c, PAOS_EINVAL, "bad item list or null buffer");
+  for (int k = 0; k < n_items; ++k) {
+    if (!(items[k] >= 0.0) || items[k] >= (double)c->batch || items[k] != (double)(int)items[k]) return fail(c, PAOS_EINVAL, "bad item index");
+    if (!(wl[k] > 0.0) || !std::isfinite(wl[k])) return fail(c, PAOS_EINVAL, "wavelength must be positive and finite");
+  }
+  const size_t count = (size_t)c->n * c->n;
+  if (!c->map_dev) HIPCHK(c, hipMalloc(&c->map_dev, count * sizeof(double)));
+  if (key == 0 || key != c->map_key) {  // (the same key again: the caller vouches that the map is the one uploaded under it)
+    for (size_t i = 0; i < count; ++i)  // the device sincos handles any finite argument; reject the rest here
+      if (!std::isfinite(host_wfe[i])) return fail(c, PAOS_EINVAL, "the phase map holds a non-finite value (fill masked pixels with 0)");
+    c->map_key = 0;
+    HIPCHK(c, hipMemcpyAsync(c->map_dev, host_wfe, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));  // the host buffer is only borrowed
+    c->map_key = key;
+  }
+  const double *ditems = nullptr, *dwl = nullptr;
+  int rc;
+  if ((rc = arena_push(c, items, (size_t)n_items, &ditems))) return rc;
+  if ((rc = arena_push(c, wl, (size_t)n_items, &dwl))) return rc;
+  const dim3 grid(pw_blocks(c), n_items), block(kPwThreads);
+  if (c->precision == PAOS_F64)
+    hipLaunchKernelGGL((phase_map_items_kernel<double, BR, Lay<double>::BC>), grid, block, 0, c->stream, (cx<double>*)c->field,
+                       c->item_stride, (const double*)c->map_dev, c->n, c->pitch, ditems, dwl);
+  else
+    F32_BR_SWITCH(c, hipLaunchKernelGGL((phase_map_items_kernel<float, FBR, Lay<float>::BC>), grid, block, 0, c->stream,
+                                        (cx<float>*)c->field, c->item_stride, (const double*)c->map_dev, c->n, c->pitch, ditems, dwl));
+  HIPCHK(c, hipGetLastError());
   return PAOS_OK;
 }
 

@@ -130,6 +130,28 @@ __global__ void phase_map_kernel(cx<T>* f, const double* staged, int n, unsigned
   }
 }
 
+// The same for several items that share ONE map (round 5: a measured surface map is the same for every wavelength of a sweep
+// and every draw of a Monte-Carlo study -- uploaded once, applied to each listed item with its own wavelength):
+// blockIdx.y walks the list.
+template <typename T, int BR, int BC>
+__global__ void phase_map_items_kernel(cx<T>* field, unsigned item_stride, const double* map, int n, unsigned pitch,
+                                       const double* items, const double* wls) {
+  cx<T>* f = field + (size_t)(int)items[blockIdx.y] * item_stride;
+  const double wl = wls[blockIdx.y];
+  const size_t total = (size_t)pitch * (n / BR);
+  size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
+    int r, c;
+    if (!layout_unmap<BR, BC>(m, n, pitch, r, c)) continue;
+    const double w = map[(size_t)r * n + c];
+    const double arg = __ddiv_rn(__dmul_rn(6.283185307179586, w), wl);  // (phase_map_kernel's own expressions)
+    double sn, cs;
+    sincos(arg, &sn, &cs);
+    const double x = (double)f[m].x, y = (double)f[m].y;
+    f[m] = {(T)__dsub_rn(__dmul_rn(x, cs), __dmul_rn(y, sn)), (T)__dadd_rn(__dmul_rn(x, sn), __dmul_rn(y, cs))};
+  }
+}
+
 // ---- stand-alone pointwise pass (op list without a transform) --------------------
 // Used when a lens (wfo.py:359-366) is not adjacent to an FFT pass it could ride on.
 template <typename T, int BR, int BC>

@@ -277,6 +277,41 @@ class ABCDProduct(ABCD):
         raise AttributeError(name)
 
 
+# Round 5: a measured surface map is one array that every wavelength of a sweep and every draw of a Monte-Carlo batch passes
+# through WFO.grid_sag with the same sampling: the map the reference would build per wavefront (wfo.py:745-867: masking,
+# Fourier shift, padding / cropping, resampling -- seconds at 4096^2) is built once per distinct (array, geometry) and shared;
+# ``_launch_phase_maps`` then uploads it once for all the items that carry it.  An entry keeps its input array alive (so that
+# the id stays unique) and is matched by the array's identity plus a cheap fingerprint of its content -- shape, type and the
+# sum of 65 536 evenly spaced samples (every element of a map up to 256^2): an array edited in place between two runs is
+# rebuilt when the edit touches a sample; ``forget_maps()`` drops the entries for a caller that edits large arrays in place.
+_SAG_MAPS = {}
+
+
+def forget_maps():
+    """Drop the kept Grid Sag maps (``_sag_map_once``) and their device-side copies' host mirrors."""
+    _SAG_MAPS.clear()
+    _FILLED_MAPS.clear()
+
+
+def _sag_fingerprint(sag):
+    a = np.ma.getdata(sag)
+    flat = a.reshape(-1)
+    return (a.shape, a.dtype.str, float(np.nansum(flat[:: max(1, flat.size // 65536)])), isinstance(sag, np.ma.MaskedArray))
+
+
+def _sag_map_once(sag, nx, ny, delx, dely, xdec, ydec, n, dx, dy):
+    key = (id(sag), nx, ny, delx, dely, xdec, ydec, n, dx, dy)
+    fp = _sag_fingerprint(sag)
+    hit = _SAG_MAPS.get(key)
+    if hit is not None and hit[0] is sag and hit[1] == fp:
+        return hit[2]
+    m = grid_sag_map(sag, nx, ny, delx, dely, xdec, ydec, (n, n), dx, dy)
+    if len(_SAG_MAPS) >= 8:
+        _SAG_MAPS.pop(next(iter(_SAG_MAPS)))
+    _SAG_MAPS[key] = (sag, fp, m)
+    return m
+
+
 def _plan_host(st, item, n, dx, dy, wl, wz_of, aperture_plan=False):
     """Host half of one loop iteration of run.py:77-178 for one wavefront -- everything but the
     pilot-beam scalars (those are advanced for the whole batch in one C call, planner.BeamBatch).
@@ -327,8 +362,8 @@ def _plan_host(st, item, n, dx, dy, wl, wz_of, aperture_plan=False):
         plan["zernike"] = dict(m=m, n=nn, norm=norm, Z=np.asarray(item["Z"], dtype=np.float64), dx=dx, dy=dy,
                                radius=radius, wl=wl, origin=item["Zorigin"], pupil=pupil)
     elif kind == "Grid Sag":  # run.py:154-164
-        plan["phase_map"] = (grid_sag_map(item["grid_sag"], item["nx"], item["ny"], item["delx"], item["dely"],
-                                          item["xdec"], item["ydec"], (n, n), dx, dy), wl)
+        plan["phase_map"] = (_sag_map_once(item["grid_sag"], item["nx"], item["ny"], item["delx"], item["dely"],
+                                           item["xdec"], item["ydec"], n, dx, dy), wl)
     elif kind == "PSD":  # run.py:166-177
         plan["phase_map"] = (psd_map((n, n), dx, dy, item["A"], item["B"], item["C"], item["fknee"], item["fmin"],
                                      item["fmax"], item["SR"], item["units"]), wl)
@@ -578,13 +613,31 @@ def _launch_phase_maps(dev, plans, wfe):
     of the LAST of Zernike / Grid Sag / PSD (each assignment at run.py:143,156,168 overwrites)."""
     if isinstance(plans, _Plans) and not plans.summary()[2]:
         return wfe
+    groups = {}  # items that carry the very same map object (round 5: _sag_map_once): one upload for all of them
     for i, p in enumerate(plans):
         if p["phase_map"] is not None:
             m, wl = p["phase_map"]
-            dev.phase_map(i, np.ma.filled(m, 0.0), wl)
+            groups.setdefault(id(m), (m, [], []))
+            groups[id(m)][1].append(i)
+            groups[id(m)][2].append(wl)
             if len(plans) == 1:
                 wfe = m
+    for m, idx, wls in groups.values():
+        if len(idx) > 1 and hasattr(dev, "phase_map_items"):
+            filled = _FILLED_MAPS.get(id(m))
+            if filled is None or filled[0] is not m:
+                if len(_FILLED_MAPS) >= 8:
+                    _FILLED_MAPS.pop(next(iter(_FILLED_MAPS)))
+                filled = _FILLED_MAPS[id(m)] = (m, np.ascontiguousarray(np.ma.filled(m, 0.0), dtype=np.float64))
+            # (the key: this map object -- it is immutable once built and kept alive by the cache, so its id names its content)
+            dev.phase_map_items(filled[1], idx, wls, key=id(m))
+        else:
+            for i, wl in zip(idx, wls):
+                dev.phase_map(i, np.ma.filled(m, 0.0), wl)
     return wfe
+
+
+_FILLED_MAPS = {}  # id(map) -> (map, its zero-filled contiguous copy): what crosses PCIe
 
 
 def _queue_apertures(comp, plans):

@@ -359,6 +359,15 @@ class ModelDevice:
             comp.lens(rows)
         comp.flush(self)
 
+    def phase_map(self, item, wfe, wl):
+        self.log.append(("phase_map", item))
+        self.u[int(item)] = self.u[int(item)] * np.exp(2.0 * np.pi * 1j * np.asarray(wfe, dtype=np.float64) / wl)
+
+    def phase_map_items(self, wfe, items, wls, key=0):
+        self.log.append(("phase_map_items", len(items)))
+        for i, wl in zip(items, wls):
+            self.u[int(i)] = self.u[int(i)] * np.exp(2.0 * np.pi * 1j * np.asarray(wfe, dtype=np.float64) / wl)
+
     def ptp(self, blocks):
         self._single(blocks, False, "ptp")
 

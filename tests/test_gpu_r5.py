@@ -144,3 +144,32 @@ def test_start_box_on_a_poisoned_buffer(n):
             assert abs(got[i][20]["power"] - want[i][20]["power"]) <= 1e-13 * want[i][20]["power"]
     finally:
         dev.close()
+
+
+def test_a_shared_grid_sag_screen_is_uploaded_once_and_equals_the_per_item_path():
+    """Round 5: SYN20 behind ONE white-noise grid-sag screen for all items (bench.py's `extra.dense`
+    chain): the map is built once (``run._sag_map_once``) and applied by ``paos_phase_map_items`` -- one upload for the
+    batch, none for the next batch.  PSFs equal those of the per-item path (every item its own copy of the array ->
+    ``paos_phase_map`` per item) bit for bit, on the same context and on the next step."""
+    import bench_extras
+    from paos_amd import _lib
+    from paos_amd.chains import syn20_wavelength
+    from paos_amd.run import run_batch
+
+    n, nb = 1024, 4
+    shared = bench_extras.dense_chain(n)
+    own = []
+    for _ in range(nb):
+        c = bench_extras.dense_chain(n)
+        own.append({k: (dict(v, grid_sag=v["grid_sag"].copy()) if v["type"] == "Grid Sag" else v) for k, v in c.items()})
+    dev = _lib.DeviceFields(n, nb)
+    try:
+        for g in (0, 1):
+            wls = [syn20_wavelength((g * nb + i) % 512) for i in range(nb)]
+            run_batch(1.0, wls, n, 4, ON_AXIS, [shared] * nb, outputs=(), dev=dev, keep_psf=True)
+            a = [dev.psf_fetch(i) for i in range(nb)]
+            run_batch(1.0, wls, n, 4, ON_AXIS, own, outputs=(), dev=dev, keep_psf=True)
+            for i in range(nb):
+                assert np.array_equal(a[i], dev.psf_fetch(i)), (g, i)
+    finally:
+        dev.close()

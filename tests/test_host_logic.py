@@ -953,3 +953,59 @@ def test_lean_walk_writes_the_first_field_inside_its_aperture_box_only():
         assert abs(got[0][20]["power"] - want[0][20]["power"]) <= 1e-13 * want[0][20]["power"]
     finally:
         prun.FUSE_APERTURES = "auto"
+
+
+def test_a_shared_grid_sag_map_is_built_once_and_applied_to_all_its_items():
+    """Round 5: one measured-surface array on a Grid Sag surface of every item of a batch -- a
+    wavelength sweep, a Monte-Carlo batch -- is turned into ITS map once (``_sag_map_once``: same array object, same
+    geometry) and applied with one ``phase_map_items`` call; an array edited in place is rebuilt; items with their own
+    arrays keep the per-item path.  Fields equal those of the reference formula item by item."""
+    import paos_amd.run as prun
+    from paos_amd.abcd import ABCD
+    from paos_amd.run import run_batch
+
+    n = 64
+    rng = np.random.default_rng(5)
+    sag = rng.standard_normal((n, n)) * 30.0e-9
+    step = 4.0 / n
+
+    def chain_with(screen):
+        base = syn20_chain()
+        out = {}
+        for key, item in base.items():
+            num = len(out) + 1
+            out[num] = dict(item, num=num)
+            if item["name"] == "Z1":
+                num = len(out) + 1
+                out[num] = {"num": num, "type": "Grid Sag", "name": "SCREEN", "is_stop": False, "save": True,
+                            "grid_sag": screen, "nx": n, "ny": n, "delx": step, "dely": step, "xdec": 0, "ydec": 0,
+                            "ABCDt": ABCD(thickness=0.0, curvature=0.0), "ABCDs": ABCD(thickness=0.0, curvature=0.0)}
+        return out
+
+    wls = [1.0e-6, 1.2e-6, 1.5e-6]
+    calls = []
+    real = prun.grid_sag_map
+    prun.grid_sag_map = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        shared = chain_with(sag)
+        dev = ModelDevice(n, 3)
+        got = run_batch(1.0, wls, n, 4, FIELD, [shared] * 3, outputs=("wfo",), dev=dev)
+        assert len(calls) == 1 and ("phase_map_items", 3) in dev.log and not any(k == "phase_map" for k, _ in dev.log)
+        run_batch(1.0, wls, n, 4, FIELD, [shared] * 3, outputs=(), dev=ModelDevice(n, 3))
+        assert len(calls) == 1  # the next batch finds the map
+        sag[3, 4] += 1.0e-9   # edited in place: the fingerprint notices (it samples every element of so small an array)
+        run_batch(1.0, wls, n, 4, FIELD, [shared] * 3, outputs=(), dev=ModelDevice(n, 3))
+        assert len(calls) == 2
+        sag[3, 4] -= 1.0e-9
+        # every item its own array: per-item maps and uploads, same fields
+        own = [chain_with(sag.copy()) for _ in wls]
+        dev2 = ModelDevice(n, 3)
+        want = run_batch(1.0, wls, n, 4, FIELD, own, outputs=("wfo",), dev=dev2)
+        assert sum(k == "phase_map" for k, _ in dev2.log) == 3
+        key = [k for k, v in shared.items() if v["name"] == "SCREEN"][0]
+        for i in range(3):
+            for k in want[i]:
+                assert rel_err(got[i][k]["wfo"], want[i][k]["wfo"]) < 1e-13, (i, k)
+        assert key in got[0]
+    finally:
+        prun.grid_sag_map = real
