@@ -21,11 +21,14 @@ python3 "$ROOT/tools/pmc_summary.py" $(find "$OUT/sq" -name "*counter_collection
 find "$OUT" -name "*.csv" -size +8M -delete
 cd "$ROOT"
 ./build/fftbench 10 > "$OUT/fftbench.txt" 2>&1
-./build/timeline > "$OUT/timeline.txt" 2>&1
-python3 bench.py --steps 20 --warmup 5 > "$OUT/bench_default.json" 2> "$OUT/bench_default.err"
-python3 bench.py --precision fp32 --steps 10 --warmup 2 --no-cpu-baseline --no-traffic > "$OUT/bench_fp32.json" 2>&1
-PAOS_NO_PRUNE=1 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --no-traffic > "$OUT/bench_noprune.json" 2>&1
+[ -x ./build/timeline ] && ./build/timeline > "$OUT/timeline.txt" 2>&1
+# (round 5: stdout of bench.py is the <= 4 KB contract line; everything else goes to the --detail record)
+python3 bench.py --steps 20 --warmup 5 --detail "$OUT/bench_default.json" > "$OUT/bench_default_line.json" 2> "$OUT/bench_default.err"
+python3 bench.py --precision fp32 --steps 10 --warmup 2 --no-cpu-baseline --no-traffic --no-extras --detail "$OUT/bench_fp32.json" > "$OUT/bench_fp32_line.json" 2>&1
+PAOS_NO_PRUNE=1 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --no-traffic --detail "$OUT/bench_noprune.json" > "$OUT/bench_noprune_line.json" 2>&1
+if [ -z "$PAOS_PROFILE_SHORT" ]; then
 python3 tests/reports/parity_report.py --sizes 1024 2048 > "$OUT/parity_gpu_vs_oracle.txt" 2>&1
 python3 tests/reports/run_configs.py > "$OUT/baseline_configs.txt" 2>&1
+fi
 head -14 "$OUT/kernel_stats.txt"
 python3 tools/bench_line.py "$OUT/bench_default.json" "$OUT/bench_fp32.json" "$OUT/bench_noprune.json"
