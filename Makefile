@@ -13,7 +13,16 @@ all: $(LIB)
 # part 0 = everything but the frugal pass-kernel families, parts 1..5 = one (type, N) family each.
 DEPS = $(CSRC)/paos_hip.hip $(CSRC)/fft_core.h $(CSRC)/fft_kernels.h $(CSRC)/frugal_pass.h $(CSRC)/pointwise.h include/paos_hip.h
 PARTS = 0 1 2 3 4 5
-OBJS = $(foreach k,$(PARTS),build/obj/part$(k).o) build/obj/comm.o build/obj/plan.o
+OBJS = $(foreach k,$(PARTS),build/obj/part$(k).o) build/obj/comm.o build/obj/plan.o build/obj/srchash.o
+
+# What the library was built from: sha256 over its sources in this order (paos_source_hash(); __graft_entry__.build() compares
+# it with the tree and rebuilds on a mismatch -- a prebuilt .so that travelled with the tree cannot silently be stale)
+HASHED = $(CSRC)/paos_hip.hip $(CSRC)/fft_core.h $(CSRC)/fft_kernels.h $(CSRC)/frugal_pass.h $(CSRC)/pointwise.h \
+         $(CSRC)/paos_comm.cpp $(CSRC)/paos_plan.cpp include/paos_hip.h include/paos_comm.h include/paos_plan.h
+build/obj/srchash.o: $(HASHED)
+	mkdir -p build/obj
+	printf 'extern "C" const char* paos_source_hash(void) { return "%s"; }\n' "$$(cat $(HASHED) | sha256sum | cut -c1-32)" > build/obj/srchash.cpp
+	g++ -O2 -fPIC -c build/obj/srchash.cpp -o $@
 
 # the scalar half of the propagation loop for a batch (include/paos_plan.h): plain C++, the
 # reference's operation order, no FMA contraction

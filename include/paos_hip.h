@@ -99,6 +99,10 @@ const char* paos_last_error(const paos_ctx* ctx);
 int paos_sync(paos_ctx* ctx);
 /* describe the build: gfx arch, layout block, pitch padding (for logs) */
 const char* paos_build_info(void);
+/* round 5: the first 32 hex digits of sha256 over the library's sources as they were when it was built (Makefile: HASHED,
+ * in that order) -- __graft_entry__.build() compares it with the tree and rebuilds on a mismatch, so a prebuilt library that
+ * travelled with a tree it was not built from is noticed */
+const char* paos_source_hash(void);
 /* the HIP stream handle (hipStream_t) of the context, for event timing */
 void* paos_stream(paos_ctx* ctx);
 

@@ -62,6 +62,7 @@ SYMBOLS = {
     "paos_profile_begin": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int]),
     "paos_profile_end": (ctypes.c_int, [_c_ctx, ctypes.POINTER(ctypes.c_int), _dbl_p]),
     "paos_profile_end_split": (ctypes.c_int, [_c_ctx, ctypes.POINTER(ctypes.c_int), _dbl_p, ctypes.POINTER(ctypes.c_int), _dbl_p]),
+    "paos_source_hash": (ctypes.c_char_p, []),
     "paos_profile_planned_bytes": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p, ctypes.POINTER(ctypes.c_int)]),
     "paos_profile_line_transforms": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p, ctypes.POINTER(ctypes.c_int)]),
     "paos_profile_end_launches": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p, ctypes.POINTER(ctypes.c_int),
