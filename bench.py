@@ -363,14 +363,14 @@ def roofline_block(m, n, nb, esz, dev, kernel_name, steps, traffic=None, traffic
         "bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
         "traffic_note": "not measured in this run (--no-traffic, an `extra` entry, or N > 1); per-kernel FETCH_SIZE / WRITE_SIZE "
-                        "of the default command under rocprofv3: profiles/r04_pmc_hbm_traffic_bench.txt",
+                        "of the default command under rocprofv3: profiles/r05_pmc_hbm_traffic_bench.txt",
         "launches": int(ms.size), "avg_launch_ms": float(ms.mean()) if ms.size else 0.0,
         "algorithmic_bytes_per_launch": float(planned.mean()) if known else None,
         "full_pass_bytes": pass_bytes,
         "what": "every pass launch of the timed steps: bytes the pruning plan has them load + store (their algorithmic bytes) "
                 "over their HIP-event time.  Round 4: between two apertures the row factors of every operator run on the "
                 "live rows and the column factors on the wanted columns only, so a launch moves about an eighth of the "
-                "batch and is bound by the fp64 issue rate of its butterflies, not by HBM (profiles/r04_sq_counters.txt); "
+                "batch and is bound by the latency chain / fp64 issue of its butterflies, not by HBM (profiles/r05_fftbench_fused_variants.txt); "
                 "`dense` is the same kernel with every line alive",
         "fused_passes_per_wavefront": m["fused_passes"],
         "launches_per_step": float(ms.size) / steps if steps else None,
@@ -440,8 +440,9 @@ def roofline_block(m, n, nb, esz, dev, kernel_name, steps, traffic=None, traffic
                 "what": "SQ_INSTS_VALU of the pass launches of the counted step (a third rocprofv3 --pmc child) x 4 cycles per "
                         "wave instruction / 1024 SIMDs, over the mean HIP-event time of a step's pass launches in this run at the 2.4 GHz "
                         "peak clock: the fraction of the vector issue slots the launches fill.  About three quarters of the "
-                        "instructions are fp64 (4 cycles); the chip holds ~1.7 GHz under this load (profiles/"
-                        "r03_timeline_workgroup_phases.txt), so the fraction of the slots it really has is ~1.4x this figure"}
+                        "instructions are fp64 (4 cycles); under the fused launches the chip holds 2.0-2.36 GHz (s_memtime / "
+                        "s_memrealtime, profiles/r05_fftbench_fused_variants.txt): the launches are a latency chain per "
+                        "workgroup at four waves per SIMD, not short of clock"}
     return block
 
 

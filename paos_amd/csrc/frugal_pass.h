@@ -135,6 +135,9 @@ struct FrugalArgs {
   // host only: the LONG value of the build to launch -- the transforms of the NEXT one or two passes of the program that the
   // launch runs as well (same axis, same lines; their item records follow this pass's in `items`: [2 or 3][batch])
   int fuse = 0;
+  // host only (round 5): a single table pass that moves few bytes -- every item loads and stores at most half of its positions --
+  // runs on the one-line workgroups of the fused launches (paos_hip.hip: frugal_launch, ONE)
+  int one_line = 0;
 };
 #if PAOS_STAMPS
 #define PAOS_STAMP(i)                                                                              \

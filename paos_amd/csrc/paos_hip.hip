@@ -697,7 +697,10 @@ void plan_pruning(const paos_ctx* c, const paos_pass* passes, int n_passes, cons
 #ifndef PAOS_LONG_ONE_LINE
 #define PAOS_LONG_ONE_LINE 1
 #endif
-template <typename T, int N, int AXIS, int KPRE, int KMID, int NFFT, int STORE = 0, int TAB = 0, int LONG = 0>
+#ifndef PAOS_SINGLE_ONE_LINE
+#define PAOS_SINGLE_ONE_LINE 1   // 0 (A/B builds): single table passes keep the two-line workgroups whatever they load and store
+#endif
+template <typename T, int N, int AXIS, int KPRE, int KMID, int NFFT, int STORE = 0, int TAB = 0, int LONG = 0, int ONE = 0>
 int frugal_launch(paos_ctx* c, const FrugalArgs& args) {
   using C = FftCfg<T, N>;
   // Round 5: the launches that run two or three passes of a chain (LONG builds) and store the field are bound by the latency
@@ -706,7 +709,9 @@ int frugal_launch(paos_ctx* c, const FrugalArgs& args) {
   // 512 threads (-6 ... -8 % rows, -2 ... -3 % columns, bit-identical: profiles/r05_fftbench_fused_variants.txt).  The 16- /
   // 32-byte pieces such tiles take out of every 128-byte block, which rule them out for byte-bound passes, cost nothing
   // here.  (The PSF- / power-summing builds keep the two-line tiles: their partial sums are laid out per two-line tile.)
-  constexpr bool kOneLine = PAOS_LONG_ONE_LINE != 0 && LONG != 0 && STORE == 0 && sizeof(T) == 8 && N == 4096;
+  // ONE = 1: a single table pass that loads AND stores at most half of its positions (the two passes of the first stretch since
+  // the start box) is as latency-bound as the fused launches and takes the same shape (launch_lowered decides per launch).
+  constexpr bool kOneLine = PAOS_LONG_ONE_LINE != 0 && (LONG != 0 || ONE != 0) && STORE == 0 && sizeof(T) == 8 && N == 4096;
   constexpr int LINES = kOneLine ? 1 : (AXIS == 0 ? C::FR_ROW_LINES : C::COL_LINES);
   constexpr int TILES = AXIS == 0 ? C::ROW_TILES : C::COL_TILES;
   // several workgroups share the 160 KiB of LDS: c128 exchanges re and im in turn; a c64 line
@@ -777,6 +782,9 @@ int frugal_nfft(paos_ctx* c, const FrugalArgs& a, int nfft) {
     if constexpr (KPRE <= 1 && KMID <= 1 && KPRE + KMID > 0) {
       if (a.psf) return nfft >= 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2, 1, 1>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1, 1, 1>(c, a);
       if (a.pow_partial) return nfft >= 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2, 2, 1>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1, 2, 1>(c, a);
+      if constexpr (sizeof(T) == 8 && N == 4096 && PAOS_LONG_ONE_LINE != 0) {
+        if (a.one_line && PAOS_SINGLE_ONE_LINE != 0) return nfft >= 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2, 0, 1, 0, 1>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1, 0, 1, 0, 1>(c, a);
+      }
       return nfft >= 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2, 0, 1>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1, 0, 1>(c, a);
     } else {
       return fail(c, PAOS_EINVAL, "no table build of this pass shape");
@@ -1188,6 +1196,15 @@ int launch_lowered(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const doubl
     }
   }
   a.tab = tables ? 1 : 0;  // (the TAB builds take "has phases" for the number of phases: their slots read one factor)
+  {  // a single table pass whose every item loads and stores at most half of its positions: one-line workgroups (frugal_launch)
+    bool light = tables && !next && !store_psf && !sum_power;
+    for (int it = 0; it < c->batch && light; ++it) {
+      const FrugalItem& fi = lp.items[it];
+      if (fi.active == 0.0) continue;
+      light = 2.0 * (fi.pos_hi - fi.pos_lo) <= (double)c->n && 2.0 * (fi.spos_hi - fi.spos_lo) <= (double)c->n;
+    }
+    a.one_line = light ? 1 : 0;
+  }
   a.fuse = next2 ? 2 + next2->nfft : (next ? next->nfft : 0);  // LONG: the transforms of the passes that ride along
   // (a fused pair runs on the one build whose four slots all read tables)
   const int kpre = next ? 1 : (tables && lp.kpre > 1 ? 1 : lp.kpre), kmid = next ? 1 : (tables && lp.kmid > 1 ? 1 : lp.kmid);
