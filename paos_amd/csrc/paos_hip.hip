@@ -979,15 +979,18 @@ int launch_mask_jobs(paos_ctx* c, MaskJobs& jobs, int count) {
   {
     const char* e = getenv("PAOS_MASK_SCAN");  // (read per launch: tests switch it)
     jobs.windows = (e && e[0] == '1') ? 0 : 1;
+    const char* pe = getenv("PAOS_MASK_PAIRS");  // (round 5: two lines per wave through 16-pixel windows; =0: one line per wave)
+    jobs.pairs = (jobs.windows != 0 && !(pe && pe[0] == '0')) ? 1 : 0;
   }
   int widest = 0, shapes = 0;
   for (int j = 0; j < count; ++j) {
     widest = std::max(widest, jobs.job[j].line_end - jobs.job[j].line0);
     shapes |= jobs.job[j].shapes;
   }
-  const dim3 grid((widest + 3) / 4, c->batch, count), block(256);
-  if (shapes & 1) hipLaunchKernelGGL(mask_lines_kernel<0>, grid, block, 0, c->stream, jobs);
-  if (shapes & 2) hipLaunchKernelGGL(mask_lines_kernel<1>, grid, block, 0, c->stream, jobs);
+  const dim3 block(256);
+  // (ellipses with pairs: a wave renders two lines, the grid covers half as many waves)
+  if (shapes & 1) hipLaunchKernelGGL(mask_lines_kernel<0>, dim3(jobs.pairs ? (widest + 7) / 8 : (widest + 3) / 4, c->batch, count), block, 0, c->stream, jobs);
+  if (shapes & 2) hipLaunchKernelGGL(mask_lines_kernel<1>, dim3((widest + 3) / 4, c->batch, count), block, 0, c->stream, jobs);
   HIPCHK(c, hipGetLastError());
   return PAOS_OK;
 }

@@ -684,22 +684,17 @@ constexpr int kMaskJobs = 8;
 struct MaskJobs {
   MaskJob job[kMaskJobs];
   int windows;       // 1: lines whose two boundary runs fit two 32-pixel windows take the one-evaluation path (PAOS_MASK_SCAN=1: 0)
+  int pairs;         // 1 (round 5): a wave renders TWO lines at once when both fit two 16-pixel windows (PAOS_MASK_PAIRS=0: 0)
   int batch_stride;  // doubles between the two parameter block sets of a job (= batch * param_stride)
   int param_stride, n;
   int* overflow;
 };
 
+// one line by the 64 lanes of a wave (the whole wave calls it: ballots, a wave-private LDS cache)
 template <int SHAPE>
-__global__ void __launch_bounds__(kMaskWaves * 64) mask_lines_kernel(MaskJobs jobs) {
-  const MaskJob& jb = jobs.job[blockIdx.z];
-  if (!(jb.shapes & (1 << SHAPE))) return;
-  const int item = blockIdx.y;
-  const double* shared = jb.shared;
-  if (shared[item] != 0.0) return;  // reads the records of an earlier, identical item
+__device__ void mask_line_render(const MaskJobs& jobs, const MaskJob& jb, int item, int line, int lane) {
   const int n = jobs.n, axis = jb.axis, param_stride = jobs.param_stride;
   int* const overflow = jobs.overflow;
-  const int line = jb.line0 + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
   if (line >= jb.line_end || line >= n) return;
   const double* p = jb.params + (size_t)item * param_stride;
   const double* p2 = jb.params + jobs.batch_stride + (size_t)item * param_stride;
@@ -881,6 +876,116 @@ __global__ void __launch_bounds__(kMaskWaves * 64) mask_lines_kernel(MaskJobs jo
     }
   }
   if (lane == 0) *out = {p0, p1, p2i, p3, lm, 0.0};
+}
+
+// Round 5: TWO lines per wave.  The window path above spends one exact-overlap evaluation per lane on 2 x 32 pixels of which
+// two to four are partially covered; everywhere but near the tips of the ellipse the two boundary runs of a line fit two
+// 16-pixel windows (same margins of 3), so lanes 0-31 render line `first` (lanes 0-15 its left window, 16-31 its right one)
+// and lanes 32-63 render line `first + 1`: half the waves, the same per-pixel functions on the same pixels, the same span
+// tests -- records bit for bit those of the 32-pixel windows and of the scan (tests/test_gpu_r4.py, PAOS_MASK_PAIRS=0 /
+// PAOS_MASK_SCAN=1).  Returns false (for the whole wave) when either line needs more: the caller then renders the two
+// lines one after the other with the 64-lane paths.
+__device__ inline bool mask_pair_render(const MaskJobs& jobs, const MaskJob& jb, int item, int first, int lane) {
+  const int n = jobs.n, axis = jb.axis, param_stride = jobs.param_stride;
+  const int half = lane >> 5, l32 = lane & 31;
+  const int line = first + half;
+  const bool valid = line < jb.line_end && line < n;
+  const double* p = jb.params + (size_t)item * param_stride;
+  const double* p2 = jb.params + jobs.batch_stride + (size_t)item * param_stride;
+  if (p[AP_ENABLE] == 0.0 || 0 != (int)p2[3]) return true;  // (not this kernel's shape: nothing to render, as the line path decides)
+  const double xc = p[AP_XC], yc = p[AP_YC], a = p[AP_A], b = p[AP_B];
+  const bool obsc = p2[1] != 0.0;
+  const double w_in = obsc ? 0.0 : 1.0, w_out = obsc ? 1.0 : 0.0;
+  const double xe = sqrt(__dmul_rn(a, a)), ye = sqrt(__dmul_rn(b, b));
+  const double full_disk = fmin(__dmul_rn(__dmul_rn(3.141592653589793, a), b), 1.0);
+  const ApertureBox box = make_box(xc, yc, xe, ye);
+  const bool in_box = valid && (axis == 0 ? (line >= box.iymin && line < box.iymax) : (line >= box.ixmin && line < box.ixmax));
+  bool ok = false;
+  int wl0 = 0, wr0 = 0;
+  if (in_box) {
+    const double sa = axis == 0 ? a : b, sc = axis == 0 ? b : a;          // semi-axes along / across the line
+    const double ca = axis == 0 ? xc : yc, cc = axis == 0 ? yc : xc;      // centre along / across
+    const double lo_c = __dsub_rn((double)line - 0.5, cc), hi_c = __dsub_rn((double)line + 0.5, cc);
+    const double near_c = (lo_c > 0.0 ? lo_c : (hi_c < 0.0 ? -hi_c : 0.0)) / sc;
+    const double far_c = fmax(fabs(lo_c), fabs(hi_c)) / sc;
+    const double half_long = near_c < 1.0 ? sa * sqrt(1.0 - near_c * near_c) : 0.0;
+    const double half_short = far_c < 1.0 ? sa * sqrt(1.0 - far_c * far_c) : 0.0;
+    const int box_lo = max(0, axis == 0 ? box.ixmin : box.iymin), box_hi = min(n, axis == 0 ? box.ixmax : box.iymax);
+    wl0 = max(box_lo, (int)floor(ca - half_long) - 3);
+    const int wl1 = (int)ceil(ca - half_short) + 3;
+    const int wr1 = min(box_hi - 1, (int)ceil(ca + half_long) + 3);
+    wr0 = wr1 - 15;
+    const int wr_need = (int)floor(ca + half_short) - 3;
+    auto sum2 = [&](double al, double ac) { const double u = al / sa, v = ac / sc; return axis == 0 ? __dadd_rn(__dmul_rn(u, u), __dmul_rn(v, v)) : __dadd_rn(__dmul_rn(v, v), __dmul_rn(u, u)); };
+    ok = wl1 - wl0 < 16 && wr_need >= wr0 && wl0 + 16 <= wr0 && half_long > 0.0;
+    if (ok) {
+      const double ia = __dsub_rn((double)(wl0 + 16) - 0.5, ca), ib = __dsub_rn((double)(wr0 - 1) + 0.5, ca);
+      ok = sum2(ia, lo_c) <= 1.0 && sum2(ib, lo_c) <= 1.0 && sum2(ia, hi_c) <= 1.0 && sum2(ib, hi_c) <= 1.0;
+      const double nc = lo_c > 0.0 ? lo_c : (hi_c < 0.0 ? hi_c : 0.0);
+      if (ok && wl0 > box_lo) {
+        const double hi_a = __dsub_rn((double)(wl0 - 1) + 0.5, ca);
+        ok = hi_a < 0.0 && sum2(hi_a, nc) > 1.0 + 1.0e-9;
+      }
+      if (ok && wr1 + 1 < box_hi) {
+        const double lo_a = __dsub_rn((double)(wr1 + 1) - 0.5, ca);
+        ok = lo_a > 0.0 && sum2(lo_a, nc) > 1.0 + 1.0e-9;
+      }
+    }
+  }
+  // a line outside the loop's range or outside the bounding box needs no window at all
+  if (!__all(!valid || !in_box || ok)) return false;  // wave-uniform
+  const int pos = l32 < 16 ? wl0 + l32 : wr0 + (l32 - 16);
+  double w = w_out;
+  if (in_box) {
+    const int c = axis == 0 ? pos : line, r = axis == 0 ? line : pos;
+    double mask = 0.0;
+    if (c >= box.ixmin && c < box.ixmax && r >= box.iymin && r < box.iymax) mask = ellipse_pixel(c, r, xc, yc, a, b, 1.0, 0.0, full_disk);
+    w = obsc ? __dsub_rn(1.0, mask) : mask;
+  }
+  const unsigned long long not_out64 = __ballot(w != w_out), is_in64 = __ballot(w == w_in);
+  if (!valid) return true;
+  MaskLine* out = jb.lines + (size_t)item * n + line;
+  double* vout = jb.vals + ((size_t)item * n + line) * (2 * kMaskW);
+  if (!in_box) {  // the line never leaves w_out (what the scan finds for it)
+    if (l32 == 0) *out = {0, 0, 0, 0, 1.0, 0.0};
+    return true;
+  }
+  const unsigned not_out = (unsigned)(not_out64 >> (32 * half)), is_in = (unsigned)(is_in64 >> (32 * half));
+  const unsigned no_l = not_out & 0xFFFFu, no_r = not_out >> 16, in_l = is_in & 0xFFFFu, in_r = is_in >> 16;
+  const int i0 = wl0 + 16, i1 = wr0;  // the span between the windows: w_in throughout
+  int p0 = no_l ? wl0 + (__ffs((int)no_l) - 1) : (i0 < i1 ? i0 : (no_r ? wr0 + (__ffs((int)no_r) - 1) : n));
+  int p3 = no_r ? wr0 + 32 - __clz((int)no_r) : (i0 < i1 ? i1 : (no_l ? wl0 + 32 - __clz((int)no_l) : 0));
+  int p1 = in_l ? wl0 + (__ffs((int)in_l) - 1) : (i0 < i1 ? i0 : (in_r ? wr0 + (__ffs((int)in_r) - 1) : -1));
+  int p2i = in_r ? wr0 + 32 - __clz((int)in_r) : (i0 < i1 ? i1 : (in_l ? wl0 + 32 - __clz((int)in_l) : -1));
+  if (p3 <= p0) { p0 = p1 = p2i = p3 = 0; }
+  else if (p1 < 0) { p1 = p2i = p3; }
+  if (p1 - p0 > kMaskW || p3 - p2i > kMaskW) {
+    if (l32 == 0) atomicAdd(jobs.overflow, 1);
+    p0 = p1 = p2i = p3 = 0;
+  }
+  if (pos >= p0 && pos < p1) vout[pos - p0] = w;
+  if (pos >= p2i && pos < p3) vout[kMaskW + pos - p2i] = w;
+  if (l32 == 0) *out = {p0, p1, p2i, p3, 1.0, 0.0};
+  return true;
+}
+
+template <int SHAPE>
+__global__ void __launch_bounds__(kMaskWaves * 64) mask_lines_kernel(MaskJobs jobs) {
+  const MaskJob& jb = jobs.job[blockIdx.z];
+  if (!(jb.shapes & (1 << SHAPE))) return;
+  const int item = blockIdx.y;
+  if (jb.shared[item] != 0.0) return;  // reads the records of an earlier, identical item
+  const int lane = threadIdx.x & 63;
+  const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (!(SHAPE == 0 && jobs.pairs != 0)) {  // one line per wave
+    mask_line_render<SHAPE>(jobs, jb, item, jb.line0 + wave, lane);
+    return;
+  }
+  const int first = jb.line0 + 2 * wave;  // (the grid covers half as many waves: launch_mask_jobs)
+  if (first >= jb.line_end || first >= jobs.n) return;
+  if (mask_pair_render(jobs, jb, item, first, lane)) return;
+  mask_line_render<0>(jobs, jb, item, first, lane);
+  mask_line_render<0>(jobs, jb, item, first + 1, lane);
 }
 
 // ---- Zernike phase ----------------------------------------------------------------
