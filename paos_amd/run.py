@@ -306,7 +306,7 @@ def _sag_map_once(sag, nx, ny, delx, dely, xdec, ydec, n, dx, dy):
     if hit is not None and hit[0] is sag and hit[1] == fp:
         return hit[2]
     m = grid_sag_map(sag, nx, ny, delx, dely, xdec, ydec, (n, n), dx, dy)
-    if len(_SAG_MAPS) >= 8:
+    if len(_SAG_MAPS) >= 2:  # (a 4096^2 map with its mask is 144 MiB: keep the last two)
         _SAG_MAPS.pop(next(iter(_SAG_MAPS)))
     _SAG_MAPS[key] = (sag, fp, m)
     return m
@@ -626,7 +626,7 @@ def _launch_phase_maps(dev, plans, wfe):
         if len(idx) > 1 and hasattr(dev, "phase_map_items"):
             filled = _FILLED_MAPS.get(id(m))
             if filled is None or filled[0] is not m:
-                if len(_FILLED_MAPS) >= 8:
+                if len(_FILLED_MAPS) >= 2:
                     _FILLED_MAPS.pop(next(iter(_FILLED_MAPS)))
                 filled = _FILLED_MAPS[id(m)] = (m, np.ascontiguousarray(np.ma.filled(m, 0.0), dtype=np.float64))
             # (the key: this map object -- it is immutable once built and kept alive by the cache, so its id names its content)
