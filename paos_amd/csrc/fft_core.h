@@ -418,9 +418,9 @@ __device__ __forceinline__ void apply_twiddle_chain(cx<T>* v, cx<T> w1) {
 // stage whose twiddles are 256th roots of unity (NS * R == 256: w^r = exp(-2 pi i k r / 256) with
 // k r < 256) reads its 15 powers from it instead of multiplying them up -- 15 ds_read_b128 for
 // 14 complex products.
-// ``w1_last`` (optional): the base twiddle tw[t] of the LAST stage of a transform whose threads hold one butterfly each
-// (N = E^3, TL = N / E: k = t there) -- a per-thread constant the caller keeps in registers, so that the stage needs no
-// table in LDS (one-line workgroups of frugal_pass.h: four of them per CU only fit without the 4 KiB table).
+// ``w1_last`` (optional): the base twiddles tw[t + s TL] of the butterflies s = 0 .. TPT - 1 a thread runs in the LAST stage
+// (N = 4096: one, k = t; N = 2048: two) -- per-thread constants the caller keeps in registers, so that the stage needs no
+// table in LDS (the four-per-CU shapes of frugal_pass.h only fit without the 4 KiB table).
 template <typename T, int N, int E, int DIR, bool SPLIT, int NS = 1, int FR = 0>
 __device__ __forceinline__ void fft_stages(cx<T>* v, void* lds, int t,
                                            const cx<T>* __restrict__ tw, const cx<double>* circle = nullptr,
@@ -448,7 +448,7 @@ __device__ __forceinline__ void fft_stages(cx<T>* v, void* lds, int t,
           PAOS_FENCE();
         }
       } else {
-        cx<T> w1 = (w1_last != nullptr && NS * R == N && TPT == 1) ? *w1_last : tw[k * (N / (NS * R))];
+        cx<T> w1 = (w1_last != nullptr && NS * R == N) ? w1_last[s] : tw[k * (N / (NS * R))];
         if constexpr (DIR < 0) w1.y = -w1.y;
         if constexpr (FR != 0) apply_twiddle_chain<R>(v + s * R, w1);
         else apply_twiddle_powers<R>(v + s * R, w1);

@@ -674,12 +674,17 @@ constexpr int frugal_record_mode() {
 // One-line workgroups (round 5: 4096-point complex128 lines, 256 threads): the only stage twiddle that is not a 256th root of
 // unity is the last stage's tw[t] -- one value per thread for the whole kernel, kept in registers -- so the 4 KiB stage table
 // stays out of LDS and FOUR workgroups (4 x 38.2 KiB) fit a CU.
-template <typename T, int N, int E, int LINES, int TILES>
-constexpr bool frugal_tw_in_regs() { return sizeof(T) == 8 && N == 4096 && E == 16 && TILES * LINES == 1; }
-template <typename T, int N, int LINES, int TILES, bool SPLIT, int KPRE, int KMID, int E = 16, int STORE = 0>
+// OCC = 1 (round 5, N = 2048 complex128, the launches that are bound by their latency chain): the same two-line workgroup of 256
+// threads, but FOUR of them per CU instead of three -- 128 VGPRs and, like the one-line shapes of 4096, no stage table in LDS
+// (the last stage's two twiddles per thread, tw[t] and tw[t + 128], live in registers): 4 x 38.6 KiB.
+template <typename T, int N, int E, int LINES, int TILES, int OCC = 0>
+constexpr bool frugal_tw_in_regs() {
+  return sizeof(T) == 8 && E == 16 && ((N == 4096 && TILES * LINES == 1) || (N == 2048 && OCC != 0 && TILES * LINES == 2));
+}
+template <typename T, int N, int LINES, int TILES, bool SPLIT, int KPRE, int KMID, int E = 16, int STORE = 0, int OCC = 0>
 constexpr size_t frugal_lds_bytes() {
   return (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT, LINES>() +
-         (frugal_tw_in_regs<T, N, E, LINES, TILES>() ? 0 : twiddle_lds_entries<N, E>() * sizeof(cx<T>)) +
+         (frugal_tw_in_regs<T, N, E, LINES, TILES, OCC>() ? 0 : twiddle_lds_entries<N, E>() * sizeof(cx<T>)) +
          (sizeof(T) == 8 ? kCircleLds * sizeof(cx<double>) : 0) + kStoreScratch +
          (frugal_record_mode<LINES, TILES, KPRE>() == 1 ? (size_t)TILES * LINES * sizeof(MaskLine) : 0);
 }
@@ -703,8 +708,9 @@ constexpr size_t frugal_lds_bytes() {
 #ifndef PAOS_F32_MINW
 #define PAOS_F32_MINW 4
 #endif
-template <typename T, int N, int THREADS>
+template <typename T, int N, int THREADS, int OCC = 0>
 constexpr int frugal_min_waves() {
+  if (OCC != 0) return 4;  // (four 256-thread workgroups per CU: 128 VGPRs)
   if (sizeof(T) == 4 && THREADS >= 1024) return 8;  // 4-row tiles of complex64: two 1024-thread workgroups per CU
   if (sizeof(T) == 4 && THREADS >= 512) return PAOS_F32_MINW;
   if (sizeof(T) == 8 && N == 4096 && THREADS == 256) return 4;  // one-line workgroups: four per CU, one wave each per SIMD
@@ -750,8 +756,8 @@ __device__ __forceinline__ void tile_power_out(double acc, double* scratch, doub
 // (items[batch + item], items[2 batch + item]): load | slot F slot F | slot F slot [F] | [slot F slot [F]] | store.  The tile never leaves the registers between the
 // two passes: one load, one store, one prologue and one launch less per pair; results are bit-identical.
 template <typename T, int N, int E, int LINES, int TILES, int AXIS, int BR, int BC, bool SPLIT,
-          int KPRE, int KMID, int NFFT, int STORE = 0, int TAB = 0, int LONG = 0>
-__global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, TILES * LINES * N / E>()))
+          int KPRE, int KMID, int NFFT, int STORE = 0, int TAB = 0, int LONG = 0, int OCC = 0>
+__global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, TILES * LINES * N / E, OCC>()))
     frugal_pass_kernel(PAOS_FRUGAL_PARAMS) {
   static_assert(LONG == 0 || (TAB != 0 && (NFFT == 2 || NFFT == 3) && KPRE == 1 && KMID == 1), "LONG builds: see above");
   FrugalArgs a;
@@ -840,7 +846,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
   // exchange areas: the load that follows each exchange barrier is then a ~100-cycle ds_read
   // instead of a dependent global load.  Published by the barrier behind the tile's loads.
   cx<T>* tw_lds = reinterpret_cast<cx<T>*>(smem + (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT, LINES>());
-  constexpr bool kTwRegs = frugal_tw_in_regs<T, N, E, LINES, TILES>();  // no stage table in LDS: tw[t] in registers (below)
+  constexpr bool kTwRegs = frugal_tw_in_regs<T, N, E, LINES, TILES, OCC>();  // no stage table in LDS: tw[t] in registers (below)
   const cx<T>* tw = kTwRegs ? reinterpret_cast<const cx<T>*>(a.tw) : tw_lds;
   // the unit circle in 256 steps for the phase factors (sincos_tab) and the twiddles of the second
   // stage: conj of every (N/256)-th entry of the twiddle table
@@ -940,9 +946,15 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
     if (stage_recs && (int)threadIdx.x < kRecDwords) rec_fetch = reinterpret_cast<const unsigned*>(h_lines + lbase)[threadIdx.x];
   }
   // (one-line workgroups: the thread's one stage twiddle rides behind the tile's loads like the table fetches do)
-  cx<T> w1_keep = cx<T>{(T)1, (T)0};
-  if constexpr (kTwRegs) w1_keep = reinterpret_cast<const cx<T>*>(a.tw)[m.t];
-  const cx<T>* const w1_last = kTwRegs ? &w1_keep : nullptr;
+  constexpr int kLastTpt = E / last_radix<N, E>();  // butterflies per thread in the last stage: their twiddles tw[t + s TL]
+  cx<T> w1_keep[kLastTpt];
+#pragma unroll
+  for (int q = 0; q < kLastTpt; ++q) w1_keep[q] = cx<T>{(T)1, (T)0};
+  if constexpr (kTwRegs) {
+#pragma unroll
+    for (int q = 0; q < kLastTpt; ++q) w1_keep[q] = reinterpret_cast<const cx<T>*>(a.tw)[m.t + q * (N / E)];
+  }
+  const cx<T>* const w1_last = kTwRegs ? w1_keep : nullptr;
 #pragma unroll
   for (int j = 0; j < kTwIt; ++j) {
     const int i = (int)threadIdx.x + j * kThreads;
@@ -969,7 +981,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
       if (i < kCircleLds) cl[i] = {(double)cl_fetch[j].x, -(double)cl_fetch[j].y};
     }
   }
-  MaskLine* rec_lds = reinterpret_cast<MaskLine*>(smem + frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, E, 0>() -
+  MaskLine* rec_lds = reinterpret_cast<MaskLine*>(smem + frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, E, 0, OCC>() -
                                                   (kRecMode == 1 ? (size_t)TILES * LINES * sizeof(MaskLine) : 0));
   if constexpr (kRecMode == 1) {
     if (stage_recs && (int)threadIdx.x < kRecDwords) reinterpret_cast<unsigned*>(rec_lds)[threadIdx.x] = rec_fetch;
@@ -1097,7 +1109,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
       ps[m.base + (unsigned)k * m.stride] = w;
       acc += w;
     }
-    double* scratch = reinterpret_cast<double*>(smem + frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, E, 0>() - kStoreScratch -
+    double* scratch = reinterpret_cast<double*>(smem + frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, E, 0, OCC>() - kStoreScratch -
                                                 (kRecMode == 1 ? (size_t)TILES * LINES * sizeof(MaskLine) : 0));
     tile_power_out<TILES * LINES * N / E>(acc, scratch, a.psf_partial + (size_t)item * (N / LINES / TILES) + wg);
     return;
@@ -1122,7 +1134,7 @@ __global__ void __launch_bounds__(TILES* LINES* N / E, (frugal_min_waves<T, N, T
       const double x = (double)v[k].x, y = (double)v[k].y;
       acc += __dadd_rn(__dmul_rn(x, x), __dmul_rn(y, y));
     }
-    double* scratch = reinterpret_cast<double*>(smem + frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, E, 0>() - kStoreScratch -
+    double* scratch = reinterpret_cast<double*>(smem + frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, E, 0, OCC>() - kStoreScratch -
                                                 (kRecMode == 1 ? (size_t)TILES * LINES * sizeof(MaskLine) : 0));
     tile_power_out<TILES * LINES * N / E>(acc, scratch, a.pow_partial + (size_t)item * (N / LINES / TILES) + wg);
   }

@@ -712,6 +712,9 @@ int frugal_launch(paos_ctx* c, const FrugalArgs& args) {
   // ONE = 1: a single table pass that loads AND stores at most half of its positions (the two passes of the first stretch since
   // the start box) is as latency-bound as the fused launches and takes the same shape (launch_lowered decides per launch).
   constexpr bool kOneLine = PAOS_LONG_ONE_LINE != 0 && (LONG != 0 || ONE != 0) && STORE == 0 && sizeof(T) == 8 && N == 4096;
+  // ... and at 2048^2, where a line is 128 threads and the workgroup already two lines of them: four workgroups per CU instead
+  // of three (frugal_pass.h: OCC)
+  constexpr int kOcc = (PAOS_LONG_ONE_LINE != 0 && (LONG != 0 || ONE != 0) && STORE == 0 && sizeof(T) == 8 && N == 2048) ? 1 : 0;
   constexpr int LINES = kOneLine ? 1 : (AXIS == 0 ? C::FR_ROW_LINES : C::COL_LINES);
   constexpr int TILES = AXIS == 0 ? C::ROW_TILES : C::COL_TILES;
   // several workgroups share the 160 KiB of LDS: c128 exchanges re and im in turn; a c64 line
@@ -733,10 +736,10 @@ int frugal_launch(paos_ctx* c, const FrugalArgs& args) {
   }
   const dim3 grid(groups, c->batch), block(TILES * LINES * N / C::E);
   constexpr size_t kMaxPad = 8192;
-  const size_t lds = frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, C::E, STORE>() + (c->lds_pad < kMaxPad ? c->lds_pad : kMaxPad);
-  auto kern = frugal_pass_kernel<T, N, C::E, LINES, TILES, AXIS, C::BR, C::BC, SPLIT, KPRE, KMID, NFFT, STORE, TAB, LONG>;
+  const size_t lds = frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, C::E, STORE, kOcc>() + (c->lds_pad < kMaxPad ? c->lds_pad : kMaxPad);
+  auto kern = frugal_pass_kernel<T, N, C::E, LINES, TILES, AXIS, C::BR, C::BC, SPLIT, KPRE, KMID, NFFT, STORE, TAB, LONG, kOcc>;
   {
-    int rc = opt_in_lds(c, (const void*)kern, frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, C::E, STORE>() + kMaxPad);
+    int rc = opt_in_lds(c, (const void*)kern, frugal_lds_bytes<T, N, LINES, TILES, SPLIT, KPRE, KMID, C::E, STORE, kOcc>() + kMaxPad);
     if (rc) return rc;
   }
   const int kind = AXIS == 0 ? PAOS_KERNEL_PASS_ROWS : PAOS_KERNEL_PASS_COLS;
@@ -782,7 +785,7 @@ int frugal_nfft(paos_ctx* c, const FrugalArgs& a, int nfft) {
     if constexpr (KPRE <= 1 && KMID <= 1 && KPRE + KMID > 0) {
       if (a.psf) return nfft >= 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2, 1, 1>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1, 1, 1>(c, a);
       if (a.pow_partial) return nfft >= 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2, 2, 1>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1, 2, 1>(c, a);
-      if constexpr (sizeof(T) == 8 && N == 4096 && PAOS_LONG_ONE_LINE != 0) {
+      if constexpr (sizeof(T) == 8 && (N == 4096 || N == 2048) && PAOS_LONG_ONE_LINE != 0) {
         if (a.one_line && PAOS_SINGLE_ONE_LINE != 0) return nfft >= 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2, 0, 1, 0, 1>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1, 0, 1, 0, 1>(c, a);
       }
       return nfft >= 2 ? frugal_launch<T, N, AXIS, KPRE, KMID, 2, 0, 1>(c, a) : frugal_launch<T, N, AXIS, KPRE, KMID, 1, 0, 1>(c, a);
