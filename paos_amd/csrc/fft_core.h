@@ -408,6 +408,13 @@ __device__ __forceinline__ void apply_twiddle_chain(cx<T>* v, cx<T> w1) {
 // which keeps a 4096-point c128 pass at ~118 VGPRs -- four waves per SIMD, i.e. two 512-thread
 // workgroups per CU whose load / compute / store phases overlap (profiles/r01_vgpr_experiments.txt).
 #define PAOS_FENCE() do { if constexpr (FR != 0) __builtin_amdgcn_sched_barrier(0); } while (0)
+// (round-5 scheduling experiments, tools/fftbench.hip builds only: bit 0 drops the fence behind an exchange -- the next stage's
+// twiddle loads and first products may then start while the exchange's last reads are in flight --, bit 1 the fence behind the
+// twiddle loop, bit 2 the fences inside the circle-twiddle loop)
+#ifndef PAOS_NOFENCE
+#define PAOS_NOFENCE 0
+#endif
+#define PAOS_FENCE_IF(bit) do { if constexpr (FR != 0 && !(PAOS_NOFENCE & (bit))) __builtin_amdgcn_sched_barrier(0); } while (0)
 #ifndef PAOS_TAIL_FENCE
 #define PAOS_TAIL_FENCE 1
 #endif
@@ -445,7 +452,7 @@ __device__ __forceinline__ void fft_stages(cx<T>* v, void* lds, int t,
           wa = wb;
           if (r + 2 < R) wb = circle[k * (r + 2)];
           v[s * R + r] = cmul(v[s * R + r], cx<T>{(T)w.x, (T)(DIR > 0 ? -w.y : w.y)});
-          PAOS_FENCE();
+          PAOS_FENCE_IF(4);
         }
       } else {
         cx<T> w1 = (w1_last != nullptr && NS * R == N) ? w1_last[s] : tw[k * (N / (NS * R))];
@@ -453,7 +460,7 @@ __device__ __forceinline__ void fft_stages(cx<T>* v, void* lds, int t,
         if constexpr (FR != 0) apply_twiddle_chain<R>(v + s * R, w1);
         else apply_twiddle_powers<R>(v + s * R, w1);
       }
-      PAOS_FENCE();
+      PAOS_FENCE_IF(2);
     }
     // (timing diagnostics, results wrong: PAOS_DIAG bit 3 drops the butterflies of every FIRST stage, bit 4 of every
     // LAST stage -- what a zero-aware first / last stage could save at the very most, profiles/r04_zero_aware_stages.txt)
@@ -516,7 +523,7 @@ __device__ __forceinline__ void fft_stages(cx<T>* v, void* lds, int t,
         if (part == 0 || !SN::LAST) PAOS_SYNC_X();
       }
     }
-    PAOS_FENCE();
+    PAOS_FENCE_IF(1);
     fft_stages<T, N, E, DIR, SPLIT, NS * R, FR>(v, lds, t, tw, circle, w1_last);
   }
 }
