@@ -674,12 +674,14 @@ constexpr int frugal_record_mode() {
 // One-line workgroups (round 5: 4096-point complex128 lines, 256 threads): the only stage twiddle that is not a 256th root of
 // unity is the last stage's tw[t] -- one value per thread for the whole kernel, kept in registers -- so the 4 KiB stage table
 // stays out of LDS and FOUR workgroups (4 x 38.2 KiB) fit a CU.
-// OCC = 1 (round 5, N = 2048 complex128, the launches that are bound by their latency chain): the same two-line workgroup of 256
-// threads, but FOUR of them per CU instead of three -- 128 VGPRs and, like the one-line shapes of 4096, no stage table in LDS
-// (the last stage's two twiddles per thread, tw[t] and tw[t + 128], live in registers): 4 x 38.6 KiB.
+// OCC = 1 (round 5, N = 2048 / 1024 complex128, the launches that are bound by their latency chain): the same workgroup of 256
+// threads (two lines of 2048 points, four of 1024), but FOUR of them per CU instead of three -- 128 VGPRs and, like the
+// one-line shapes of 4096, no stage table in LDS (the last stage's two / four twiddles per thread, tw[t + s N / 16], live in
+// registers): 4 x 38.6 KiB.
 template <typename T, int N, int E, int LINES, int TILES, int OCC = 0>
 constexpr bool frugal_tw_in_regs() {
-  return sizeof(T) == 8 && E == 16 && ((N == 4096 && TILES * LINES == 1) || (N == 2048 && OCC != 0 && TILES * LINES == 2));
+  return sizeof(T) == 8 && E == 16 && ((N == 4096 && TILES * LINES == 1) || (N == 2048 && OCC != 0 && TILES * LINES == 2) ||
+                                       (N == 1024 && OCC != 0 && TILES * LINES == 4));
 }
 template <typename T, int N, int LINES, int TILES, bool SPLIT, int KPRE, int KMID, int E = 16, int STORE = 0, int OCC = 0>
 constexpr size_t frugal_lds_bytes() {

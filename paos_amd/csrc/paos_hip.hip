@@ -714,6 +714,8 @@ int frugal_launch(paos_ctx* c, const FrugalArgs& args) {
   constexpr bool kOneLine = PAOS_LONG_ONE_LINE != 0 && (LONG != 0 || ONE != 0) && STORE == 0 && sizeof(T) == 8 && N == 4096;
   // ... and at 2048^2, where a line is 128 threads and the workgroup already two lines of them: four workgroups per CU instead
   // of three (frugal_pass.h: OCC)
+  // (1024^2: measured too -- four rows per workgroup keep four twiddles per thread in registers and the shapes spill 30-100 B:
+  // fused two-pass launches 0.866 -> 0.878 ms, three-pass 1.22 -> 1.31: stays on three workgroups per CU.  profiles/r05_ab_variants_bench.txt)
   constexpr int kOcc = (PAOS_LONG_ONE_LINE != 0 && (LONG != 0 || ONE != 0) && STORE == 0 && sizeof(T) == 8 && N == 2048) ? 1 : 0;
   constexpr int LINES = kOneLine ? 1 : (AXIS == 0 ? C::FR_ROW_LINES : C::COL_LINES);
   constexpr int TILES = AXIS == 0 ? C::ROW_TILES : C::COL_TILES;

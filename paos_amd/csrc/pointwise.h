@@ -1085,7 +1085,30 @@ __global__ void zernike_kernel(cx<T>* field, const double* table, const double* 
         for (int am = 0; am <= nmax; ++am) order(am, (nmax - am) / 2);
       }
       const double turns = __dmul_rn(6.283185307179586, wfe);
-      for (int g = 0; g < glen; ++g) {
+      // (round 5) four members at a time, their loads issued before the first store: the fields of different items never
+      // alias, which the compiler cannot know -- one load -> sincos -> store chain per member was a 32-deep latency chain
+      // per pixel (0.37 ms per step of a 32-wavelength sweep); the arithmetic per member is unchanged
+      int g = 0;
+      for (; g + 4 <= glen; g += 4) {
+        cx<T>* f4[4];
+        cx<double> v4[4];
+        double iw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int it = (int)members[g + q];
+          f4[q] = field + (size_t)it * item_stride + m;
+          iw[q] = params[(size_t)it * param_stride + ZP_INV_WL];
+          v4[q] = {(double)f4[q]->x, (double)f4[q]->y};
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          double sn, cs;
+          sincos_fast(__dmul_rn(turns, iw[q]), &sn, &cs);
+          *f4[q] = {(T)__dsub_rn(__dmul_rn(v4[q].x, cs), __dmul_rn(v4[q].y, sn)),
+                    (T)__dadd_rn(__dmul_rn(v4[q].x, sn), __dmul_rn(v4[q].y, cs))};
+        }
+      }
+      for (; g < glen; ++g) {
         const int it = (int)members[g];
         const double arg = __dmul_rn(turns, params[(size_t)it * param_stride + ZP_INV_WL]);
         double sn, cs;
