@@ -1009,3 +1009,95 @@ def test_a_shared_grid_sag_map_is_built_once_and_applied_to_all_its_items():
         assert key in got[0]
     finally:
         prun.grid_sag_map = real
+
+
+def test_batch_planner_equals_the_per_item_planner():
+    """Round 5: ``run._plan_batch`` plans the apertures of a whole batch with array arithmetic.  Against ``_plan_host`` item by
+    item, on random batches -- ellipses and rectangles, apertures and obscurations, missing centres, different sampling per
+    item: the parameter blocks, the line-record test, the live rows and the handles' numbers are identical (==, not close);
+    a non-finite radius skips the aperture for that item only; an aperture that misses the grid raises the reference's
+    TypeError; a batch with a coordinate break or an off-axis item takes the per-item path and still agrees."""
+    import paos_amd.run as prun
+    from paos_amd.abcd import ABCD
+
+    rng = np.random.default_rng(11)
+    n, nb = 1024, 12
+
+    def items_of(shape, kind_type, nan_centre=False, bad_radius=None):
+        out = []
+        for i in range(nb):
+            ap = {"shape": shape, "type": kind_type, "xc": float("nan") if nan_centre else float(rng.normal(0, 0.05)),
+                  "yc": float(rng.normal(0, 0.05)), "xrad": float(rng.uniform(0.2, 0.6)), "yrad": float(rng.uniform(0.2, 0.6))}
+            if bad_radius == i:
+                ap["xrad"] = float("nan")
+            out.append({"type": "Standard", "is_stop": bool(i % 2), "save": False, "aperture": ap,
+                        "ABCDt": ABCD(thickness=0.1), "ABCDs": ABCD(thickness=0.1)})
+        return out
+
+    def both(items, states):
+        dxs = [4.0 / n * (1 + 0.01 * i) for i in range(nb)]
+        dys = [4.0 / n * (1 + 0.02 * i) for i in range(nb)]
+        wls = [1e-6] * nb
+        fast = prun._plan_batch(states, items, n, dxs, dys, wls, lambda i: 0.5)
+        slow = [prun._plan_host(st, it, n, dxs[i], dys[i], wls[i], lambda: 0.5) for i, (st, it) in enumerate(zip(states, items))]
+        return fast, slow
+
+    on_axis = [prun._Item(1.0, 1e-6, n, 4, {"us": 0.0, "ut": 0.0}) for _ in range(nb)]
+    for shape in ("elliptical", "rectangular"):
+        for kind_type in ("aperture", "obscuration"):
+            for nan_centre in (False, True):
+                fast, slow = both(items_of(shape, kind_type, nan_centre), on_axis)
+                assert fast.ap is not None
+                blocks, codes = fast.ap.blocks()
+                for i in range(nb):
+                    h, o = slow[i]["aperture"]
+                    assert list(blocks[i]) == h.block(obscuration=o), (shape, kind_type, i)
+                    assert codes[i] == (_lib.SHAPE_ELLIPSE if shape == "elliptical" else _lib.SHAPE_RECT)
+                    fh, fo = fast[i]["aperture"]
+                    assert fo == o and type(fh) is type(h) and fh.block(obscuration=fo) == h.block(obscuration=o)
+                    assert fast[i]["stop"] == slow[i]["stop"]
+                assert fast.ap.fits_line_records(n, "fp64") == all(
+                    prun._aperture_fits_line_records(*slow[i]["aperture"], n, "fp64") for i in range(nb))
+                la, lb = [[0, n] for _ in range(nb)], [[0, n] for _ in range(nb)]
+                prun._live_rows_after(fast, la, n)
+                prun._live_rows_after(slow, lb, n)
+                assert la == lb
+                assert fast.summary() == (True, False, False, True)
+    # one item without a finite radius: no aperture for that item, handles for the others, same as item by item
+    fast, slow = both(items_of("elliptical", "aperture", bad_radius=5), on_axis)
+    assert fast.ap is None and fast[5]["aperture"] is None and slow[5]["aperture"] is None
+    assert all(fast[i]["aperture"][0].block() == slow[i]["aperture"][0].block() for i in range(nb) if i != 5)
+    # an aperture whose box misses the grid: the reference fails on `u *= None`
+    far = items_of("elliptical", "aperture")
+    far[3]["aperture"]["xc"] = 50.0
+    with pytest.raises(TypeError):
+        both(far, on_axis)
+    # an off-axis item: the per-item path, which scales the radii by the ray slopes (run.py:97-108)
+    off = [prun._Item(1.0, 1e-6, n, 4, {"us": 0.01 if i == 2 else 0.0, "ut": 0.0}) for i in range(nb)]
+    fast, slow = both(items_of("elliptical", "aperture"), off)
+    assert fast.ap is None
+    assert all(fast[i]["aperture"][0].block() == slow[i]["aperture"][0].block() for i in range(nb))
+
+
+def test_gate_arrays_are_remembered_per_column_and_forgotten_when_a_matrix_is_edited():
+    """``run._gate_arrays``: the (Mt, Ms, fl, T, n1n2) arrays of a surface are computed once per column of ABCD objects (matched by
+    identity) and recomputed when any matrix is edited in place (abcd.EPOCH) or another object sits in the column."""
+    import paos_amd.run as prun
+    from paos_amd.abcd import ABCD
+
+    col_t = [ABCD(thickness=0.1 * (i + 1), curvature=0.5) for i in range(5)]
+    col_s = [ABCD(thickness=0.1 * (i + 1), curvature=0.25) for i in range(5)]
+    a = prun._gate_arrays(col_t, col_s)
+    want = prun._surface_gates([{"ABCDt": t, "ABCDs": s} for t, s in zip(col_t, col_s)])
+    for got, ref in zip(a, want):
+        assert list(got) == list(ref)
+    assert prun._gate_arrays(list(col_t), list(col_s)) is a          # same objects, another list: found
+    other = list(col_t)
+    other[2] = ABCD(thickness=9.0)
+    b = prun._gate_arrays(other, col_s)
+    assert b is not a and b[3][2] == 9.0                              # another object in the column: recomputed
+    m = col_t[1].ABCD.copy()
+    m[0, 1] = 7.0
+    col_t[1].ABCD = m                                                 # edited in place: the epoch moves
+    c = prun._gate_arrays(col_t, col_s)
+    assert c is not a and c[3][1] == col_t[1].gates()[2]
