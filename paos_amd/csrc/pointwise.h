@@ -1085,23 +1085,24 @@ __global__ void zernike_kernel(cx<T>* field, const double* table, const double* 
         for (int am = 0; am <= nmax; ++am) order(am, (nmax - am) / 2);
       }
       const double turns = __dmul_rn(6.283185307179586, wfe);
-      // (round 5) four members at a time, their loads issued before the first store: the fields of different items never
+      // (round 5) eight members at a time, their loads issued before the first store: the fields of different items never
       // alias, which the compiler cannot know -- one load -> sincos -> store chain per member was a 32-deep latency chain
       // per pixel (0.37 ms per step of a 32-wavelength sweep); the arithmetic per member is unchanged
+      constexpr int kZernikeGroup = 8;  // (4: 0.37 -> 0.29 ms per step, 8: see profiles/r05_ab_variants_bench.txt)
       int g = 0;
-      for (; g + 4 <= glen; g += 4) {
-        cx<T>* f4[4];
-        cx<double> v4[4];
-        double iw[4];
+      for (; g + kZernikeGroup <= glen; g += kZernikeGroup) {
+        cx<T>* f4[kZernikeGroup];
+        cx<double> v4[kZernikeGroup];
+        double iw[kZernikeGroup];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < kZernikeGroup; ++q) {
           const int it = (int)members[g + q];
           f4[q] = field + (size_t)it * item_stride + m;
           iw[q] = params[(size_t)it * param_stride + ZP_INV_WL];
           v4[q] = {(double)f4[q]->x, (double)f4[q]->y};
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < kZernikeGroup; ++q) {
           double sn, cs;
           sincos_fast(__dmul_rn(turns, iw[q]), &sn, &cs);
           *f4[q] = {(T)__dsub_rn(__dmul_rn(v4[q].x, cs), __dmul_rn(v4[q].y, sn)),
