@@ -17,6 +17,7 @@ launches.
 """
 import atexit
 import gc
+import itertools
 import math
 import threading
 from copy import deepcopy
@@ -288,9 +289,11 @@ _SAG_MAPS = {}
 
 
 def forget_maps():
-    """Drop the kept Grid Sag maps (``_sag_map_once``) and their device-side copies' host mirrors."""
+    """Drop what the module keeps between calls: the Grid Sag maps (``_sag_map_once``) with their zero-filled copies, and the
+    gate arrays remembered per column of ABCD objects (``_gate_arrays``: they keep those objects alive)."""
     _SAG_MAPS.clear()
     _FILLED_MAPS.clear()
+    _GATE_COLUMNS.clear()
 
 
 def _sag_fingerprint(sag):
@@ -628,16 +631,18 @@ def _launch_phase_maps(dev, plans, wfe):
             if filled is None or filled[0] is not m:
                 if len(_FILLED_MAPS) >= 2:
                     _FILLED_MAPS.pop(next(iter(_FILLED_MAPS)))
-                filled = _FILLED_MAPS[id(m)] = (m, np.ascontiguousarray(np.ma.filled(m, 0.0), dtype=np.float64))
-            # (the key: this map object -- it is immutable once built and kept alive by the cache, so its id names its content)
-            dev.phase_map_items(filled[1], idx, wls, key=id(m))
+                filled = _FILLED_MAPS[id(m)] = (m, np.ascontiguousarray(np.ma.filled(m, 0.0), dtype=np.float64), next(_MAP_SERIAL))
+            # (the key under which the library keeps the copy on the device: a serial number given to this map object when it was
+            # first sent -- never the object's id, which the allocator hands out again once an evicted map has been freed)
+            dev.phase_map_items(filled[1], idx, wls, key=filled[2])
         else:
             for i, wl in zip(idx, wls):
                 dev.phase_map(i, np.ma.filled(m, 0.0), wl)
     return wfe
 
 
-_FILLED_MAPS = {}  # id(map) -> (map, its zero-filled contiguous copy): what crosses PCIe
+_FILLED_MAPS = {}  # id(map) -> (map, its zero-filled contiguous copy: what crosses PCIe, serial number = the library's content key)
+_MAP_SERIAL = itertools.count(1)
 
 
 def _queue_apertures(comp, plans):
