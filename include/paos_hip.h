@@ -244,9 +244,20 @@ int paos_phase_map(paos_ctx* ctx, int item, const double* host_wfe, double wl);
  * sweep and every draw of a Monte-Carlo study): items[k] (indices, as doubles) get u *= exp(2 pi i wfe / wl[k]).  The map
  * crosses PCIe once and stays on the device; `key` != 0 names its content: a later call with the same key skips the
  * validation and the upload (the caller vouches that the host buffer still holds what was uploaded under that key;
- * 0 = always upload).  Does not synchronise when the key matches. */
+ * 0 = always upload).  `host_wfe` may be NULL when a map is kept under `key` (paos_psd_screen).  Does not synchronise when
+ * the key matches. */
 int paos_phase_map_items(paos_ctx* ctx, const double* host_wfe, unsigned long long key, int n_items, const double* items,
                          const double* wl);
+/* Round 5: the random screen of WFO.psd built ON THE DEVICE (wfo.py:908-943 calling psd.py:100-160): the host draws the
+ * white noise -- `host_noise`, then `host_rough` (n x n doubles each; NumPy's generator is the reference's, so a seeded run
+ * stays comparable) -- and the library runs  fft2(noise) * sqrt(A / (B + (rho / fknee)^C) / (2 pi rho) * cell) * gain,
+ * zero outside [fmin, fmax]  ->  ifft2  ->  (Re + SR * rough) * 2 * unit  on its own passes, in the reference's order of
+ * operations.  params[12] = {1 / (n dx), 1 / (n dy), A, B, C, fknee, fmin, fmax, cell, gain = sqrt(n0 n1), SR, unit}.
+ * The map stays on the device under `key` (!= 0): paos_phase_map_items(ctx, NULL, key, ...) applies it; `host_out`
+ * (n x n doubles or NULL) receives a copy (the `wfe` entry the reference returns).  complex128 contexts only.
+ * Synchronises.  Host restatement, and the bit-exact reference for the fixtures: paos_amd/phase_maps.py psd_map. */
+int paos_psd_screen(paos_ctx* ctx, const double* host_noise, const double* host_rough, const double* params,
+                    unsigned long long key, double* host_out);
 /* WFO.ptp (wfo.py:462-472): ifft2(exp(-i coef (fx^2+fy^2)) fft2(u)), ortho norms, shifts
  * cancelled; sx, sy = 1/(n dx), 1/(n dy) (np.fft.fftfreq spacing), coef = pi wl dz. */
 int paos_ptp(paos_ctx* ctx, const double* params);

@@ -106,6 +106,7 @@ SYMBOLS = {
     "paos_start_rows": (ctypes.c_int, [_c_ctx, ctypes.c_double, ctypes.c_double, ctypes.c_int, _dbl_p, _dbl_p, _dbl_p]),
     "paos_zero_outside_rows": (ctypes.c_int, [_c_ctx, _dbl_p]),
     "paos_phase_map_items": (ctypes.c_int, [_c_ctx, _dbl_p, ctypes.c_ulonglong, ctypes.c_int, _dbl_p, _dbl_p]),
+    "paos_psd_screen": (ctypes.c_int, [_c_ctx, _dbl_p, _dbl_p, _dbl_p, ctypes.c_ulonglong, _dbl_p]),
     "paos_start_box": (ctypes.c_int, [_c_ctx, ctypes.c_double, ctypes.c_double, ctypes.c_int, _dbl_p, _dbl_p, _dbl_p, _dbl_p]),
     "paos_zero_outside_box": (ctypes.c_int, [_c_ctx, _dbl_p, _dbl_p]),
     "paos_norm2_enqueue_box": (ctypes.c_int, [_c_ctx, _dbl_p, _dbl_p, _dbl_p, ctypes.POINTER(ctypes.c_int)]),
@@ -484,15 +485,37 @@ class DeviceFields:
     def phase_map_items(self, wfe, items, wls, key=0):
         """u[i] *= exp(2 pi i wfe / wl_i) for the listed items, which share the host map ``wfe`` (metres): one upload.
         ``key`` != 0 names the map's content: the same key again re-uses the copy already on the device."""
-        w = np.ascontiguousarray(wfe, dtype=np.float64)
-        if w.shape != (self.n, self.n):
-            raise ValueError(f"phase map must have shape {(self.n, self.n)}")
+        w = None
+        if wfe is not None:  # (None: the map the device keeps under ``key`` -- psd_screen)
+            w = np.ascontiguousarray(wfe, dtype=np.float64)
+            if w.shape != (self.n, self.n):
+                raise ValueError(f"phase map must have shape {(self.n, self.n)}")
         it = np.ascontiguousarray(items, dtype=np.float64).reshape(-1)
         wl = np.ascontiguousarray(wls, dtype=np.float64).reshape(-1)
         if it.size != wl.size or it.size < 1:
             raise ValueError("one wavelength per listed item is required")
-        self._check(self._lib.paos_phase_map_items(self._ctx, _dptr(w), int(key) & 0xFFFFFFFFFFFFFFFF, int(it.size), _dptr(it), _dptr(wl)),
-                    "paos_phase_map_items")
+        self._check(self._lib.paos_phase_map_items(self._ctx, _dptr(w) if w is not None else None, int(key) & 0xFFFFFFFFFFFFFFFF,
+                                                   int(it.size), _dptr(it), _dptr(wl)), "paos_phase_map_items")
+
+    def psd_screen(self, noise, rough, params, key, want_map=False):
+        """The random screen of ``WFO.psd`` from the host's two white-noise draws (``paos_psd_screen``: fft2, power-law filter,
+        ifft2, roughness on the library's own passes); it stays on the device under ``key`` for ``phase_map_items(None, ...,
+        key=key)``.  ``params``: the twelve numbers of ``phase_maps.psd_device_params``.  Returns the map when asked to."""
+        nz = np.ascontiguousarray(noise, dtype=np.float64)
+        if nz.shape != (self.n, self.n):
+            raise ValueError(f"the noise must have shape {(self.n, self.n)}")
+        rg = None
+        if rough is not None:
+            rg = np.ascontiguousarray(rough, dtype=np.float64)
+            if rg.shape != (self.n, self.n):
+                raise ValueError(f"the roughness draw must have shape {(self.n, self.n)}")
+        pr = np.ascontiguousarray(params, dtype=np.float64).reshape(-1)
+        if pr.size != 12:
+            raise ValueError("twelve PSD parameters are required")
+        out = np.empty((self.n, self.n), dtype=np.float64) if want_map else None
+        self._check(self._lib.paos_psd_screen(self._ctx, _dptr(nz), _dptr(rg) if rg is not None else None, _dptr(pr),
+                                              int(key) & 0xFFFFFFFFFFFFFFFF, _dptr(out) if out is not None else None), "paos_psd_screen")
+        return out
 
     def ptp(self, blocks):
         b = as_blocks(blocks, self.batch, PHASE_STRIDE)

@@ -100,6 +100,8 @@ struct paos_ctx {
   double* psf = nullptr;  // batch x item_stride intensities kept on the device, blocked like the field (paos_psf_keep)
   double* map_dev = nullptr;      // one n x n phase map kept on the device (paos_phase_map_items) and the key it was uploaded under
   unsigned long long map_key = 0;
+  cx<double>* psd_scratch = nullptr;  // one item in the field's layout: the spectrum of a PSD screen (paos_psd_screen)
+  int* psd_bad = nullptr;
   double* psf_partial = nullptr;  // per-workgroup sums of a pass that stores the PSF (paos_run_program: final_intensity)
   int psf_nparts = 0;
   double* pow_partial = nullptr;  // per-workgroup sums of |u|^2 of a pass that stores the FIELD (final_intensity = 2)
@@ -389,7 +391,7 @@ int pass_launch(paos_ctx* c, const PassArgs& a) {
   constexpr int LINES = AXIS == 0 ? C::ROW_LINES : C::COL_LINES;
   constexpr int TILES = AXIS == 0 ? C::ROW_TILES : C::COL_TILES;
   constexpr bool SPLIT = AXIS == 0 ? C::ROW_SPLIT : C::COL_SPLIT;
-  const dim3 grid(N / LINES / TILES, c->batch), block(TILES * LINES * N / C::E);
+  const dim3 grid(N / LINES / TILES, a.batch), block(TILES * LINES * N / C::E);  // (a.batch: c->batch, or 1 for the PSD scratch item)
   const size_t lds = (size_t)TILES * LINES * line_lds_bytes<T, N, SPLIT>();
   return launch_pass(c, fused_pass_kernel<T, N, C::E, LINES, TILES, AXIS, C::BR, BC, SPLIT, C::MINW, 1, 0, FEAT>,
                      grid, block, lds, a, AXIS == 0 ? PAOS_KERNEL_PASS_ROWS : PAOS_KERNEL_PASS_COLS);
@@ -1434,8 +1436,7 @@ int run_passes_impl(paos_ctx* c, const paos_pass* passes, int n_passes, const do
       const int lines = passes[n_passes - 1].axis == 0 ? (c->n >= 2048 ? c->br / 2 : c->br) : 2;  // FftCfg: FR_ROW_LINES / COL_LINES
       power_groups = c->n / lines;
       if (c->pow_nparts < c->n / 2) {  // (sized for the finest tiling of either axis)
-        if (c->map_dev) (void)hipFree(c->map_dev);
-  if (c->pow_partial) (void)hipFree(c->pow_partial);
+        if (c->pow_partial) (void)hipFree(c->pow_partial);
         c->pow_partial = nullptr; c->pow_nparts = 0;
         HIPCHK(c, hipMalloc(&c->pow_partial, (size_t)c->batch * (c->n / 2) * sizeof(double)));
         c->pow_nparts = c->n / 2;
@@ -1866,6 +1867,9 @@ int paos_ctx_destroy(paos_ctx* c) {
   if (c->norm2) (void)hipFree(c->norm2);
   if (c->norm2_host) (void)hipHostFree(c->norm2_host);
   if (c->psf) (void)hipFree(c->psf);
+  if (c->map_dev) (void)hipFree(c->map_dev);
+  if (c->psd_scratch) (void)hipFree(c->psd_scratch);
+  if (c->psd_bad) (void)hipFree(c->psd_bad);
   if (c->pow_partial) (void)hipFree(c->pow_partial);
   if (c->dyn_scale) (void)hipFree(c->dyn_scale);
   if (c->ptab) (void)hipFree(c->ptab);
@@ -2551,7 +2555,8 @@ int paos_phase_map_items(paos_ctx* c, const double* host_wfe, unsigned long long
                          const double* wl) {
   SETTLE_SCALE(c);
   if (c) (void)hipSetDevice(c->device);
-  if (!c || !host_wfe || !items || !wl || n_items < 1 || n_items > c->batch) return fail(c, PAOS_EINVAL, "bad item list or null buffer");
+  if (!c || !items || !wl || n_items < 1 || n_items > c->batch) return fail(c, PAOS_EINVAL, "bad item list or null buffer");
+  if (!host_wfe && (key == 0 || key != c->map_key || !c->map_dev)) return fail(c, PAOS_EINVAL, "no host map, and no map kept on the device under this key");
   for (int k = 0; k < n_items; ++k) {
     if (!(items[k] >= 0.0) || items[k] >= (double)c->batch || items[k] != (double)(int)items[k]) return fail(c, PAOS_EINVAL, "bad item index");
     if (!(wl[k] > 0.0) || !std::isfinite(wl[k])) return fail(c, PAOS_EINVAL, "wavelength must be positive and finite");
@@ -2578,6 +2583,58 @@ int paos_phase_map_items(paos_ctx* c, const double* host_wfe, unsigned long long
     F32_BR_SWITCH(c, hipLaunchKernelGGL((phase_map_items_kernel<float, FBR, Lay<float>::BC>), grid, block, 0, c->stream,
                                         (cx<float>*)c->field, c->item_stride, (const double*)c->map_dev, c->n, c->pitch, ditems, dwl));
   HIPCHK(c, hipGetLastError());
+  return PAOS_OK;
+}
+
+int paos_psd_screen(paos_ctx* c, const double* host_noise, const double* host_rough, const double* params, unsigned long long key,
+                    double* host_out) {
+  if (c) (void)hipSetDevice(c->device);
+  if (!c || !host_noise || !params || key == 0) return fail(c, PAOS_EINVAL, "null argument (or key 0)");
+  if (c->precision != PAOS_F64) return fail(c, PAOS_EUNSUPPORTED, "PSD screens are built on complex128 contexts (build the map on the host for fp32 mode)");
+  PsdParams p{params[0], params[1], params[2], params[3], params[4], params[5], params[6], params[7], params[8], params[9], params[10], params[11]};
+  for (int k = 0; k < 12; ++k)
+    if (std::isnan(params[k])) return fail(c, PAOS_EINVAL, "a PSD parameter is NaN");
+  const size_t count = (size_t)c->n * c->n;
+  if (!c->map_dev) HIPCHK(c, hipMalloc(&c->map_dev, count * sizeof(double)));
+  if (!c->psd_scratch) HIPCHK(c, hipMalloc(&c->psd_scratch, (size_t)c->item_stride * sizeof(cx<double>)));
+  if (!c->psd_bad) HIPCHK(c, hipMalloc(&c->psd_bad, sizeof(int)));
+  c->map_key = 0;
+  double* noise = (double*)c->staging;  // n x n x 16 bytes: the white noise, then the roughness draw
+  double* rough = (host_rough && p.SR != 0.0) ? noise + count : nullptr;
+  HIPCHK(c, hipMemcpyAsync(noise, host_noise, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  if (rough) HIPCHK(c, hipMemcpyAsync(rough, host_rough, count * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemsetAsync(c->psd_bad, 0, sizeof(int), c->stream));
+  // control blocks of the four passes (one item): forward, inverse, scale 1 / n
+  std::vector<double> hb((size_t)3 * FP_STRIDE, 0.0);
+  hb[0 * FP_STRIDE + FP_ENABLE] = 1.0;
+  hb[1 * FP_STRIDE + FP_ENABLE] = 1.0; hb[1 * FP_STRIDE + 1] = 1.0;
+  hb[2 * FP_STRIDE + FP_ENABLE] = 1.0; hb[2 * FP_STRIDE + 3] = 1.0 / c->n;
+  const double* dblocks = nullptr;
+  int rc;
+  if ((rc = arena_push(c, hb.data(), hb.size(), &dblocks))) return rc;
+  const dim3 grid(pw_blocks(c)), block(kPwThreads);
+  hipLaunchKernelGGL((psd_load_kernel<BR, Lay<double>::BC>), grid, block, 0, c->stream, c->psd_scratch, (const double*)noise, c->n, c->pitch);
+  PassArgs a{};
+  a.field = c->psd_scratch; a.tw = c->tw; a.blocks = dblocks; a.tables = nullptr; a.mask = nullptr; a.batch = 1;
+  a.fft1 = 0; a.fft2 = -1; a.pitch = c->pitch; a.item_stride = c->item_stride;
+  for (int axis = 0; axis < 2; ++axis)  // spectrum = fft2(noise)
+    if ((rc = pass_t<double>(c, axis, a, 0))) return rc;
+  hipLaunchKernelGGL((psd_filter_kernel<BR, Lay<double>::BC>), grid, block, 0, c->stream, c->psd_scratch, c->n, c->pitch, p);
+  a.fft1 = 1; a.n_mid = 1; a.mid[0] = {PAOS_PW_SCALE, 0, 2};
+  for (int axis = 0; axis < 2; ++axis)  // ifft2: each axis carries its 1 / n
+    if ((rc = pass_t<double>(c, axis, a, 0))) return rc;
+  hipLaunchKernelGGL((psd_finish_kernel<BR, Lay<double>::BC>), grid, block, 0, c->stream, c->map_dev, (const cx<double>*)c->psd_scratch,
+                     (const double*)rough, c->n, c->pitch, p, c->psd_bad);
+  HIPCHK(c, hipGetLastError());
+  int bad = 0;
+  HIPCHK(c, hipMemcpyAsync(&bad, c->psd_bad, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // (the host buffers were only borrowed)
+  if (bad) return fail(c, PAOS_EINVAL, "the PSD screen holds a non-finite value");
+  if (host_out) {
+    rc = copy_to_host(c, host_out, c->map_dev, count * sizeof(double));
+    if (rc) return rc;
+  }
+  c->map_key = key;
   return PAOS_OK;
 }
 

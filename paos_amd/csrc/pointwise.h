@@ -152,6 +152,67 @@ __global__ void phase_map_items_kernel(cx<T>* field, unsigned item_stride, const
   }
 }
 
+// ---- PSD screen built on the device (round 5: wfo.py:908-943 + psd.py:100-160; the host restatement is
+// paos_amd/phase_maps.py: psd_map) ----------------------------------------------------------------------------
+// The white noise comes from the host (NumPy's generator is the reference's); fft2 -> filter -> ifft2 run on the library's
+// own passes over one scratch item in the field's layout.
+struct PsdParams {
+  double fx, fy;         // 1 / (n dx), 1 / (n dy): np.fft.fftfreq's step
+  double A, B, C, fknee;
+  double fmin, fmax;
+  double cell;           // frequency-bin area (rho[0,2] - rho[0,1]) * (rho[2,0] - rho[1,0])
+  double gain;           // sqrt(n0 * n1)
+  double SR, unit;
+};
+
+template <int BR, int BC>
+__global__ void psd_load_kernel(cx<double>* f, const double* noise, int n, unsigned pitch) {
+  const size_t total = (size_t)pitch * (n / BR);
+  size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
+    int r, c;
+    if (!layout_unmap<BR, BC>(m, n, pitch, r, c)) { f[m] = {0.0, 0.0}; continue; }
+    f[m] = {noise[(size_t)r * n + c], 0.0};
+  }
+}
+
+// spectrum *= sqrt(A / (B + (rho / fknee)^C) / (2 pi rho) * cell) * sqrt(n0 n1), zero outside [fmin, fmax] -- psd.py:113-142
+// in the reference's order of operations (the pow is the device library's: a few ulp from glibc's)
+template <int BR, int BC>
+__global__ void psd_filter_kernel(cx<double>* f, int n, unsigned pitch, PsdParams p) {
+  const size_t total = (size_t)pitch * (n / BR);
+  size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
+    int r, c;
+    if (!layout_unmap<BR, BC>(m, n, pitch, r, c)) continue;
+    const double gx = __dmul_rn((double)(c < n / 2 ? c : c - n), p.fx), gy = __dmul_rn((double)(r < n / 2 ? r : r - n), p.fy);
+    double rho = sqrt(__dadd_rn(__dmul_rn(gx, gx), __dmul_rn(gy, gy)));
+    if (rho == 0.0) rho = 1e-100;
+    if (rho < p.fmin || rho > p.fmax) { f[m] = {0.0, 0.0}; continue; }
+    double d = __ddiv_rn(p.A, __dadd_rn(p.B, pow(__ddiv_rn(rho, p.fknee), p.C)));
+    d = __ddiv_rn(d, __dmul_rn(6.283185307179586, rho));
+    d = __dmul_rn(d, p.cell);
+    const double g = __dmul_rn(sqrt(d), p.gain);
+    f[m] = {__dmul_rn(f[m].x, g), __dmul_rn(f[m].y, g)};
+  }
+}
+
+// screen = Re(ifft2) + SR * roughness; *= 2; *= unit -- written row-major; `bad` counts non-finite values
+template <int BR, int BC>
+__global__ void psd_finish_kernel(double* map, const cx<double>* f, const double* rough, int n, unsigned pitch, PsdParams p, int* bad) {
+  const size_t total = (size_t)pitch * (n / BR);
+  size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; m < total; m += (size_t)gridDim.x * blockDim.x) {
+    int r, c;
+    if (!layout_unmap<BR, BC>(m, n, pitch, r, c)) continue;
+    double v = f[m].x;
+    if (rough) v = __dadd_rn(v, __dmul_rn(p.SR, rough[(size_t)r * n + c]));
+    v = __dmul_rn(__dmul_rn(v, 2.0), p.unit);
+    if (!isfinite(v)) atomicAdd(bad, 1);
+    map[(size_t)r * n + c] = v;
+  }
+}
+
 // ---- stand-alone pointwise pass (op list without a transform) --------------------
 // Used when a lens (wfo.py:359-366) is not adjacent to an FFT pass it could ride on.
 template <typename T, int BR, int BC>

@@ -21,7 +21,13 @@ same NumPy build:
   roughness.  ``PSD.sfe_rms`` (a sympy integral, psd.py:166-193) only feeds a debug log line in
   the reference and is not evaluated.
 """
+import itertools
+
 import numpy as np
+
+# keys under which a context keeps ONE map on the device (paos_phase_map_items / paos_psd_screen): a serial number per map,
+# never an object id (ids are handed out again)
+MAP_SERIAL = itertools.count(1)
 
 _UNIT_TO_M = {"m": 1.0, "mm": 1.0e-3, "um": 1.0e-6, "micron": 1.0e-6, "nm": 1.0e-9}
 
@@ -144,10 +150,8 @@ def _radial_frequency(shape, dx, dy):
     return rho
 
 
-def psd_map(shape, dx, dy, A=10.0, B=0.0, C=0.0, fknee=1.0, fmin=None, fmax=None, SR=0.0, units="m"):
-    """The WFE map ``WFO.psd`` applies and returns (wfo.py:908-943 + psd.py:100-160).  The two draws come from
-    NumPy's legacy global generator in the reference's order (screen first, roughness second)."""
-    rho = _radial_frequency(shape, dx, dy)
+def _psd_band(shape, dx, dy, fmin, fmax):
+    """[fmin, fmax] with the reference's defaults and its check (wfo.py:915-925)."""
     nyquist = 0.5 * np.sqrt(dx**-2 + dy**-2)
     if fmax is None:
         fmax = nyquist
@@ -155,15 +159,77 @@ def psd_map(shape, dx, dy, A=10.0, B=0.0, C=0.0, fknee=1.0, fmin=None, fmax=None
         assert fmax <= nyquist, f"fmax must be less than or equal to f_Nyq ({nyquist})"
     if fmin is None:
         fmin = 1 / (shape[0] * np.max([dx, dy]))
+    return fmin, fmax
 
+
+def psd_map(shape, dx, dy, A=10.0, B=0.0, C=0.0, fknee=1.0, fmin=None, fmax=None, SR=0.0, units="m"):
+    """The WFE map ``WFO.psd`` applies and returns (wfo.py:908-943 + psd.py:100-160).  The two draws come from
+    NumPy's legacy global generator in the reference's order (screen first, roughness second)."""
+    fmin, fmax = _psd_band(shape, dx, dy, fmin, fmax)  # (the reference's check comes before its draws)
+    noise, rough = psd_draws(shape)
+    return psd_map_from_draws(noise, rough, shape, dx, dy, A, B, C, fknee, fmin, fmax, SR, units)
+
+
+def psd_map_from_draws(noise, rough, shape, dx, dy, A=10.0, B=0.0, C=0.0, fknee=1.0, fmin=None, fmax=None, SR=0.0, units="m"):
+    """psd.py:113-160 on the two white-noise arrays of :func:`psd_draws` (``rough`` may be None when SR is 0)."""
+    rho = _radial_frequency(shape, dx, dy)
+    fmin, fmax = _psd_band(shape, dx, dy, fmin, fmax)
     n0, n1 = shape  # the reference draws an array of the pupil's shape, whatever it calls the two numbers (psd.py:103)
-    spectrum = np.fft.fft2(np.random.randn(n0, n1))
+    spectrum = np.fft.fft2(noise)
     cell = (rho[0, 2] - rho[0, 1]) * (rho[2, 0] - rho[1, 0])  # frequency-bin area
     density = A / (B + (rho / fknee) ** C) / (2 * np.pi * rho) * cell
     spectrum *= np.sqrt(density) * np.sqrt(n0 * n1)
     spectrum[np.logical_or(rho < fmin, rho > fmax)] = 0.0
     screen = np.ma.masked_array(np.fft.ifft2(spectrum).real, mask=np.zeros((n0, n1)).astype(bool))
-    screen += SR * np.random.randn(n0, n1)
+    screen += SR * (rough if rough is not None else 0.0)
     screen *= 2
     screen *= _unit_factor(units)
     return screen
+
+
+# Grids from this size up build their PSD screens on the device (below it the host's two small FFTs cost nothing, and
+# the host path is the one the reference's vectors pin bit for bit: tests/golden/r2_phase_maps.npz)
+PSD_ON_DEVICE_FROM = 1024
+
+
+def psd_on_device(dev, n):
+    """Does ``dev`` build the screen itself?  complex128 contexts of the library, n >= PSD_ON_DEVICE_FROM."""
+    return hasattr(dev, "psd_screen") and getattr(dev, "precision", "fp64") == "fp64" and n >= PSD_ON_DEVICE_FROM
+
+
+class PsdScreen:
+    """One ``WFO.psd`` call's screen before it is built: the two draws (taken when the call is planned, so the generator is
+    consumed in the reference's order) and the call's arguments.  ``run`` builds it on the device when the context can
+    (``DeviceFields.psd_screen``: complex128), on the host otherwise."""
+
+    __slots__ = ("noise", "rough", "args", "params")
+
+    def __init__(self, shape, dx, dy, A=10.0, B=0.0, C=0.0, fknee=1.0, fmin=None, fmax=None, SR=0.0, units="m"):
+        self.args = (shape, dx, dy, A, B, C, fknee, fmin, fmax, SR, units)
+        self.params = psd_device_params(*self.args)  # (the reference's fmax check fires here, before the draws)
+        self.noise, rough = psd_draws(shape)
+        self.rough = rough if SR != 0.0 else None
+
+    def host_map(self):
+        return psd_map_from_draws(self.noise, self.rough, *self.args)
+
+
+def psd_device_params(shape, dx, dy, A=10.0, B=0.0, C=0.0, fknee=1.0, fmin=None, fmax=None, SR=0.0, units="m"):
+    """The twelve numbers ``paos_psd_screen`` takes (include/paos_hip.h) for the screen :func:`psd_map` would build: the
+    frequency steps as ``np.fft.fftfreq`` forms them, the band, the frequency-bin area from the same three corner values of
+    ``rho`` and ``sqrt(n0 n1)`` -- each computed with the host path's own expressions, so the device multiplies by the same
+    doubles."""
+    n0, n1 = shape
+    fmin, fmax = _psd_band(shape, dx, dy, fmin, fmax)
+    fx, fy = np.fft.fftfreq(n1, dx)[:3], np.fft.fftfreq(n0, dy)[:3]
+    rho = np.sqrt(np.add.outer(fy**2, fx**2))  # rho[:3, :3] of _radial_frequency (the nudged origin is not read)
+    cell = (rho[0, 2] - rho[0, 1]) * (rho[2, 0] - rho[1, 0])
+    return np.array([1.0 / (n1 * dx), 1.0 / (n0 * dy), A, B, C, fknee, fmin, fmax, cell, np.sqrt(n0 * n1), SR,
+                     float(_unit_factor(units))], dtype=np.float64)
+
+
+def psd_draws(shape):
+    """The two white-noise arrays of one ``WFO.psd`` call, from NumPy's legacy global generator in the reference's order
+    (psd.py:103 the screen, psd.py:148 the roughness -- drawn whatever SR is, like the reference)."""
+    n0, n1 = shape
+    return np.random.randn(n0, n1), np.random.randn(n0, n1)

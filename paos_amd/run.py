@@ -17,7 +17,6 @@ launches.
 """
 import atexit
 import gc
-import itertools
 import math
 import threading
 from copy import deepcopy
@@ -31,7 +30,8 @@ from .aperture import EllipticalAperture, RectangularAperture, bbox_misses_grid,
 from .coordinate_break import coordinate_break
 from . import passes as _passes
 from .passes import PassCompiler, SeparableCompiler
-from .phase_maps import grid_sag_map, psd_map
+from . import phase_maps as _phase_maps
+from .phase_maps import MAP_SERIAL as _MAP_SERIAL, PsdScreen, grid_sag_map
 from .planner import (BeamBatch, gram_polynomials, jacobi_recurrence, orthonorm_matrix,
                       zernike_block)
 from .zernike import zernike_tables
@@ -368,8 +368,10 @@ def _plan_host(st, item, n, dx, dy, wl, wz_of, aperture_plan=False):
         plan["phase_map"] = (_sag_map_once(item["grid_sag"], item["nx"], item["ny"], item["delx"], item["dely"],
                                            item["xdec"], item["ydec"], n, dx, dy), wl)
     elif kind == "PSD":  # run.py:166-177
-        plan["phase_map"] = (psd_map((n, n), dx, dy, item["A"], item["B"], item["C"], item["fknee"], item["fmin"],
-                                     item["fmax"], item["SR"], item["units"]), wl)
+        # (the draws are taken here, in the reference's order; the screen itself is built when the surface is launched: on the
+        # device where the context can -- _launch_phase_maps)
+        plan["phase_map"] = (PsdScreen((n, n), dx, dy, item["A"], item["B"], item["C"], item["fknee"], item["fmin"],
+                                       item["fmax"], item["SR"], item["units"]), wl)
     return plan
 
 
@@ -620,6 +622,19 @@ def _launch_phase_maps(dev, plans, wfe):
     for i, p in enumerate(plans):
         if p["phase_map"] is not None:
             m, wl = p["phase_map"]
+            if isinstance(m, PsdScreen):  # a random screen of this item's own
+                if _phase_maps.psd_on_device(dev, m.args[0][0]):
+                    # fft2 -> power-law filter -> ifft2 -> roughness on the library's passes (paos_psd_screen); the map stays on
+                    # the device and comes back only where the reference returns it (one wavefront: the surface's `wfe`)
+                    serial = next(_MAP_SERIAL)
+                    out = dev.psd_screen(m.noise, m.rough, m.params, key=serial, want_map=len(plans) == 1)
+                    dev.phase_map_items(None, [i], [wl], key=serial)
+                    if len(plans) == 1:
+                        wfe = np.ma.masked_array(out, mask=np.zeros(out.shape, dtype=bool))
+                    p["phase_map"] = None  # (its two draws: 2 x 8 n^2 bytes per item)
+                    continue
+                m = m.host_map()  # complex64 contexts: the screen is built in doubles on the host
+                p["phase_map"] = None
             groups.setdefault(id(m), (m, [], []))
             groups[id(m)][1].append(i)
             groups[id(m)][2].append(wl)
@@ -642,7 +657,6 @@ def _launch_phase_maps(dev, plans, wfe):
 
 
 _FILLED_MAPS = {}  # id(map) -> (map, its zero-filled contiguous copy: what crosses PCIe, serial number = the library's content key)
-_MAP_SERIAL = itertools.count(1)
 
 
 def _queue_apertures(comp, plans):

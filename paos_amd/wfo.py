@@ -12,7 +12,8 @@ import numpy as np
 
 from . import _lib
 from .aperture import bbox_misses_grid, make_aperture, EllipticalAperture
-from .phase_maps import grid_sag_map, psd_map
+from . import phase_maps as _phase_maps
+from .phase_maps import MAP_SERIAL, PsdScreen, grid_sag_map
 from .planner import PilotBeam, gram_polynomials, jacobi_recurrence, orthonorm_matrix, zernike_block
 from .zernike import Zernike, norm_factors
 
@@ -182,6 +183,13 @@ class WFO:
         roughness; returns the WFE map.  The draw uses NumPy's legacy global generator like the
         reference (``np.random.seed`` makes it reproducible)."""
         b = self._beam
-        wfe = psd_map((b.n, b.n), b.dx, b.dy, A, B, C, fknee, fmin, fmax, SR, units)
+        screen = PsdScreen((b.n, b.n), b.dx, b.dy, A, B, C, fknee, fmin, fmax, SR, units)
+        if _phase_maps.psd_on_device(self._dev, b.n):
+            # round 5: fft2 -> filter -> ifft2 -> roughness on the library's own passes (paos_psd_screen)
+            key = next(MAP_SERIAL)
+            out = self._dev.psd_screen(screen.noise, screen.rough, screen.params, key=key, want_map=True)
+            self._dev.phase_map_items(None, [0], [b.wl], key=key)
+            return np.ma.masked_array(out, mask=np.zeros(out.shape, dtype=bool))
+        wfe = screen.host_map()
         self._dev.phase_map(0, np.ma.filled(wfe, 0.0), b.wl)
         return wfe

@@ -363,8 +363,32 @@ class ModelDevice:
         self.log.append(("phase_map", item))
         self.u[int(item)] = self.u[int(item)] * np.exp(2.0 * np.pi * 1j * np.asarray(wfe, dtype=np.float64) / wl)
 
+    def psd_screen(self, noise, rough, params, key, want_map=False):
+        """paos_psd_screen in NumPy, from the twelve numbers alone (the arithmetic of csrc/pointwise.h: psd_filter_kernel)."""
+        fx, fy, A, B, C, fknee, fmin, fmax, cell, gain, SR, unit = [float(v) for v in params]
+        n = self.n
+        k = np.where(np.arange(n) < n // 2, np.arange(n), np.arange(n) - n).astype(np.float64)
+        gx, gy = np.meshgrid(k * fx, k * fy)
+        rho = np.sqrt(gx * gx + gy * gy)
+        rho[rho == 0] = 1e-100
+        spec = np.fft.fft2(np.asarray(noise, dtype=np.float64))
+        with np.errstate(all="ignore"):
+            g = np.sqrt(A / (B + (rho / fknee) ** C) / (6.283185307179586 * rho) * cell) * gain
+        spec = np.where((rho < fmin) | (rho > fmax), 0.0, spec * g)
+        v = np.fft.ifft2(spec).real
+        if rough is not None:
+            v = v + SR * np.asarray(rough, dtype=np.float64)
+        self._kept_map = (int(key), v * 2 * unit)
+        self.log.append(("psd_screen", int(key)))
+        return self._kept_map[1].copy() if want_map else None
+
     def phase_map_items(self, wfe, items, wls, key=0):
         self.log.append(("phase_map_items", len(items)))
+        if wfe is None:
+            kept = getattr(self, "_kept_map", None)
+            if kept is None or kept[0] != int(key) or not key:
+                raise RuntimeError("paos_phase_map_items failed: no host map, and no map kept on the device under this key")
+            wfe = kept[1]
         for i, wl in zip(items, wls):
             self.u[int(i)] = self.u[int(i)] * np.exp(2.0 * np.pi * 1j * np.asarray(wfe, dtype=np.float64) / wl)
 

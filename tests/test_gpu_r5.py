@@ -173,3 +173,119 @@ def test_a_shared_grid_sag_screen_is_uploaded_once_and_equals_the_per_item_path(
                 assert np.array_equal(a[i], dev.psf_fetch(i)), (g, i)
     finally:
         dev.close()
+
+
+def test_psd_screen_built_on_the_device_vs_reference_vectors():
+    """Round 5: ``paos_psd_screen`` -- fft2(noise) -> power-law filter -> ifft2 -> roughness on the
+    library's own passes -- against the reference's vectors (tests/golden/r2_phase_maps.npz; the host path reproduces them
+    bit for bit, test_gpu_r2.py): the maps to 1e-13 of their peak, the fields behind them to 1e-12."""
+    from conftest import load_golden
+    from paos_amd import phase_maps
+    from paos_amd.wfo import WFO
+
+    g = load_golden("r2_phase_maps.npz")
+    cases = {"powerlaw": dict(A=7.0, B=0.0, C=1.5, fknee=1.0, fmin=None, fmax=None, SR=0.0, units="nm"),
+             "knee_sr": dict(A=12.0, B=1.0, C=2.2, fknee=3.0, fmin=0.5, fmax=6.0, SR=2.0, units="nm")}
+    keep = phase_maps.PSD_ON_DEVICE_FROM
+    try:
+        phase_maps.PSD_ON_DEVICE_FROM = 64
+        for tag, kw in cases.items():
+            for anam in (False, True):
+                w = WFO(1.0, 2.0e-6, 64, 4)
+                if anam:
+                    w.Magnification(1.25, 0.8)
+                w._wfo = g["u0"]
+                np.random.seed(1234)
+                ret = w.psd(**kw)
+                key = f"psd_{tag}{'_anam' if anam else ''}"
+                want = g[key + "_wfe"]
+                assert isinstance(ret, np.ma.MaskedArray) and not np.ma.getmaskarray(ret).any()
+                assert np.abs(np.ma.filled(ret, 0.0) - want).max() <= 1e-13 * np.abs(want).max(), key
+                assert rel_err(w.wfo, g[key + "_u"]) < 1e-12, key
+    finally:
+        phase_maps.PSD_ON_DEVICE_FROM = keep
+
+
+@pytest.mark.parametrize("n", [1024, 4096])
+def test_psd_screen_on_the_device_equals_the_host_path(n):
+    """... and at the sizes that take the device path by default, against the host path (NumPy's FFTs) on the same draws:
+    maps to 1e-13 of their peak, the generator left in the same state, the kept map applied to two items of a batch with
+    their own wavelengths; the error paths of the two entry points."""
+    from paos_amd import _lib, phase_maps
+
+    kw = dict(A=12.0, B=1.0, C=2.2, fknee=3.0, fmin=None, fmax=None, SR=0.5, units="nm")
+    dx = dy = 4.0 / n
+    np.random.seed(5)
+    screen = phase_maps.PsdScreen((n, n), dx, dy, **kw)
+    state = np.random.get_state()[1].copy()
+    np.random.seed(5)
+    want = np.ma.filled(phase_maps.psd_map((n, n), dx, dy, **kw), 0.0)
+    assert np.array_equal(state, np.random.get_state()[1])
+    dev = _lib.DeviceFields(n, 2)
+    try:
+        assert phase_maps.psd_on_device(dev, n)
+        dev.fill(1.0)
+        got = dev.psd_screen(screen.noise, screen.rough, screen.params, key=41, want_map=True)
+        assert np.abs(got - want).max() <= 1e-13 * np.abs(want).max()
+        wls = [1.0e-6, 1.7e-6]
+        dev.phase_map_items(None, [0, 1], wls, key=41)
+        for i, wl in enumerate(wls):
+            assert rel_err(dev.download(i), np.exp(2j * np.pi * want / wl)) < 1e-12, i
+        with pytest.raises(_lib.PaosHipError, match="no map kept"):
+            dev.phase_map_items(None, [0], [1.0e-6], key=42)
+        with pytest.raises(_lib.PaosHipError):
+            dev.psd_screen(screen.noise, None, screen.params, key=0)
+        bad = screen.params.copy()
+        bad[2] = np.nan
+        with pytest.raises(_lib.PaosHipError, match="NaN"):
+            dev.psd_screen(screen.noise, None, bad, key=43)
+        inf = screen.noise.copy()
+        inf[3, 5] = np.inf
+        with pytest.raises(_lib.PaosHipError, match="non-finite"):
+            dev.psd_screen(inf, None, screen.params, key=44)
+        with pytest.raises(_lib.PaosHipError, match="no map kept"):  # ... and a failed build leaves no map behind
+            dev.phase_map_items(None, [0], [1.0e-6], key=44)
+    finally:
+        dev.close()
+    if n == 1024:
+        f32 = _lib.DeviceFields(n, 1, precision="fp32")
+        try:
+            assert not phase_maps.psd_on_device(f32, n)
+            with pytest.raises(_lib.PaosHipError, match="complex128"):
+                f32.psd_screen(screen.noise, None, screen.params, key=45)
+        finally:
+            f32.close()
+
+
+def test_run_with_a_psd_surface_builds_the_screen_on_the_device():
+    """``run()`` of SYN20 behind a PSD surface at 1024^2: the surface's `wfe` and every saved field equal those of the
+    host-built screen (same seed) to 1e-13 / 1e-11."""
+    from paos_amd import phase_maps
+    from paos_amd.abcd import ABCD
+    from paos_amd.chains import syn20_chain
+    from paos_amd.run import run
+
+    n = 1024
+    chain = {}
+    for item in syn20_chain().values():
+        num = len(chain) + 1
+        chain[num] = dict(item, num=num, save=True)
+        if item["name"] == "Z1":
+            num = len(chain) + 1
+            chain[num] = dict(A=9.0, B=0.0, C=1.8, fknee=1.0, fmin=None, fmax=None, SR=0.3, units="nm", num=num, type="PSD",
+                              name="SCREEN", is_stop=False, save=True, ABCDt=ABCD(thickness=0.0, curvature=0.0),
+                              ABCDs=ABCD(thickness=0.0, curvature=0.0))
+    key = [k for k, v in chain.items() if v["name"] == "SCREEN"][0]
+    keep = phase_maps.PSD_ON_DEVICE_FROM
+    try:
+        np.random.seed(9)
+        got = run(1.0, 1.1e-6, n, 4, ON_AXIS, chain)
+        phase_maps.PSD_ON_DEVICE_FROM = 1 << 20
+        np.random.seed(9)
+        want = run(1.0, 1.1e-6, n, 4, ON_AXIS, chain)
+    finally:
+        phase_maps.PSD_ON_DEVICE_FROM = keep
+    a, b = np.ma.filled(got[key]["wfe"], 0.0), np.ma.filled(want[key]["wfe"], 0.0)
+    assert np.abs(b).max() > 0 and np.abs(a - b).max() <= 1e-13 * np.abs(b).max()
+    for k in want:
+        assert rel_err(got[k]["wfo"], want[k]["wfo"]) < 1e-11, k

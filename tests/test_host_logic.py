@@ -1011,6 +1011,78 @@ def test_a_shared_grid_sag_map_is_built_once_and_applied_to_all_its_items():
         prun.grid_sag_map = real
 
 
+def test_psd_screens_are_built_by_the_device_from_the_hosts_draws():
+    """Round 5: from ``phase_maps.PSD_ON_DEVICE_FROM`` up, a PSD surface hands the context its two
+    white-noise draws and twelve numbers (``psd_screen``) instead of a finished map.  The draws are NumPy's, in the
+    reference's order, so the generator ends in the same state either way; the twelve numbers reproduce the host path's
+    map (<= 1e-13 of its peak, on the NumPy model of the kernels); complex64 contexts and small grids keep the host path."""
+    import paos_amd.run as prun
+    from paos_amd import phase_maps
+    from paos_amd.abcd import ABCD
+    from paos_amd.run import run_batch
+
+    n = 64
+    kw = dict(A=12.0, B=1.0, C=2.2, fknee=3.0, fmin=0.5, fmax=6.0, SR=2.0, units="nm")
+
+    def chain():
+        out = {}
+        for key, item in syn20_chain().items():
+            num = len(out) + 1
+            out[num] = dict(item, num=num)
+            if item["name"] == "Z1":
+                num = len(out) + 1
+                out[num] = dict(kw, num=num, type="PSD", name="SCREEN", is_stop=False, save=True,
+                                ABCDt=ABCD(thickness=0.0, curvature=0.0), ABCDs=ABCD(thickness=0.0, curvature=0.0))
+        return out
+
+    key = [k for k, v in chain().items() if v["name"] == "SCREEN"][0]
+    keep = phase_maps.PSD_ON_DEVICE_FROM
+    try:
+        phase_maps.PSD_ON_DEVICE_FROM = n
+        dev = ModelDevice(n, 1)
+        np.random.seed(77)
+        got = run_batch(1.0, [1.0e-6], n, 4, FIELD, [chain()], outputs=("wfo",), dev=dev)[0]
+        after_device = np.random.get_state()[1].copy()
+        assert any(k == "psd_screen" for k, _ in dev.log) and not any(k == "phase_map" for k, _ in dev.log)
+        phase_maps.PSD_ON_DEVICE_FROM = 1 << 20  # ... and the host path
+        dev2 = ModelDevice(n, 1)
+        np.random.seed(77)
+        want = run_batch(1.0, [1.0e-6], n, 4, FIELD, [chain()], outputs=("wfo",), dev=dev2)[0]
+        assert np.array_equal(after_device, np.random.get_state()[1])
+        assert any(k == "phase_map" for k, _ in dev2.log) and not any(k == "psd_screen" for k, _ in dev2.log)
+        # the map a single wavefront's surface returns (run(): the surface's `wfe`)
+        maps = []
+        for first in (n, 1 << 20):
+            phase_maps.PSD_ON_DEVICE_FROM = first
+            np.random.seed(78)
+            d1 = ModelDevice(n, 1)
+            d1.fill(1.0)
+            maps.append(prun._launch_phase_maps(d1, [{"phase_map": (phase_maps.PsdScreen((n, n), 0.03, 0.04, **kw), 1.0e-6)}], None))
+        a, b = np.ma.filled(maps[0], 0.0), np.ma.filled(maps[1], 0.0)
+        assert np.abs(b).max() > 0 and np.abs(a - b).max() <= 1e-13 * np.abs(b).max()
+        assert isinstance(maps[0], np.ma.MaskedArray) and not np.ma.getmaskarray(maps[0]).any()
+        for k in want:
+            assert rel_err(got[k]["wfo"], want[k]["wfo"]) < 1e-12, k
+        # a batch: every item its own screen, in item order
+        phase_maps.PSD_ON_DEVICE_FROM = n
+        dev3 = ModelDevice(n, 2)
+        np.random.seed(77)
+        two = run_batch(1.0, [1.0e-6, 1.3e-6], n, 4, FIELD, [chain(), chain()], outputs=("wfo",), dev=dev3)
+        assert sum(k == "psd_screen" for k, _ in dev3.log) == 2
+        assert rel_err(two[0][key]["wfo"], want[key]["wfo"]) < 1e-12
+        # complex64 contexts build the screen on the host, in doubles
+        phase_maps.PSD_ON_DEVICE_FROM = n
+        dev4 = ModelDevice(n, 1, precision="fp32")
+        assert not phase_maps.psd_on_device(dev4, n)
+        # the reference's check of fmax still fires when the call is planned
+        bad = chain()
+        bad[key] = dict(bad[key], fmax=1.0e9)
+        with pytest.raises(AssertionError, match="fmax"):
+            run_batch(1.0, [1.0e-6], n, 4, FIELD, [bad], dev=ModelDevice(n, 1))
+    finally:
+        phase_maps.PSD_ON_DEVICE_FROM = keep
+
+
 def test_batch_planner_equals_the_per_item_planner():
     """Round 5: ``run._plan_batch`` plans the apertures of a whole batch with array arithmetic.  Against ``_plan_host`` item by
     item, on random batches -- ellipses and rectangles, apertures and obscurations, missing centres, different sampling per

@@ -368,6 +368,20 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (getenv("PAOS_BENCH_DENSE1")) {  // byte-bound (dense) passes of 32 wavefronts: two-line workgroups against one-line ones
+    for (int round = 0; round < 2; ++round) {
+      bench_copy<double>(4096, 32, reps);
+      bench_frugal<double, 4096, 0, 0, 0, 1>("rows single, 2 lines", 32, reps, pad);
+      bench_frugal<double, 4096, 0, 0, 0, 1, 1>("rows single, 1 line", 32, reps, pad);
+      bench_frugal<double, 4096, 1, 0, 0, 1>("cols single, 2 lines", 32, reps, pad);
+      bench_frugal<double, 4096, 1, 0, 0, 1, 1>("cols single, 1 line", 32, reps, pad);
+      bench_frugal<double, 4096, 0, 0, 1, 2>("rows double 1 phase, 2 lines", 32, reps, pad);
+      bench_frugal<double, 4096, 0, 0, 1, 2, 1>("rows double 1 phase, 1 line", 32, reps, pad);
+      bench_frugal<double, 4096, 1, 0, 1, 2>("cols double 1 phase, 2 lines", 32, reps, pad);
+      bench_frugal<double, 4096, 1, 0, 1, 2, 1>("cols double 1 phase, 1 line", 32, reps, pad);
+    }
+    return 0;
+  }
   bench_frugal<double, 4096, 0, 0, 0, 1>("rows single", b4, reps, pad);
   bench_frugal<double, 4096, 1, 0, 0, 1>("cols single", b4, reps, pad);
   bench_frugal<double, 4096, 0, 0, 1, 2>("rows double 1 phase", b4, reps, pad);
