@@ -576,6 +576,13 @@ def contract_line(full):
                           "kind": cpu.get("kind"), "sample": str(cpu.get("sample", ""))[:260]} if cpu else None),
         "detail": full.get("detail_file"),
     }
+    extra = full.get("extra") or {}
+    if extra:  # the side measurements in one number each (wavefronts/s; everything else about them is in the detail file)
+        brief = {k: _r(v.get("value")) for k, v in extra.items() if isinstance(v, dict) and v.get("unit") == "wavefronts/s"}
+        psd = extra.get("psd_screen") or {}
+        if psd.get("device_ms") is not None:
+            brief["psd_screen_ms"] = {"device": _r(psd.get("device_ms")), "host": _r(psd.get("host_ms"))}
+        line["extra_wavefronts_per_s"] = brief
     if full.get("error"):
         line["error"] = str(full["error"])[:800]
     text = json.dumps(line, allow_nan=False, separators=(",", ":"))

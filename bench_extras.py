@@ -91,6 +91,36 @@ def _dense(args, esz, measure, roofline_block):
         dev.close()
 
 
+def _psd_screen(args):
+    """One ``WFO.psd`` screen at the headline grid: the host's two draws + ``paos_psd_screen`` (round 5) against the host
+    path (NumPy's fft2 / ifft2: the reference's own arithmetic), same seed -- what each costs and how far apart the maps are."""
+    from paos_amd import _lib, phase_maps
+
+    n = args.grid
+    kw = dict(A=12.0, B=1.0, C=2.2, fknee=3.0, fmin=None, fmax=None, SR=0.5, units="nm")
+    dx = 4.0 / n
+    dev = _lib.DeviceFields(n, 1, "fp64")
+    try:
+        state = np.random.get_state()
+        np.random.seed(3)
+        t0 = time.perf_counter()
+        screen = phase_maps.PsdScreen((n, n), dx, dx, **kw)
+        t1 = time.perf_counter()
+        dev.psd_screen(screen.noise, screen.rough, screen.params, key=1)  # first call: allocations, LDS opt-ins
+        t2 = time.perf_counter()
+        got = dev.psd_screen(screen.noise, screen.rough, screen.params, key=2, want_map=True)
+        t3 = time.perf_counter()
+        want = np.ma.filled(screen.host_map(), 0.0)
+        t4 = time.perf_counter()
+        np.random.set_state(state)
+        return {"grid": n, "draws_ms": 1e3 * (t1 - t0), "device_ms": 1e3 * (t3 - t2), "device_first_call_ms": 1e3 * (t2 - t1),
+                "host_ms": 1e3 * (t4 - t3), "max_abs_diff_over_peak": float(np.abs(got - want).max() / np.abs(want).max()),
+                "what": "draws: the two np.random.randn(n, n) of the call (host, the reference's generator); device: upload of both + "
+                        "fft2 -> filter -> ifft2 -> roughness on the library's passes + the map's download; host: the same on NumPy"}
+    finally:
+        dev.close()
+
+
 def _timed_batch(pup, wls, n, zoom, field, chains, precision="fp64", reps=3, **kw):
     from paos_amd import _lib
     from paos_amd.run import run_batch
@@ -190,5 +220,6 @@ def extras(args, esz, measure, roofline_block, sweep_report):
         guarded("fp32_4096", lambda: _syn20(4096, 32, "fp32", steps, warmup, 8, measure, roofline_block, sweep_report,
                                             label="SYN20, walked sweep, 4096^2 in fp32 mode (complex64 field, fp64 phase arguments)"))
     guarded("dense", lambda: _dense(args, esz, measure, roofline_block))
+    guarded("psd_screen", lambda: _psd_screen(args))
     guarded("configs", _configs)
     return out

@@ -524,12 +524,17 @@ def test_bench_contract_line_is_small_strict_json():
                                          traffic, dense=dense),
         "dominant_launch": dom,
         "ptp_step": {"frac_bytes_moved": 0.636, "ms_per_wavefront": float("nan")},
-        "extra": {"big": ["z" * 100] * 300, "inf": float("inf"), "arr": np.arange(4), "np": np.float64(1.5)},
+        "extra": {"big": ["z" * 100] * 300, "inf": float("inf"), "arr": np.arange(4), "np": np.float64(1.5),
+                  "2048^2": {"value": np.float64(6990.123456), "unit": "wavefronts/s", "roofline": {"w": "v" * 4000}},
+                  "dense": {"value": float("nan"), "unit": "wavefronts/s"}, "broken": {"error": "e" * 3000},
+                  "psd_screen": {"device_ms": 31.23456, "host_ms": 2950.5, "what": "p" * 500}},
         "cpu_baseline": {"value": 0.0213, "unit": "wavefronts/s", "cores": 1, "kind": "port", "sample": "s" * 1000},
         "detail_file": "bench_detail.json",
     }
     text = bench.contract_line(full)
     assert len(text) < 4096 and "\n" not in text
+    brief = json.loads(text)["extra_wavefronts_per_s"]  # one number per side measurement, nothing else of them
+    assert brief == {"2048^2": 6990.0, "dense": None, "psd_screen_ms": {"device": 31.23, "host": 2950.0}}, brief  # (4 significant digits)
     line = json.loads(text, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))  # NaN / Infinity would raise
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
