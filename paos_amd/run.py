@@ -282,9 +282,9 @@ class ABCDProduct(ABCD):
 # through WFO.grid_sag with the same sampling: the map the reference would build per wavefront (wfo.py:745-867: masking,
 # Fourier shift, padding / cropping, resampling -- seconds at 4096^2) is built once per distinct (array, geometry) and shared;
 # ``_launch_phase_maps`` then uploads it once for all the items that carry it.  An entry keeps its input array alive (so that
-# the id stays unique) and is matched by the array's identity plus a cheap fingerprint of its content -- shape, type and the
-# sum of 65 536 evenly spaced samples (every element of a map up to 256^2): an array edited in place between two runs is
-# rebuilt when the edit touches a sample; ``forget_maps()`` drops the entries for a caller that edits large arrays in place.
+# the id stays unique) and is matched by the array's identity plus a digest of ALL of its bytes (xxh3: ~5 ms for a 4096^2 map
+# on the GPU box's host, taken once per walk and array -- ``_SAG_SEEN``), so an array edited in place between two runs,
+# wherever, is rebuilt.
 _SAG_MAPS = {}
 
 
@@ -292,14 +292,44 @@ def forget_maps():
     """Drop what the module keeps between calls: the Grid Sag maps (``_sag_map_once``) with their zero-filled copies, and the
     gate arrays remembered per column of ABCD objects (``_gate_arrays``: they keep those objects alive)."""
     _SAG_MAPS.clear()
+    _SAG_SEEN.clear()
     _FILLED_MAPS.clear()
     _GATE_COLUMNS.clear()
 
 
+_SAG_SEEN = {}  # id(array) -> (array, fingerprint) within ONE walk (cleared when a walk starts): the items of a batch share it
+
+
+def _digest(buf):
+    """A 64-bit digest of every byte of a contiguous uint8 view (xxh3: ~5 ms for the 128 MiB of a 4096^2 map on the GPU
+    box's host).  Without the xxhash module: the wrap-around uint64 sums of the rows and of the columns of the bytes laid
+    out as a matrix, hashed -- an edit, a flip or a roll changes one of them."""
+    try:
+        import xxhash
+
+        return xxhash.xxh3_64_intdigest(buf)
+    except ImportError:
+        import zlib
+
+        words = buf[: buf.size // 8 * 8].view(np.uint64)
+        side = max(1, int(np.sqrt(words.size)))
+        mat = words[: words.size // side * side].reshape(-1, side)
+        tail = bytes(words[mat.size:]) + bytes(buf[buf.size // 8 * 8:])
+        return zlib.crc32(mat.sum(axis=0, dtype=np.uint64).tobytes() + mat.sum(axis=1, dtype=np.uint64).tobytes() + tail)
+
+
 def _sag_fingerprint(sag):
-    a = np.ma.getdata(sag)
-    flat = a.reshape(-1)
-    return (a.shape, a.dtype.str, float(np.nansum(flat[:: max(1, flat.size // 65536)])), isinstance(sag, np.ma.MaskedArray))
+    """Shape, type, masked-or-not and a digest of every byte of the array (and of its mask), once per walk and array."""
+    seen = _SAG_SEEN.get(id(sag))
+    if seen is not None and seen[0] is sag:
+        return seen[1]
+    a = np.ascontiguousarray(np.ma.getdata(sag))
+    digests = [_digest(a.reshape(-1).view(np.uint8))]
+    if isinstance(sag, np.ma.MaskedArray) and sag.mask is not np.ma.nomask:
+        digests.append(_digest(np.ascontiguousarray(np.ma.getmaskarray(sag)).reshape(-1).view(np.uint8)))
+    fp = (a.shape, a.dtype.str, isinstance(sag, np.ma.MaskedArray), tuple(digests))
+    _SAG_SEEN[id(sag)] = (sag, fp)
+    return fp
 
 
 def _sag_map_once(sag, nx, ny, delx, dely, xdec, ydec, n, dx, dy):
@@ -745,6 +775,7 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
     ``lean`` (a _WalkState, optional): the caller reads no arrays at saved surfaces, only powers (through
     ``lean.rows`` / ``lean.psf_ticket``) -- the walk may then leave dead rows unwritten at the start and, when
     ``psf_at`` names the last surface, have the last pass store the PSF instead of the field."""
+    _SAG_SEEN.clear()  # (a Grid Sag array is hashed once per walk, not once per item)
     keys = [list(c.keys()) for c in chains]
     if any(k != keys[0] for k in keys[1:]):
         raise ValueError("batched chains must list the same surfaces (same keys, same order)")

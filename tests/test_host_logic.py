@@ -993,7 +993,7 @@ def test_a_shared_grid_sag_map_is_built_once_and_applied_to_all_its_items():
         assert len(calls) == 1 and ("phase_map_items", 3) in dev.log and not any(k == "phase_map" for k, _ in dev.log)
         run_batch(1.0, wls, n, 4, FIELD, [shared] * 3, outputs=(), dev=ModelDevice(n, 3))
         assert len(calls) == 1  # the next batch finds the map
-        sag[3, 4] += 1.0e-9   # edited in place: the fingerprint notices (it samples every element of so small an array)
+        sag[3, 4] += 1.0e-9   # edited in place: the fingerprint (a digest of every byte, once per walk) notices
         run_batch(1.0, wls, n, 4, FIELD, [shared] * 3, outputs=(), dev=ModelDevice(n, 3))
         assert len(calls) == 2
         sag[3, 4] -= 1.0e-9
@@ -1007,8 +1007,23 @@ def test_a_shared_grid_sag_map_is_built_once_and_applied_to_all_its_items():
             for k in want[i]:
                 assert rel_err(got[i][k]["wfo"], want[i][k]["wfo"]) < 1e-13, (i, k)
         assert key in got[0]
+        # ... wherever the edit is, masks included; the digest is taken once per walk and array
+        big = rng.standard_normal((700, 900))
+        prun._SAG_SEEN.clear()
+        f0 = prun._sag_fingerprint(big)
+        assert prun._sag_fingerprint(big) is f0
+        big[613, 7] = np.nextafter(big[613, 7], 1.0)
+        assert prun._sag_fingerprint(big) is f0  # (same walk: not looked at again)
+        prun._SAG_SEEN.clear()
+        assert prun._sag_fingerprint(big) != f0
+        masked = np.ma.masked_array(big, mask=np.zeros(big.shape, dtype=bool))
+        f1 = prun._sag_fingerprint(masked)
+        masked.mask[5, 5] = True
+        prun._SAG_SEEN.clear()
+        assert prun._sag_fingerprint(masked) != f1
     finally:
         prun.grid_sag_map = real
+        prun._SAG_SEEN.clear()
 
 
 def test_psd_screens_are_built_by_the_device_from_the_hosts_draws():
