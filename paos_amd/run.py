@@ -669,7 +669,8 @@ def _launch_phase_maps(dev, plans, wfe):
             groups[id(m)][1].append(i)
             groups[id(m)][2].append(wl)
             if len(plans) == 1:
-                wfe = m
+                # (a map _sag_map_once keeps is handed out as a copy: the caller owns what run() returns, like the reference's)
+                wfe = m.copy() if any(hit[2] is m for hit in _SAG_MAPS.values()) else m
     for m, idx, wls in groups.values():
         if len(idx) > 1 and hasattr(dev, "phase_map_items"):
             filled = _FILLED_MAPS.get(id(m))
