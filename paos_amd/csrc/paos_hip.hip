@@ -927,10 +927,21 @@ int ensure_mask_store(paos_ctx* c) {
 // be rendered -- and point the items' slots at it.  Called for the passes of a program in order, before anything is
 // launched: launches follow in the same order on one stream, so a set re-used further down the program is
 // overwritten only after the pass that read it.
+// How ellipse records are rendered (read per call: tests switch it).  PAOS_MASK_SCAN=1: the chunk scan of rounds 2-3 (0);
+// PAOS_MASK_PAIRS=0: one line per wave through two 32-pixel windows (1), =1: two lines per wave through 16-pixel windows
+// where they fit (2); default: four lines per wave through 8-pixel windows where they fit (3).
+int mask_render_mode() {
+  const char* e = getenv("PAOS_MASK_SCAN");
+  if (e && e[0] == '1') return 0;
+  const char* pe = getenv("PAOS_MASK_PAIRS");
+  return (pe && pe[0] == '0') ? 1 : ((pe && pe[0] == '1') ? 2 : 3);
+}
+
 int assign_mask_set(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const double* blocks) {
   std::vector<double> key;
-  key.reserve((size_t)2 * c->batch * FP_STRIDE + c->batch + 2);
+  key.reserve((size_t)2 * c->batch * FP_STRIDE + c->batch + 3);
   key.push_back((double)p.axis);
+  key.push_back((double)mask_render_mode());  // (the renderers give the same records bit for bit -- and a test that says so must render twice)
   const double* ap = blocks + (size_t)lp.mask_block * c->batch * FP_STRIDE;
   key.insert(key.end(), ap, ap + (size_t)2 * c->batch * FP_STRIDE);  // the two consecutive block sets
   key.insert(key.end(), lp.mask_shared.begin(), lp.mask_shared.end());
@@ -984,10 +995,9 @@ MaskJob mask_job(paos_ctx* c, const paos_pass& p, const LoweredPass& lp, const d
 int launch_mask_jobs(paos_ctx* c, MaskJobs& jobs, int count) {
   jobs.batch_stride = c->batch * (int)FP_STRIDE; jobs.param_stride = (int)FP_STRIDE; jobs.n = c->n; jobs.overflow = c->mask_overflow;
   {
-    const char* e = getenv("PAOS_MASK_SCAN");  // (read per launch: tests switch it)
-    jobs.windows = (e && e[0] == '1') ? 0 : 1;
-    const char* pe = getenv("PAOS_MASK_PAIRS");  // (round 5: two lines per wave through 16-pixel windows; =0: one line per wave)
-    jobs.pairs = (jobs.windows != 0 && !(pe && pe[0] == '0')) ? 1 : 0;
+    const int mode = mask_render_mode();
+    jobs.windows = mode != 0 ? 1 : 0;
+    jobs.pairs = mode >= 2 ? mode - 1 : 0;
   }
   int widest = 0, shapes = 0;
   for (int j = 0; j < count; ++j) {
@@ -995,8 +1005,9 @@ int launch_mask_jobs(paos_ctx* c, MaskJobs& jobs, int count) {
     shapes |= jobs.job[j].shapes;
   }
   const dim3 block(256);
-  // (ellipses with pairs: a wave renders two lines, the grid covers half as many waves)
-  if (shapes & 1) hipLaunchKernelGGL(mask_lines_kernel<0>, dim3(jobs.pairs ? (widest + 7) / 8 : (widest + 3) / 4, c->batch, count), block, 0, c->stream, jobs);
+  // (ellipses: a wave renders four / two lines, the grid covers a quarter / half as many waves)
+  const int per_wg = 4 * (jobs.pairs >= 2 ? 4 : (jobs.pairs ? 2 : 1));
+  if (shapes & 1) hipLaunchKernelGGL(mask_lines_kernel<0>, dim3((widest + per_wg - 1) / per_wg, c->batch, count), block, 0, c->stream, jobs);
   if (shapes & 2) hipLaunchKernelGGL(mask_lines_kernel<1>, dim3((widest + 3) / 4, c->batch, count), block, 0, c->stream, jobs);
   HIPCHK(c, hipGetLastError());
   return PAOS_OK;

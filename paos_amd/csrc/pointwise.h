@@ -745,7 +745,7 @@ constexpr int kMaskJobs = 8;
 struct MaskJobs {
   MaskJob job[kMaskJobs];
   int windows;       // 1: lines whose two boundary runs fit two 32-pixel windows take the one-evaluation path (PAOS_MASK_SCAN=1: 0)
-  int pairs;         // 1 (round 5): a wave renders TWO lines at once when both fit two 16-pixel windows (PAOS_MASK_PAIRS=0: 0)
+  int pairs;         // (round 5) 2: a wave renders FOUR lines at once when all fit two 8-pixel windows, else / 1: TWO through 16-pixel windows (PAOS_MASK_PAIRS=1), 0: one line per wave (=0)
   int batch_stride;  // doubles between the two parameter block sets of a job (= batch * param_stride)
   int param_stride, n;
   int* overflow;
@@ -939,17 +939,21 @@ __device__ void mask_line_render(const MaskJobs& jobs, const MaskJob& jb, int it
   if (lane == 0) *out = {p0, p1, p2i, p3, lm, 0.0};
 }
 
-// Round 5: TWO lines per wave.  The window path above spends one exact-overlap evaluation per lane on 2 x 32 pixels of which
-// two to four are partially covered; everywhere but near the tips of the ellipse the two boundary runs of a line fit two
-// 16-pixel windows (same margins of 3), so lanes 0-31 render line `first` (lanes 0-15 its left window, 16-31 its right one)
-// and lanes 32-63 render line `first + 1`: half the waves, the same per-pixel functions on the same pixels, the same span
-// tests -- records bit for bit those of the 32-pixel windows and of the scan (tests/test_gpu_r4.py, PAOS_MASK_PAIRS=0 /
-// PAOS_MASK_SCAN=1).  Returns false (for the whole wave) when either line needs more: the caller then renders the two
-// lines one after the other with the 64-lane paths.
-__device__ inline bool mask_pair_render(const MaskJobs& jobs, const MaskJob& jb, int item, int first, int lane) {
+// Round 5: TWO -- then FOUR -- lines per wave.  The window path above spends one exact-overlap evaluation per lane on 2 x 32
+// pixels of which two to four are partially covered; everywhere but near the tips of the ellipse the two boundary runs of a
+// line fit two 16-pixel windows (margins of 3) and, away from the last few per cent of the lines at either tip, two 8-pixel
+// windows (margins of 1: what makes a window exact are the tests below, not its margins).  LPW lines per wave: 64 / LPW lanes
+// render one line, the lower half of them its left window, the upper half its right one -- a half or a quarter of the waves,
+// the same per-pixel functions on the same pixels, the same span tests: records bit for bit those of the 32-pixel windows and
+// of the scan (tests/test_gpu_r4.py, PAOS_MASK_PAIRS=0 / 1, PAOS_MASK_SCAN=1).  Returns false (for the whole wave) when one
+// of the lines needs more: the caller then renders them with the next wider windows.
+template <int LPW>
+__device__ inline bool mask_multi_render(const MaskJobs& jobs, const MaskJob& jb, int item, int first, int lane) {
+  constexpr int G = 64 / LPW, W = G / 2, M = W >= 16 ? 3 : 1;  // lanes per line, pixels per window, margin
+  constexpr unsigned kWin = (1u << W) - 1u;
   const int n = jobs.n, axis = jb.axis, param_stride = jobs.param_stride;
-  const int half = lane >> 5, l32 = lane & 31;
-  const int line = first + half;
+  const int grp = lane / G, lg = lane % G;
+  const int line = first + grp;
   const bool valid = line < jb.line_end && line < n;
   const double* p = jb.params + (size_t)item * param_stride;
   const double* p2 = jb.params + jobs.batch_stride + (size_t)item * param_stride;
@@ -972,15 +976,15 @@ __device__ inline bool mask_pair_render(const MaskJobs& jobs, const MaskJob& jb,
     const double half_long = near_c < 1.0 ? sa * sqrt(1.0 - near_c * near_c) : 0.0;
     const double half_short = far_c < 1.0 ? sa * sqrt(1.0 - far_c * far_c) : 0.0;
     const int box_lo = max(0, axis == 0 ? box.ixmin : box.iymin), box_hi = min(n, axis == 0 ? box.ixmax : box.iymax);
-    wl0 = max(box_lo, (int)floor(ca - half_long) - 3);
-    const int wl1 = (int)ceil(ca - half_short) + 3;
-    const int wr1 = min(box_hi - 1, (int)ceil(ca + half_long) + 3);
-    wr0 = wr1 - 15;
-    const int wr_need = (int)floor(ca + half_short) - 3;
+    wl0 = max(box_lo, (int)floor(ca - half_long) - M);
+    const int wl1 = (int)ceil(ca - half_short) + M;
+    const int wr1 = min(box_hi - 1, (int)ceil(ca + half_long) + M);
+    wr0 = wr1 - (W - 1);
+    const int wr_need = (int)floor(ca + half_short) - M;
     auto sum2 = [&](double al, double ac) { const double u = al / sa, v = ac / sc; return axis == 0 ? __dadd_rn(__dmul_rn(u, u), __dmul_rn(v, v)) : __dadd_rn(__dmul_rn(v, v), __dmul_rn(u, u)); };
-    ok = wl1 - wl0 < 16 && wr_need >= wr0 && wl0 + 16 <= wr0 && half_long > 0.0;
+    ok = wl1 - wl0 < W && wr_need >= wr0 && wl0 + W <= wr0 && half_long > 0.0;
     if (ok) {
-      const double ia = __dsub_rn((double)(wl0 + 16) - 0.5, ca), ib = __dsub_rn((double)(wr0 - 1) + 0.5, ca);
+      const double ia = __dsub_rn((double)(wl0 + W) - 0.5, ca), ib = __dsub_rn((double)(wr0 - 1) + 0.5, ca);
       ok = sum2(ia, lo_c) <= 1.0 && sum2(ib, lo_c) <= 1.0 && sum2(ia, hi_c) <= 1.0 && sum2(ib, hi_c) <= 1.0;
       const double nc = lo_c > 0.0 ? lo_c : (hi_c < 0.0 ? hi_c : 0.0);
       if (ok && wl0 > box_lo) {
@@ -995,7 +999,7 @@ __device__ inline bool mask_pair_render(const MaskJobs& jobs, const MaskJob& jb,
   }
   // a line outside the loop's range or outside the bounding box needs no window at all
   if (!__all(!valid || !in_box || ok)) return false;  // wave-uniform
-  const int pos = l32 < 16 ? wl0 + l32 : wr0 + (l32 - 16);
+  const int pos = lg < W ? wl0 + lg : wr0 + (lg - W);
   double w = w_out;
   if (in_box) {
     const int c = axis == 0 ? pos : line, r = axis == 0 ? line : pos;
@@ -1008,12 +1012,12 @@ __device__ inline bool mask_pair_render(const MaskJobs& jobs, const MaskJob& jb,
   MaskLine* out = jb.lines + (size_t)item * n + line;
   double* vout = jb.vals + ((size_t)item * n + line) * (2 * kMaskW);
   if (!in_box) {  // the line never leaves w_out (what the scan finds for it)
-    if (l32 == 0) *out = {0, 0, 0, 0, 1.0, 0.0};
+    if (lg == 0) *out = {0, 0, 0, 0, 1.0, 0.0};
     return true;
   }
-  const unsigned not_out = (unsigned)(not_out64 >> (32 * half)), is_in = (unsigned)(is_in64 >> (32 * half));
-  const unsigned no_l = not_out & 0xFFFFu, no_r = not_out >> 16, in_l = is_in & 0xFFFFu, in_r = is_in >> 16;
-  const int i0 = wl0 + 16, i1 = wr0;  // the span between the windows: w_in throughout
+  const unsigned not_out = (unsigned)(not_out64 >> (G * grp)), is_in = (unsigned)(is_in64 >> (G * grp));
+  const unsigned no_l = not_out & kWin, no_r = (not_out >> W) & kWin, in_l = is_in & kWin, in_r = (is_in >> W) & kWin;
+  const int i0 = wl0 + W, i1 = wr0;  // the span between the windows: w_in throughout
   int p0 = no_l ? wl0 + (__ffs((int)no_l) - 1) : (i0 < i1 ? i0 : (no_r ? wr0 + (__ffs((int)no_r) - 1) : n));
   int p3 = no_r ? wr0 + 32 - __clz((int)no_r) : (i0 < i1 ? i1 : (no_l ? wl0 + 32 - __clz((int)no_l) : 0));
   int p1 = in_l ? wl0 + (__ffs((int)in_l) - 1) : (i0 < i1 ? i0 : (in_r ? wr0 + (__ffs((int)in_r) - 1) : -1));
@@ -1021,12 +1025,12 @@ __device__ inline bool mask_pair_render(const MaskJobs& jobs, const MaskJob& jb,
   if (p3 <= p0) { p0 = p1 = p2i = p3 = 0; }
   else if (p1 < 0) { p1 = p2i = p3; }
   if (p1 - p0 > kMaskW || p3 - p2i > kMaskW) {
-    if (l32 == 0) atomicAdd(jobs.overflow, 1);
+    if (lg == 0) atomicAdd(jobs.overflow, 1);
     p0 = p1 = p2i = p3 = 0;
   }
   if (pos >= p0 && pos < p1) vout[pos - p0] = w;
   if (pos >= p2i && pos < p3) vout[kMaskW + pos - p2i] = w;
-  if (l32 == 0) *out = {p0, p1, p2i, p3, 1.0, 0.0};
+  if (lg == 0) *out = {p0, p1, p2i, p3, 1.0, 0.0};
   return true;
 }
 
@@ -1042,11 +1046,15 @@ __global__ void __launch_bounds__(kMaskWaves * 64) mask_lines_kernel(MaskJobs jo
     mask_line_render<SHAPE>(jobs, jb, item, jb.line0 + wave, lane);
     return;
   }
-  const int first = jb.line0 + 2 * wave;  // (the grid covers half as many waves: launch_mask_jobs)
+  const int per = jobs.pairs >= 2 ? 4 : 2;  // lines per wave (the grid covers a half / a quarter as many waves: launch_mask_jobs)
+  const int first = jb.line0 + per * wave;
   if (first >= jb.line_end || first >= jobs.n) return;
-  if (mask_pair_render(jobs, jb, item, first, lane)) return;
-  mask_line_render<0>(jobs, jb, item, first, lane);
-  mask_line_render<0>(jobs, jb, item, first + 1, lane);
+  if (per == 4 && mask_multi_render<4>(jobs, jb, item, first, lane)) return;
+  for (int f = first; f < first + per; f += 2) {
+    if (mask_multi_render<2>(jobs, jb, item, f, lane)) continue;
+    mask_line_render<0>(jobs, jb, item, f, lane);
+    mask_line_render<0>(jobs, jb, item, f + 1, lane);
+  }
 }
 
 // ---- Zernike phase ----------------------------------------------------------------

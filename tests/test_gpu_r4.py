@@ -199,8 +199,9 @@ def test_two_passes_in_one_launch_change_no_bit(n, precision):
 @pytest.mark.parametrize("n", [1024, 4096])
 def test_two_window_aperture_records_equal_the_scan(n):
     """The aperture line records of an ellipse are rendered with one exact-overlap evaluation per line where the two
-    boundary runs of the line fit two 32-pixel windows (pointwise.h: mask_lines_kernel), and by the chunk scan of rounds
-    2-3 elsewhere; PAOS_MASK_SCAN=1 forces the scan.  Random ellipses -- round and flat, centred and near the edge of
+    boundary runs of the line fit two 32-pixel windows (pointwise.h: mask_lines_kernel) -- round 5: per two lines through
+    16-pixel windows, per four through 8-pixel ones --, and by the chunk scan of rounds 2-3 elsewhere; PAOS_MASK_SCAN=1
+    forces the scan, PAOS_MASK_PAIRS=0 / 1 the wider windows.  Random ellipses -- round and flat, centred and near the edge of
     the grid, apertures and obscurations -- riding on a row pass and on a column pass over a random field: the two
     renderings give the same field bit for bit."""
     import os
@@ -221,20 +222,27 @@ def test_two_window_aperture_records_equal_the_scan(n):
                 a = b = max(a, b)
             blocks = np.array([[[1.0, xc, yc, a, b]], [[0.0, obsc, 1.0, float(_lib.SHAPE_ELLIPSE), 0.0]], [[1.0, 0.0, 0.0, 0.0, 0.0]]])
             got = {}
-            for mode in ("windows", "scan"):
-                if mode == "scan":
-                    os.environ["PAOS_MASK_SCAN"] = "1"
+            # default: four lines per wave through 8-pixel windows where they fit (round 5), else two through 16-pixel ones,
+            # else one through 32-pixel ones, else the scan; the switches force the older paths.  The context keys its kept
+            # record sets by the mode too, so every mode renders (checked: `rendered` grows)
+            for mode, env in (("windows", {}), ("pairs", {"PAOS_MASK_PAIRS": "1"}), ("lines", {"PAOS_MASK_PAIRS": "0"}),
+                              ("scan", {"PAOS_MASK_SCAN": "1"})):
+                os.environ.update(env)
                 try:
                     out = []
+                    rendered = dev.record_set_stats()[1]
                     for axis in (0, 1):
                         dev.upload(0, u)
                         dev.run_passes([{"axis": axis, "fft1": 2, "fft2": -1, "pre": [(_lib.PW_MASK, 0, 0)], "mid": [], "post": []}], blocks)
                         out.append(dev.download(0))
+                    assert dev.record_set_stats()[1] == rendered + 2, mode
                     got[mode] = out
                 finally:
-                    os.environ.pop("PAOS_MASK_SCAN", None)
-            for x, y in zip(got["windows"], got["scan"]):
-                assert np.array_equal(x, y), (trial, a, b, xc, yc, obsc)
+                    for k in env:
+                        os.environ.pop(k, None)
+            for mode in ("pairs", "lines", "scan"):
+                for x, y in zip(got["windows"], got[mode]):
+                    assert np.array_equal(x, y), (mode, trial, a, b, xc, yc, obsc)
             # ... and the mask is what the stand-alone aperture kernel applies: |F^-1| of the row pass is the masked field
             if obsc == 0.0:
                 back = np.fft.ifft(got["windows"][0], axis=1)
