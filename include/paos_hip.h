@@ -304,6 +304,13 @@ int paos_run_program(paos_ctx* ctx, const paos_pass* passes, int n_passes, const
  * (row-major doubles, NaN where rho > 1 -- the masked array of wfo.py:654). */
 int paos_zernike(paos_ctx* ctx, int nmax, int kdim, const double* table, const double* params,
                  int param_stride, double* host_wfe);
+/* Round 5: paos_zernike for a caller who knows that some items hold COPIES of one field -- the surface right behind the
+ * start of a wavelength sweep or of a Monte-Carlo batch (wfo.py:118 fills every wavefront with the same constant under the
+ * same aperture): same_as[i] = index of an item whose field equals item i's.  Items that share their wfe map (records equal
+ * but for the wavelength) AND their field are served by one load per pixel; the values written are those of paos_zernike
+ * bit for bit.  NULL = paos_zernike. */
+int paos_zernike_like(paos_ctx* ctx, int nmax, int kdim, const double* table, const double* params,
+                      int param_stride, const double* same_as, double* host_wfe);
 
 
 /* ---- PolyOrthoNorm / Zorthonorm ------------------------------------------------ */

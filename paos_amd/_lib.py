@@ -100,6 +100,7 @@ SYMBOLS = {
     "paos_start": (ctypes.c_int, [_c_ctx, ctypes.c_double, ctypes.c_double, ctypes.c_int, _dbl_p, _dbl_p]),
     "paos_pupil_aperture": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p]),
     "paos_pupil_upload": (ctypes.c_int, [_c_ctx, ctypes.c_int, _dbl_p]),
+    "paos_zernike_like": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, _dbl_p, _dbl_p, ctypes.c_int, _dbl_p, _dbl_p]),
     "paos_zernike_gram": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, _dbl_p, _dbl_p, ctypes.c_int,
                                          ctypes.c_int, _dbl_p, ctypes.c_int, _dbl_p]),
     "paos_zernike_pupil": (ctypes.c_int, [_c_ctx, ctypes.c_int, ctypes.c_int, _dbl_p, _dbl_p, ctypes.c_int, _dbl_p]),
@@ -588,13 +589,21 @@ class DeviceFields:
                     "paos_run_passes")
         return None
 
-    def zernike(self, nmax, kdim, table, blocks, want_wfe=False, pupil=False):
-        """``pupil=True``: only pixels inside the pupil set by pupil_aperture / pupil_upload."""
+    def zernike(self, nmax, kdim, table, blocks, want_wfe=False, pupil=False, same_as=None):
+        """``pupil=True``: only pixels inside the pupil set by pupil_aperture / pupil_upload.  ``same_as`` ([batch] item
+        indices, without ``pupil``): items known to hold copies of one field (paos_zernike_like)."""
         t = np.ascontiguousarray(table, dtype=np.float64).reshape(-1)
         b = np.ascontiguousarray(blocks, dtype=np.float64)
         if b.ndim != 2 or b.shape[0] != self.batch:
             raise ValueError("zernike blocks must be [batch][stride]")
         out = np.empty((self.n, self.n), dtype=np.float64) if want_wfe else None
+        if same_as is not None and not pupil:
+            like = np.ascontiguousarray(same_as, dtype=np.float64).reshape(-1)
+            if like.size != self.batch:
+                raise ValueError("same_as must name an item per item")
+            self._check(self._lib.paos_zernike_like(self._ctx, int(nmax), int(kdim), _dptr(t), _dptr(b), int(b.shape[1]),
+                                                    _dptr(like), _dptr(out) if want_wfe else None), "paos_zernike_like")
+            return out
         fn = self._lib.paos_zernike_pupil if pupil else self._lib.paos_zernike
         self._check(fn(self._ctx, int(nmax), int(kdim), _dptr(t), _dptr(b), int(b.shape[1]),
                        _dptr(out) if want_wfe else None),

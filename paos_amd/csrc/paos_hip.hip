@@ -2720,7 +2720,7 @@ int paos_wts(paos_ctx* c, const double* params, int inverse) {
 }
 
 static int zernike_apply(paos_ctx* c, int nmax, int kdim, const double* table, const double* params,
-                         int param_stride, double* host_wfe, bool use_pupil) {
+                         int param_stride, double* host_wfe, bool use_pupil, const double* same_as = nullptr) {
   if (!c || !table || !params) return fail(c, PAOS_EINVAL, "null argument");
   if (nmax < 0 || kdim < nmax / 2 + 1 || param_stride < ZP_HEAD + 2 * (nmax + 1) * kdim)
     return fail(c, PAOS_EINVAL, "inconsistent Zernike table dimensions");
@@ -2757,10 +2757,24 @@ static int zernike_apply(paos_ctx* c, int nmax, int kdim, const double* table, c
     }
     if (members.empty()) members.push_back(0.0);
   }
-  const double *dgoff = nullptr, *dglen = nullptr, *dmembers = nullptr;
+  const double *dgoff = nullptr, *dglen = nullptr, *dmembers = nullptr, *dtwins = nullptr;
   if ((rc = arena_push(c, goff.data(), goff.size(), &dgoff))) return rc;
   if ((rc = arena_push(c, glen.data(), glen.size(), &dglen))) return rc;
   if ((rc = arena_push(c, members.data(), members.size(), &dmembers))) return rc;
+  if (same_as) {  // a group whose members all hold copies of one field reads the leader's (paos_zernike_like)
+    std::vector<double> twins(c->batch, 0.0);
+    bool any = false;
+    for (int i = 0; i < c->batch; ++i) {
+      if (!(same_as[i] >= 0.0) || same_as[i] >= (double)c->batch || same_as[i] != (double)(int)same_as[i])
+        return fail(c, PAOS_EINVAL, "same_as must hold item indices");
+      if (glen[i] < 2.0) continue;
+      bool all = true;
+      for (int g = 0; g < (int)glen[i]; ++g) all = all && same_as[(int)members[(size_t)goff[i] + g]] == same_as[i];
+      twins[i] = all ? 1.0 : 0.0;
+      any = any || all;
+    }
+    if (any && (rc = arena_push(c, twins.data(), twins.size(), &dtwins))) return rc;
+  }
   const dim3 grid(pw_blocks(c), c->batch), block(kPwThreads);
   double* wfe = host_wfe ? (double*)c->staging : nullptr;
   const double* pupil = use_pupil ? c->mask : nullptr;
@@ -2791,7 +2805,7 @@ static int zernike_apply(paos_ctx* c, int nmax, int kdim, const double* table, c
 #define ZK_LAUNCH(T, BRV, NC)                                                                                          \
   hipLaunchKernelGGL((zernike_kernel<T, BRV, Lay<T>::BC, NC>), grid, block, 0, c->stream, (cx<T>*)c->field, dt, dp,   \
                      param_stride, c->n, c->pitch, c->item_stride, nmax, kdim, wfe, pupil, m_first, m_end, dgoff, dglen, \
-                     dmembers)
+                     dmembers, dtwins)
   if (c->precision == PAOS_F64) {
     if (nmax <= 8) ZK_LAUNCH(double, BR, 8); else ZK_LAUNCH(double, BR, 0);
   } else {
@@ -2808,6 +2822,13 @@ int paos_zernike(paos_ctx* c, int nmax, int kdim, const double* table, const dou
   SETTLE_SCALE(c);
   if (c) (void)hipSetDevice(c->device);  // one process may drive several GPUs
   return zernike_apply(c, nmax, kdim, table, params, param_stride, host_wfe, false);
+}
+
+int paos_zernike_like(paos_ctx* c, int nmax, int kdim, const double* table, const double* params,
+                      int param_stride, const double* same_as, double* host_wfe) {
+  SETTLE_SCALE(c);
+  if (c) (void)hipSetDevice(c->device);
+  return zernike_apply(c, nmax, kdim, table, params, param_stride, host_wfe, false, same_as);
 }
 
 int paos_zernike_pupil(paos_ctx* c, int nmax, int kdim, const double* table, const double* params,

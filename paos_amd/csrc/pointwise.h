@@ -1073,7 +1073,7 @@ __global__ void zernike_kernel(cx<T>* field, const double* table, const double* 
                                int param_stride, int n, unsigned pitch, unsigned item_stride,
                                int nmax, int kdim, double* wfe_out, const double* pupil,
                                unsigned m_first, unsigned m_end, const double* grp_off, const double* grp_len,
-                               const double* grp_members) {
+                               const double* grp_members, const double* grp_twins = nullptr) {
   // Items whose records differ in the wavelength only (a wavelength sweep through one lens file: same sampling,
   // same coefficients) have the same wfe map: the first of them evaluates the polynomials once per pixel and applies
   // the phase to every member of its group (grp_members[grp_off[item] ...], grp_len[item] of them; 0 = this item is
@@ -1082,6 +1082,9 @@ __global__ void zernike_kernel(cx<T>* field, const double* table, const double* 
   const int glen = (int)grp_len[item];
   if (glen == 0) return;
   const double* members = grp_members + (int)grp_off[item];
+  // (round 5) grp_twins[item] != 0: the caller vouches that the fields of this group's members are copies of the leader's
+  // (the surface right behind the start of a sweep, paos_zernike_like): one load per pixel instead of one per member
+  const bool twins = grp_twins && grp_twins[item] != 0.0;
   const double* p = params + (size_t)item * param_stride;
   const double dx = p[ZP_DX], dy = p[ZP_DY], radius = p[ZP_RADIUS];
   const bool origin_y = p[ZP_ORIGIN_Y] != 0.0;
@@ -1158,6 +1161,8 @@ __global__ void zernike_kernel(cx<T>* field, const double* table, const double* 
       // alias, which the compiler cannot know -- one load -> sincos -> store chain per member was a 32-deep latency chain
       // per pixel (0.37 ms per step of a 32-wavelength sweep); the arithmetic per member is unchanged
       constexpr int kZernikeGroup = 8;  // (4: 0.37 -> 0.29 ms per step, 8: see profiles/r05_ab_variants_bench.txt)
+      cx<double> lead = {0.0, 0.0};
+      if (twins) { const cx<T>* fl = field + (size_t)item * item_stride + m; lead = {(double)fl->x, (double)fl->y}; }
       int g = 0;
       for (; g + kZernikeGroup <= glen; g += kZernikeGroup) {
         cx<T>* f4[kZernikeGroup];
@@ -1168,7 +1173,7 @@ __global__ void zernike_kernel(cx<T>* field, const double* table, const double* 
           const int it = (int)members[g + q];
           f4[q] = field + (size_t)it * item_stride + m;
           iw[q] = params[(size_t)it * param_stride + ZP_INV_WL];
-          v4[q] = {(double)f4[q]->x, (double)f4[q]->y};
+          if (twins) v4[q] = lead; else v4[q] = {(double)f4[q]->x, (double)f4[q]->y};
         }
 #pragma unroll
         for (int q = 0; q < kZernikeGroup; ++q) {
@@ -1184,7 +1189,7 @@ __global__ void zernike_kernel(cx<T>* field, const double* table, const double* 
         double sn, cs;
         sincos_fast(arg, &sn, &cs);
         cx<T>* f = field + (size_t)it * item_stride;
-        const cx<double> v = {(double)f[m].x, (double)f[m].y};
+        const cx<double> v = twins ? lead : cx<double>{(double)f[m].x, (double)f[m].y};
         f[m] = {(T)__dsub_rn(__dmul_rn(v.x, cs), __dmul_rn(v.y, sn)),
                 (T)__dadd_rn(__dmul_rn(v.x, sn), __dmul_rn(v.y, cs))};
       }

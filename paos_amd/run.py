@@ -59,6 +59,10 @@ STOP_DEFERRED = _os.environ.get("PAOS_STOP_DEFERRED", "1") != "0"
 # ... and a lean walk's first field is written inside the aperture's bounding BOX only (rows and columns: paos_start_box,
 # round 5; rounds 3-4 wrote whole rows); PAOS_START_BOX=0 writes whole rows again.
 START_BOX = _os.environ.get("PAOS_START_BOX", "1") != "0"
+# Items that start from the same constant under the same aperture hold copies of one field until something that depends on the
+# wavelength touches them: a Zernike surface right behind the start reads one field per group of copies (paos_zernike_like,
+# round 5).  PAOS_TWIN_FIELDS=0: every item's field is read.
+TWIN_FIELDS = _os.environ.get("PAOS_TWIN_FIELDS", "1") != "0"
 _MASK_RUN = 192  # kMaskW of csrc/frugal_pass.h
 
 
@@ -584,7 +588,7 @@ def _launch_apertures(dev, plans):
             dev.aperture(code, blocks)
 
 
-def _launch_zernike(dev, plans, want_wfe=False):
+def _launch_zernike(dev, plans, want_wfe=False, same_as=None):
     if isinstance(plans, _Plans) and not plans.summary()[1]:
         return None
     zs = [p["zernike"] for p in plans]
@@ -616,6 +620,8 @@ def _launch_zernike(dev, plans, want_wfe=False):
 
     coeffs = [z["Z"] if z is not None else None for z in zs]
     if not any(ortho):
+        if same_as is not None:  # (the items named hold copies of one field: the surface right behind the start)
+            return dev.zernike(nmax, kdim, table, build(coeffs), want_wfe=want_wfe, same_as=same_as)
         return dev.zernike(nmax, kdim, table, build(coeffs), want_wfe=want_wfe)
 
     # PolyOrthoNorm (zernike.py:320-402): U = M Z, so sum_k c_k U_k = sum_n (M^T c)_n Z_n -- the
@@ -787,6 +793,7 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
     state, n = beams.state, beams.n
     comp = (SeparableCompiler if _passes.SEPARABLE else PassCompiler)(len(states), dev.n)
     npass = 0
+    twins = None  # per item the index of an item whose field is a copy of its own (None: nothing known)
     # rows of each item known to be exactly zero in memory (outside [lo, hi)): set by stand-alone
     # apertures, kept by stops / Zernike / phase screens (they multiply), handed to the next pass
     # program (which skips them) and forgotten once that program has run
@@ -919,20 +926,24 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
                 stale[0] = rows0 is not None
                 stale_cols[0] = cols0 if stale[0] else None
                 want_wfe = len(plans) == 1 and bool(items[0]["save"])
-                wfe = _launch_zernike(dev, plans, want_wfe=want_wfe)
+                # still copies of each other unless this surface puts a wavefront error on them
+                untouched = not any(p["zernike"] is not None or p["phase_map"] is not None for p in plans)
+                copies = same_as if len(set(same_as)) < len(same_as) else None
+                wfe = _launch_zernike(dev, plans, want_wfe=want_wfe, same_as=copies if TWIN_FIELDS else None)
                 wfe = _launch_phase_maps(dev, plans, wfe)
                 if saved:
                     if lean is not None:
                         keep_reads_field()
                         lean.rows = known_rows()
                         lean.cols = stale_cols[0] if (stale[0] and lean.rows is not None) else None
-                        # still copies of each other unless this surface put a wavefront error on them
-                        untouched = not any(p["zernike"] is not None or p["phase_map"] is not None for p in plans)
-                        lean.same_as = same_as if untouched and len(set(same_as)) < len(same_as) else None
+                        lean.same_as = copies if untouched else None
                     on_saved(key, items, plans, wfe)
                     if lean is not None:
                         lean.same_as, lean.cols = None, None
                 _queue_steps(comp, lens, stw, ptp, wts, inv_stw, inv_wts)
+                # (round 5) ... and they stay copies until something wavelength-dependent is applied or queued: a Zernike surface
+                # right behind the start (SYN20's S02) reads one field per group of them (paos_zernike_like)
+                twins = copies if (TWIN_FIELDS and untouched and not comp.pending()) else None
                 continue
         fuse_ap = FUSE_APERTURES
         any_stop, any_zern, any_map, any_ap = plans.summary()
@@ -994,7 +1005,11 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
                 dev.norm2_release(prog_power[0])
             prog_power[0] = None
         want_wfe = len(plans) == 1 and bool(items[0]["save"])
-        wfe = _launch_zernike(dev, plans, want_wfe=want_wfe)
+        if twins is not None and (comp.pending() or fuse_ap or any_ap or any_stop):
+            twins = None  # (something has been applied to the fields, or waits to be)
+        wfe = _launch_zernike(dev, plans, want_wfe=want_wfe, same_as=twins)
+        if any_zern or any_map:
+            twins = None
         wfe = _launch_phase_maps(dev, plans, wfe)
         if saved:
             if lean is not None:
@@ -1007,6 +1022,8 @@ def _walk(dev, states, chains, on_saved, stats=None, fresh=None, lean=None, psf_
             if lean is not None:
                 lean.rows, lean.psf_ticket, lean.cols = None, None, None
         _queue_steps(comp, lens, stw, ptp, wts, inv_stw, inv_wts)
+        if comp.pending():
+            twins = None
     if power_state is not None and power_state["ticket"] is not None and not power_state.get("used"):
         dev.norm2_release(power_state["ticket"])  # (taken for a stop on the last surface, which nobody saved)
         power_state["ticket"] = None

@@ -196,11 +196,21 @@ class ModelDevice:
             cm, sm = cm * cr - sm * sr, sm * cr + cm * sr
         return rho, terms
 
-    def zernike(self, nmax, kdim, table, blocks, want_wfe=False, pupil=False):
-        """Mirror of csrc/pointwise.h zernike_kernel (same recurrences, NumPy)."""
-        self.log.append(("zernike", nmax))
+    def zernike(self, nmax, kdim, table, blocks, want_wfe=False, pupil=False, same_as=None):
+        """Mirror of csrc/pointwise.h zernike_kernel (same recurrences, NumPy).  ``same_as``: the library takes the caller's
+        word that those items hold copies of one field (paos_zernike_like); the model checks it on every pixel the kernel
+        reads (the unit disk)."""
+        self.log.append(("zernike", nmax) if same_as is None else ("zernike_like", nmax))
         table = np.asarray(table).reshape(nmax + 1, kdim, 3)
         wfe0 = None
+        if same_as is not None:
+            before = self.u.copy()
+            for i, b in enumerate(np.asarray(blocks)):
+                j = int(same_as[i])
+                if b[0] and j != i:
+                    inside = self._zernike_terms(nmax, kdim, table, b)[0] <= 1.0
+                    if not np.array_equal(before[i][inside], before[j][inside]):
+                        raise AssertionError(f"zernike(same_as=...): item {i} does not hold a copy of item {j}'s field")
         for i, b in enumerate(np.asarray(blocks)):
             if not b[0]:
                 continue

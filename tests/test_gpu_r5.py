@@ -289,3 +289,54 @@ def test_run_with_a_psd_surface_builds_the_screen_on_the_device():
     assert np.abs(b).max() > 0 and np.abs(a - b).max() <= 1e-13 * np.abs(b).max()
     for k in want:
         assert rel_err(got[k]["wfo"], want[k]["wfo"]) < 1e-11, k
+
+
+@pytest.mark.parametrize("n", [1024, 4096])
+def test_zernike_like_equals_zernike_bit_for_bit(n):
+    """Round 5: ``paos_zernike_like`` -- items that the caller knows to hold copies of one field (the surface right behind
+    the start of a sweep) and that share their wfe map are served by one load per pixel.  Eleven items in three start
+    groups (two apertures, one of them with and without the stop) and two coefficient sets -- so some wfe groups are twins
+    throughout, one is mixed and takes the ordinary loads: fields bit for bit those of ``paos_zernike``; a hint that
+    names no item raises."""
+    from paos_amd import _lib
+    from paos_amd.aperture import make_aperture
+    from paos_amd.planner import jacobi_recurrence, zernike_block
+    from paos_amd.zernike import Zernike, norm_factors
+
+    nb, k = 11, 15
+    dx = 4.0 / n
+    rng = np.random.default_rng(n)
+    m, nn = Zernike.j2mn(k, "noll")
+    norm = norm_factors(m, nn, True)
+    coef = [rng.standard_normal(k) * 40e-9, rng.standard_normal(k) * 25e-9]
+    aps = [make_aperture(n, dx, dx, 0.0, 0.0, hx=0.5, hy=0.5, shape="elliptical"),
+           make_aperture(n, dx, dx, 0.01, -0.02, hx=0.45, hy=0.4, shape="elliptical")]
+    start_group = [0, 0, 0, 0, 1, 1, 1, 2, 2, 0, 1]          # (aperture, stop) -> three distinct fields
+    which_ap = {0: 0, 1: 1, 2: 1}
+    stop_of = {0: 1.0, 1: 1.0, 2: 0.0}
+    coef_of = [0, 0, 0, 1, 0, 0, 1, 1, 1, 0, 0]               # wfe groups: items with coefficient set 0 / 1
+    wls = [0.8e-6 + 0.1e-6 * i for i in range(nb)]
+    blocks = []
+    nmax = kdim = None
+    for i in range(nb):
+        b, nmax, kdim = zernike_block(m, nn, norm, coef[coef_of[i]], dx, dx, 0.5, wls[i])
+        blocks.append(b)
+    table = jacobi_recurrence(nmax)
+    same_as = [start_group.index(g) for g in start_group]
+    dev = _lib.DeviceFields(n, nb)
+    try:
+        out = {}
+        for mode in ("plain", "like"):
+            dev.start(1.0, _lib.SHAPE_ELLIPSE, [aps[which_ap[g]].block() for g in start_group], [stop_of[g] for g in start_group])
+            if mode == "like":
+                dev.zernike(nmax, kdim, table, blocks, same_as=same_as)
+            else:
+                dev.zernike(nmax, kdim, table, blocks)
+            out[mode] = [dev.download(i) for i in range(nb)]
+        for i in range(nb):
+            assert np.array_equal(out["plain"][i], out["like"][i]), i
+            assert not np.array_equal(out["plain"][i], out["plain"][(i + 1) % nb])
+        with pytest.raises(_lib.PaosHipError, match="item indices"):
+            dev.zernike(nmax, kdim, table, blocks, same_as=[nb] * nb)
+    finally:
+        dev.close()

@@ -1098,6 +1098,47 @@ def test_psd_screens_are_built_by_the_device_from_the_hosts_draws():
         phase_maps.PSD_ON_DEVICE_FROM = keep
 
 
+def test_zernike_right_behind_the_start_reads_one_field_per_group_of_copies():
+    """Round 5: the wavefronts of a sweep start as copies of one field (same constant, same aperture at the entrance pupil)
+    and stay copies until something wavelength-dependent touches them; SYN20's Zernike surface sits right behind the start,
+    so the walk tells the library (``zernike(same_as=...)`` -> paos_zernike_like).  The model device checks the claim on
+    every pixel the kernel reads; the fields equal those of a walk with the hint switched off; a chain that propagates
+    before its Zernike surface, or stops / clips on it, gives no hint."""
+    import paos_amd.run as prun
+    from paos_amd.run import run_batch
+
+    n, nb = 64, 3
+    wls = [1.0e-6, 1.3e-6, 1.7e-6]
+
+    def walk(chains, **kw):
+        dev = ModelDevice(n, nb)
+        out = run_batch(1.0, wls, n, 4, FIELD, chains, outputs=("wfo",), dev=dev, **kw)
+        return dev, out
+
+    chains = [syn20_chain() for _ in range(nb)]
+    dev, got = walk(chains)
+    assert any(k == "zernike_like" for k, _ in dev.log) and not any(k == "zernike" for k, _ in dev.log)
+    keep = prun.TWIN_FIELDS
+    try:
+        prun.TWIN_FIELDS = False
+        dev0, want = walk(chains)
+    finally:
+        prun.TWIN_FIELDS = keep
+    assert not any(k == "zernike_like" for k, _ in dev0.log) and any(k == "zernike" for k, _ in dev0.log)
+    for i in range(nb):
+        for k in want[i]:
+            assert np.array_equal(got[i][k]["wfo"], want[i][k]["wfo"]), (i, k)
+    # a propagation between the start and the Zernike surface: the fields have diverged, no hint
+    from paos_amd.abcd import ABCD
+
+    moved = [syn20_chain() for _ in range(nb)]
+    for c in moved:
+        first = next(iter(c))
+        c[first] = dict(c[first], ABCDt=ABCD(thickness=0.3, curvature=0.0), ABCDs=ABCD(thickness=0.3, curvature=0.0))
+    dev2, _ = walk(moved)
+    assert not any(k == "zernike_like" for k, _ in dev2.log) and any(k == "zernike" for k, _ in dev2.log)
+
+
 def test_batch_planner_equals_the_per_item_planner():
     """Round 5: ``run._plan_batch`` plans the apertures of a whole batch with array arithmetic.  Against ``_plan_host`` item by
     item, on random batches -- ellipses and rectangles, apertures and obscurations, missing centres, different sampling per
