@@ -100,6 +100,12 @@ struct paos_ctx {
   double* psf = nullptr;  // batch x item_stride intensities kept on the device, blocked like the field (paos_psf_keep)
   double* map_dev = nullptr;      // one n x n phase map kept on the device (paos_phase_map_items) and the key it was uploaded under
   unsigned long long map_key = 0;
+  // (round 5) the power sums of the last start, kept with everything they depend on (shape, constant, aperture records,
+  // stop flags): the entrance pupil of a wavelength sweep or a Monte-Carlo study is the same step after step, and the sums
+  // are a pure function of those -- the next start with the same key copies them instead of evaluating the exact pixel
+  // overlaps again (start_power_kernel + norm2_final_kernel: 0.08 ms of a 14.6 ms SYN20 step).  PAOS_START_POWER_MEMO=0: never.
+  std::vector<double> start_key;
+  double* start_norm2 = nullptr;  // [batch]
   cx<double>* psd_scratch = nullptr;  // one item in the field's layout: the spectrum of a PSD screen (paos_psd_screen)
   int* psd_bad = nullptr;
   double* psf_partial = nullptr;  // per-workgroup sums of a pass that stores the PSF (paos_run_program: final_intensity)
@@ -1880,6 +1886,7 @@ int paos_ctx_destroy(paos_ctx* c) {
   if (c->psf) (void)hipFree(c->psf);
   if (c->map_dev) (void)hipFree(c->map_dev);
   if (c->psd_scratch) (void)hipFree(c->psd_scratch);
+  if (c->start_norm2) (void)hipFree(c->start_norm2);
   if (c->psd_bad) (void)hipFree(c->psd_bad);
   if (c->pow_partial) (void)hipFree(c->pow_partial);
   if (c->dyn_scale) (void)hipFree(c->dyn_scale);
@@ -2021,9 +2028,27 @@ static int start_impl(paos_ctx* c, double re, double im, int shape, const double
   if ((rc = arena_push(c, glen.data(), glen.size(), &dglen))) return rc;
   if ((rc = arena_push(c, members.data(), members.size(), &dmembers))) return rc;
   const dim3 block(kPwThreads);
+  // the power sums: found (same shape, constant, aperture records and stop flags as the last start) or evaluated and kept
+  bool power_found = false;
+  if (any_stop) {
+    static const bool memo = [] { const char* e = getenv("PAOS_START_POWER_MEMO"); return !(e && e[0] == '0'); }();
+    std::vector<double> key;
+    key.reserve(3 + (size_t)c->batch * (AP_STRIDE + 1));
+    key.push_back((double)shape); key.push_back(re); key.push_back(im);
+    key.insert(key.end(), aperture, aperture + (size_t)c->batch * AP_STRIDE);
+    key.insert(key.end(), flags.begin(), flags.end());
+    power_found = memo && c->start_norm2 && key.size() == c->start_key.size() &&
+                  !std::memcmp(key.data(), c->start_key.data(), key.size() * sizeof(double));
+    if (power_found) {
+      HIPCHK(c, hipMemcpyAsync(c->norm2, c->start_norm2, (size_t)c->batch * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    } else {
+      c->start_key.clear();  // (set again behind the launches below)
+      if (memo) c->start_key = std::move(key);
+    }
+  }
 #define START_LAUNCH(T, BRV, S)                                                                         \
   do {                                                                                                  \
-    if (any_stop) {                                                                                     \
+    if (any_stop && !power_found) {                                                                     \
       hipLaunchKernelGGL((start_power_kernel<T, BRV, Lay<T>::BC, S>), dim3(c->nparts, c->batch), block, 0, \
                          c->stream, dp, c->n, c->pitch, c->item_stride, re, im, c->partial, dcompute);  \
       hipLaunchKernelGGL(norm2_final_kernel, dim3(c->batch), block, 0, c->stream, c->partial, c->norm2,   \
@@ -2040,6 +2065,10 @@ static int start_impl(paos_ctx* c, double re, double im, int shape, const double
   }
 #undef START_LAUNCH
   HIPCHK(c, hipGetLastError());
+  if (any_stop && !power_found && !c->start_key.empty()) {  // keep the sums just evaluated (c->norm2 is rewritten by every reduction)
+    if (!c->start_norm2) HIPCHK(c, hipMalloc(&c->start_norm2, (size_t)c->batch * sizeof(double)));
+    HIPCHK(c, hipMemcpyAsync(c->start_norm2, c->norm2, (size_t)c->batch * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+  }
   return PAOS_OK;
 }
 

@@ -340,3 +340,40 @@ def test_zernike_like_equals_zernike_bit_for_bit(n):
             dev.zernike(nmax, kdim, table, blocks, same_as=[nb] * nb)
     finally:
         dev.close()
+
+
+def test_start_power_sums_are_found_again_only_for_the_same_start():
+    """Round 5: the power sums of a start (exact pixel overlaps of the aperture, per distinct aperture of the batch) are kept
+    with everything they depend on; the next start with the same shape, constant, records and stop flags copies them.  A
+    second start equals the first bit for bit, a start with another aperture / other flags / another constant equals that of
+    a fresh context, and so does the first one again afterwards."""
+    from paos_amd import _lib
+    from paos_amd.aperture import make_aperture
+
+    n, nb = 1024, 3
+    dx = 4.0 / n
+    a1 = [make_aperture(n, dx, dx, 0.0, 0.0, hx=0.5, hy=0.5, shape="elliptical").block() for _ in range(nb)]
+    a2 = [make_aperture(n, dx, dx, 0.0, 0.01 * i, hx=0.45, hy=0.4, shape="elliptical").block() for i in range(nb)]
+    cases = [(1.0, a1, [1.0] * nb), (1.0, a1, [1.0] * nb), (1.0, a2, [1.0] * nb), (1.0, a2, [1.0, 0.0, 1.0]), (0.5 + 0.25j, a2, [1.0, 0.0, 1.0]),
+             (1.0, a1, [1.0] * nb)]
+
+    def fields(dev, case):
+        value, aps, stops = case
+        dev.start(value, _lib.SHAPE_ELLIPSE, aps, stops)
+        return [dev.download(i) for i in range(nb)]
+
+    dev = _lib.DeviceFields(n, nb)
+    try:
+        for k, case in enumerate(cases):
+            got = fields(dev, case)
+            fresh = _lib.DeviceFields(n, nb)
+            try:
+                want = fields(fresh, case)
+            finally:
+                fresh.close()
+            for i in range(nb):
+                assert np.array_equal(got[i], want[i]), (k, i)
+            p = np.array([np.sum(np.abs(g) ** 2) for g in got])
+            assert np.allclose(p[np.array(case[2]) != 0.0], 1.0, rtol=1e-12)
+    finally:
+        dev.close()
