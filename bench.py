@@ -286,9 +286,13 @@ def measure_traffic(grid, batch, precision):
                     per_dispatch[k] = (name, val + float(row["Counter_Value"]))
             seq = [per_dispatch[k] for k in sorted(per_dispatch)]
             # the child runs a warm-up step first: the counted step is the steady state the timed region measures.
-            # A step opens with the start-of-chain power kernel: keep what follows the last one.
-            starts = [i for i, (name, _) in enumerate(seq) if "start_power_kernel" in name]
-            series[counter] = seq[starts[-1]:] if starts else seq
+            # A step opens with the kernel that writes the start field -- behind the start's power kernel and its final
+            # reduction when the sums are not found from the step before (round 5): keep what follows the last opening.
+            writes = [i for i, (name, _) in enumerate(seq) if "start_write_kernel" in name]
+            first = writes[-1] if writes else 0
+            if first >= 2 and "start_power_kernel" in seq[first - 2][0] and "norm2_final_kernel" in seq[first - 1][0]:
+                first -= 2
+            series[counter] = seq[first:]
             if counter == "FETCH_SIZE":  # durations of the non-pass kernels (under the profiler: indicative)
                 rows = []
                 for path in glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True):
@@ -300,8 +304,11 @@ def measure_traffic(grid, batch, precision):
                                 continue
                             rows.append((t0, row.get("Kernel_Name", ""), (t1 - t0) * 1e-6))
                 rows.sort()
-                opens = [i for i, r in enumerate(rows) if "start_power_kernel" in r[1]]
-                for _, name, dt in (rows[opens[-1]:] if opens else rows):  # the counted step, like the counters
+                opens = [i for i, r in enumerate(rows) if "start_write_kernel" in r[1]]
+                first = opens[-1] if opens else 0
+                if first >= 2 and "start_power_kernel" in rows[first - 2][1] and "norm2_final_kernel" in rows[first - 1][1]:
+                    first -= 2
+                for _, name, dt in rows[first:]:  # the counted step, like the counters
                     trace_ms[name] = trace_ms.get(name, 0.0) + dt
         except Exception as exc:  # noqa: BLE001 -- the bench line must come out whatever the profiler does
             return None, f"rocprofv3 --pmc {counter}: {type(exc).__name__}: {exc}"
