@@ -241,6 +241,17 @@ def measure(dev, n, precision, wavelengths_of, chains, steps, warmup, comm=None,
             "per_step_sets": per_step_sets, "first_timed_step": first_step + warmup, "res": res}
 
 
+def counted_step_from(kernel_names):
+    """Index of the first dispatch of the LAST chain step in a list of kernel names in dispatch order.  A step opens with the
+    kernel that writes the start field -- behind the start's power kernel and its final reduction when the power sums are
+    not found from the step before (round 5: they are kept across identical starts)."""
+    writes = [i for i, name in enumerate(kernel_names) if "start_write_kernel" in name]
+    first = writes[-1] if writes else 0
+    if first >= 2 and "start_power_kernel" in kernel_names[first - 2] and "norm2_final_kernel" in kernel_names[first - 1]:
+        first -= 2
+    return first
+
+
 def measure_traffic(grid, batch, precision):
     """HBM bytes of every kernel of ONE chain step from the PMC counters, collected the way MI355X_MICROARCH.md
     prescribes: this script once under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and once under `... --pmc WRITE_SIZE`
@@ -288,11 +299,7 @@ def measure_traffic(grid, batch, precision):
             # the child runs a warm-up step first: the counted step is the steady state the timed region measures.
             # A step opens with the kernel that writes the start field -- behind the start's power kernel and its final
             # reduction when the sums are not found from the step before (round 5): keep what follows the last opening.
-            writes = [i for i, (name, _) in enumerate(seq) if "start_write_kernel" in name]
-            first = writes[-1] if writes else 0
-            if first >= 2 and "start_power_kernel" in seq[first - 2][0] and "norm2_final_kernel" in seq[first - 1][0]:
-                first -= 2
-            series[counter] = seq[first:]
+            series[counter] = seq[counted_step_from([name for name, _ in seq]):]
             if counter == "FETCH_SIZE":  # durations of the non-pass kernels (under the profiler: indicative)
                 rows = []
                 for path in glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True):
@@ -304,11 +311,7 @@ def measure_traffic(grid, batch, precision):
                                 continue
                             rows.append((t0, row.get("Kernel_Name", ""), (t1 - t0) * 1e-6))
                 rows.sort()
-                opens = [i for i, r in enumerate(rows) if "start_write_kernel" in r[1]]
-                first = opens[-1] if opens else 0
-                if first >= 2 and "start_power_kernel" in rows[first - 2][1] and "norm2_final_kernel" in rows[first - 1][1]:
-                    first -= 2
-                for _, name, dt in rows[first:]:  # the counted step, like the counters
+                for _, name, dt in rows[counted_step_from([r[1] for r in rows]):]:  # the counted step, like the counters
                     trace_ms[name] = trace_ms.get(name, 0.0) + dt
         except Exception as exc:  # noqa: BLE001 -- the bench line must come out whatever the profiler does
             return None, f"rocprofv3 --pmc {counter}: {type(exc).__name__}: {exc}"

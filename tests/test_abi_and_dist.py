@@ -600,3 +600,19 @@ def test_dmabuf_ipc_is_exported_only_for_an_rccl_communicator():
     """) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr
+
+
+def test_bench_finds_the_counted_step_of_a_pmc_child_run():
+    """bench.measure_traffic keeps the dispatches of the LAST step of its child runs (a warm-up step, then the counted one).
+    Since round 5 the start's power kernel runs only when the sums are not found from the step before, so a step is
+    recognised by the kernel that writes the start field -- with the power kernel and its reduction in front when present."""
+    import bench
+
+    power = ["void paos::start_power_kernel<double, 4, 2, 0>(...)", "paos::norm2_final_kernel(...)"]
+    body = ["void paos::start_write_kernel<double, 4, 2, 0>(...)", "void paos::norm2_partial_kernel<double>(...)",
+            "paos::norm2_final_kernel(...)", "void paos::zernike_kernel<double, 4, 2, 8>(...)",
+            "void paos::frugal_pass_kernel<double, 4096, ...>(...)", "void paos::mask_lines_kernel<0>(...)"]
+    assert bench.counted_step_from(power + body + body) == len(power) + len(body)           # sums found on the second step
+    assert bench.counted_step_from(power + body + power + body) == len(power) + len(body)   # PAOS_START_POWER_MEMO=0
+    assert bench.counted_step_from(body) == 0 and bench.counted_step_from(power + body) == 0
+    assert bench.counted_step_from(["void paos::frugal_pass_kernel<...>(...)"]) == 0        # (a chain without a start: everything)
