@@ -1173,7 +1173,13 @@ __global__ void zernike_kernel(cx<T>* field, const double* table, const double* 
           const int it = (int)members[g + q];
           f4[q] = field + (size_t)it * item_stride + m;
           iw[q] = params[(size_t)it * param_stride + ZP_INV_WL];
-          if (twins) v4[q] = lead; else v4[q] = {(double)f4[q]->x, (double)f4[q]->y};
+        }
+        if (twins) {
+#pragma unroll
+          for (int q = 0; q < kZernikeGroup; ++q) v4[q] = lead;
+        } else {
+#pragma unroll
+          for (int q = 0; q < kZernikeGroup; ++q) v4[q] = {(double)f4[q]->x, (double)f4[q]->y};
         }
 #pragma unroll
         for (int q = 0; q < kZernikeGroup; ++q) {
