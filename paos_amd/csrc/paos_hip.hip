@@ -942,12 +942,17 @@ int mask_render_mode() {
   const char* pe = getenv("PAOS_MASK_PAIRS");
   return (pe && pe[0] == '0') ? 1 : ((pe && pe[0] == '1') ? 2 : 3);
 }
+// ... and rectangle records: 64 lines per wave from one column profile (round 5); PAOS_MASK_RECT_BLOCKS=0: one line per wave
+bool mask_rect_blocks() {
+  const char* e = getenv("PAOS_MASK_RECT_BLOCKS");
+  return !(e && e[0] == '0');
+}
 
 int assign_mask_set(paos_ctx* c, const paos_pass& p, LoweredPass& lp, const double* blocks) {
   std::vector<double> key;
   key.reserve((size_t)2 * c->batch * FP_STRIDE + c->batch + 3);
   key.push_back((double)p.axis);
-  key.push_back((double)mask_render_mode());  // (the renderers give the same records bit for bit -- and a test that says so must render twice)
+  key.push_back((double)(mask_render_mode() + (mask_rect_blocks() ? 0 : 8)));  // (the renderers give the same records bit for bit -- and a test that says so must render twice)
   const double* ap = blocks + (size_t)lp.mask_block * c->batch * FP_STRIDE;
   key.insert(key.end(), ap, ap + (size_t)2 * c->batch * FP_STRIDE);  // the two consecutive block sets
   key.insert(key.end(), lp.mask_shared.begin(), lp.mask_shared.end());
@@ -1004,6 +1009,7 @@ int launch_mask_jobs(paos_ctx* c, MaskJobs& jobs, int count) {
     const int mode = mask_render_mode();
     jobs.windows = mode != 0 ? 1 : 0;
     jobs.pairs = mode >= 2 ? mode - 1 : 0;
+    jobs.rect_blocks = mask_rect_blocks() ? 1 : 0;
   }
   int widest = 0, shapes = 0;
   for (int j = 0; j < count; ++j) {
@@ -1014,7 +1020,8 @@ int launch_mask_jobs(paos_ctx* c, MaskJobs& jobs, int count) {
   // (ellipses: a wave renders four / two lines, the grid covers a quarter / half as many waves)
   const int per_wg = 4 * (jobs.pairs >= 2 ? 4 : (jobs.pairs ? 2 : 1));
   if (shapes & 1) hipLaunchKernelGGL(mask_lines_kernel<0>, dim3((widest + per_wg - 1) / per_wg, c->batch, count), block, 0, c->stream, jobs);
-  if (shapes & 2) hipLaunchKernelGGL(mask_lines_kernel<1>, dim3((widest + 3) / 4, c->batch, count), block, 0, c->stream, jobs);
+  const int rect_per_wg = 4 * (jobs.rect_blocks ? 64 : 1);
+  if (shapes & 2) hipLaunchKernelGGL(mask_lines_kernel<1>, dim3((widest + rect_per_wg - 1) / rect_per_wg, c->batch, count), block, 0, c->stream, jobs);
   HIPCHK(c, hipGetLastError());
   return PAOS_OK;
 }

@@ -746,6 +746,7 @@ struct MaskJobs {
   MaskJob job[kMaskJobs];
   int windows;       // 1: lines whose two boundary runs fit two 32-pixel windows take the one-evaluation path (PAOS_MASK_SCAN=1: 0)
   int pairs;         // (round 5) 2: a wave renders FOUR lines at once when all fit two 8-pixel windows, else / 1: TWO through 16-pixel windows (PAOS_MASK_PAIRS=1), 0: one line per wave (=0)
+  int rect_blocks;   // 1 (round 5): a wave renders 64 lines of a rectangle's records at once -- one column profile for all of them (PAOS_MASK_RECT_BLOCKS=0: 0)
   int batch_stride;  // doubles between the two parameter block sets of a job (= batch * param_stride)
   int param_stride, n;
   int* overflow;
@@ -1034,6 +1035,74 @@ __device__ inline bool mask_multi_render(const MaskJobs& jobs, const MaskJob& jb
   return true;
 }
 
+// Round 5: the records of a RECTANGLE, 64 lines per wave.  The mask is separable -- along a line the record holds the counts of
+// the line's axis over S, the same for every line inside the box, and `lm` the count of the other axis over S -- so the column
+// profile the one-line path scans for every line (32 sub-sample tests per pixel) is scanned once per wave and copied; lane l
+// owns line first + l and forms its `lm`.  The same per-pixel function on the same pixels: records bit for bit those of
+// mask_line_render<1> (tests/test_gpu_r5.py, PAOS_MASK_RECT_BLOCKS=0).  `prof`: 2 kMaskW doubles of LDS of this wave.
+__device__ inline void mask_rect_block_render(const MaskJobs& jobs, const MaskJob& jb, int item, int first, int lane, double* prof) {
+  const int n = jobs.n, axis = jb.axis, param_stride = jobs.param_stride;
+  if (first >= jb.line_end || first >= n) return;
+  const double* p = jb.params + (size_t)item * param_stride;
+  const double* p2 = jb.params + jobs.batch_stride + (size_t)item * param_stride;
+  if (p[AP_ENABLE] == 0.0 || 1 != (int)p2[3]) return;
+  const double xc = p[AP_XC], yc = p[AP_YC], a = p[AP_A], b = p[AP_B];
+  const int subpix = (int)p2[2];
+  const double hw = a / 2.0, hh = b / 2.0;
+  const ApertureBox box = make_box(xc, yc, fabs(hw), fabs(hh));
+  const int line = first + lane;
+  const bool valid = line < jb.line_end && line < n;
+  const bool in_box = valid && (axis == 0 ? (line >= box.iymin && line < box.iymax) : (line >= box.ixmin && line < box.ixmax));
+  const int c_other = axis == 0 ? subpixel_count_1d(line, yc, hh, subpix) : subpixel_count_1d(line, xc, hw, subpix);
+  const double lm = in_box ? (double)c_other / (double)subpix : 0.0;
+  const unsigned long long in_lines = __ballot(in_box);
+  int p0 = n, p1 = -1, p2i = -1, p3 = 0;  // first non-out, first in, last in + 1, last non-out + 1 -- of every line inside the box
+  auto weight = [&](int pos) {  // mask_line_render<1>'s pixel rule for a line inside the box
+    const bool inside = axis == 0 ? (pos >= box.ixmin && pos < box.ixmax) : (pos >= box.iymin && pos < box.iymax);
+    return inside ? (double)(axis == 0 ? subpixel_count_1d(pos, xc, hw, subpix) : subpixel_count_1d(pos, yc, hh, subpix)) / (double)subpix : 0.0;
+  };
+  if (in_lines) {
+    const int scan_lo = max(0, (axis == 0 ? box.ixmin : box.iymin)) & ~63, scan_hi = min(n, axis == 0 ? box.ixmax : box.iymax);
+    for (int base = scan_lo; base < scan_hi; base += 64) {
+      const double w = weight(base + lane);
+      const unsigned long long not_out = __ballot(w != 0.0), is_in = __ballot(w == 1.0);
+      if (not_out) {
+        p0 = min(p0, base + (int)__ffsll((long long)not_out) - 1);
+        p3 = max(p3, base + 64 - (int)__clzll((long long)not_out));
+      }
+      if (is_in) {
+        if (p1 < 0) p1 = base + (int)__ffsll((long long)is_in) - 1;
+        p2i = base + 64 - (int)__clzll((long long)is_in);
+      }
+    }
+  }
+  if (p3 <= p0) { p0 = p1 = p2i = p3 = 0; }           // the lines never leave w_out
+  else if (p1 < 0) { p1 = p2i = p3; }                  // no interior: one partial run [p0, p3)
+  if (p1 - p0 > kMaskW || p3 - p2i > kMaskW) {
+    if (lane == 0) atomicAdd(jobs.overflow, __popcll(in_lines));
+    p0 = p1 = p2i = p3 = 0;
+  }
+  for (int side = 0; side < 2; ++side) {
+    const int lo = side == 0 ? p0 : p2i, hi = side == 0 ? p1 : p3;
+    for (int pos = lo + lane; pos < hi; pos += 64) prof[side * kMaskW + pos - lo] = weight(pos);
+  }
+  // the profile is written and read by this wave only: order the LDS traffic, no workgroup barrier
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  if (valid) {
+    MaskLine* out = jb.lines + (size_t)item * n + line;
+    if (in_box) *out = {p0, p1, p2i, p3, lm, 0.0}; else *out = {0, 0, 0, 0, lm, 0.0};
+  }
+  const int len0 = p1 - p0, len1 = p3 - p2i;
+  for (unsigned long long todo = in_lines; todo; todo &= todo - 1) {
+    const int k = (int)__ffsll((long long)todo) - 1;
+    double* vout = jb.vals + ((size_t)item * n + (first + k)) * (2 * kMaskW);
+    for (int j = lane; j < len0; j += 64) vout[j] = prof[j];
+    for (int j = lane; j < len1; j += 64) vout[kMaskW + j] = prof[kMaskW + j];
+  }
+}
+
 template <int SHAPE>
 __global__ void __launch_bounds__(kMaskWaves * 64) mask_lines_kernel(MaskJobs jobs) {
   const MaskJob& jb = jobs.job[blockIdx.z];
@@ -1042,6 +1111,11 @@ __global__ void __launch_bounds__(kMaskWaves * 64) mask_lines_kernel(MaskJobs jo
   if (jb.shared[item] != 0.0) return;  // reads the records of an earlier, identical item
   const int lane = threadIdx.x & 63;
   const int wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (SHAPE == 1 && jobs.rect_blocks != 0) {  // 64 lines per wave (the grid covers a 64th of the waves: launch_mask_jobs)
+    __shared__ double prof[kMaskWaves][2 * kMaskW];
+    mask_rect_block_render(jobs, jb, item, jb.line0 + 64 * wave, lane, prof[threadIdx.x >> 6]);
+    return;
+  }
   if (!(SHAPE == 0 && jobs.pairs != 0)) {  // one line per wave
     mask_line_render<SHAPE>(jobs, jb, item, jb.line0 + wave, lane);
     return;

@@ -377,3 +377,50 @@ def test_start_power_sums_are_found_again_only_for_the_same_start():
             assert np.allclose(p[np.array(case[2]) != 0.0], 1.0, rtol=1e-12)
     finally:
         dev.close()
+
+
+@pytest.mark.parametrize("n", [1024, 4096])
+def test_rectangle_records_rendered_64_lines_at_a_time_equal_the_one_line_renderer(n):
+    """Round 5: the line records of a rectangular aperture (a field stop, a slit) are rendered 64 lines per wave from ONE
+    column profile (pointwise.h: mask_rect_block_render); PAOS_MASK_RECT_BLOCKS=0 keeps the one-line-per-wave renderer,
+    which scans the profile for every line.  Random rectangles -- wide and narrow, centred and near the edge of the grid,
+    partly off it -- riding on a row pass and on a column pass over a random field: the same field bit for bit, and what
+    comes back is the masked field."""
+    import os
+
+    from paos_amd import _lib
+
+    rng = np.random.default_rng(11 * n)
+    u = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    dev = _lib.DeviceFields(n, 1, "fp64")
+    try:
+        for trial in range(8):
+            w, h = rng.uniform(3.0, 0.8 * n, 2)
+            if trial == 3:
+                h = 2.4  # a slit a few pixels high
+            xc, yc = (n / 2 + rng.uniform(-3, 3, 2)) if trial % 2 == 0 else rng.uniform(0.05 * n, 0.95 * n, 2)
+            blocks = np.array([[[1.0, xc, yc, w, h]], [[0.0, 0.0, 32.0, float(_lib.SHAPE_RECT), 0.0]], [[1.0, 0.0, 0.0, 0.0, 0.0]]])
+            got = {}
+            for mode, env in (("blocks", {}), ("lines", {"PAOS_MASK_RECT_BLOCKS": "0"})):
+                os.environ.update(env)
+                try:
+                    out = []
+                    rendered = dev.record_set_stats()[1]
+                    for axis in (0, 1):
+                        dev.upload(0, u)
+                        dev.run_passes([{"axis": axis, "fft1": 2, "fft2": -1, "pre": [(_lib.PW_MASK, 0, 0)], "mid": [], "post": []}], blocks)
+                        out.append(dev.download(0))
+                    assert dev.record_set_stats()[1] == rendered + 2, mode
+                    got[mode] = out
+                finally:
+                    for k in env:
+                        os.environ.pop(k, None)
+            for x, y in zip(got["blocks"], got["lines"]):
+                assert np.array_equal(x, y), (trial, w, h, xc, yc)
+            back = np.fft.ifft(got["blocks"][0], axis=1)
+            yy, xx = np.mgrid[0:n, 0:n]
+            outside = (np.abs(xx - xc) > w / 2 + 1.5) | (np.abs(yy - yc) > h / 2 + 1.5)
+            inside = (np.abs(xx - xc) < w / 2 - 1.5) & (np.abs(yy - yc) < h / 2 - 1.5)
+            assert (np.abs(back[outside]) < 1e-9).all() and np.allclose(back[inside], u[inside], rtol=0, atol=1e-9)
+    finally:
+        dev.close()
