@@ -217,6 +217,10 @@ def extras(args, esz, measure, roofline_block, sweep_report):
         guarded(f"{n2}^2", lambda n2=n2, nb2=nb2: _syn20(n2, nb2, args.precision, steps, warmup, esz, measure, roofline_block,
                                                           sweep_report))
     if args.precision == "fp64":
+        # the headline workload with twice the wavefronts per step: what the per-step costs that do not grow with the batch
+        # (launch gaps, tails, the start) are worth -- the headline stays at 32 per step, as in every round
+        guarded("4096^2 x 64", lambda: _syn20(4096, 64, "fp64", steps, warmup, esz, measure, roofline_block, sweep_report,
+                                               label="SYN20, walked sweep, 4096^2 fp64, 64 wavefronts per step"))
         guarded("fp32_4096", lambda: _syn20(4096, 32, "fp32", steps, warmup, 8, measure, roofline_block, sweep_report,
                                             label="SYN20, walked sweep, 4096^2 in fp32 mode (complex64 field, fp64 phase arguments)"))
     guarded("dense", lambda: _dense(args, esz, measure, roofline_block))
