@@ -204,7 +204,7 @@ def _configs():
 
 
 def extras(args, esz, measure, roofline_block, sweep_report):
-    steps, warmup = max(args.steps, 5), max(args.warmup, 2)
+    steps, warmup = min(max(args.steps, 5), 20), max(args.warmup, 2)
     out = {}
 
     def guarded(name, fn):

@@ -23,7 +23,7 @@ cd "$ROOT"
 ./build/fftbench 10 > "$OUT/fftbench.txt" 2>&1
 [ -x ./build/timeline ] && ./build/timeline > "$OUT/timeline.txt" 2>&1
 # (round 5: stdout of bench.py is the <= 4 KB contract line; everything else goes to the --detail record)
-python3 bench.py --steps 20 --warmup 5 --detail "$OUT/bench_default.json" > "$OUT/bench_default_line.json" 2> "$OUT/bench_default.err"
+python3 bench.py --detail "$OUT/bench_default.json" > "$OUT/bench_default_line.json" 2> "$OUT/bench_default.err"
 python3 bench.py --precision fp32 --steps 10 --warmup 2 --no-cpu-baseline --no-traffic --no-extras --detail "$OUT/bench_fp32.json" > "$OUT/bench_fp32_line.json" 2>&1
 PAOS_NO_PRUNE=1 python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras --no-traffic --detail "$OUT/bench_noprune.json" > "$OUT/bench_noprune_line.json" 2>&1
 if [ -z "$PAOS_PROFILE_SHORT" ]; then
